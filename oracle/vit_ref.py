@@ -1,0 +1,626 @@
+"""CPU oracle for the ViT / CaiT attention+MLP training path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a NumPy restatement of the reference's algorithm for the hot path named in
+BASELINE.json.  It is imported only by tests/, by
+__graft_entry__.smoke() and by bench.py's cpu_baseline leg, and only as the checker.  The
+product path (self-attention-experiments-vision_amd/) never imports it and has no CPU
+fallback.
+
+PARITY PIN STATUS: **parity unpinned numerically**.  The reference (NZ99/
+self-attention-experiments-vision) is a JAX/Flax repo; jax, flax and optax are not
+installable here (ordinary ModuleNotFoundError, no network, no wheels - SURVEY.md 8c) and
+the reference's own tests (models/vit_test.py:13-26, models/cait_test.py:13-40) assert
+shapes only.  What *is* pinned (tests/test_oracle.py):
+  * every known answer derivable from the reference source (SURVEY.md 8c i-viii): zero
+    head => logits == 0 and loss == ln(1000); logits shapes; parameter counts; is_training
+    invariance of ViT; LayerScale init == eps; softmax rows sum to 1; smooth_labels values;
+  * agreement (<=1e-6 rel, fp32) with an independent PyTorch-CPU composition
+    (oracle/torch_ref.py) that shares no code with this file;
+  * frozen golden outputs under tests/golden/ (made by tests/golden/make_golden.py).
+
+Third-party semantics restated here (not vendored in /root/reference): flax.linen
+(unpinned git, ~0.3.4; requirements.txt:16), jax ~=0.2.13 (requirements.txt:7), optax
+(unpinned git; requirements.txt:18), einops ~=0.3 (requirements.txt:15).
+
+All `ref:` citations are paths relative to /root/reference.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# configs  (ref: models/create_model.py:10-37 ViT, :79-168 CaiT)
+# --------------------------------------------------------------------------------------
+
+
+@dataclass(frozen=True)
+class Cfg:
+    kind: str  # 'vit' | 'cait'
+    num_layers: int
+    num_heads: int
+    embed_dim: int
+    patch: int
+    num_classes: int = 1000
+    img_size: int = 224
+    expand_ratio: float = 4.0
+    # CaiT only
+    num_layers_token_only: int = 0
+    stoch_depth_rate: float = 0.0
+    layerscale_eps: float = 0.0
+
+    @property
+    def n_patches(self) -> int:
+        return (self.img_size // self.patch) ** 2
+
+    @property
+    def seq_len(self) -> int:  # tokens seen by the SA encoder
+        return self.n_patches + (1 if self.kind == "vit" else 0)
+
+    @property
+    def hidden(self) -> int:  # ref: models/layers/feedforwards/ff.py:24
+        return max(1, int(self.expand_ratio * self.embed_dim))
+
+
+def _vit(L, H, d, p):
+    return dict(kind="vit", num_layers=L, num_heads=H, embed_dim=d, patch=p)
+
+
+def _cait(L, H, d, sd, eps):
+    return dict(kind="cait", num_layers=L, num_heads=H, embed_dim=d, patch=16,
+                num_layers_token_only=2, stoch_depth_rate=sd, layerscale_eps=eps)
+
+
+MODEL_ZOO: Dict[str, dict] = {
+    # ref: models/create_model.py:10-37
+    "vit_b_patch32": _vit(12, 12, 768, 32),
+    "vit_b_patch16": _vit(12, 12, 768, 16),
+    "vit_l_patch32": _vit(24, 16, 1024, 32),
+    "vit_l_patch16": _vit(24, 16, 1024, 16),
+    # absent from the reference, named by BASELINE.json configs 1-2
+    "vit_ti_patch16": _vit(12, 3, 192, 16),
+    "vit_s_patch16": _vit(12, 6, 384, 16),
+    # ref: models/create_model.py:79-168
+    "cait_xxs_24": _cait(24, 4, 192, 0.05, 1e-5),
+    "cait_xxs_36": _cait(36, 4, 192, 0.1, 1e-6),
+    "cait_xs_24": _cait(24, 6, 288, 0.05, 1e-5),
+    "cait_xs_36": _cait(36, 6, 288, 0.1, 1e-6),
+    "cait_s_24": _cait(24, 8, 384, 0.1, 1e-6),
+    "cait_s_36": _cait(36, 8, 384, 0.2, 1e-6),
+    "cait_s_48": _cait(48, 8, 384, 0.3, 1e-6),
+    "cait_m_24": _cait(24, 16, 768, 0.2, 1e-5),
+    "cait_m_36": _cait(36, 16, 768, 0.3, 1e-6),
+    "cait_m_48": _cait(48, 16, 768, 0.4, 1e-6),
+}
+
+
+def get_cfg(model_name: str, num_classes: int = 1000, img_size: int = 224) -> Cfg:
+    """ref: models/create_model.py:6-8,214-215 (unknown name -> RuntimeError)."""
+    if model_name not in MODEL_ZOO:
+        raise RuntimeError("Model not found.")
+    return Cfg(num_classes=num_classes, img_size=img_size, **MODEL_ZOO[model_name])
+
+
+# --------------------------------------------------------------------------------------
+# dtype policy: 'f64' / 'f32' compute straight through; 'bf16' rounds to bfloat16 at every
+# point where the reference's dtype=bfloat16 graph materialises a bf16 tensor.
+# --------------------------------------------------------------------------------------
+
+
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even fp32 -> bf16 -> fp32 (NaN kept NaN)."""
+    x32 = np.ascontiguousarray(x, dtype=np.float32)
+    u = x32.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    out = (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32).reshape(x32.shape)
+    return np.where(np.isnan(x32), x32, out)
+
+
+class Policy:
+    def __init__(self, mode: str = "f32"):
+        assert mode in ("f64", "f32", "bf16")
+        self.mode = mode
+        self.acc = np.float64 if mode == "f64" else np.float32
+
+    def lo(self, x):
+        """Cast to the module `dtype` (what jnp.asarray(x, self.dtype) does)."""
+        if self.mode == "bf16":
+            return bf16_round(x)
+        return np.asarray(x, dtype=self.acc)
+
+    def hi(self, x):
+        """Array in the promoted (parameter) precision: fp32 in the reference."""
+        return np.asarray(x, dtype=self.acc)
+
+
+# --------------------------------------------------------------------------------------
+# primitives  (third-party semantics)
+# --------------------------------------------------------------------------------------
+
+
+def dense(pol: Policy, x, kernel, bias=None):
+    """flax nn.Dense: y = asarray(x,dtype) @ asarray(kernel,dtype) (+ asarray(bias,dtype)).
+    Kernel layout is [in, out].  Call sites: ff.py:26-31, patch_embed.py:23-25, vit.py:96-98."""
+    y = pol.lo(np.matmul(pol.lo(x), pol.lo(kernel)))
+    if bias is not None:
+        y = pol.lo(y + pol.lo(bias))
+    return y
+
+
+def layer_norm(pol: Policy, x, scale, bias, eps: float = 1e-6):
+    """flax nn.LayerNorm(dtype): fp32 statistics, biased E[x^2]-E[x]^2 variance, eps=1e-6,
+    scale/bias cast to dtype before use, result cast to dtype.  Sites: vit.py:19,26,57."""
+    x32 = pol.hi(x)
+    mean = x32.mean(axis=-1, keepdims=True)
+    mean2 = (x32 * x32).mean(axis=-1, keepdims=True)
+    var = mean2 - mean * mean
+    mul = (1.0 / np.sqrt(var + pol.acc(eps))) * pol.lo(scale)
+    y = (x32 - mean) * mul + pol.lo(bias)
+    return pol.lo(y)
+
+
+def gelu_tanh(pol: Policy, x):
+    """jax.nn.gelu(approximate=True), the default behind nn.activation.gelu (vit.py:14)."""
+    x = pol.hi(x)
+    c = pol.acc(math.sqrt(2.0 / math.pi))
+    return pol.lo(0.5 * x * (1.0 + np.tanh(c * (x + pol.acc(0.044715) * x * x * x))))
+
+
+def softmax_last(pol: Policy, x):
+    """flax nn.softmax over the last axis (attention.py:48)."""
+    x = pol.hi(x)
+    e = pol.lo(np.exp(pol.lo(x - x.max(axis=-1, keepdims=True))))
+    s = pol.lo(e.sum(axis=-1, keepdims=True))
+    return pol.lo(e / s)
+
+
+def patchify(images, ph: int, pw: int):
+    """einops 'b (h ph) (w pw) c -> b (h w) (ph pw c)'  (patch_embed.py:19-22)."""
+    b, H, W, c = images.shape
+    h, w = H // ph, W // pw
+    x = images.reshape(b, h, ph, w, pw, c).transpose(0, 1, 3, 2, 4, 5)
+    return x.reshape(b, h * w, ph * pw * c)
+
+
+# --------------------------------------------------------------------------------------
+# layers
+# --------------------------------------------------------------------------------------
+
+
+def talking_heads(pol: Policy, transform, x):
+    """einsum('h i, b h ... -> b i ...')  (talking_heads.py:13).  No dtype => fp32 output."""
+    return np.einsum("hi,bhqk->biqk", pol.hi(transform), pol.hi(x))
+
+
+def attention_block(pol: Policy, p: dict, xq, xkv, num_heads: int, talking: bool = False):
+    """AttentionBlock.__call__  (models/layers/attentions/attention.py:21-67).
+    p: {'queries','keys','values': {'kernel':[d,H,hd]}, 'DenseGeneral_0': {'kernel':[H,hd,d]},
+        optional 'TalkingHeadsBlock_0/1': {'talking_heads_transform':[H,H]}}"""
+    B, Nq, d = xq.shape
+    H = num_heads
+    assert d % H == 0  # attention.py:25
+    hd = d // H
+    wq = np.asarray(p["queries"]["kernel"]).reshape(d, d)
+    wk = np.asarray(p["keys"]["kernel"]).reshape(d, d)
+    wv = np.asarray(p["values"]["kernel"]).reshape(d, d)
+    wo = np.asarray(p["DenseGeneral_0"]["kernel"]).reshape(d, -1)
+    q = dense(pol, xq, wq).reshape(B, Nq, H, hd)  # attention.py:35
+    k = dense(pol, xkv, wk).reshape(B, -1, H, hd)  # :36
+    v = dense(pol, xkv, wv).reshape(B, -1, H, hd)  # :37
+    q = pol.lo(q / pol.acc(math.sqrt(hd)))  # :39  (weak-typed scalar: stays in dtype)
+    s = pol.lo(np.einsum("bqhd,bkhd->bhqk", q, k))  # :41
+    if talking:
+        hp = Policy("f64" if pol.mode == "f64" else "f32")  # TalkingHeadsBlock has no dtype: fp32 (A.5)
+        s = talking_heads(hp, p["TalkingHeadsBlock_0"]["talking_heads_transform"], s)  # :44-46
+        w = softmax_last(hp, s)  # :48, fp32 by promotion
+        w = talking_heads(hp, p["TalkingHeadsBlock_1"]["talking_heads_transform"], w)  # :50-52
+    else:
+        w = softmax_last(pol, s)  # :48
+    o = pol.lo(np.einsum("bhqk,bkhd->bqhd", w, v))  # :57  (dropout rate 0 => identity, :54)
+    out = dense(pol, o.reshape(B, Nq, d), wo)  # :60-63
+    return out
+
+
+def ff_block(pol: Policy, p: dict, x):
+    """FFBlock.__call__  (models/layers/feedforwards/ff.py:16-34)."""
+    h = dense(pol, x, p["Dense_0"]["kernel"], p["Dense_0"]["bias"])
+    h = gelu_tanh(pol, h)
+    return dense(pol, h, p["Dense_1"]["kernel"], p["Dense_1"]["bias"])
+
+
+def vit_encoder_block(pol: Policy, p: dict, inputs, num_heads: int):
+    """EncoderBlock.__call__  (models/vit.py:17-32)."""
+    x = layer_norm(pol, inputs, p["LayerNorm_0"]["scale"], p["LayerNorm_0"]["bias"])
+    x = attention_block(pol, p["SelfAttentionBlock_0"], x, x, num_heads)
+    x = pol.hi(x) + pol.hi(inputs)  # vit.py:24  (bf16 + fp32 -> fp32)
+    y = layer_norm(pol, x, p["LayerNorm_1"]["scale"], p["LayerNorm_1"]["bias"])
+    y = ff_block(pol, p["FFBlock_0"], y)
+    return x + pol.hi(y)  # vit.py:31
+
+
+def vit_forward(params: dict, images, cfg: Cfg, mode: str = "f32", is_training: bool = False,
+                return_tokens: bool = False):
+    """ViT.__call__  (models/vit.py:73-99).  images NHWC [B,S,S,3].  is_training is accepted
+    and ignored: every dropout rate is 0 for every create_model() ViT (create_model.py:10-37)."""
+    pol = Policy(mode)
+    p = params["params"] if "params" in params else params
+    assert cfg.embed_dim % cfg.num_heads == 0  # vit.py:75
+    x = patchify(pol.lo(images), cfg.patch, cfg.patch)
+    x = dense(pol, x, p["PatchEmbedBlock_0"]["Dense_0"]["kernel"])  # no bias
+    B = x.shape[0]
+    cls = np.tile(pol.hi(p["cls"]), (B, 1, 1))  # vit.py:81-84
+    x = np.concatenate([cls, pol.hi(x)], axis=1)  # :85  -> fp32
+    enc = p["Encoder_0"]
+    x = x + pol.hi(enc["AddAbsPosEmbed_0"]["pos_embed"])  # position_embed.py:52-57
+    for l in range(cfg.num_layers):
+        x = vit_encoder_block(pol, enc[f"EncoderBlock_{l}"], x, cfg.num_heads)
+    z = layer_norm(pol, x, enc["LayerNorm_0"]["scale"], enc["LayerNorm_0"]["bias"])  # vit.py:57
+    logits = dense(pol, z[:, 0], p["Dense_0"]["kernel"], p["Dense_0"]["bias"])  # :95-98
+    if return_tokens:
+        return logits, x
+    return logits
+
+
+def layer_scale(pol: Policy, p: dict, x):
+    """LayerScaleBlock  (models/layers/normalizations/layerscale.py:18-23)."""
+    return pol.lo(pol.hi(x) * pol.lo(p["layerscale"]))
+
+
+def stochastic_depth(x, keep_mask: Optional[np.ndarray], drop_rate: float, is_training: bool):
+    """StochasticDepthBlock  (models/layers/regularization/stochastic_depth.py:11-28).
+    keep_mask = floor(keep_prob + U[0,1)) per sample, supplied by the caller (the JAX rng stream
+    cannot be reproduced); out = x / keep_prob * mask."""
+    if (not is_training) or drop_rate == 0.0:
+        return x
+    keep = 1.0 - drop_rate
+    m = np.asarray(keep_mask, dtype=x.dtype).reshape((-1,) + (1,) * (x.ndim - 1))
+    return x / x.dtype.type(keep) * m
+
+
+def cait_encoder_block(pol, p, inputs, cfg: Cfg, is_training, masks):
+    """CaiT EncoderBlock  (models/cait.py:28-53)."""
+    x = layer_norm(pol, inputs, p["LayerNorm_0"]["scale"], p["LayerNorm_0"]["bias"])
+    x = attention_block(pol, p["SelfAttentionBlock_0"], x, x, cfg.num_heads, talking=True)
+    x = layer_scale(pol, p["LayerScaleBlock_0"], x)
+    x = stochastic_depth(pol.hi(x), None if masks is None else masks[0], cfg.stoch_depth_rate, is_training)
+    x = x + pol.hi(inputs)
+    y = layer_norm(pol, x, p["LayerNorm_1"]["scale"], p["LayerNorm_1"]["bias"])
+    y = ff_block(pol, p["FFBlock_0"], y)
+    y = layer_scale(pol, p["LayerScaleBlock_1"], y)
+    y = stochastic_depth(pol.hi(y), None if masks is None else masks[1], cfg.stoch_depth_rate, is_training)
+    return x + y
+
+
+def cait_ca_block(pol, p, inputs, cls_token, cfg: Cfg, is_training, masks):
+    """CAEncoderBlock  (models/cait.py:96-122) with ClassSelfAttentionBlock (:10-15)."""
+    x = np.concatenate([cls_token, inputs], axis=1)
+    x = layer_norm(pol, x, p["LayerNorm_0"]["scale"], p["LayerNorm_0"]["bias"])
+    x = attention_block(pol, p["ClassSelfAttentionBlock_0"], x[:, 0:1, :], x, cfg.num_heads)
+    x = layer_scale(pol, p["LayerScaleBlock_0"], x)
+    x = stochastic_depth(pol.hi(x), None if masks is None else masks[0], cfg.stoch_depth_rate, is_training)
+    cls_token = cls_token + x
+    y = layer_norm(pol, cls_token, p["LayerNorm_1"]["scale"], p["LayerNorm_1"]["bias"])
+    y = ff_block(pol, p["FFBlock_0"], y)
+    y = layer_scale(pol, p["LayerScaleBlock_1"], y)
+    y = stochastic_depth(pol.hi(y), None if masks is None else masks[1], cfg.stoch_depth_rate, is_training)
+    return cls_token + y
+
+
+def cait_forward(params: dict, images, cfg: Cfg, mode: str = "f32", is_training: bool = False,
+                 keep_masks: Optional[np.ndarray] = None):
+    """CaiT.__call__  (models/cait.py:140-183).  keep_masks: [(L+L_ca), 2, B] of 0/1 when
+    is_training and stoch_depth_rate>0.  NOTE the reference runs the SA encoder in fp32 even
+    with dtype=bf16 (cait.py:147-154 does not forward dtype); this oracle applies
+    `mode` uniformly - the build runs CaiT in bf16 and is checked against mode='f32'."""
+    pol = Policy(mode)
+    p = params["params"] if "params" in params else params
+    x = patchify(pol.lo(images), cfg.patch, cfg.patch)
+    x = dense(pol, x, p["PatchEmbedBlock_0"]["Dense_0"]["kernel"])
+    enc = p["Encoder_0"]
+    x = pol.hi(x) + pol.hi(enc["AddAbsPosEmbed_0"]["pos_embed"])
+    for l in range(cfg.num_layers):
+        mk = None if keep_masks is None else keep_masks[l]
+        x = cait_encoder_block(pol, enc[f"EncoderBlock_{l}"], x, cfg, is_training, mk)
+    B = x.shape[0]
+    cls = np.tile(pol.hi(p["cls"]), (B, 1, 1))
+    for l in range(cfg.num_layers_token_only):
+        mk = None if keep_masks is None else keep_masks[cfg.num_layers + l]
+        cls = cait_ca_block(pol, p[f"CAEncoderBlock_{l}"], x, cls, cfg, is_training, mk)
+    x = np.concatenate([cls, x], axis=1)  # cait.py:175
+    x = layer_norm(pol, x, p["LayerNorm_0"]["scale"], p["LayerNorm_0"]["bias"])
+    return dense(pol, x[:, 0], p["Dense_0"]["kernel"], p["Dense_0"]["bias"])
+
+
+def forward(params, images, cfg: Cfg, mode="f32", is_training=False, keep_masks=None):
+    if cfg.kind == "vit":
+        return vit_forward(params, images, cfg, mode, is_training)
+    return cait_forward(params, images, cfg, mode, is_training, keep_masks)
+
+
+# --------------------------------------------------------------------------------------
+# loss / metrics / optimizer  (train.py:18-38,77-100; simple_train.py:23-34; utils.py:20-37)
+# --------------------------------------------------------------------------------------
+
+
+def one_hot(labels, num_classes: int, dtype=np.float32):
+    """jax.nn.one_hot (train.py:18-19)."""
+    return (np.asarray(labels)[:, None] == np.arange(num_classes)[None, :]).astype(dtype)
+
+
+def smooth_labels(y, alpha: float):
+    """optax.smooth_labels: (1-a)*y + a/K  (train.py:88)."""
+    return (1.0 - alpha) * y + alpha / y.shape[-1]
+
+
+def log_softmax(x):
+    m = x.max(axis=-1, keepdims=True)
+    s = x - m
+    return s - np.log(np.exp(s).sum(axis=-1, keepdims=True))
+
+
+def softmax_cross_entropy(logits, y):
+    """optax.softmax_cross_entropy: -sum(y * log_softmax(logits))  (train.py:90)."""
+    return -(y * log_softmax(logits)).sum(axis=-1)
+
+
+def loss_fn(logits, labels, label_smoothing: float = 0.1, mix_labels=None, ratio=None):
+    """train.py:83-90 (mean over the local batch; the /device_count at :91 is defect B4 and is
+    not replicated).  logits are cast to fp32 first (:89)."""
+    logits = np.asarray(logits, dtype=np.float64 if logits.dtype == np.float64 else np.float32)
+    K = logits.shape[-1]
+    y = one_hot(labels, K, logits.dtype)
+    if mix_labels is not None:
+        y1 = one_hot(mix_labels, K, logits.dtype)
+        r = np.asarray(ratio, dtype=logits.dtype)[:, None]
+        y = r * y + (1.0 - r) * y1
+    y = smooth_labels(y, label_smoothing)
+    return softmax_cross_entropy(logits, y).mean()
+
+
+def dloss_dlogits(logits, labels, label_smoothing: float = 0.1):
+    """Analytic gradient of loss_fn wrt logits: (softmax - y_smooth)/B."""
+    logits = np.asarray(logits)
+    K = logits.shape[-1]
+    y = smooth_labels(one_hot(labels, K, logits.dtype), label_smoothing)
+    return (np.exp(log_softmax(logits)) - y) / logits.shape[0]
+
+
+def topk_correct(logits, labels, topk=(1, 5)):
+    """utils.py:20-31: label in the k largest logits (argsort ascending, last k)."""
+    order = np.argsort(logits, axis=-1)
+    out = {}
+    for k in topk:
+        pred = order[..., -k:]
+        out[f"top_{k}_acc"] = (pred == np.asarray(labels)[:, None]).any(axis=-1).astype(np.float32)
+    return out
+
+
+def global_norm(tree_leaves):
+    return math.sqrt(sum(float((np.asarray(g, dtype=np.float64) ** 2).sum()) for g in tree_leaves))
+
+
+def adamw_update(p, g, m, v, step: int, lr: float, weight_decay: float = 0.0, clip_scale: float = 1.0,
+                 b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8):
+    """One leaf of optax.chain(clip_by_global_norm, scale_by_adam, additive_weight_decay,
+    scale(-lr)) + apply_updates (train.py:25-27 with the descent sign of simple_train.py:27;
+    SURVEY A.3, defect B3).  `step` is 1-based; clip_scale = min(1, c/||g||) computed by the
+    caller over the whole tree.  Returns (p, m, v)."""
+    g = g * clip_scale
+    m = b1 * m + (1.0 - b1) * g
+    v = b2 * v + (1.0 - b2) * g * g
+    mhat = m / (1.0 - b1 ** step)
+    vhat = v / (1.0 - b2 ** step)
+    u = mhat / (np.sqrt(vhat) + eps) + weight_decay * p
+    return p - lr * u, m, v
+
+
+def warmup_cosine_lr(step: int, base_lr: float, warmup_steps: int, total_steps: int, end_value: float = 1e-5,
+                     init_value: float = 0.0):
+    """optax.warmup_cosine_decay_schedule as used at train.py:214-220: linear init->peak over
+    warmup_steps, then cosine from peak to end_value over (total_steps - warmup_steps)."""
+    if step < warmup_steps:
+        return init_value + (base_lr - init_value) * step / max(1, warmup_steps)
+    t = min(1.0, (step - warmup_steps) / max(1, total_steps - warmup_steps))
+    return end_value + (base_lr - end_value) * 0.5 * (1.0 + math.cos(math.pi * t))
+
+
+# --------------------------------------------------------------------------------------
+# parameter construction  (Flax tree of SURVEY A.6; initialisers of the reference)
+# --------------------------------------------------------------------------------------
+
+
+def _lecun_normal(rng, shape, fan_in):
+    """jax variance_scaling(1.0,'fan_in','truncated_normal'): N(0, 1/fan_in) truncated at 2 sigma,
+    std corrected by 1/.87962566103423978."""
+    std = math.sqrt(1.0 / fan_in) / 0.87962566103423978
+    x = rng.standard_normal(size=shape)
+    bad = np.abs(x) > 2.0
+    while bad.any():
+        x[bad] = rng.standard_normal(size=int(bad.sum()))
+        bad = np.abs(x) > 2.0
+    return (x * std).astype(np.float32)
+
+
+def _orthogonal(rng, n):
+    a = rng.standard_normal(size=(n, n))
+    q, r = np.linalg.qr(a)
+    return (q * np.sign(np.diag(r))[None, :]).astype(np.float32)
+
+
+def _attn_params(rng, d, H, talking, randomize):
+    hd = d // H
+    p = {
+        "queries": {"kernel": _lecun_normal(rng, (d, H, hd), d)},
+        "keys": {"kernel": _lecun_normal(rng, (d, H, hd), d)},
+        "values": {"kernel": _lecun_normal(rng, (d, H, hd), d)},
+        "DenseGeneral_0": {"kernel": _lecun_normal(rng, (H, hd, d), d)},
+    }
+    if talking:
+        for i in (0, 1):
+            t = _orthogonal(rng, H)
+            if randomize:
+                t = t + 0.1 * rng.standard_normal(size=(H, H)).astype(np.float32)
+            p[f"TalkingHeadsBlock_{i}"] = {"talking_heads_transform": t.astype(np.float32)}
+    return p
+
+
+def _ln_params(rng, d, randomize):
+    if randomize:
+        return {"scale": (1.0 + 0.1 * rng.standard_normal(d)).astype(np.float32),
+                "bias": (0.1 * rng.standard_normal(d)).astype(np.float32)}
+    return {"scale": np.ones(d, np.float32), "bias": np.zeros(d, np.float32)}
+
+
+def _ff_params(rng, d, F, randomize):
+    b0 = (0.02 * rng.standard_normal(F)).astype(np.float32) if randomize else np.zeros(F, np.float32)
+    b1 = (0.02 * rng.standard_normal(d)).astype(np.float32) if randomize else np.zeros(d, np.float32)
+    return {"Dense_0": {"kernel": _lecun_normal(rng, (d, F), d), "bias": b0},
+            "Dense_1": {"kernel": _lecun_normal(rng, (F, d), F), "bias": b1}}
+
+
+def init_params(cfg: Cfg, seed: int = 0, randomize: bool = False) -> dict:
+    """Parameter tree with the reference's names/shapes and initialisers
+    (lecun-normal Dense kernels, zero biases, zero cls, normal(0.02) pos-embed, LN 1/0,
+    orthogonal talking-heads, LayerScale eps, ZERO head kernel: vit.py:83,98;
+    position_embed.py:49; talking_heads.py:12; layerscale.py:5-10).
+    randomize=True replaces every zero/one/eps init by non-trivial random values so that parity
+    tests exercise every term (a zero head hides everything: SURVEY 8c)."""
+    rng = np.random.default_rng(seed)
+    d, H, F = cfg.embed_dim, cfg.num_heads, cfg.hidden
+    pdim = cfg.patch * cfg.patch * 3
+    N = cfg.seq_len
+    p: dict = {"PatchEmbedBlock_0": {"Dense_0": {"kernel": _lecun_normal(rng, (pdim, d), pdim)}}}
+    p["cls"] = ((0.02 * rng.standard_normal((1, 1, d))).astype(np.float32) if randomize
+                else np.zeros((1, 1, d), np.float32))
+    enc: dict = {"AddAbsPosEmbed_0": {"pos_embed": (0.02 * rng.standard_normal((1, N, d))).astype(np.float32)}}
+    for l in range(cfg.num_layers):
+        blk = {"LayerNorm_0": _ln_params(rng, d, randomize),
+               "SelfAttentionBlock_0": _attn_params(rng, d, H, cfg.kind == "cait", randomize),
+               "LayerNorm_1": _ln_params(rng, d, randomize),
+               "FFBlock_0": _ff_params(rng, d, F, randomize)}
+        if cfg.kind == "cait":
+            for i in (0, 1):
+                ls = np.full(d, cfg.layerscale_eps, np.float32)
+                if randomize:
+                    ls = (0.5 + 0.5 * rng.random(d)).astype(np.float32)
+                blk[f"LayerScaleBlock_{i}"] = {"layerscale": ls}
+        enc[f"EncoderBlock_{l}"] = blk
+    if cfg.kind == "vit":
+        enc["LayerNorm_0"] = _ln_params(rng, d, randomize)
+    p["Encoder_0"] = enc
+    if cfg.kind == "cait":
+        for l in range(cfg.num_layers_token_only):
+            blk = {"LayerNorm_0": _ln_params(rng, d, randomize),
+                   "ClassSelfAttentionBlock_0": _attn_params(rng, d, H, False, randomize),
+                   "LayerNorm_1": _ln_params(rng, d, randomize),
+                   "FFBlock_0": _ff_params(rng, d, F, randomize)}
+            for i in (0, 1):
+                ls = np.full(d, cfg.layerscale_eps, np.float32)
+                if randomize:
+                    ls = (0.5 + 0.5 * rng.random(d)).astype(np.float32)
+                blk[f"LayerScaleBlock_{i}"] = {"layerscale": ls}
+            p[f"CAEncoderBlock_{l}"] = blk
+        p["LayerNorm_0"] = _ln_params(rng, d, randomize)
+    hk = (_lecun_normal(rng, (d, cfg.num_classes), d) if randomize
+          else np.zeros((d, cfg.num_classes), np.float32))
+    hb = ((0.02 * rng.standard_normal(cfg.num_classes)).astype(np.float32) if randomize
+          else np.zeros(cfg.num_classes, np.float32))
+    p["Dense_0"] = {"kernel": hk, "bias": hb}
+    return {"params": p}
+
+
+def flatten(tree: dict, prefix: str = "") -> Dict[str, np.ndarray]:
+    out = {}
+    for k, v in tree.items():
+        key = f"{prefix}/{k}" if prefix else k
+        if isinstance(v, dict):
+            out.update(flatten(v, key))
+        else:
+            out[key] = v
+    return out
+
+
+def unflatten(flat: Dict[str, np.ndarray]) -> dict:
+    tree: dict = {}
+    for k, v in flat.items():
+        node = tree
+        parts = k.split("/")
+        for part in parts[:-1]:
+            node = node.setdefault(part, {})
+        node[parts[-1]] = v
+    return tree
+
+
+def param_count(params: dict) -> int:
+    return int(sum(np.asarray(v).size for v in flatten(params).values()))
+
+
+# flops model of SURVEY 8d (the figure bench.py's roofline uses)
+def train_flops_per_image(cfg: Cfg) -> float:
+    d, C = cfg.embed_dim, cfg.num_classes
+    n = cfg.n_patches
+    pe = 2.0 * n * (cfg.patch * cfg.patch * 3) * d
+    if cfg.kind == "vit":
+        N = n + 1
+        layer = 24.0 * N * d * d + 4.0 * N * N * d
+        return 3.0 * (cfg.num_layers * layer + 2.0 * d * C) + 2.0 * pe
+    H = cfg.num_heads
+    sa = 24.0 * n * d * d + 4.0 * n * n * d + 4.0 * H * H * n * n
+    ca = 20.0 * d * d + 4.0 * (n + 1) * d * d + 4.0 * (n + 1) * d
+    return 3.0 * (cfg.num_layers * sa + cfg.num_layers_token_only * ca + 2.0 * d * C) + 2.0 * pe
+
+
+def param_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
+    """Flat {name: shape} of the Flax tree without allocating anything."""
+    d, H, F, C = cfg.embed_dim, cfg.num_heads, cfg.hidden, cfg.num_classes
+    hd = d // H
+    out: Dict[str, Tuple[int, ...]] = {}
+
+    def attn(prefix, talking):
+        for n in ("queries", "keys", "values"):
+            out[f"{prefix}/{n}/kernel"] = (d, H, hd)
+        out[f"{prefix}/DenseGeneral_0/kernel"] = (H, hd, d)
+        if talking:
+            for i in (0, 1):
+                out[f"{prefix}/TalkingHeadsBlock_{i}/talking_heads_transform"] = (H, H)
+
+    def ln(prefix):
+        out[f"{prefix}/scale"] = (d,)
+        out[f"{prefix}/bias"] = (d,)
+
+    def ff(prefix):
+        out[f"{prefix}/Dense_0/kernel"] = (d, F)
+        out[f"{prefix}/Dense_0/bias"] = (F,)
+        out[f"{prefix}/Dense_1/kernel"] = (F, d)
+        out[f"{prefix}/Dense_1/bias"] = (d,)
+
+    out["params/PatchEmbedBlock_0/Dense_0/kernel"] = (cfg.patch * cfg.patch * 3, d)
+    out["params/cls"] = (1, 1, d)
+    out["params/Encoder_0/AddAbsPosEmbed_0/pos_embed"] = (1, cfg.seq_len, d)
+    for l in range(cfg.num_layers):
+        b = f"params/Encoder_0/EncoderBlock_{l}"
+        ln(f"{b}/LayerNorm_0")
+        attn(f"{b}/SelfAttentionBlock_0", cfg.kind == "cait")
+        ln(f"{b}/LayerNorm_1")
+        ff(f"{b}/FFBlock_0")
+        if cfg.kind == "cait":
+            for i in (0, 1):
+                out[f"{b}/LayerScaleBlock_{i}/layerscale"] = (d,)
+    if cfg.kind == "vit":
+        ln("params/Encoder_0/LayerNorm_0")
+    else:
+        for l in range(cfg.num_layers_token_only):
+            b = f"params/CAEncoderBlock_{l}"
+            ln(f"{b}/LayerNorm_0")
+            attn(f"{b}/ClassSelfAttentionBlock_0", False)
+            ln(f"{b}/LayerNorm_1")
+            ff(f"{b}/FFBlock_0")
+            for i in (0, 1):
+                out[f"{b}/LayerScaleBlock_{i}/layerscale"] = (d,)
+        ln("params/LayerNorm_0")
+    out["params/Dense_0/kernel"] = (d, C)
+    out["params/Dense_0/bias"] = (C,)
+    return out
