@@ -1,0 +1,75 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the ViT/CaiT training path.
+// Wave = 64 lanes everywhere; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define SAVIT_OK 0
+#define SAVIT_EINVAL 1001  // shape / alignment contract violated (host-side check)
+
+#define SAVIT_CHECK_ARG(cond) \
+  do {                        \
+    if (!(cond)) return SAVIT_EINVAL; \
+  } while (0)
+
+#define SAVIT_LAUNCH_RET() return (int)hipGetLastError()
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even; a plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// jax.nn.gelu(approximate=True): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+// tanh(z) = 1 - 2/(1+exp(2z)) keeps full fp32 accuracy away from 0 and is exact at +-inf.
+__device__ __forceinline__ float tanh_fast(float z) {
+  float e = __expf(2.0f * z);
+  return 1.0f - 2.0f / (1.0f + e);
+}
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float c = 0.7978845608028654f;
+  float z = c * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanh_fast(z));
+}
+// d/dx gelu_tanh(x)
+__device__ __forceinline__ float gelu_tanh_grad_f(float x) {
+  const float c = 0.7978845608028654f;
+  float x2 = x * x;
+  float z = c * (x + 0.044715f * x * x2);
+  float t = tanh_fast(z);
+  float dz = c * (1.0f + 3.0f * 0.044715f * x2);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * dz;
+}
+
+// Bijective XCD-aware remap of a linear workgroup id: blocks b and b+8 share an XCD (speed only,
+// never correctness), so give each XCD a contiguous chunk of the tile list.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (orig >> 3);
+}

@@ -1,0 +1,256 @@
+// Weight-gradient GEMM  dW[Kin, Nout] += X[M, Kin]^T . dY[M, Nout]   (bf16 in, fp32 accumulate).
+//
+// Backward of every nn.Dense / nn.DenseGeneral kernel on the hot path (reference: jax.value_and_grad at
+// /root/reference/train.py:94-95 differentiating attention.py:29-37,60-63, ff.py:26-31, patch_embed.py:23-25,
+// vit.py:96-98).  The reduction runs over the token dimension M (25k-148k), both operands are row-major
+// activations, i.e. the reduction index is the SLOW index of both.  gfx950 design:
+//   * tiles of 64 tokens x BI (X) and 64 tokens x BJ (dY) go HBM -> LDS by LDS-DMA (buffer_load ... lds);
+//     rows >= M are zero-filled by the descriptor's bounds check;
+//   * MFMA fragments are read with ds_read_b64_tr_b16 (hardware transpose: 4 tokens x 16 columns per
+//     16-lane group), so no transposed copy of any activation ever exists in HBM;
+//   * the 16-B chunk index inside each 256-B LDS segment is XORed with (token&3)<<2 (on the DMA source
+//     address and on the read address) so the 4 token rows of a transpose block hit 4 different bank groups;
+//   * v_mfma_f32_32x32x16_bf16, un-swapped: one accumulator register = 32 consecutive columns of 2 rows =
+//     two 128-B segments, the shape global fp32 atomics run at full rate with;
+//   * split over M: grid.y groups each own a contiguous token range and add their partial tile into the
+//     fp32 gradient with global_atomic_add_f32 (order-dependent in the last bits, like any atomic sum).
+#include "common.h"
+#include "savit.h"
+
+namespace {
+
+constexpr int TK = 64;  // tokens per reduction tile
+
+struct WgradParams {
+  const bf16_t* X;
+  const bf16_t* dY;
+  float* dW;
+  int M, Kin, Nout, ldx, lddy, lddw;
+  int tiles_i, tiles_j, splits, tiles_per_split;
+  int patch, img_size, tokens, token_offset, grid_side, chunks_per_prow;
+};
+
+__device__ __forceinline__ bf16x4 ds_read_tr16_b64(const char* p) {
+  // hardware transpose read; the builtin lets hipcc count the read in lgkmcnt and fold constant offsets
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(p));
+}
+
+template <int BI, int BJ, int WGI, int WGJ, bool PATCH>
+__global__ __launch_bounds__(64 * WGI * WGJ) void gemm_wgrad_kernel(const WgradParams p) {
+  constexpr int NW = WGI * WGJ;
+  constexpr int WTI = BI / WGI, WTJ = BJ / WGJ;
+  constexpr int II = WTI / 32, JJ = WTJ / 32;
+  constexpr int XROW = BI * 2, YROW = BJ * 2;           // LDS row bytes
+  constexpr int X_BYTES = TK * XROW, Y_BYTES = TK * YROW;
+  constexpr int STAGE_BYTES = X_BYTES + Y_BYTES;
+  constexpr int X_INSTR = X_BYTES / 1024 / NW, Y_INSTR = Y_BYTES / 1024 / NW;
+  static_assert(X_BYTES % (1024 * NW) == 0 && Y_BYTES % (1024 * NW) == 0, "tile/wave mismatch");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wi = wave / WGJ, wj = wave % WGJ;
+
+  const int ntile = p.tiles_i * p.tiles_j;
+  const int tid = blockIdx.x;
+  const int ti = tid / p.tiles_j, tj = tid - ti * p.tiles_j;
+  const int i0 = ti * BI, j0 = tj * BJ;
+  const int split = blockIdx.y;
+  const int kt_begin = split * p.tiles_per_split;
+  const int kt_total = (p.M + TK - 1) / TK;
+  int kt_end = kt_begin + p.tiles_per_split;
+  if (kt_end > kt_total) kt_end = kt_total;
+  if (kt_begin >= kt_end) return;
+  (void)ntile;
+
+  // descriptors: X over the whole activation (or image) buffer, dY likewise; token rows >= M must read zero,
+  // so token validity is folded into the per-lane offset (0xfffffff0 is out of range by construction).
+  size_t xbytes = PATCH ? (size_t)(p.M / (p.grid_side * p.grid_side)) * p.img_size * p.img_size * 6 : (size_t)p.M * p.ldx * 2;
+  size_t ybytes = PATCH ? (size_t)(p.M / (p.grid_side * p.grid_side)) * p.tokens * p.lddy * 2 : (size_t)p.M * p.lddy * 2;
+  if (xbytes > 0xffffffe0ull) xbytes = 0xffffffe0ull;
+  if (ybytes > 0xffffffe0ull) ybytes = 0xffffffe0ull;
+  const auto srdX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X), 0, (uint32_t)xbytes, 0x00020000);
+  const auto srdY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dY), 0, (uint32_t)ybytes, 0x00020000);
+
+  // staging: a wave-instruction writes 1 KiB = (1024/ROW) rows; lane -> (row, physical chunk)
+  auto stage = [&](int kt, int buf) {
+    char* sX = smem + buf * STAGE_BYTES;
+    char* sY = sX + X_BYTES;
+    const int m0 = kt * TK;
+    {
+      constexpr int LPR = XROW / 16;  // lanes (chunks) per row
+      constexpr int RPI = 64 / LPR;   // rows per instruction
+#pragma unroll
+      for (int i = 0; i < X_INSTR; ++i) {
+        const int inst = wave * X_INSTR + i;
+        const int r = inst * RPI + lane / LPR;  // token row inside the tile
+        const int pc = lane % LPR;
+        const int c = pc ^ ((r & 3) << 2);     // logical chunk (XOR acts inside each 256-B segment)
+        const int m = m0 + r;
+        uint32_t voff = 0xfffffff0u;
+        if (m < p.M) {
+          if (PATCH) {
+            const int ppi = p.grid_side * p.grid_side;
+            const int b = m / ppi, pp = m - b * ppi;
+            const int pi = pp / p.grid_side, pj = pp - pi * p.grid_side;
+            const int kc = i0 / 8 + c;
+            const int ph = kc / p.chunks_per_prow, within = kc - ph * p.chunks_per_prow;
+            const size_t pix = ((size_t)b * p.img_size + (size_t)pi * p.patch + ph) * p.img_size + (size_t)pj * p.patch;
+            voff = (uint32_t)(pix * 6 + (size_t)within * 16);
+          } else {
+            voff = (uint32_t)((size_t)m * p.ldx * 2 + (size_t)(i0 + c * 8) * 2);
+          }
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdX, (__attribute__((address_space(3))) void*)(sX + inst * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+    {
+      constexpr int LPR = YROW / 16;
+      constexpr int RPI = 64 / LPR;
+#pragma unroll
+      for (int i = 0; i < Y_INSTR; ++i) {
+        const int inst = wave * Y_INSTR + i;
+        const int r = inst * RPI + lane / LPR;
+        const int pc = lane % LPR;
+        const int c = pc ^ ((r & 3) << 2);
+        const int m = m0 + r;
+        uint32_t voff = 0xfffffff0u;
+        if (m < p.M) {
+          size_t row = m;
+          if (PATCH) {
+            const int ppi = p.grid_side * p.grid_side;
+            const int b = m / ppi, pp = m - b * ppi;
+            row = (size_t)b * p.tokens + p.token_offset + pp;
+          }
+          voff = (uint32_t)(row * p.lddy * 2 + (size_t)(j0 + c * 8) * 2);
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdY, (__attribute__((address_space(3))) void*)(sY + inst * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+  };
+
+  // transpose-read geometry (32x32x16 operand): 16-lane group g: column sub-block (g&1), k-half h = g>>1;
+  // lane t of the group addresses token row q = t>>2, columns 4*(t&3)..+3 of the 4x16 block.
+  const int g = lane >> 4, t = lane & 15;
+  const int q = t >> 2, h = g >> 1;
+  const int colx = wi * WTI + 16 * (g & 1) + 4 * (t & 3);  // + 32*ii
+  const int coly = wj * WTJ + 16 * (g & 1) + 4 * (t & 3);  // + 32*jj
+  auto tr_off = [&](int col, int rowbytes, int tok) -> int {
+    const int chunk = col >> 3;
+    const int pch = chunk ^ ((tok & 3) << 2);
+    return tok * rowbytes + pch * 16 + (col & 7) * 2;
+  };
+
+  f32x16 acc[II][JJ];
+#pragma unroll
+  for (int a = 0; a < II; ++a)
+#pragma unroll
+    for (int b = 0; b < JJ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  stage(kt_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
+    const char* sX = smem + cur * STAGE_BYTES;
+    const char* sY = sX + X_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < TK / 16; ++ks) {
+      const int tok0 = 16 * ks + 8 * h + q;  // first transpose block; second is +4 tokens
+      bf16x8 xa[II], yb[JJ];
+#pragma unroll
+      for (int a = 0; a < II; ++a) {
+        const bf16x4 lo = ds_read_tr16_b64(sX + tr_off(colx + 32 * a, XROW, tok0));
+        const bf16x4 hi = ds_read_tr16_b64(sX + tr_off(colx + 32 * a, XROW, tok0 + 4));
+        xa[a] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int b = 0; b < JJ; ++b) {
+        const bf16x4 lo = ds_read_tr16_b64(sY + tr_off(coly + 32 * b, YROW, tok0));
+        const bf16x4 hi = ds_read_tr16_b64(sY + tr_off(coly + 32 * b, YROW, tok0 + 4));
+        yb[b] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int a = 0; a < II; ++a)
+#pragma unroll
+        for (int b = 0; b < JJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[a], yb[b], acc[a][b], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // epilogue: D[i][j]: j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int jl = lane & 31, hi5 = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < II; ++a)
+#pragma unroll
+    for (int b = 0; b < JJ; ++b) {
+      const int j = j0 + wj * WTJ + 32 * b + jl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wi * WTI + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi5;
+        if (i < p.Kin && j < p.Nout) atomicAdd(p.dW + (size_t)i * p.lddw + j, acc[a][b][r]);
+      }
+    }
+}
+
+template <int BI, int BJ, int WGI, int WGJ>
+int launch_wgrad(WgradParams p, hipStream_t s) {
+  p.tiles_i = (p.Kin + BI - 1) / BI;
+  p.tiles_j = (p.Nout + BJ - 1) / BJ;
+  const int kt_total = (p.M + TK - 1) / TK;
+  int splits = p.splits;
+  if (splits <= 0) {
+    const int tiles = p.tiles_i * p.tiles_j;
+    splits = (256 * 2 + tiles - 1) / tiles;  // ~2 workgroups per CU
+    if (splits < 1) splits = 1;
+  }
+  if (splits > kt_total) splits = kt_total;
+  p.tiles_per_split = (kt_total + splits - 1) / splits;
+  p.splits = (kt_total + p.tiles_per_split - 1) / p.tiles_per_split;
+  const dim3 grid(p.tiles_i * p.tiles_j, p.splits), block(64 * WGI * WGJ);
+  const size_t lds = 2 * TK * (BI + BJ) * 2;
+  if (p.patch) {
+    auto kfn = gemm_wgrad_kernel<BI, BJ, WGI, WGJ, true>;
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kfn, grid, block, lds, s, p);
+  } else {
+    auto kfn = gemm_wgrad_kernel<BI, BJ, WGI, WGJ, false>;
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kfn, grid, block, lds, s, p);
+  }
+  SAVIT_LAUNCH_RET();
+}
+
+}  // namespace
+
+extern "C" int savit_gemm_bf16_wgrad(const void* X, const void* dY, float* dW, int M, int Kin, int Nout, int ldx, int lddy,
+                                     int lddw, int splits, int patch, int img_size, int tokens, int token_offset, void* stream) {
+  SAVIT_CHECK_ARG(X && dY && dW && M >= 0 && Kin > 0 && Nout > 0 && lddw >= Nout);
+  SAVIT_CHECK_ARG(Kin % 8 == 0 && Nout % 8 == 0 && lddy % 8 == 0 && lddy >= Nout);
+  SAVIT_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)dY % 16) == 0);
+  WgradParams p{};
+  p.X = (const bf16_t*)X; p.dY = (const bf16_t*)dY; p.dW = dW;
+  p.M = M; p.Kin = Kin; p.Nout = Nout; p.ldx = ldx; p.lddy = lddy; p.lddw = lddw; p.splits = splits;
+  p.patch = patch; p.img_size = img_size; p.tokens = tokens; p.token_offset = token_offset;
+  if (patch) {
+    SAVIT_CHECK_ARG(patch % 8 == 0 && img_size % patch == 0 && Kin == patch * patch * 3 && tokens > 0 && token_offset >= 0);
+    p.grid_side = img_size / patch;
+    p.chunks_per_prow = patch * 3 / 8;
+    SAVIT_CHECK_ARG(M % (p.grid_side * p.grid_side) == 0 && token_offset + p.grid_side * p.grid_side <= tokens);
+  } else {
+    SAVIT_CHECK_ARG(ldx % 8 == 0 && ldx >= Kin);
+  }
+  if (M == 0) return SAVIT_OK;
+  return launch_wgrad<128, 128, 2, 2>(p, (hipStream_t)stream);
+}

@@ -1,0 +1,219 @@
+// LayerNorm forward / backward for the fp32 residual stream (HBM-bound kernels).
+// Semantics: flax nn.LayerNorm(dtype=bf16) as used at /root/reference models/vit.py:19,26,57 and
+// models/cait.py:30,42,99,111,176 - fp32 statistics, biased variance E[x^2]-E[x]^2, eps 1e-6,
+// scale/bias rounded to bf16 before use, output bf16.
+//
+// Layout: x fp32 [rows, d] row-major, y bf16 [rows, d].  One wave (64 lanes) owns one row; a lane
+// holds d/64 elements as float4 chunks (lane i takes chunks i, i+64, ...), so every wave-level load
+// is a coalesced 1 KiB and reductions are wave shuffles only.  d % 4 == 0, d <= 4096.
+// Algorithmic bytes: fwd (4+2)*rows*d + 8*rows; bwd (2+4+4+4+2)*rows*d.
+#include "common.h"
+#include "savit.h"
+
+namespace {
+
+constexpr int LN_THREADS = 256;
+constexpr int LN_WAVES = LN_THREADS / 64;
+constexpr int LN_MAX_CHUNKS = 16;  // 16 float4 * 64 lanes = 4096 columns
+
+template <int CH>  // CH = ceil(d/4/64) chunks per lane
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                             int rows, int d, long x_stride, float eps, int round_params) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nchunk = d >> 2;
+  float4 g[CH], b[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ci = lane + 64 * c;
+    if (ci < nchunk) {
+      g[c] = reinterpret_cast<const float4*>(gamma)[ci];
+      b[c] = reinterpret_cast<const float4*>(beta)[ci];
+      if (round_params) {
+        g[c] = make_float4(round_bf16(g[c].x), round_bf16(g[c].y), round_bf16(g[c].z), round_bf16(g[c].w));
+        b[c] = make_float4(round_bf16(b[c].x), round_bf16(b[c].y), round_bf16(b[c].z), round_bf16(b[c].w));
+      }
+    } else {
+      g[c] = make_float4(0, 0, 0, 0);
+      b[c] = make_float4(0, 0, 0, 0);
+    }
+  }
+  const float inv_d = 1.0f / (float)d;
+  for (int row = blockIdx.x * LN_WAVES + wave; row < rows; row += gridDim.x * LN_WAVES) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * x_stride);
+    float4 v[CH];
+    float s = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ci = lane + 64 * c;
+      v[c] = (ci < nchunk) ? xr[ci] : make_float4(0, 0, 0, 0);
+      s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+      s2 += (v[c].x * v[c].x + v[c].y * v[c].y) + (v[c].z * v[c].z + v[c].w * v[c].w);
+    }
+    s = wave_sum(s);
+    s2 = wave_sum(s2);
+    const float mean = s * inv_d;
+    const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+    uint2* yr = reinterpret_cast<uint2*>(y + (size_t)row * d);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ci = lane + 64 * c;
+      if (ci < nchunk) {
+        float o0 = (v[c].x - mean) * (rstd * g[c].x) + b[c].x;
+        float o1 = (v[c].y - mean) * (rstd * g[c].y) + b[c].y;
+        float o2 = (v[c].z - mean) * (rstd * g[c].z) + b[c].z;
+        float o3 = (v[c].w - mean) * (rstd * g[c].w) + b[c].w;
+        yr[ci] = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+      }
+    }
+  }
+}
+
+// Backward.  dy bf16 [rows,d] (cotangent of the bf16 LN output), x fp32, mean/rstd from forward.
+//   xhat = (x-mean)*rstd ; g = dy*gamma ; dx = rstd*(g - mean_d(g) - xhat*mean_d(g*xhat))
+//   out  = dx (+ dres_in)           -> fp32 dx_out (gradient of the residual stream) and optional bf16 copy
+//   dgamma += sum_rows dy*xhat ; dbeta += sum_rows dy ; dcolsum += sum_rows out   (fp32 atomics, one per
+//   block and column after an in-register per-lane + LDS cross-wave reduction)
+template <int CH>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                             const float* __restrict__ rstd_in, const float* __restrict__ dres_in,
+                                                             float* __restrict__ dx_out, bf16_t* __restrict__ dx_bf16,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ dcolsum, int rows, int d, long x_stride, long out_stride,
+                                                             int round_params) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nchunk = d >> 2;
+  float4 g[CH], dg[CH], db[CH], dc[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ci = lane + 64 * c;
+    g[c] = (ci < nchunk) ? reinterpret_cast<const float4*>(gamma)[ci] : make_float4(0, 0, 0, 0);
+    if (round_params) g[c] = make_float4(round_bf16(g[c].x), round_bf16(g[c].y), round_bf16(g[c].z), round_bf16(g[c].w));
+    dg[c] = make_float4(0, 0, 0, 0);
+    db[c] = make_float4(0, 0, 0, 0);
+    dc[c] = make_float4(0, 0, 0, 0);
+  }
+  const float inv_d = 1.0f / (float)d;
+  for (int row = blockIdx.x * LN_WAVES + wave; row < rows; row += gridDim.x * LN_WAVES) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * x_stride);
+    const uint2* dyr = reinterpret_cast<const uint2*>(dy + (size_t)row * d);
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float4 xh[CH], gy[CH];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ci = lane + 64 * c;
+      if (ci < nchunk) {
+        const float4 xv = xr[ci];
+        const uint2 dv = dyr[ci];
+        const float d0 = __uint_as_float(dv.x << 16), d1 = __uint_as_float(dv.x & 0xffff0000u);
+        const float d2 = __uint_as_float(dv.y << 16), d3 = __uint_as_float(dv.y & 0xffff0000u);
+        xh[c] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        gy[c] = make_float4(d0 * g[c].x, d1 * g[c].y, d2 * g[c].z, d3 * g[c].w);
+        dg[c].x += d0 * xh[c].x; dg[c].y += d1 * xh[c].y; dg[c].z += d2 * xh[c].z; dg[c].w += d3 * xh[c].w;
+        db[c].x += d0; db[c].y += d1; db[c].z += d2; db[c].w += d3;
+        c1 += (gy[c].x + gy[c].y) + (gy[c].z + gy[c].w);
+        c2 += (gy[c].x * xh[c].x + gy[c].y * xh[c].y) + (gy[c].z * xh[c].z + gy[c].w * xh[c].w);
+      } else {
+        xh[c] = make_float4(0, 0, 0, 0);
+        gy[c] = make_float4(0, 0, 0, 0);
+      }
+    }
+    c1 = wave_sum(c1) * inv_d;
+    c2 = wave_sum(c2) * inv_d;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ci = lane + 64 * c;
+      if (ci < nchunk) {
+        float4 o = make_float4(rstd * (gy[c].x - c1 - xh[c].x * c2), rstd * (gy[c].y - c1 - xh[c].y * c2),
+                               rstd * (gy[c].z - c1 - xh[c].z * c2), rstd * (gy[c].w - c1 - xh[c].w * c2));
+        if (dres_in) {
+          const float4 r = reinterpret_cast<const float4*>(dres_in + (size_t)row * out_stride)[ci];
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        reinterpret_cast<float4*>(dx_out + (size_t)row * out_stride)[ci] = o;
+        if (dx_bf16)
+          reinterpret_cast<uint2*>(dx_bf16 + (size_t)row * out_stride)[ci] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+        dc[c].x += o.x; dc[c].y += o.y; dc[c].z += o.z; dc[c].w += o.w;
+      }
+    }
+  }
+  // cross-wave reduction through LDS, then one atomic per (block, column)
+  __shared__ float4 red[LN_WAVES][64];
+  float* outs[3] = {dgamma, dbeta, dcolsum};
+#pragma unroll
+  for (int which = 0; which < 3; ++which) {
+    if (outs[which] == nullptr) continue;  // uniform
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float4 v = which == 0 ? dg[c] : (which == 1 ? db[c] : dc[c]);
+      __syncthreads();
+      red[wave][lane] = v;
+      __syncthreads();
+      if (wave == 0) {
+        float4 t = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < LN_WAVES; ++w) {
+          t.x += red[w][lane].x; t.y += red[w][lane].y; t.z += red[w][lane].z; t.w += red[w][lane].w;
+        }
+        const int ci = lane + 64 * c;
+        if (ci < nchunk) {
+          float* o = outs[which] + 4 * ci;
+          atomicAdd(o + 0, t.x); atomicAdd(o + 1, t.y); atomicAdd(o + 2, t.z); atomicAdd(o + 3, t.w);
+        }
+      }
+    }
+  }
+}
+
+inline int ln_grid(int rows, int cap) {
+  int g = (rows + LN_WAVES - 1) / LN_WAVES;
+  return g < cap ? (g < 1 ? 1 : g) : cap;
+}
+
+}  // namespace
+
+#define LN_DISPATCH(CHV, KERNEL, GRID, ...)                                                        \
+  switch (CHV) {                                                                                    \
+    case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(GRID), dim3(LN_THREADS), 0, s, __VA_ARGS__); break;  \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(GRID), dim3(LN_THREADS), 0, s, __VA_ARGS__); break;  \
+    case 3: hipLaunchKernelGGL(KERNEL<3>, dim3(GRID), dim3(LN_THREADS), 0, s, __VA_ARGS__); break;  \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(GRID), dim3(LN_THREADS), 0, s, __VA_ARGS__); break;  \
+    case 5: case 6: case 7: case 8:                                                                 \
+      hipLaunchKernelGGL(KERNEL<8>, dim3(GRID), dim3(LN_THREADS), 0, s, __VA_ARGS__); break;        \
+    default: hipLaunchKernelGGL(KERNEL<16>, dim3(GRID), dim3(LN_THREADS), 0, s, __VA_ARGS__); break; \
+  }
+
+extern "C" int savit_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                   int rows, int d, long x_stride, float eps, int round_params_bf16, void* stream) {
+  SAVIT_CHECK_ARG(x && gamma && beta && y && x_stride >= d && (x_stride % 4) == 0 && rows >= 0 && d > 0 && (d % 4) == 0 && d <= 64 * 4 * LN_MAX_CHUNKS);
+  if (rows == 0) return SAVIT_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int ch = (d / 4 + 63) / 64;
+  const int grid = ln_grid(rows, 256 * 16);
+  LN_DISPATCH(ch, ln_fwd_kernel, grid, x, gamma, beta, (bf16_t*)y, mean, rstd, rows, d, x_stride, eps, round_params_bf16);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                   const float* dres_in, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* dcolsum,
+                                   int rows, int d, long x_stride, long out_stride, int round_params_bf16, void* stream) {
+  SAVIT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && x_stride >= d && out_stride >= d && (x_stride % 4) == 0 &&
+                  (out_stride % 4) == 0 && rows >= 0 && d > 0 && (d % 4) == 0 && d <= 64 * 4 * LN_MAX_CHUNKS);
+  if (rows == 0) return SAVIT_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int ch = (d / 4 + 63) / 64;
+  const int grid = ln_grid(rows, 256 * 4);  // fewer blocks: one atomic per block and column at the end
+  LN_DISPATCH(ch, ln_bwd_kernel, grid, (const bf16_t*)dy, x, gamma, mean, rstd, dres_in, dx, (bf16_t*)dx_bf16, dgamma, dbeta,
+              dcolsum, rows, d, x_stride, out_stride, round_params_bf16);
+  SAVIT_LAUNCH_RET();
+}

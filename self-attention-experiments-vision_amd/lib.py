@@ -1,0 +1,78 @@
+"""ctypes binding of the C-ABI library (include/savit.h).  There is NO fallback: if libsavit.so is
+missing or a symbol is absent, importing callers get a RuntimeError - the product path never routes
+through PyTorch eager math or the CPU oracle."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_float, c_int, c_long, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsavit.so")
+
+SAVIT_EINVAL = 1001
+
+EPI_BF16, EPI_BIAS_GELU, EPI_RESID, EPI_DGELU, EPI_F32, EPI_PATCH = range(6)
+
+
+class GemmArgs(Structure):
+    """Mirror of `savit_gemm_args` (include/savit.h)."""
+    _fields_ = [
+        ("A", c_void_p), ("Bt", c_void_p), ("C", c_void_p), ("C2", c_void_p), ("bias", c_void_p), ("aux", c_void_p),
+        ("colscale", c_void_p), ("rowscale", c_void_p), ("colsum", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("lda", c_int), ("ldb", c_int), ("ldc", c_int), ("ldaux", c_int),
+        ("epilogue", c_int), ("alpha", c_float), ("alpha_cols", c_int), ("rows_per_sample", c_int),
+        ("round_out_bf16", c_int), ("round_bias_bf16", c_int),
+        ("img_size", c_int), ("patch", c_int), ("tokens", c_int), ("token_offset", c_int),
+        ("tile", c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/savit.h declares must be here (tests check both ways)
+_SIGNATURES = {
+    "savit_abi_version": (c_int, []),
+    "savit_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_float,
+                                    c_int, c_void_p]),
+    "savit_layernorm_bwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_long, c_long, c_int, c_void_p]),
+    "savit_gemm_bf16_tn": (c_int, [POINTER(GemmArgs), c_void_p]),
+    "savit_gemm_bf16_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_int, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load() -> ctypes.CDLL:
+    """Load libsavit.so (once).  Raises RuntimeError loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c \"import __graft_entry__ as g; g.build()\"` "
+            "(or `make -C self-attention-experiments-vision_amd/csrc`). There is no CPU/PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise RuntimeError(f"libsavit.so does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.savit_abi_version() != 1:
+        raise RuntimeError("libsavit.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code == 0:
+        return
+    if code == SAVIT_EINVAL:
+        raise ValueError(f"{what}: argument contract violated (SAVIT_EINVAL)")
+    raise RuntimeError(f"{what}: HIP error {code}")

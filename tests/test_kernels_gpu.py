@@ -1,0 +1,284 @@
+"""Per-kernel parity tests (GPU).  Every kernel is called through the C-ABI (ctypes -> libsavit.so) and
+checked against fp32/fp64 CPU math from the oracle on the same seeded, bf16-rounded inputs.
+
+Tolerances (SURVEY A.5 ii): a bf16-output kernel must equal bf16(oracle_fp32) up to rounding-boundary
+flips: relative L2 <= 1e-3 (north_star) - in practice ~1e-4 - and max |err| <= 1 bf16 ulp of the value
+scale; fp32 outputs: relative L2 <= 2e-5 plus the bf16 rounding the reference applies at that point."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_ref
+
+pytestmark = pytest.mark.gpu
+
+bf16 = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import savit_amd  # noqa: F401
+    from savit_amd import ops as _ops
+
+    return _ops
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(np.asarray(x)).cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def host(t):
+    return t.detach().float().cpu().numpy()
+
+
+def rb(x):  # bf16-rounded fp32 numpy
+    return vit_ref.bf16_round(np.asarray(x, np.float32))
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,d", [(1, 192), (5, 192), (197 * 3, 384), (394, 768), (131, 1024), (64, 288), (7, 32)])
+def test_layernorm_fwd(ops, rows, d):
+    rng = np.random.default_rng(rows * 1000 + d)
+    x = (rng.standard_normal((rows, d)) * 2 + 0.3).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    y, mean, rstd = ops.layernorm_fwd(dev(x), dev(g), dev(b))
+    ref = vit_ref.layer_norm(vit_ref.Policy("bf16"), x, g, b)  # fp32 stats, bf16 params/out (A.2)
+    out = host(y)
+    assert rel(out, ref) < 1e-3
+    assert np.abs(out - ref).max() <= 2 ** -7 * max(1.0, np.abs(ref).max())
+    assert rel(host(mean), x.mean(-1)) < 1e-5
+    assert rel(host(rstd), 1 / np.sqrt(x.astype(np.float64).var(-1) + 1e-6)) < 1e-4
+
+
+def test_layernorm_fwd_strided_rows(ops):
+    """cls-row view: x[:, 0, :] of a [B, N, d] residual stream (final LN feeds only row 0: vit.py:95)."""
+    rng = np.random.default_rng(0)
+    B, N, d = 6, 197, 384
+    x = rng.standard_normal((B, N, d)).astype(np.float32)
+    g = np.ones(d, np.float32)
+    b = np.zeros(d, np.float32)
+    xt = dev(x)
+    y, _, _ = ops.layernorm_fwd(xt[:, 0, :], dev(g), dev(b))
+    ref = vit_ref.layer_norm(vit_ref.Policy("bf16"), x[:, 0, :], g, b)
+    assert rel(host(y), ref) < 1e-3
+
+
+@pytest.mark.parametrize("rows,d,with_res", [(5, 192, False), (197 * 4, 384, True), (394, 768, True), (33, 1024, True)])
+def test_layernorm_bwd(ops, rows, d, with_res):
+    rng = np.random.default_rng(rows + d)
+    x = (rng.standard_normal((rows, d)) * 1.5 + 0.2).astype(np.float32)
+    g = rb(1 + 0.1 * rng.standard_normal(d))
+    b = rb(0.1 * rng.standard_normal(d))
+    dy = rb(rng.standard_normal((rows, d)))
+    dres = rng.standard_normal((rows, d)).astype(np.float32) if with_res else None
+    # fp64 autograd reference
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    gt = torch.tensor(g, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    yt = torch.nn.functional.layer_norm(xt, (d,), gt, bt, eps=1e-6)
+    yt.backward(torch.tensor(dy, dtype=torch.float64))
+    dx_ref = xt.grad.numpy() + (dres if with_res else 0)
+    y, mean, rstd = ops.layernorm_fwd(dev(x), dev(g), dev(b))
+    dgamma = torch.zeros(d, device="cuda")
+    dbeta = torch.zeros(d, device="cuda")
+    dcol = torch.zeros(d, device="cuda")
+    dxb = torch.empty((rows, d), dtype=bf16, device="cuda")
+    dx = ops.layernorm_bwd(dev(dy, bf16), dev(x), dev(g), mean, rstd, dgamma, dbeta,
+                           dres_in=None if dres is None else dev(dres), dx_bf16=dxb, dcolsum=dcol)
+    assert rel(host(dx), dx_ref) < 2e-5
+    assert rel(host(dxb), rb(dx_ref)) < 1e-3
+    assert rel(host(dgamma), gt.grad.numpy()) < 1e-4
+    assert rel(host(dbeta), bt.grad.numpy()) < 1e-4
+    assert rel(host(dcol), dx_ref.sum(0)) < 1e-4 or np.abs(host(dcol) - dx_ref.sum(0)).max() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------ GEMM TN
+def _mk(rng, M, K, scale=1.0):
+    return rb(rng.standard_normal((M, K)) * scale)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 256, 128), (197 * 2, 192 * 3, 192), (591, 768, 768), (1000, 384, 1536),
+                                   (37, 1000, 192), (300, 64, 128)])
+def test_gemm_bf16_plain(ops, tile, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    A, Bt = _mk(rng, M, K), _mk(rng, N, K, 1 / np.sqrt(K))
+    C = torch.full((M, N), float("nan"), dtype=bf16, device="cuda")
+    ops.gemm_tn(dev(A, bf16), dev(Bt, bf16), C, 0, tile=tile)
+    ref = A.astype(np.float64) @ Bt.astype(np.float64).T
+    out = host(C)
+    assert np.isfinite(out).all()
+    assert rel(out, rb(ref)) < 1e-3, rel(out, rb(ref))
+
+
+def test_gemm_identity_asymmetric(ops):
+    """A = I with an asymmetric B catches row/col swaps in the C-write (guide section 3)."""
+    K = 128
+    A = np.eye(K, dtype=np.float32)
+    Bt = rb(np.arange(K * K, dtype=np.float32).reshape(K, K) % 251 - 100)
+    C = torch.zeros((K, K), dtype=bf16, device="cuda")
+    ops.gemm_tn(dev(A, bf16), dev(Bt, bf16), C, 0)
+    assert np.array_equal(host(C), rb(Bt.T))
+
+
+def test_gemm_qkv_alpha_and_strided_views(ops):
+    rng = np.random.default_rng(5)
+    M, d, H = 197 * 2, 384, 6
+    x, W = _mk(rng, M, d), _mk(rng, 3 * d, d, 1 / np.sqrt(d))
+    C = torch.zeros((M, 3 * d), dtype=bf16, device="cuda")
+    ops.gemm_tn(dev(x, bf16), dev(W, bf16), C, 0, alpha=1 / 8.0, alpha_cols=d)
+    ref = x.astype(np.float64) @ W.astype(np.float64).T
+    ref[:, :d] /= 8.0
+    assert rel(host(C), rb(ref)) < 1e-3
+    # A as a column slice of a wider buffer (lda > K), C as a column slice too
+    wide = torch.zeros((M, 3 * d), dtype=bf16, device="cuda")
+    wide[:, d:2 * d] = dev(x, bf16)
+    Cw = torch.zeros((M, 4 * d), dtype=bf16, device="cuda")
+    ops.gemm_tn(wide[:, d:2 * d], dev(W[:d], bf16), Cw[:, d:2 * d], 0)
+    assert rel(host(Cw[:, d:2 * d]), rb(x.astype(np.float64) @ W[:d].astype(np.float64).T)) < 1e-3
+    assert float(Cw[:, :d].abs().max()) == 0 and float(Cw[:, 2 * d:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("tile", [1, 2])
+def test_gemm_bias_gelu(ops, tile):
+    rng = np.random.default_rng(6)
+    M, d, F = 197 * 3, 192, 768
+    x, W = _mk(rng, M, d), _mk(rng, F, d, 1 / np.sqrt(d))
+    b = (0.1 * rng.standard_normal(F)).astype(np.float32)
+    U = torch.zeros((M, F), dtype=bf16, device="cuda")
+    Aact = torch.zeros((M, F), dtype=bf16, device="cuda")
+    ops.gemm_tn(dev(x, bf16), dev(W, bf16), U, 1, C2=Aact, bias=dev(b), tile=tile)
+    u_ref = rb(x.astype(np.float64) @ W.astype(np.float64).T + rb(b))
+    assert rel(host(U), u_ref) < 1e-3
+    pol = vit_ref.Policy("f32")
+    a_ref = rb(vit_ref.gelu_tanh(pol, host(U)))  # gelu of the kernel's own rounded u
+    assert rel(host(Aact), a_ref) < 1e-3
+    assert np.abs(host(Aact) - a_ref).max() <= 2 ** -7 * max(1.0, np.abs(a_ref).max())
+
+
+@pytest.mark.parametrize("tile", [1, 2])
+def test_gemm_residual_layerscale_stochdepth(ops, tile):
+    rng = np.random.default_rng(7)
+    B, N, d, F = 3, 197, 192, 768
+    M = B * N
+    a, W = _mk(rng, M, F), _mk(rng, d, F, 1 / np.sqrt(F))
+    bias = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    res = rng.standard_normal((M, d)).astype(np.float32)
+    ls = (0.5 + rng.random(d)).astype(np.float32)
+    keep = np.array([1 / 0.9, 0.0, 1 / 0.9], np.float32)
+    out = torch.zeros((M, d), dtype=torch.float32, device="cuda")
+    ops.gemm_tn(dev(a, bf16), dev(W, bf16), out, 2, bias=dev(bias), aux=dev(res), colscale=dev(ls), rowscale=dev(keep),
+                rows_per_sample=N, tile=tile)
+    branch = rb(a.astype(np.float64) @ W.astype(np.float64).T + rb(bias))
+    ref = res + np.repeat(keep, N)[:, None] * ls[None, :] * branch
+    assert rel(host(out), ref) < 1e-3
+    assert np.array_equal(host(out)[N:2 * N], res[N:2 * N])  # dropped sample: residual only
+    out2 = torch.zeros((M, d), dtype=torch.float32, device="cuda")
+    ops.gemm_tn(dev(a, bf16), dev(W, bf16), out2, 2, aux=dev(res), tile=tile)  # plain ViT form, no bias
+    assert rel(host(out2), res + rb(a.astype(np.float64) @ W.astype(np.float64).T)) < 2e-4
+
+
+def test_gemm_dgelu_and_colsum(ops):
+    rng = np.random.default_rng(8)
+    M, d, F = 197 * 2 + 5, 192, 768
+    dy, W2 = _mk(rng, M, d), _mk(rng, F, d, 1 / np.sqrt(d))  # d_a = dy @ W2^T as TN: Bt = W2 [F, d]
+    u = _mk(rng, M, F)
+    dU = torch.zeros((M, F), dtype=bf16, device="cuda")
+    cs = torch.zeros(F, device="cuda")
+    ops.gemm_tn(dev(dy, bf16), dev(W2, bf16), dU, 3, aux=dev(u, bf16), colsum=cs)
+    ut = torch.tensor(u, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.gelu(ut, approximate="tanh").backward(torch.tensor(dy.astype(np.float64) @ W2.astype(np.float64).T))
+    ref = ut.grad.numpy()
+    assert rel(host(dU), rb(ref)) < 1e-3
+    assert rel(host(cs), host(dU).astype(np.float64).sum(0)) < 1e-4
+
+
+def test_gemm_f32_head(ops):
+    rng = np.random.default_rng(9)
+    B, d, C = 37, 192, 1000
+    z, Wh = _mk(rng, B, d), _mk(rng, C, d, 1 / np.sqrt(d))
+    b = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    out = torch.zeros((B, C), dtype=torch.float32, device="cuda")
+    ops.gemm_tn(dev(z, bf16), dev(Wh, bf16), out, 4, bias=dev(b), round_out_bf16=True)
+    ref = rb(z.astype(np.float64) @ Wh.astype(np.float64).T + rb(b))
+    assert rel(host(out), ref) < 1e-3
+    ops.gemm_tn(dev(z, bf16), dev(Wh, bf16), out, 4, bias=dev(b), round_out_bf16=False, round_bias_bf16=False)
+    assert rel(host(out), z.astype(np.float64) @ Wh.astype(np.float64).T + b) < 2e-5
+
+
+@pytest.mark.parametrize("img,P,d,tok_off", [(32, 8, 64, 1), (224, 16, 192, 1), (64, 32, 128, 0), (224, 16, 384, 0)])
+def test_patch_embed_gemm(ops, img, P, d, tok_off):
+    rng = np.random.default_rng(img + P)
+    B = 3
+    n = (img // P) ** 2
+    tokens = n + tok_off
+    images = rb(rng.standard_normal((B, img, img, 3)))
+    Wpe = _mk(rng, d, P * P * 3, 1 / np.sqrt(P * P * 3))  # [d, K] = kernel^T
+    pos = (0.02 * rng.standard_normal((tokens, d))).astype(np.float32)
+    x0 = torch.full((B * tokens, d), 7.0, dtype=torch.float32, device="cuda")
+    ops.gemm_tn(dev(images, bf16), dev(Wpe, bf16), x0, 5, aux=dev(pos), patch_geom=(img, P, tokens, tok_off))
+    tok = vit_ref.patchify(images, P, P).astype(np.float64) @ Wpe.astype(np.float64).T  # [B, n, d]
+    ref = rb(tok) + pos[None, tok_off:, :]
+    out = host(x0).reshape(B, tokens, d)
+    assert rel(out[:, tok_off:], ref) < 1e-3
+    if tok_off:
+        assert np.all(out[:, 0] == 7.0)  # cls row untouched
+
+
+# ------------------------------------------------------------------------------------------ wgrad
+@pytest.mark.parametrize("M,Kin,Nout,splits", [(64, 128, 128, 1), (197 * 2, 192, 576, 0), (1000, 384, 384, 3), (197 * 3 + 1, 768, 192, 0),
+                                               (37, 192, 1000, 0), (2000, 1536, 384, 0)])
+def test_wgrad(ops, M, Kin, Nout, splits):
+    rng = np.random.default_rng(M + Kin)
+    X, dY = _mk(rng, M, Kin), _mk(rng, M, Nout)
+    dW = torch.zeros((Kin, Nout), dtype=torch.float32, device="cuda")
+    ops.gemm_wgrad(dev(X, bf16), dev(dY, bf16), dW, splits=splits)
+    ref = X.astype(np.float64).T @ dY.astype(np.float64)
+    assert rel(host(dW), ref) < 2e-5, rel(host(dW), ref)
+    ops.gemm_wgrad(dev(X, bf16), dev(dY, bf16), dW, splits=splits)  # accumulates
+    assert rel(host(dW), 2 * ref) < 2e-5
+
+
+def test_wgrad_padded_dy_columns(ops):
+    """Head: dlogits lives in a [B, 1024] buffer, dW is [d, 1000]."""
+    rng = np.random.default_rng(11)
+    B, d, C, Cp = 130, 192, 1000, 1024
+    z = _mk(rng, B, d)
+    dl = np.zeros((B, Cp), np.float32)
+    dl[:, :C] = _mk(rng, B, C)
+    dW = torch.zeros((d, C), dtype=torch.float32, device="cuda")
+    ops.gemm_wgrad(dev(z, bf16), dev(dl, bf16), dW)
+    assert rel(host(dW), z.astype(np.float64).T @ dl[:, :C].astype(np.float64)) < 2e-5
+
+
+@pytest.mark.parametrize("img,P,d,tok_off", [(32, 8, 64, 1), (224, 16, 192, 1), (64, 32, 128, 0)])
+def test_wgrad_patch(ops, img, P, d, tok_off):
+    rng = np.random.default_rng(img)
+    B = 2
+    n = (img // P) ** 2
+    tokens = n + tok_off
+    images = rb(rng.standard_normal((B, img, img, 3)))
+    dx0 = _mk(rng, B * tokens, d)
+    dW = torch.zeros((P * P * 3, d), dtype=torch.float32, device="cuda")
+    ops.gemm_wgrad(dev(images, bf16), dev(dx0, bf16), dW, patch_geom=(img, P, tokens, tok_off))
+    patches = vit_ref.patchify(images, P, P).reshape(B * n, -1).astype(np.float64)
+    dy = dx0.reshape(B, tokens, d)[:, tok_off:].reshape(B * n, d).astype(np.float64)
+    assert rel(host(dW), patches.T @ dy) < 2e-5
+
+
+def test_contract_violations_raise(ops):
+    A = torch.zeros((64, 96), dtype=bf16, device="cuda")  # K % 64 != 0
+    with pytest.raises(ValueError):
+        ops.gemm_tn(A, torch.zeros((64, 96), dtype=bf16, device="cuda"), torch.zeros((64, 64), dtype=bf16, device="cuda"), 0)
+    with pytest.raises(ValueError):
+        ops.layernorm_fwd(torch.zeros((4, 64)), torch.zeros(64), torch.zeros(64))  # CPU tensors: no CPU path
