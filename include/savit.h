@@ -36,12 +36,15 @@ int savit_layernorm_fwd(const float* x, const float* gamma, const float* beta, v
 
 /* Backward of the above (reference: jax.value_and_grad at train.py:94-95).
  * dy bf16 [rows,d]; dres_in fp32 (nullable) is the cotangent arriving on the residual skip, added to the result;
- * dx fp32 and dx_bf16 (nullable) use row stride out_stride; dgamma/dbeta/dcolsum fp32 [d] are ACCUMULATED
- * (atomics; caller zeroes); dcolsum (nullable) = column sums of dx (the bias gradient of the Dense that fed
+ * dx fp32 and dx_bf16 (nullable) use row stride out_stride; dgamma/dbeta/dcolsum fp32 [d] (each nullable) are
+ * ACCUMULATED (caller zeroes); dcolsum (nullable) = column sums of dx (the bias gradient of the Dense that fed
  * this residual add: ff.py:31). */
 int savit_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
                         const float* dres_in, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* dcolsum,
-                        int rows, int d, long x_stride, long out_stride, int round_params_bf16, void* stream);
+                        int rows, int d, long x_stride, long out_stride, int round_params_bf16, void* workspace,
+                        long workspace_bytes, void* stream);
+/* Scratch the call above needs (per-block partial column sums; 16-B aligned, contents undefined afterwards). */
+long savit_layernorm_bwd_workspace_bytes(int rows, int d);
 
 /* ---- Dense / DenseGeneral GEMMs with fused epilogues (bf16 MFMA, fp32 accumulate).
  * C[M,N] = epilogue( A[M,K] . Bt[N,K]^T ).  A and Bt are bf16, K contiguous ("TN"); K % 64 == 0, N % 4 == 0.
@@ -86,9 +89,49 @@ int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream);
 /* Weight-gradient GEMM: dW[Kin, Nout] += X[M, Kin]^T . dY[M, Nout]  (fp32 atomics into dW; caller zeroes).
  * X, dY bf16 row-major; reduction over M is split over `splits` workgroup groups (0 = auto).
  * patch != 0: X rows are gathered from NHWC images as in SAVIT_EPI_PATCH and dY row for (b,p) is
- * b*tokens + token_offset + p of a fp32->bf16 cotangent buffer [B*tokens, lddy]. */
+ * b*tokens + token_offset + p of the bf16 cotangent buffer [B*tokens, lddy]. */
 int savit_gemm_bf16_wgrad(const void* X, const void* dY, float* dW, int M, int Kin, int Nout, int ldx, int lddy, int lddw,
                           int splits, int patch, int img_size, int tokens, int token_offset, void* stream);
+
+
+/* ---- Fused multi-head self-attention (attention.py:39-58): per (batch, head)
+ *   S = (q/sqrt(hd)) k^T ; P = softmax_k(S) ; O = P v.      head_dim must be 64, N <= 256.
+ * qkv bf16 [B*N, ld_qkv]: columns [0,d) = queries ALREADY scaled by 1/sqrt(hd) (SAVIT_EPI_BF16 alpha), [d,2d) keys,
+ * [2d,3d) values, head-major (h*64+e) inside each (the DenseGeneral (H,hd) feature order, attention.py:29-33).
+ * o bf16 [B*N, d]; lse fp32 [B,H,N] = log-sum-exp of each score row (saved for backward; nullable). */
+int savit_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int head_dim, int ld_qkv, void* stream);
+/* Backward: dqkv bf16 [B*N, ld_qkv] receives dQ*dq_scale | dK | dV (dq_scale = 1/sqrt(hd) undoes the folded scale
+ * so that the QKV input-gradient GEMM is a plain product).  P is recomputed from lse; no atomics. */
+int savit_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int N, int H,
+                        int head_dim, int ld_qkv, float dq_scale, void* stream);
+
+/* ---- token assembly (vit.py:81-85, position_embed.py:52-57): x0[b,0,:] = cls + pos[0,:] (patch rows are written by
+ * SAVIT_EPI_PATCH); and the backward of both adds: dpos[t,:] += sum_b dx0[b,t,:], dcls += sum_b dx0[b,0,:]. */
+int savit_cls_pos_rows(const float* cls, const float* pos, float* x0, int B, long row_stride, int d, void* stream);
+int savit_pos_cls_grad(const float* dx0, float* dpos, float* dcls, int B, int N, int d, int has_cls, void* stream);
+
+/* ---- loss (train.py:83-90): one_hot -> optional mix (ratio*y + (1-ratio)*y1) -> optax.smooth_labels ->
+ * optax.softmax_cross_entropy -> mean.  logits fp32 [B, ld]; labels int32 [B].  Outputs (each nullable):
+ * loss_rows [B]; loss_mean[0] += mean; dlogits bf16 [B, ld_dlogits] = (softmax - y)*grad_scale, columns >= C zeroed;
+ * dbias[C] += column sums of dlogits; top1/top5 [B] = 1.0 when the label is among the k largest logits (utils.py:20-31). */
+int savit_softmax_xent(const float* logits, int ld_logits, const int* labels, const int* mix_labels, const float* ratio,
+                       float label_smoothing, float grad_scale, float* loss_rows, float* loss_mean, void* dlogits_bf16,
+                       int ld_dlogits, float* dbias, float* top1, float* top5, int B, int C, void* stream);
+
+/* ---- optimizer (train.py:25-27,100; simple_train.py:25-27): out[0] += sum(g^2); then one fused pass
+ *   g' = g*grad_scale*clip ; m,v Adam moments ; p -= lr * ( mhat/(sqrt(vhat)+eps) + weight_decay*p )
+ * clip = 1 if ||g*grad_scale|| < max_norm else max_norm/||.|| (optax.clip_by_global_norm), read from grad_sumsq ON DEVICE
+ * (nullable / max_norm <= 0: no clipping).  step is 1-based.  n % 4 == 0. */
+int savit_sumsq(const float* g, long n, float* out, void* stream);
+int savit_adamw_step(float* params, const float* grads, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                     float weight_decay, int step, const float* grad_sumsq, float max_norm, float grad_scale, void* stream);
+
+/* ---- operand preparation: fp32 master weights [batch][R][C] -> bf16 [batch][R][C] (dst_n) and/or transposed
+ * [batch][C][R] (dst_t); fp32 -> bf16 elementwise; input batches [H,W,C,N] fp32 -> [N,H,W,C] bf16 (train.py:80-81). */
+int savit_cast_transpose_bf16(const float* src, long src_batch_stride, int batch, int R, int C, void* dst_n,
+                              long dst_n_batch_stride, int ld_n, void* dst_t, long dst_t_batch_stride, int ld_t, void* stream);
+int savit_cast_bf16(const float* src, void* dst, long n, void* stream);
+int savit_hwcn_to_nhwc_bf16(const float* src, void* dst, int H, int W, int C, int N, void* stream);
 
 #ifdef __cplusplus
 }

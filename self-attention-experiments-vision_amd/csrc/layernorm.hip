@@ -79,16 +79,15 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
 // Backward.  dy bf16 [rows,d] (cotangent of the bf16 LN output), x fp32, mean/rstd from forward.
 //   xhat = (x-mean)*rstd ; g = dy*gamma ; dx = rstd*(g - mean_d(g) - xhat*mean_d(g*xhat))
 //   out  = dx (+ dres_in)           -> fp32 dx_out (gradient of the residual stream) and optional bf16 copy
-//   dgamma += sum_rows dy*xhat ; dbeta += sum_rows dy ; dcolsum += sum_rows out   (fp32 atomics, one per
-//   block and column after an in-register per-lane + LDS cross-wave reduction)
+//   dgamma += sum_rows dy*xhat ; dbeta += sum_rows dy ; dcolsum += sum_rows out   (per-lane registers ->
+//   LDS cross-wave -> per-block partial slab -> finalize kernel)
 template <int CH>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                              const float* __restrict__ rstd_in, const float* __restrict__ dres_in,
                                                              float* __restrict__ dx_out, bf16_t* __restrict__ dx_bf16,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             float* __restrict__ dcolsum, int rows, int d, long x_stride, long out_stride,
-                                                             int round_params) {
+                                                             float* __restrict__ partial, int rows, int d, long x_stride,
+                                                             long out_stride, int round_params) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nchunk = d >> 2;
@@ -147,12 +146,12 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
       }
     }
   }
-  // cross-wave reduction through LDS, then one atomic per (block, column)
+  // cross-wave reduction through LDS, then ONE plain store per (block, column) into the partial slab
+  // partial[block][which][d]; ln_bwd_finalize_kernel sums the slab (all blocks adding straight into the
+  // same 3*d addresses would serialise: same-address fp32 atomics run ~14x below the chip rate).
   __shared__ float4 red[LN_WAVES][64];
-  float* outs[3] = {dgamma, dbeta, dcolsum};
 #pragma unroll
   for (int which = 0; which < 3; ++which) {
-    if (outs[which] == nullptr) continue;  // uniform
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const float4 v = which == 0 ? dg[c] : (which == 1 ? db[c] : dc[c]);
@@ -166,12 +165,36 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
           t.x += red[w][lane].x; t.y += red[w][lane].y; t.z += red[w][lane].z; t.w += red[w][lane].w;
         }
         const int ci = lane + 64 * c;
-        if (ci < nchunk) {
-          float* o = outs[which] + 4 * ci;
-          atomicAdd(o + 0, t.x); atomicAdd(o + 1, t.y); atomicAdd(o + 2, t.z); atomicAdd(o + 3, t.w);
-        }
+        if (ci < nchunk) reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 3 + which) * d)[ci] = t;
       }
     }
+  }
+}
+
+// Sums the partial slab [nblk][3][d] over blocks: grid (ceil(3d/64), FIN_SPLIT); a block handles 64 columns x
+// its share of slab rows with 4 row-lanes per column, reduces in LDS and issues one atomic per column
+// (FIN_SPLIT adders per address).
+constexpr int FIN_SPLIT = 8;
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int d,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ dcolsum) {
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);  // in [0, 3d)
+  const int rl = threadIdx.x >> 6;                        // row lane 0..3
+  const int per = (nblk + FIN_SPLIT - 1) / FIN_SPLIT;
+  const int r0 = blockIdx.y * per;
+  const int r1 = min(nblk, r0 + per);
+  float s = 0.f;
+  if (col < 3 * d) {
+    for (int r = r0 + rl; r < r1; r += 4) s += partial[(size_t)r * 3 * d + col];
+  }
+  __shared__ float red[4][64];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col < 3 * d) {
+    s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    const int which = col / d, c = col - which * d;
+    float* out = which == 0 ? dgamma : (which == 1 ? dbeta : dcolsum);
+    if (out != nullptr) atomicAdd(out + c, s);
   }
 }
 
@@ -204,16 +227,31 @@ extern "C" int savit_layernorm_fwd(const float* x, const float* gamma, const flo
   SAVIT_LAUNCH_RET();
 }
 
+static int ln_bwd_grid(int rows) { return ln_grid(rows, 256 * 3); }
+
+extern "C" long savit_layernorm_bwd_workspace_bytes(int rows, int d) {
+  if (rows <= 0 || d <= 0) return 0;
+  return (long)ln_bwd_grid(rows) * 3 * d * (long)sizeof(float);
+}
+
 extern "C" int savit_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                    const float* dres_in, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* dcolsum,
-                                   int rows, int d, long x_stride, long out_stride, int round_params_bf16, void* stream) {
+                                   int rows, int d, long x_stride, long out_stride, int round_params_bf16, void* workspace,
+                                   long workspace_bytes, void* stream) {
   SAVIT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && x_stride >= d && out_stride >= d && (x_stride % 4) == 0 &&
                   (out_stride % 4) == 0 && rows >= 0 && d > 0 && (d % 4) == 0 && d <= 64 * 4 * LN_MAX_CHUNKS);
   if (rows == 0) return SAVIT_OK;
+  SAVIT_CHECK_ARG(workspace != nullptr && ((uintptr_t)workspace % 16) == 0 &&
+                  workspace_bytes >= savit_layernorm_bwd_workspace_bytes(rows, d));
   hipStream_t s = (hipStream_t)stream;
   const int ch = (d / 4 + 63) / 64;
-  const int grid = ln_grid(rows, 256 * 4);  // fewer blocks: one atomic per block and column at the end
-  LN_DISPATCH(ch, ln_bwd_kernel, grid, (const bf16_t*)dy, x, gamma, mean, rstd, dres_in, dx, (bf16_t*)dx_bf16, dgamma, dbeta,
-              dcolsum, rows, d, x_stride, out_stride, round_params_bf16);
+  const int grid = ln_bwd_grid(rows);
+  float* partial = (float*)workspace;
+  LN_DISPATCH(ch, ln_bwd_kernel, grid, (const bf16_t*)dy, x, gamma, mean, rstd, dres_in, dx, (bf16_t*)dx_bf16, partial, rows, d,
+              x_stride, out_stride, round_params_bf16);
+  if (dgamma || dbeta || dcolsum) {
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * d + 63) / 64, FIN_SPLIT), dim3(256), 0, s, partial, grid, d, dgamma,
+                       dbeta, dcolsum);
+  }
   SAVIT_LAUNCH_RET();
 }

@@ -1,0 +1,296 @@
+// Small HBM-/latency-bound kernels around the encoder blocks: cls/pos rows, loss, optimizer, weight casts.
+// Reference call sites are cited per kernel (paths relative to /root/reference).
+#include "common.h"
+#include "savit.h"
+
+namespace {
+
+// ---- x0[b, 0, :] = cls + pos[0]   (models/vit.py:81-85 concat of the tiled cls token; position_embed.py:56)
+__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ x0, int B,
+                                long row_stride, int d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
+  const int per = d >> 2;
+  if (i >= B * per) return;
+  const int b = i / per, c = i - b * per;
+  const float4 a = reinterpret_cast<const float4*>(cls)[c];
+  const float4 p = reinterpret_cast<const float4*>(pos)[c];
+  reinterpret_cast<float4*>(x0 + (size_t)b * row_stride)[c] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+}
+
+// ---- dpos[t,:] += sum_b dx0[b,t,:] ; dcls += sum_b dx0[b,0,:]   (backward of the two adds above)
+__global__ void pos_cls_grad_kernel(const float* __restrict__ dx0, float* __restrict__ dpos, float* __restrict__ dcls, int B,
+                                    int N, int d, int has_cls) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // float4 index over [N, d]
+  const int per = d >> 2;
+  if (i >= N * per) return;
+  float4 s = make_float4(0, 0, 0, 0);
+  const size_t stride = (size_t)N * per;
+  const float4* src = reinterpret_cast<const float4*>(dx0) + i;
+#pragma unroll 4
+  for (int b = 0; b < B; ++b) {
+    const float4 v = src[(size_t)b * stride];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float4* o = reinterpret_cast<float4*>(dpos) + i;
+  float4 cur = *o;
+  *o = make_float4(cur.x + s.x, cur.y + s.y, cur.z + s.z, cur.w + s.w);
+  if (has_cls && i < per && dcls != nullptr) {
+    float4* oc = reinterpret_cast<float4*>(dcls) + i;
+    float4 c2 = *oc;
+    *oc = make_float4(c2.x + s.x, c2.y + s.y, c2.z + s.z, c2.w + s.w);
+  }
+}
+
+// ---- label-smoothed softmax cross-entropy, forward + gradient  (train.py:83-90; optax.smooth_labels,
+// optax.softmax_cross_entropy).  One 256-thread block per row.
+//   y = one_hot(label) [mixed with one_hot(label2) by ratio] ; y = (1-a) y + a/C ; loss_row = -sum y log_softmax(z)
+//   dz = (softmax(z) - y) * grad_scale     (grad_scale = 1/B for the batch mean)
+constexpr int CE_THREADS = 256;
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+#pragma unroll
+  for (int w = 1; w < CE_THREADS / 64; ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+  return r;
+}
+
+__global__ __launch_bounds__(CE_THREADS) void xent_kernel(const float* __restrict__ logits, int ld, const int* __restrict__ labels,
+                                                           const int* __restrict__ labels2, const float* __restrict__ ratio,
+                                                           float alpha, float grad_scale, float* __restrict__ loss_rows,
+                                                           float* __restrict__ loss_mean, bf16_t* __restrict__ dz_bf16, int ld_dz,
+                                                           float* __restrict__ dbias, float* __restrict__ top1,
+                                                           float* __restrict__ top5, int B, int C) {
+  __shared__ float red[CE_THREADS / 64];
+  const int row = blockIdx.x;
+  const float* z = logits + (size_t)row * ld;
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < C; c += CE_THREADS) m = fmaxf(m, z[c]);
+  m = block_reduce(m, red, true);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += CE_THREADS) s += __expf(z[c] - m);
+  s = block_reduce(s, red, false);
+  const float lse = m + __logf(s);
+  const int l1 = labels[row];
+  const int l2 = labels2 ? labels2[row] : l1;
+  const float r1 = labels2 ? ratio[row] : 1.0f;
+  const float zl = z[l1];
+  float lsum = 0.f, above = 0.f;
+  for (int c = threadIdx.x; c < C; c += CE_THREADS) {
+    const float zc = z[c];
+    float y = (c == l1 ? r1 : 0.f) + (c == l2 ? (1.0f - r1) : 0.f);
+    y = (1.0f - alpha) * y + alpha / (float)C;
+    const float logp = zc - lse;
+    lsum -= y * logp;
+    const float dz = (__expf(logp) - y) * grad_scale;
+    if (dz_bf16) dz_bf16[(size_t)row * ld_dz + c] = f32_to_bf16(dz);
+    if (dbias) atomicAdd(dbias + c, round_bf16(dz));
+    above += (zc > zl) ? 1.f : 0.f;
+  }
+  if (dz_bf16)
+    for (int c = C + threadIdx.x; c < ld_dz; c += CE_THREADS) dz_bf16[(size_t)row * ld_dz + c] = 0;
+  lsum = block_reduce(lsum, red, false);
+  above = block_reduce(above, red, false);
+  if (threadIdx.x == 0) {
+    if (loss_rows) loss_rows[row] = lsum;
+    if (loss_mean) atomicAdd(loss_mean, lsum / (float)B);
+    if (top1) top1[row] = above < 0.5f ? 1.f : 0.f;   // utils.py:20-31: label among the k largest logits
+    if (top5) top5[row] = above < 4.5f ? 1.f : 0.f;
+  }
+}
+
+// ---- global gradient norm, stage 1: out[0] += sum g^2   (optax.clip_by_global_norm, train.py:25)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float v = g[(n4 << 2) + threadIdx.x];
+    s += v * v;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---- fused AdamW over the flat parameter buffer  (optax.chain(clip_by_global_norm, scale_by_adam,
+// additive_weight_decay, scale(-lr)) + apply_updates: train.py:25-27,100 with the descent sign of
+// simple_train.py:27).  28 B/param of HBM traffic, one launch for the whole model.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                     float wd, float bc1, float bc2, const float* __restrict__ sumsq, float max_norm,
+                                                     float grad_scale) {
+  float gs = grad_scale;
+  if (sumsq != nullptr && max_norm > 0.f) {
+    const float norm = sqrtf(*sumsq) * grad_scale;
+    if (!(norm < max_norm)) gs *= max_norm / norm;
+  }
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = gp[k] * gs;
+      mp[k] = b1 * mp[k] + (1.0f - b1) * gg;
+      vp[k] = b2 * vp[k] + (1.0f - b2) * gg * gg;
+      const float u = (mp[k] / bc1) / (sqrtf(vp[k] / bc2) + eps) + wd * pp[k];
+      pp[k] -= lr * u;
+    }
+    reinterpret_cast<float4*>(p)[i] = pv;
+    reinterpret_cast<float4*>(m)[i] = mv;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+}
+
+// ---- fp32 master weights -> bf16 MFMA operands in both layouts (batched over layers)
+// src [batch][R][C] fp32 (batch stride src_bs elements) -> dst_n [batch][R][C] bf16 and dst_t [batch][C][R] bf16.
+// 64x64 tile through LDS so both reads and both writes are coalesced.
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, long src_bs, int R, int C,
+                                                              bf16_t* __restrict__ dst_n, long dn_bs, int ldn,
+                                                              bf16_t* __restrict__ dst_t, long dt_bs, int ldt) {
+  __shared__ float tile[64][65];
+  const int bz = blockIdx.z;
+  const float* s = src + (size_t)bz * src_bs;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int r = r0 + rr, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < C) v = s[(size_t)r * C + c];
+    tile[rr][tx] = v;
+    if (dst_n != nullptr && r < R && c < C) dst_n[(size_t)bz * dn_bs + (size_t)r * ldn + c] = f32_to_bf16(v);
+  }
+  __syncthreads();
+  if (dst_t != nullptr) {
+    for (int cc = ty; cc < 64; cc += 4) {
+      const int c = c0 + cc, r = r0 + tx;
+      if (r < R && c < C) dst_t[(size_t)bz * dt_bs + (size_t)c * ldt + r] = f32_to_bf16(tile[tx][cc]);
+    }
+  }
+}
+
+// ---- fp32 -> bf16 elementwise (images, small buffers)
+__global__ void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    reinterpret_cast<uint2*>(dst)[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = f32_to_bf16(src[(n4 << 2) + threadIdx.x]);
+}
+
+// ---- batch layout change of the input pipeline: [H, W, C, N] fp32 -> [N, H, W, C] bf16  (train.py:80-81)
+__global__ __launch_bounds__(256) void hwcn_to_nhwc_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long hwc,
+                                                                 int n) {
+  __shared__ float tile[64][65];
+  const long p0 = (long)blockIdx.x * 64;  // position in hwc
+  const int n0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int pp = ty; pp < 64; pp += 4) {
+    const long pos = p0 + pp;
+    const int nn = n0 + tx;
+    tile[pp][tx] = (pos < hwc && nn < n) ? src[pos * n + nn] : 0.f;
+  }
+  __syncthreads();
+  for (int nn = ty; nn < 64; nn += 4) {
+    const long pos = p0 + tx;
+    const int ni = n0 + nn;
+    if (pos < hwc && ni < n) dst[(size_t)ni * hwc + pos] = f32_to_bf16(tile[tx][nn]);
+  }
+}
+
+}  // namespace
+
+extern "C" int savit_cls_pos_rows(const float* cls, const float* pos, float* x0, int B, long row_stride, int d, void* stream) {
+  SAVIT_CHECK_ARG(cls && pos && x0 && B >= 0 && d > 0 && d % 4 == 0 && row_stride >= d && row_stride % 4 == 0);
+  if (B == 0) return SAVIT_OK;
+  const int n = B * (d / 4);
+  hipLaunchKernelGGL(cls_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, cls, pos, x0, B, row_stride, d);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_pos_cls_grad(const float* dx0, float* dpos, float* dcls, int B, int N, int d, int has_cls, void* stream) {
+  SAVIT_CHECK_ARG(dx0 && dpos && B >= 0 && N > 0 && d > 0 && d % 4 == 0 && (!has_cls || dcls));
+  if (B == 0) return SAVIT_OK;
+  const int n = N * (d / 4);
+  hipLaunchKernelGGL(pos_cls_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx0, dpos, dcls, B, N, d, has_cls);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_softmax_xent(const float* logits, int ld_logits, const int* labels, const int* mix_labels, const float* ratio,
+                                  float label_smoothing, float grad_scale, float* loss_rows, float* loss_mean, void* dlogits_bf16,
+                                  int ld_dlogits, float* dbias, float* top1, float* top5, int B, int C, void* stream) {
+  SAVIT_CHECK_ARG(logits && labels && B >= 0 && C > 0 && ld_logits >= C);
+  SAVIT_CHECK_ARG((mix_labels == nullptr) == (ratio == nullptr));
+  SAVIT_CHECK_ARG(dlogits_bf16 == nullptr || ld_dlogits >= C);
+  if (B == 0) return SAVIT_OK;
+  hipLaunchKernelGGL(xent_kernel, dim3(B), dim3(CE_THREADS), 0, (hipStream_t)stream, logits, ld_logits, labels, mix_labels, ratio,
+                     label_smoothing, grad_scale, loss_rows, loss_mean, (bf16_t*)dlogits_bf16, ld_dlogits, dbias, top1, top5, B, C);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_sumsq(const float* g, long n, float* out, void* stream) {
+  SAVIT_CHECK_ARG(g && out && n >= 0 && ((uintptr_t)g % 16) == 0);
+  if (n == 0) return SAVIT_OK;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_adamw_step(float* params, const float* grads, float* m, float* v, long n, float lr, float b1, float b2,
+                                float eps, float weight_decay, int step, const float* grad_sumsq, float max_norm, float grad_scale,
+                                void* stream) {
+  SAVIT_CHECK_ARG(params && grads && m && v && n >= 0 && n % 4 == 0 && step >= 1);
+  SAVIT_CHECK_ARG(((uintptr_t)params % 16) == 0 && ((uintptr_t)grads % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0);
+  if (n == 0) return SAVIT_OK;
+  const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n, lr, b1, b2, eps,
+                     weight_decay, bc1, bc2, grad_sumsq, max_norm, grad_scale);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_cast_transpose_bf16(const float* src, long src_batch_stride, int batch, int R, int C, void* dst_n,
+                                         long dst_n_batch_stride, int ld_n, void* dst_t, long dst_t_batch_stride, int ld_t,
+                                         void* stream) {
+  SAVIT_CHECK_ARG(src && batch >= 0 && R > 0 && C > 0 && (dst_n || dst_t));
+  SAVIT_CHECK_ARG((dst_n == nullptr || ld_n >= C) && (dst_t == nullptr || ld_t >= R));
+  if (batch == 0) return SAVIT_OK;
+  hipLaunchKernelGGL(cast_transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream, src,
+                     src_batch_stride, R, C, (bf16_t*)dst_n, dst_n_batch_stride, ld_n, (bf16_t*)dst_t, dst_t_batch_stride, ld_t);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_cast_bf16(const float* src, void* dst, long n, void* stream) {
+  SAVIT_CHECK_ARG(src && dst && n >= 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0);
+  if (n == 0) return SAVIT_OK;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_hwcn_to_nhwc_bf16(const float* src, void* dst, int H, int W, int C, int N, void* stream) {
+  SAVIT_CHECK_ARG(src && dst && H > 0 && W > 0 && C > 0 && N >= 0);
+  if (N == 0) return SAVIT_OK;
+  const long hwc = (long)H * W * C;
+  hipLaunchKernelGGL(hwcn_to_nhwc_bf16_kernel, dim3((unsigned)((hwc + 63) / 64), (N + 63) / 64), dim3(256), 0, (hipStream_t)stream, src,
+                     (bf16_t*)dst, hwc, N);
+  SAVIT_LAUNCH_RET();
+}

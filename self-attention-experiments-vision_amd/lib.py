@@ -34,10 +34,25 @@ _SIGNATURES = {
     "savit_abi_version": (c_int, []),
     "savit_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_float,
                                     c_int, c_void_p]),
-    "savit_layernorm_bwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_long, c_long, c_int, c_void_p]),
+    "savit_layernorm_bwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_long, c_long, c_int, c_void_p, c_long, c_void_p]),
+    "savit_layernorm_bwd_workspace_bytes": (c_long, [c_int, c_int]),
     "savit_gemm_bf16_tn": (c_int, [POINTER(GemmArgs), c_void_p]),
     "savit_gemm_bf16_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_void_p]),
+    "savit_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "savit_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                    c_void_p]),
+    "savit_cls_pos_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p]),
+    "savit_pos_cls_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "savit_softmax_xent": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                   c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "savit_sumsq": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
+    "savit_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float, c_int,
+                                 c_void_p, c_float, c_float, c_void_p]),
+    "savit_cast_transpose_bf16": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_long, c_int, c_void_p, c_long, c_int,
+                                          c_void_p]),
+    "savit_cast_bf16": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
+    "savit_hwcn_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None

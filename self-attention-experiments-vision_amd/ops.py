@@ -66,8 +66,9 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
                   dgamma: torch.Tensor, dbeta: torch.Tensor, dres_in: Optional[torch.Tensor] = None,
                   dx: Optional[torch.Tensor] = None, dx_bf16: Optional[torch.Tensor] = None,
-                  dcolsum: Optional[torch.Tensor] = None, round_params: bool = True):
-    """Backward of layernorm_fwd; dgamma/dbeta/dcolsum are accumulated (caller zeroes)."""
+                  dcolsum: Optional[torch.Tensor] = None, round_params: bool = True, workspace: Optional[torch.Tensor] = None):
+    """Backward of layernorm_fwd; dgamma/dbeta/dcolsum are accumulated (caller zeroes).  workspace: optional
+    uint8/any CUDA tensor of >= savit_layernorm_bwd_workspace_bytes(rows, d) bytes (allocated here if None)."""
     _chk(dy, bf16, "dy", 2)
     _chk(x, f32, "x", 2)
     rows, d, xs = _rows2d(x, "x")
@@ -86,13 +87,21 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
     for name, t in (("dgamma", dgamma), ("dbeta", dbeta), ("dcolsum", dcolsum), ("mean", mean), ("rstd", rstd), ("gamma", gamma)):
         if t is not None:
             _chk(t, f32, name, 1)
-    if dgamma.numel() != d or dbeta.numel() != d or (dcolsum is not None and dcolsum.numel() != d) or gamma.numel() != d:
-        raise ValueError("per-column buffers must have d elements")
+    for t in (dgamma, dbeta, dcolsum, gamma):
+        if t is not None and t.numel() != d:
+            raise ValueError("per-column buffers must have d elements")
     if mean.numel() < rows or rstd.numel() < rows:
         raise ValueError("mean/rstd too small")
     L = _lib.load()
+    need = L.savit_layernorm_bwd_workspace_bytes(rows, d)
+    if workspace is None:
+        workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=x.device)
+    wbytes = workspace.numel() * workspace.element_size()
+    if not workspace.is_cuda or wbytes < need:
+        raise ValueError("layernorm_bwd: workspace too small")
     _lib.check(L.savit_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres_in), _p(dx), _p(dx_bf16), _p(dgamma),
-                                     _p(dbeta), _p(dcolsum), rows, d, xs, os_, int(round_params), _stream()), "savit_layernorm_bwd")
+                                     _p(dbeta), _p(dcolsum), rows, d, xs, os_, int(round_params), _p(workspace), wbytes, _stream()),
+               "savit_layernorm_bwd")
     return dx
 
 
@@ -200,3 +209,179 @@ def gemm_wgrad(X: torch.Tensor, dY: torch.Tensor, dW: torch.Tensor, splits: int 
     _lib.check(L.savit_gemm_bf16_wgrad(_p(X), _p(dY), _p(dW), Mv, Kin, Nout, ldx, lddy, lddw, int(splits), pg[0], pg[1], pg[2],
                                        pg[3], _stream()), "savit_gemm_bf16_wgrad")
     return dW
+
+
+# ---------------------------------------------------------------------------------------------
+def attention_fwd(qkv: torch.Tensor, B: int, N: int, H: int, out: Optional[torch.Tensor] = None,
+                  lse: Optional[torch.Tensor] = None):
+    """Fused softmax attention (attention.py:39-58).  qkv bf16 [B*N, 3*H*64] with pre-scaled queries."""
+    _chk(qkv, bf16, "qkv", 2)
+    rows, cols, ld = _rows2d(qkv, "qkv")
+    d = H * 64
+    if rows < B * N or cols < 3 * d:
+        raise ValueError(f"qkv {tuple(qkv.shape)} too small for B={B} N={N} H={H}")
+    o = out if out is not None else torch.empty((B * N, d), dtype=bf16, device=qkv.device)
+    lse = lse if lse is not None else torch.empty((B, H, N), dtype=f32, device=qkv.device)
+    _chk(o, bf16, "out", 2)
+    _chk(lse, f32, "lse")
+    if not o.is_contiguous() or tuple(o.shape) != (B * N, d) or lse.numel() < B * H * N or not lse.is_contiguous():
+        raise ValueError("attention_fwd: bad output buffers")
+    L = _lib.load()
+    _lib.check(L.savit_attention_fwd(_p(qkv), _p(o), _p(lse), B, N, H, 64, ld, _stream()), "savit_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(qkv: torch.Tensor, o: torch.Tensor, d_o: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int,
+                  dq_scale: float, dqkv: Optional[torch.Tensor] = None):
+    _chk(qkv, bf16, "qkv", 2)
+    _chk(o, bf16, "o", 2)
+    _chk(d_o, bf16, "d_o", 2)
+    _chk(lse, f32, "lse")
+    rows, cols, ld = _rows2d(qkv, "qkv")
+    d = H * 64
+    if rows < B * N or cols < 3 * d:
+        raise ValueError("qkv too small")
+    for name, t in (("o", o), ("d_o", d_o)):
+        if tuple(t.shape) != (B * N, d) or not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous [B*N, d]")
+    if lse.numel() < B * H * N or not lse.is_contiguous():
+        raise ValueError("lse too small")
+    if dqkv is None:
+        dqkv = torch.empty((B * N, 3 * d), dtype=bf16, device=qkv.device)
+    _chk(dqkv, bf16, "dqkv", 2)
+    r2, c2, ld2 = _rows2d(dqkv, "dqkv")
+    if r2 < B * N or c2 < 3 * d or ld2 != ld:
+        raise ValueError("dqkv must have qkv's shape and row stride")
+    L = _lib.load()
+    _lib.check(L.savit_attention_bwd(_p(qkv), _p(o), _p(d_o), _p(lse), _p(dqkv), B, N, H, 64, ld, float(dq_scale), _stream()),
+               "savit_attention_bwd")
+    return dqkv
+
+
+# ---------------------------------------------------------------------------------------------
+def cls_pos_rows(cls: torch.Tensor, pos: torch.Tensor, x0: torch.Tensor, B: int, N: int):
+    """x0[b, 0, :] = cls + pos[0]; x0 fp32 [B*N, d]."""
+    _chk(x0, f32, "x0", 2)
+    d = x0.shape[1]
+    _chk(cls, f32, "cls")
+    _chk(pos, f32, "pos")
+    if cls.numel() != d or pos.numel() < d or x0.shape[0] < B * N or not x0.is_contiguous():
+        raise ValueError("cls_pos_rows: bad shapes")
+    L = _lib.load()
+    _lib.check(L.savit_cls_pos_rows(_p(cls), _p(pos), _p(x0), B, N * d, d, _stream()), "savit_cls_pos_rows")
+
+
+def pos_cls_grad(dx0: torch.Tensor, dpos: torch.Tensor, dcls: Optional[torch.Tensor], B: int, N: int):
+    _chk(dx0, f32, "dx0", 2)
+    d = dx0.shape[1]
+    _chk(dpos, f32, "dpos")
+    if dx0.shape[0] < B * N or not dx0.is_contiguous() or dpos.numel() != N * d or not dpos.is_contiguous():
+        raise ValueError("pos_cls_grad: bad shapes")
+    if dcls is not None:
+        _chk(dcls, f32, "dcls")
+        if dcls.numel() != d:
+            raise ValueError("dcls size")
+    L = _lib.load()
+    _lib.check(L.savit_pos_cls_grad(_p(dx0), _p(dpos), _p(dcls), B, N, d, int(dcls is not None), _stream()), "savit_pos_cls_grad")
+
+
+def softmax_xent(logits: torch.Tensor, labels: torch.Tensor, label_smoothing: float = 0.1, grad_scale: Optional[float] = None,
+                 mix_labels: Optional[torch.Tensor] = None, ratio: Optional[torch.Tensor] = None, loss_rows=None, loss_mean=None,
+                 dlogits=None, dbias=None, top1=None, top5=None):
+    """train.py:83-90.  logits fp32 [B, C]; labels int32 [B]."""
+    _chk(logits, f32, "logits", 2)
+    B, C, ld = _rows2d(logits, "logits")
+    _chk(labels, torch.int32, "labels", 1)
+    if labels.numel() != B:
+        raise ValueError("labels size")
+    if (mix_labels is None) != (ratio is None):
+        raise ValueError("mix_labels and ratio go together")
+    if mix_labels is not None:
+        _chk(mix_labels, torch.int32, "mix_labels", 1)
+        _chk(ratio, f32, "ratio", 1)
+        if mix_labels.numel() != B or ratio.numel() != B:
+            raise ValueError("mix sizes")
+    ld_dz = 0
+    if dlogits is not None:
+        _chk(dlogits, bf16, "dlogits", 2)
+        r, c, ld_dz = _rows2d(dlogits, "dlogits")
+        if r < B or c < C:
+            raise ValueError("dlogits too small")
+    for name, t, n in (("loss_rows", loss_rows, B), ("loss_mean", loss_mean, 1), ("dbias", dbias, C), ("top1", top1, B), ("top5", top5, B)):
+        if t is not None:
+            _chk(t, f32, name)
+            if t.numel() < n:
+                raise ValueError(f"{name} too small")
+    gs = (1.0 / B) if grad_scale is None else float(grad_scale)
+    L = _lib.load()
+    _lib.check(L.savit_softmax_xent(_p(logits), ld, _p(labels), _p(mix_labels), _p(ratio), float(label_smoothing), gs, _p(loss_rows),
+                                    _p(loss_mean), _p(dlogits), ld_dz, _p(dbias), _p(top1), _p(top5), B, C, _stream()), "savit_softmax_xent")
+
+
+def sumsq(g: torch.Tensor, out: torch.Tensor):
+    _chk(g, f32, "g", 1)
+    _chk(out, f32, "out")
+    L = _lib.load()
+    _lib.check(L.savit_sumsq(_p(g), g.numel(), _p(out), _stream()), "savit_sumsq")
+
+
+def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float, b1: float = 0.9,
+               b2: float = 0.999, eps: float = 1e-8, weight_decay: float = 0.0, grad_sumsq: Optional[torch.Tensor] = None,
+               max_norm: float = 0.0, grad_scale: float = 1.0):
+    for name, t in (("p", p), ("g", g), ("m", m), ("v", v)):
+        _chk(t, f32, name, 1)
+        if t.numel() != p.numel() or not t.is_contiguous():
+            raise ValueError("adamw_step: size mismatch")
+    if grad_sumsq is not None:
+        _chk(grad_sumsq, f32, "grad_sumsq")
+    L = _lib.load()
+    _lib.check(L.savit_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(b1), float(b2), float(eps),
+                                  float(weight_decay), int(step), _p(grad_sumsq), float(max_norm), float(grad_scale), _stream()),
+               "savit_adamw_step")
+
+
+def cast_transpose_bf16(src: torch.Tensor, batch: int, R: int, C: int, src_bs: int, dst_n: Optional[torch.Tensor], dn_bs: int,
+                        dst_t: Optional[torch.Tensor], dt_bs: int, ld_n: Optional[int] = None, ld_t: Optional[int] = None):
+    """src fp32 (flat) holds `batch` [R,C] matrices src_bs elements apart -> bf16 copies as-is / transposed."""
+    _chk(src, f32, "src")
+    if src.numel() < (batch - 1) * src_bs + R * C:
+        raise ValueError("src too small")
+    ld_n = C if ld_n is None else ld_n
+    ld_t = R if ld_t is None else ld_t
+    if dst_n is not None:
+        _chk(dst_n, bf16, "dst_n")
+        if dst_n.numel() < (batch - 1) * dn_bs + (R - 1) * ld_n + C:
+            raise ValueError("dst_n too small")
+    if dst_t is not None:
+        _chk(dst_t, bf16, "dst_t")
+        if dst_t.numel() < (batch - 1) * dt_bs + (C - 1) * ld_t + R:
+            raise ValueError("dst_t too small")
+    L = _lib.load()
+    _lib.check(L.savit_cast_transpose_bf16(_p(src), src_bs, batch, R, C, _p(dst_n), dn_bs, ld_n, _p(dst_t), dt_bs, ld_t, _stream()),
+               "savit_cast_transpose_bf16")
+
+
+def cast_bf16(src: torch.Tensor, dst: torch.Tensor):
+    _chk(src, f32, "src")
+    _chk(dst, bf16, "dst")
+    if src.numel() != dst.numel() or not src.is_contiguous() or not dst.is_contiguous():
+        raise ValueError("cast_bf16: size/contiguity")
+    L = _lib.load()
+    _lib.check(L.savit_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "savit_cast_bf16")
+    return dst
+
+
+def hwcn_to_nhwc_bf16(src: torch.Tensor, dst: Optional[torch.Tensor] = None):
+    """[H,W,C,N] fp32 -> [N,H,W,C] bf16  (train.py:80-81)."""
+    _chk(src, f32, "src", 4)
+    if not src.is_contiguous():
+        raise ValueError("src must be contiguous")
+    H, W, C, N = src.shape
+    if dst is None:
+        dst = torch.empty((N, H, W, C), dtype=bf16, device=src.device)
+    _chk(dst, bf16, "dst", 4)
+    if tuple(dst.shape) != (N, H, W, C) or not dst.is_contiguous():
+        raise ValueError("dst shape")
+    L = _lib.load()
+    _lib.check(L.savit_hwcn_to_nhwc_bf16(_p(src), _p(dst), H, W, C, N, _stream()), "savit_hwcn_to_nhwc_bf16")
+    return dst

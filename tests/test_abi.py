@@ -22,7 +22,7 @@ def built():
 def _declared():
     src = open(os.path.join(ROOT, "include", "savit.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(savit_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|long)\s+(savit_\w+)\s*\(", src)))
 
 
 def test_header_symbols_exported(built):

@@ -282,3 +282,153 @@ def test_contract_violations_raise(ops):
         ops.gemm_tn(A, torch.zeros((64, 96), dtype=bf16, device="cuda"), torch.zeros((64, 64), dtype=bf16, device="cuda"), 0)
     with pytest.raises(ValueError):
         ops.layernorm_fwd(torch.zeros((4, 64)), torch.zeros(64), torch.zeros(64))  # CPU tensors: no CPU path
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attn_ref(qkv, B, N, H):
+    """fp64 reference on the bf16-rounded inputs; q columns are already scaled."""
+    d = H * 64
+    x = qkv.astype(np.float64).reshape(B, N, 3, H, 64)
+    q, k, v = x[:, :, 0], x[:, :, 1], x[:, :, 2]
+    s = np.einsum("bqhd,bkhd->bhqk", q, k)
+    m = s.max(-1, keepdims=True)
+    e = np.exp(s - m)
+    l = e.sum(-1, keepdims=True)
+    p = e / l
+    o = np.einsum("bhqk,bkhd->bqhd", p, v).reshape(B * N, d)
+    return o, (m + np.log(l))[..., 0], p
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (3, 196, 6), (1, 50, 12), (2, 32, 1), (1, 256, 2), (2, 17, 2), (1, 1, 1)])
+def test_attention_fwd(ops, B, N, H):
+    rng = np.random.default_rng(B * 100 + N)
+    d = H * 64
+    qkv = rb(rng.standard_normal((B * N, 3 * d)))
+    qkv[:, :d] = rb(qkv[:, :d] / 8.0 * 3.0)  # pre-scaled queries, with a spread that makes softmax peaky
+    o, lse = ops.attention_fwd(dev(qkv, bf16), B, N, H)
+    o_ref, lse_ref, _ = _attn_ref(qkv, B, N, H)
+    assert np.isfinite(host(o)).all()
+    assert rel(host(o), o_ref) < 3e-3, rel(host(o), o_ref)  # P is rounded to bf16 as an MFMA operand
+    assert np.abs(host(lse) - lse_ref).max() < 1e-4 * max(1.0, np.abs(lse_ref).max())
+
+
+def test_attention_fwd_spike(ops):
+    """One key dominating one query (rule 26: force the data-dependent path; here: large max, masked tail)."""
+    rng = np.random.default_rng(3)
+    B, N, H = 1, 197, 2
+    d = H * 64
+    qkv = rb(rng.standard_normal((B * N, 3 * d)) * 0.5)
+    qkv[5, :64] = 4.0
+    qkv[190, d:d + 64] = 4.0  # key 190 matches query 5 strongly: s = 1024
+    o, lse = ops.attention_fwd(dev(qkv, bf16), B, N, H)
+    o_ref, lse_ref, _ = _attn_ref(qkv, B, N, H)
+    assert np.isfinite(host(o)).all()
+    assert rel(host(o), o_ref) < 3e-3
+    assert abs(host(lse)[0, 0, 5] - lse_ref[0, 0, 5]) < 1e-2
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (2, 196, 2), (1, 50, 4), (1, 33, 1), (1, 256, 1)])
+def test_attention_bwd(ops, B, N, H):
+    rng = np.random.default_rng(B * 10 + N)
+    d = H * 64
+    qkv = rb(rng.standard_normal((B * N, 3 * d)))
+    qkv[:, :d] = rb(qkv[:, :d] / 8.0 * 2.0)
+    d_o = rb(rng.standard_normal((B * N, d)))
+    t = torch.tensor(qkv.astype(np.float64), requires_grad=True)
+    x = t.view(B, N, 3, H, 64)
+    q, k, v = x[:, :, 0].permute(0, 2, 1, 3), x[:, :, 1].permute(0, 2, 1, 3), x[:, :, 2].permute(0, 2, 1, 3)
+    p = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
+    o_t = (p @ v).permute(0, 2, 1, 3).reshape(B * N, d)
+    o_t.backward(torch.tensor(d_o.astype(np.float64)))
+    g = t.grad.numpy()
+    qkv_d = dev(qkv, bf16)
+    o, lse = ops.attention_fwd(qkv_d, B, N, H)
+    dqkv = ops.attention_bwd(qkv_d, o, dev(d_o, bf16), lse, B, N, H, dq_scale=1.0)
+    out = host(dqkv)
+    assert np.isfinite(out).all()
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        r = rel(out[:, sl], g[:, sl])
+        assert r < 1e-2, (name, r)  # P, dS pass through bf16 MFMA operands; O is bf16
+    dq2 = host(ops.attention_bwd(qkv_d, o, dev(d_o, bf16), lse, B, N, H, dq_scale=0.125))[:, :d]
+    assert rel(dq2, g[:, :d] * 0.125) < 1e-2
+
+
+# ------------------------------------------------------------------------------------------ train ops
+def test_cls_pos_and_grad(ops):
+    rng = np.random.default_rng(0)
+    B, N, d = 5, 17, 64
+    cls = rng.standard_normal(d).astype(np.float32)
+    pos = rng.standard_normal((N, d)).astype(np.float32)
+    x0 = torch.zeros((B * N, d), device="cuda")
+    ops.cls_pos_rows(dev(cls), dev(pos), x0, B, N)
+    out = host(x0).reshape(B, N, d)
+    assert np.allclose(out[:, 0], cls + pos[0]) and np.all(out[:, 1:] == 0)
+    dx0 = rng.standard_normal((B * N, d)).astype(np.float32)
+    dpos = torch.zeros((N, d), device="cuda")
+    dcls = torch.zeros(d, device="cuda")
+    ops.pos_cls_grad(dev(dx0), dpos, dcls, B, N)
+    assert rel(host(dpos), dx0.reshape(B, N, d).sum(0)) < 1e-6
+    assert rel(host(dcls), dx0.reshape(B, N, d)[:, 0].sum(0)) < 1e-6
+
+
+@pytest.mark.parametrize("mix", [False, True])
+def test_softmax_xent(ops, mix):
+    rng = np.random.default_rng(1)
+    B, C, Cp = 37, 1000, 1024
+    logits = (rng.standard_normal((B, C)) * 3).astype(np.float32)
+    labels = rng.integers(0, C, B)
+    l2 = rng.integers(0, C, B) if mix else None
+    ratio = rng.random(B).astype(np.float32) if mix else None
+    loss_rows = torch.zeros(B, device="cuda")
+    loss_mean = torch.zeros(1, device="cuda")
+    dz = torch.full((B, Cp), 3.0, dtype=bf16, device="cuda")
+    dbias = torch.zeros(C, device="cuda")
+    t1 = torch.zeros(B, device="cuda")
+    t5 = torch.zeros(B, device="cuda")
+    ops.softmax_xent(dev(logits), dev(labels.astype(np.int32)), 0.1, None, None if l2 is None else dev(l2.astype(np.int32)),
+                     None if ratio is None else dev(ratio), loss_rows, loss_mean, dz, dbias, t1, t5)
+    ref = vit_ref.loss_fn(logits.astype(np.float64), labels, 0.1, l2, ratio)
+    assert abs(float(loss_mean) - ref) < 1e-5 * max(1.0, abs(ref))
+    if not mix:
+        g = vit_ref.dloss_dlogits(logits.astype(np.float64), labels, 0.1)
+        assert rel(host(dz)[:, :C], rb(g)) < 1e-3
+        assert float(dz[:, C:].abs().max()) == 0
+        assert rel(host(dbias), host(dz)[:, :C].astype(np.float64).sum(0)) < 1e-4
+        tk = vit_ref.topk_correct(logits, labels)
+        assert np.array_equal(host(t1), tk["top_1_acc"]) and np.array_equal(host(t5), tk["top_5_acc"])
+
+
+def test_adamw_and_clip(ops):
+    rng = np.random.default_rng(2)
+    n = 4096 + 4
+    p0 = rng.standard_normal(n).astype(np.float32)
+    p, m, v = p0.astype(np.float64), np.zeros(n), np.zeros(n)
+    pt, mt, vt = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        g = rng.standard_normal(n).astype(np.float32) * 3
+        ss = torch.zeros(1, device="cuda")
+        ops.sumsq(dev(g), ss)
+        norm = np.sqrt((g.astype(np.float64) ** 2).sum())
+        assert abs(float(ss) - norm ** 2) < 1e-3 * norm ** 2
+        clip = 1.0 if norm < 1.0 else 1.0 / norm
+        p, m, v = vit_ref.adamw_update(p, g.astype(np.float64), m, v, step, 3e-3, 1e-4, clip)
+        ops.adamw_step(pt, dev(g), mt, vt, step, 3e-3, weight_decay=1e-4, grad_sumsq=ss, max_norm=1.0)
+    assert rel(host(pt), p) < 1e-6 and rel(host(mt), m) < 1e-5 and rel(host(vt), v) < 1e-4  # fp32 moments vs fp64 oracle
+
+
+def test_cast_transpose_and_layout(ops):
+    rng = np.random.default_rng(3)
+    L, R, C, bs = 3, 100, 72, 100 * 72 + 40
+    src = rng.standard_normal(L * bs).astype(np.float32)
+    dn = torch.zeros(L * R * C, dtype=bf16, device="cuda")
+    dt = torch.zeros(L * R * C, dtype=bf16, device="cuda")
+    ops.cast_transpose_bf16(dev(src), L, R, C, bs, dn, R * C, dt, R * C)
+    for l in range(L):
+        mat = src[l * bs:l * bs + R * C].reshape(R, C)
+        assert np.array_equal(host(dn)[l * R * C:(l + 1) * R * C].reshape(R, C), rb(mat))
+        assert np.array_equal(host(dt)[l * R * C:(l + 1) * R * C].reshape(C, R), rb(mat.T))
+    x = rng.standard_normal((8, 6, 3, 5)).astype(np.float32)  # H W C N
+    y = ops.hwcn_to_nhwc_bf16(dev(x))
+    assert np.array_equal(host(y), rb(np.transpose(x, (3, 0, 1, 2))))
+    z = rng.standard_normal(1003).astype(np.float32)
+    assert np.array_equal(host(ops.cast_bf16(dev(z), torch.empty(1003, dtype=bf16, device="cuda"))), rb(z))
