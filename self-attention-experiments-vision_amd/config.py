@@ -1,0 +1,92 @@
+"""Model configurations of the hot path (reference: /root/reference/models/create_model.py:10-37 ViT
+branches, :79-168 CaiT branches) plus the two DeiT sizes BASELINE.json names that the reference lacks."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict
+
+
+@dataclass(frozen=True)
+class ModelConfig:
+    kind: str  # 'vit' | 'cait'
+    num_layers: int
+    num_heads: int
+    embed_dim: int
+    patch: int
+    num_classes: int = 1000
+    img_size: int = 224
+    expand_ratio: float = 4.0
+    num_layers_token_only: int = 0  # CaiT class-attention layers (cait.py:162)
+    stoch_depth_rate: float = 0.0
+    layerscale_eps: float = 0.0
+
+    @property
+    def n_patches(self) -> int:
+        return (self.img_size // self.patch) ** 2
+
+    @property
+    def seq_len(self) -> int:
+        """tokens in the self-attention encoder: patches (+ cls for ViT: vit.py:85)."""
+        return self.n_patches + (1 if self.kind == "vit" else 0)
+
+    @property
+    def hidden(self) -> int:
+        """FFBlock hidden width, ff.py:24."""
+        return max(1, int(self.expand_ratio * self.embed_dim))
+
+    @property
+    def head_dim(self) -> int:
+        return self.embed_dim // self.num_heads
+
+    @property
+    def patch_dim(self) -> int:
+        return self.patch * self.patch * 3
+
+
+def _vit(L, H, d, p):
+    return dict(kind="vit", num_layers=L, num_heads=H, embed_dim=d, patch=p)
+
+
+def _cait(L, H, d, sd, eps):
+    return dict(kind="cait", num_layers=L, num_heads=H, embed_dim=d, patch=16, num_layers_token_only=2,
+                stoch_depth_rate=sd, layerscale_eps=eps)
+
+
+MODEL_ZOO: Dict[str, dict] = {
+    "vit_b_patch32": _vit(12, 12, 768, 32),   # create_model.py:10-16
+    "vit_b_patch16": _vit(12, 12, 768, 16),   # :17-23  (== DeiT-B/16, BASELINE config 3)
+    "vit_l_patch32": _vit(24, 16, 1024, 32),  # :24-30
+    "vit_l_patch16": _vit(24, 16, 1024, 16),  # :31-37  (BASELINE config 5 at img_size=384)
+    "vit_ti_patch16": _vit(12, 3, 192, 16),   # BASELINE config 1 (absent from the reference)
+    "vit_s_patch16": _vit(12, 6, 384, 16),    # BASELINE config 2, DeiT-S (absent from the reference)
+    "cait_xxs_24": _cait(24, 4, 192, 0.05, 1e-5),
+    "cait_xxs_36": _cait(36, 4, 192, 0.1, 1e-6),
+    "cait_xs_24": _cait(24, 6, 288, 0.05, 1e-5),
+    "cait_xs_36": _cait(36, 6, 288, 0.1, 1e-6),
+    "cait_s_24": _cait(24, 8, 384, 0.1, 1e-6),
+    "cait_s_36": _cait(36, 8, 384, 0.2, 1e-6),
+    "cait_s_48": _cait(48, 8, 384, 0.3, 1e-6),
+    "cait_m_24": _cait(24, 16, 768, 0.2, 1e-5),
+    "cait_m_36": _cait(36, 16, 768, 0.3, 1e-6),
+    "cait_m_48": _cait(48, 16, 768, 0.4, 1e-6),
+}
+
+
+def get_config(model_name: str, num_classes: int = 1000, img_size: int = 224) -> ModelConfig:
+    if model_name not in MODEL_ZOO:
+        raise RuntimeError("Model not found.")  # create_model.py:214-215
+    return ModelConfig(num_classes=num_classes, img_size=img_size, **MODEL_ZOO[model_name])
+
+
+def train_flops_per_image(cfg: ModelConfig) -> float:
+    """Algorithmic FLOPs of one train step per image (no recompute counted)."""
+    d, C, n = cfg.embed_dim, cfg.num_classes, cfg.n_patches
+    pe = 2.0 * n * cfg.patch_dim * d
+    if cfg.kind == "vit":
+        N = n + 1
+        layer = 24.0 * N * d * d + 4.0 * N * N * d
+        return 3.0 * (cfg.num_layers * layer + 2.0 * d * C) + 2.0 * pe
+    H = cfg.num_heads
+    sa = 24.0 * n * d * d + 4.0 * n * n * d + 4.0 * H * H * n * n
+    ca = 20.0 * d * d + 4.0 * (n + 1) * d * d + 4.0 * (n + 1) * d
+    return 3.0 * (cfg.num_layers * sa + cfg.num_layers_token_only * ca + 2.0 * d * C) + 2.0 * pe

@@ -1,0 +1,490 @@
+"""ViT training engine: owns the HBM layout (flat fp32 parameters / gradients, bf16 MFMA operand copies,
+per-layer saved activations) and the fixed launch sequence of forward, loss and backward.
+
+Reference path being replaced: the pmapped `train_step` of /root/reference/train.py:77-100 around
+`ViT.__call__` (models/vit.py:73-99): forward, label-smoothed CE, reverse-mode AD.  Everything that touches
+tensors is a C-ABI kernel call (lib.py); PyTorch only allocates device memory and provides the stream.
+
+HBM layout
+  params / grads : ONE fp32 buffer each, layer-major
+      [embed: Wpe | cls | pos] [layer 0: ln1 g,b | Wqkv | Wo | ln2 g,b | W1 | b1 | W2 | b2] ... [final: lnf g,b | Wh | bh]
+    so the optimizer is a single launch and gradient buckets for the data-parallel all-reduce are contiguous
+    slices that become final in reverse order during backward.  Kernels are Flax-layout [in, out]; q/k/v
+    kernels are fused into Wqkv [d, 3d] (the Flax tree exposes strided views).
+  wbf : bf16 copies of every matrix in BOTH layouts ([in,out] for input-gradient GEMMs, [out,in] for forward
+    GEMMs - all GEMMs are "TN"), refreshed by 6 batched cast/transposes after each optimizer step.
+  activations : per layer x_in, x_mid (fp32 residual stream), h1, h2, o, qkv, u, a (bf16), LN stats, LSE.
+
+The launch plan (ctypes function + prebuilt argument tuple per kernel) is built once per batch size, so a step is
+a flat loop of ~260 asynchronous launches with no allocation - and therefore capturable in a hipGraph.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import lib as _lib
+from .config import ModelConfig
+
+bf16 = torch.bfloat16
+f32 = torch.float32
+
+
+def _align(n: int, a: int = 64) -> int:
+    return (n + a - 1) // a * a
+
+
+class ParamLayout:
+    """Offsets (in fp32 elements) of every tensor in the flat parameter buffer."""
+
+    def __init__(self, cfg: ModelConfig):
+        if cfg.kind != "vit":
+            raise NotImplementedError("ParamLayout: only the ViT family is laid out here")
+        self.cfg = cfg
+        d, F, C, N, L = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers
+        self.off: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        cur = 0
+
+        def add(name, shape):
+            nonlocal cur
+            n = 1
+            for s in shape:
+                n *= s
+            self.off[name] = (cur, tuple(shape))
+            cur += _align(n, 4)
+
+        add("Wpe", (cfg.patch_dim, d))
+        add("cls", (d,))
+        add("pos", (N, d))
+        cur = _align(cur, 64)
+        self.embed_end = cur
+        self.layer_start: List[int] = []
+        for l in range(L):
+            self.layer_start.append(cur)
+            add(f"l{l}.ln1_g", (d,))
+            add(f"l{l}.ln1_b", (d,))
+            add(f"l{l}.Wqkv", (d, 3 * d))
+            add(f"l{l}.Wo", (d, d))
+            add(f"l{l}.ln2_g", (d,))
+            add(f"l{l}.ln2_b", (d,))
+            add(f"l{l}.W1", (d, F))
+            add(f"l{l}.b1", (F,))
+            add(f"l{l}.W2", (F, d))
+            add(f"l{l}.b2", (d,))
+            cur = _align(cur, 64)
+        self.layer_stride = (self.layer_start[1] - self.layer_start[0]) if L > 1 else (cur - self.layer_start[0])
+        self.final_start = cur
+        add("lnf_g", (d,))
+        add("lnf_b", (d,))
+        add("Wh", (d, C))
+        add("bh", (C,))
+        self.total = _align(cur, 64)
+
+    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        o, shape = self.off[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return flat[o:o + n].view(*shape)
+
+    def flax_tree(self, flat: torch.Tensor) -> dict:
+        """Flax-shaped nested dict of VIEWS into `flat`."""
+        cfg = self.cfg
+        d, H, hd = cfg.embed_dim, cfg.num_heads, cfg.head_dim
+        v = lambda n: self.view(flat, n)  # noqa: E731
+        enc = {"AddAbsPosEmbed_0": {"pos_embed": v("pos").view(1, cfg.seq_len, d)}}
+        for l in range(cfg.num_layers):
+            wqkv = v(f"l{l}.Wqkv")
+            enc[f"EncoderBlock_{l}"] = {
+                "LayerNorm_0": {"scale": v(f"l{l}.ln1_g"), "bias": v(f"l{l}.ln1_b")},
+                "SelfAttentionBlock_0": {
+                    "queries": {"kernel": wqkv[:, 0:d].unflatten(1, (H, hd))},
+                    "keys": {"kernel": wqkv[:, d:2 * d].unflatten(1, (H, hd))},
+                    "values": {"kernel": wqkv[:, 2 * d:3 * d].unflatten(1, (H, hd))},
+                    "DenseGeneral_0": {"kernel": v(f"l{l}.Wo").view(H, hd, d)},
+                },
+                "LayerNorm_1": {"scale": v(f"l{l}.ln2_g"), "bias": v(f"l{l}.ln2_b")},
+                "FFBlock_0": {"Dense_0": {"kernel": v(f"l{l}.W1"), "bias": v(f"l{l}.b1")},
+                              "Dense_1": {"kernel": v(f"l{l}.W2"), "bias": v(f"l{l}.b2")}},
+            }
+        enc["LayerNorm_0"] = {"scale": v("lnf_g"), "bias": v("lnf_b")}
+        return {"params": {
+            "PatchEmbedBlock_0": {"Dense_0": {"kernel": v("Wpe")}},
+            "cls": v("cls").view(1, 1, d),
+            "Encoder_0": enc,
+            "Dense_0": {"kernel": v("Wh"), "bias": v("bh")},
+        }}
+
+
+def _copy_tree(dst: dict, src: dict, path: str = ""):
+    for k, dv in dst.items():
+        if k not in src:
+            raise KeyError(f"missing parameter {path}/{k}")
+        sv = src[k]
+        if isinstance(dv, dict):
+            _copy_tree(dv, sv, f"{path}/{k}")
+        else:
+            t = torch.as_tensor(sv) if not isinstance(sv, torch.Tensor) else sv
+            if tuple(t.shape) != tuple(dv.shape):
+                raise ValueError(f"{path}/{k}: shape {tuple(t.shape)} != {tuple(dv.shape)}")
+            dv.copy_(t.to(device=dv.device, dtype=dv.dtype))
+    extra = set(src) - set(dst)
+    if extra:
+        raise KeyError(f"unexpected parameters under {path}: {sorted(extra)}")
+
+
+class _Plan:
+    """A recorded sequence of kernel launches: (ctypes fn, args-without-stream, label)."""
+
+    def __init__(self):
+        self.calls: List[Tuple[Callable, tuple, str]] = []
+        self.keep: List[object] = []  # ctypes structs that must outlive the plan
+
+    def add(self, fn, args: tuple, label: str):
+        self.calls.append((fn, args, label))
+
+    def run(self, stream: int):
+        for fn, args, label in self.calls:
+            rc = fn(*args, stream)
+            if rc != 0:
+                _lib.check(rc, label)
+
+
+class ViTEngine:
+    def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True):
+        if cfg.kind != "vit":
+            raise NotImplementedError("ViTEngine handles the ViT family; CaiT uses CaiTEngine")
+        if cfg.head_dim != 64:
+            raise NotImplementedError("attention kernels are built for head_dim 64")
+        if cfg.seq_len > 256:
+            raise NotImplementedError("attention kernels keep the whole head in LDS: seq_len <= 256")
+        if cfg.embed_dim % 64 != 0 or cfg.patch % 8 != 0 or cfg.num_classes % 8 != 0:
+            raise ValueError("embed_dim % 64, patch % 8 and num_classes % 8 must be 0")
+        if not torch.cuda.is_available():
+            raise RuntimeError("ViTEngine needs a GPU: there is no CPU path")
+        self.L = _lib.load()
+        self.cfg = cfg
+        self.B = int(batch)
+        self.dev = torch.device(device)
+        self.rp = int(round_like_reference)
+        self.layout = ParamLayout(cfg)
+        d, F, C, N, NL = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers
+        self.M = self.B * N
+        self.Cp = _align(C, 64)
+        z = lambda *s, dt=f32: torch.zeros(*s, dtype=dt, device=self.dev)  # noqa: E731
+        e = lambda *s, dt=f32: torch.empty(*s, dtype=dt, device=self.dev)  # noqa: E731
+        # ---- parameters, gradients, optimizer state
+        self.params = z(self.layout.total)
+        self.grads = z(self.layout.total)
+        self.adam_m = None
+        self.adam_v = None
+        self.step_count = 0
+        self.gnorm_sq = z(1)
+        # ---- bf16 operand copies
+        self.w = {
+            "Wqkv_n": e(NL, d, 3 * d, dt=bf16), "Wqkv_t": e(NL, 3 * d, d, dt=bf16),
+            "Wo_n": e(NL, d, d, dt=bf16), "Wo_t": e(NL, d, d, dt=bf16),
+            "W1_n": e(NL, d, F, dt=bf16), "W1_t": e(NL, F, d, dt=bf16),
+            "W2_n": e(NL, F, d, dt=bf16), "W2_t": e(NL, d, F, dt=bf16),
+            "Wpe_t": e(d, cfg.patch_dim, dt=bf16),
+            "Wh_t": e(C, d, dt=bf16), "Wh_n": z(d, self.Cp, dt=bf16),
+        }
+        # ---- activations (saved for backward)
+        M = self.M
+        self.x = [e(M, d) for _ in range(NL + 1)]      # residual stream entering layer l (x[NL] = encoder output)
+        self.xmid = [e(M, d) for _ in range(NL)]
+        self.h1 = [e(M, d, dt=bf16) for _ in range(NL)]
+        self.h2 = [e(M, d, dt=bf16) for _ in range(NL)]
+        self.qkv = [e(M, 3 * d, dt=bf16) for _ in range(NL)]
+        self.o = [e(M, d, dt=bf16) for _ in range(NL)]
+        self.u = [e(M, F, dt=bf16) for _ in range(NL)]
+        self.a = [e(M, F, dt=bf16) for _ in range(NL)]
+        self.stats = [e(4, M) for _ in range(NL)]      # mean1, rstd1, mean2, rstd2
+        self.lse = [e(self.B, cfg.num_heads, N) for _ in range(NL)]
+        self.zcls = e(self.B, d, dt=bf16)
+        self.fstats = e(2, self.B)
+        self.logits = e(self.B, C)
+        # ---- backward scratch
+        self.dres = e(M, d)
+        self.dres_b = e(M, d, dt=bf16)
+        self.d_u = e(M, F, dt=bf16)
+        self.d_h = e(M, d, dt=bf16)
+        self.d_o = e(M, d, dt=bf16)
+        self.dqkv = e(M, 3 * d, dt=bf16)
+        self.dlogits = z(self.B, self.Cp, dt=bf16)
+        self.d_z = e(self.B, d, dt=bf16)
+        ws = self.L.savit_layernorm_bwd_workspace_bytes(M, d)
+        self.ln_ws = torch.empty(max(int(ws), 16), dtype=torch.uint8, device=self.dev)
+        # ---- loss I/O
+        self.labels = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
+        self.loss = z(1)
+        self.loss_rows = z(self.B)
+        self.top1 = z(self.B)
+        self.top5 = z(self.B)
+        self.images: Optional[torch.Tensor] = None  # bf16 NHWC, set by forward()
+        self._img_buf = e(self.B, cfg.img_size, cfg.img_size, 3, dt=bf16)
+        self._fwd_plan: Optional[_Plan] = None
+        self._bwd_plan: Optional[_Plan] = None
+        self._cast_plan: Optional[_Plan] = None
+        self.bwd_hooks: Dict[str, Callable[[], None]] = {}  # label -> callback run right after that launch (DDP buckets)
+        self.weights_stale = True
+
+    # ------------------------------------------------------------------------------------ parameters
+    def param_tree(self) -> dict:
+        return self.layout.flax_tree(self.params)
+
+    def grad_tree(self) -> dict:
+        return self.layout.flax_tree(self.grads)
+
+    def load_params(self, tree: dict):
+        """Copy a Flax-shaped tree (numpy arrays or tensors) into the flat buffer."""
+        src = tree["params"] if "params" in tree else tree
+        _copy_tree(self.param_tree()["params"], src)
+        self.weights_stale = True
+
+    def init_params(self, seed: int = 0):
+        """Reference initialisers: lecun-normal Dense kernels (truncated at 2 sigma), zero biases,
+        zero cls (vit.py:83), normal(0.02) pos-embed (position_embed.py:49), LN scale 1 / bias 0, ZERO head kernel
+        (vit.py:98)."""
+        g = torch.Generator(device="cpu").manual_seed(int(seed))
+        self.params.zero_()
+        lay, cfg = self.layout, self.cfg
+
+        def lecun(name, fan_in):
+            o, shape = lay.off[name]
+            std = math.sqrt(1.0 / fan_in) / 0.87962566103423978
+            t = torch.empty(shape, dtype=f32)
+            torch.nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=g)
+            lay.view(self.params, name).copy_(t)
+
+        lecun("Wpe", cfg.patch_dim)
+        lay.view(self.params, "pos").copy_(torch.randn(lay.off["pos"][1], generator=g) * 0.02)
+        for l in range(cfg.num_layers):
+            lay.view(self.params, f"l{l}.ln1_g").fill_(1.0)
+            lay.view(self.params, f"l{l}.ln2_g").fill_(1.0)
+            lecun(f"l{l}.Wqkv", cfg.embed_dim)
+            lecun(f"l{l}.Wo", cfg.embed_dim)
+            lecun(f"l{l}.W1", cfg.embed_dim)
+            lecun(f"l{l}.W2", cfg.hidden)
+        lay.view(self.params, "lnf_g").fill_(1.0)
+        self.weights_stale = True
+
+    # ------------------------------------------------------------------------------------ plans
+    def _off_ptr(self, buf: torch.Tensor, name: str) -> int:
+        return buf.data_ptr() + self.layout.off[name][0] * 4
+
+    def _gemm(self, plan: _Plan, label: str, **kw):
+        a = _lib.GemmArgs()
+        for k, v in kw.items():
+            setattr(a, k, v)
+        if not a.rows_per_sample:
+            a.rows_per_sample = 1
+        a.round_bias_bf16 = self.rp
+        plan.keep.append(a)
+        plan.add(self.L.savit_gemm_bf16_tn, (ctypes.byref(a),), label)
+
+    def _build_cast_plan(self) -> _Plan:
+        P, L, lay, cfg = _Plan(), self.L, self.layout, self.cfg
+        d, F, C, NL = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.num_layers
+        ls = lay.layer_stride
+        for name, R, Cc in (("Wqkv", d, 3 * d), ("Wo", d, d), ("W1", d, F), ("W2", F, d)):
+            P.add(L.savit_cast_transpose_bf16, (self._off_ptr(self.params, f"l0.{name}"), ls, NL, R, Cc, self.w[name + "_n"].data_ptr(),
+                                                R * Cc, Cc, self.w[name + "_t"].data_ptr(), R * Cc, R), f"cast {name}")
+        P.add(L.savit_cast_transpose_bf16, (self._off_ptr(self.params, "Wpe"), 0, 1, cfg.patch_dim, d, None, 0, d,
+                                            self.w["Wpe_t"].data_ptr(), 0, cfg.patch_dim), "cast Wpe")
+        P.add(L.savit_cast_transpose_bf16, (self._off_ptr(self.params, "Wh"), 0, 1, d, C, self.w["Wh_n"].data_ptr(), 0, self.Cp,
+                                            self.w["Wh_t"].data_ptr(), 0, d), "cast Wh")
+        return P
+
+    def _build_fwd_plan(self) -> _Plan:
+        P, L, cfg = _Plan(), self.L, self.cfg
+        d, F, C, N, NL, H, B, M = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers, cfg.num_heads, self.B, self.M
+        pp = lambda n: self._off_ptr(self.params, n)  # noqa: E731
+        x = self.x
+        # tokens: patch-embed GEMM writes rows 1.. of each image, cls kernel writes row 0  (vit.py:77-85, position_embed.py:56)
+        self._gemm(P, "patch_embed", A=self._img_buf.data_ptr(), Bt=self.w["Wpe_t"].data_ptr(), C=x[0].data_ptr(), aux=pp("pos"),
+                   M=B * cfg.n_patches, N=d, K=cfg.patch_dim, lda=0, ldb=cfg.patch_dim, ldc=d, ldaux=d, epilogue=_lib.EPI_PATCH,
+                   img_size=cfg.img_size, patch=cfg.patch, tokens=N, token_offset=1)
+        P.add(L.savit_cls_pos_rows, (pp("cls"), pp("pos"), x[0].data_ptr(), B, N * d, d), "cls_rows")
+        alpha = 1.0 / math.sqrt(cfg.head_dim)
+        for l in range(NL):
+            st = self.stats[l]
+            w = lambda n, l=l: self.w[n][l].data_ptr()  # noqa: E731
+            P.add(L.savit_layernorm_fwd, (x[l].data_ptr(), pp(f"l{l}.ln1_g"), pp(f"l{l}.ln1_b"), self.h1[l].data_ptr(), st[0].data_ptr(),
+                                          st[1].data_ptr(), M, d, d, 1e-6, self.rp), f"l{l}.ln1")
+            self._gemm(P, f"l{l}.qkv", A=self.h1[l].data_ptr(), Bt=w("Wqkv_t"), C=self.qkv[l].data_ptr(), M=M, N=3 * d, K=d, lda=d, ldb=d,
+                       ldc=3 * d, epilogue=_lib.EPI_BF16, alpha=alpha, alpha_cols=d)
+            P.add(L.savit_attention_fwd, (self.qkv[l].data_ptr(), self.o[l].data_ptr(), self.lse[l].data_ptr(), B, N, H, 64, 3 * d),
+                  f"l{l}.attn")
+            self._gemm(P, f"l{l}.proj", A=self.o[l].data_ptr(), Bt=w("Wo_t"), C=self.xmid[l].data_ptr(), aux=x[l].data_ptr(), M=M, N=d, K=d,
+                       lda=d, ldb=d, ldc=d, ldaux=d, epilogue=_lib.EPI_RESID)
+            P.add(L.savit_layernorm_fwd, (self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), pp(f"l{l}.ln2_b"), self.h2[l].data_ptr(),
+                                          st[2].data_ptr(), st[3].data_ptr(), M, d, d, 1e-6, self.rp), f"l{l}.ln2")
+            self._gemm(P, f"l{l}.fc1", A=self.h2[l].data_ptr(), Bt=w("W1_t"), C=self.u[l].data_ptr(), C2=self.a[l].data_ptr(),
+                       bias=pp(f"l{l}.b1"), M=M, N=F, K=d, lda=d, ldb=d, ldc=F, epilogue=_lib.EPI_BIAS_GELU)
+            self._gemm(P, f"l{l}.fc2", A=self.a[l].data_ptr(), Bt=w("W2_t"), C=x[l + 1].data_ptr(), bias=pp(f"l{l}.b2"),
+                       aux=self.xmid[l].data_ptr(), M=M, N=d, K=F, lda=F, ldb=F, ldc=d, ldaux=d, epilogue=_lib.EPI_RESID)
+        # final LayerNorm on the cls rows only (vit.py:57,95: only row 0 reaches the head), then the head Dense
+        P.add(L.savit_layernorm_fwd, (x[NL].data_ptr(), pp("lnf_g"), pp("lnf_b"), self.zcls.data_ptr(), self.fstats[0].data_ptr(),
+                                      self.fstats[1].data_ptr(), B, d, N * d, 1e-6, self.rp), "lnf")
+        self._gemm(P, "head", A=self.zcls.data_ptr(), Bt=self.w["Wh_t"].data_ptr(), C=self.logits.data_ptr(), bias=pp("bh"), M=B, N=C, K=d,
+                   lda=d, ldb=d, ldc=C, epilogue=_lib.EPI_F32, round_out_bf16=self.rp)
+        return P
+
+    def _build_bwd_plan(self) -> _Plan:
+        P, L, cfg = _Plan(), self.L, self.cfg
+        d, F, C, N, NL, H, B, M = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers, cfg.num_heads, self.B, self.M
+        pp = lambda n: self._off_ptr(self.params, n)  # noqa: E731
+        gp = lambda n: self._off_ptr(self.grads, n)  # noqa: E731
+        ws, wsb = self.ln_ws.data_ptr(), self.ln_ws.numel()
+
+        def wgrad(label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0)):
+            P.add(L.savit_gemm_bf16_wgrad, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, 0, patch[0], patch[1], patch[2], patch[3]), label)
+
+        # ---- head: dWh, d z_cls, final LayerNorm backward into the (zeroed) residual gradient
+        wgrad("head.wgrad", self.zcls.data_ptr(), self.dlogits.data_ptr(), gp("Wh"), B, d, C, d, self.Cp, C)
+        self._gemm(P, "head.dgrad", A=self.dlogits.data_ptr(), Bt=self.w["Wh_n"].data_ptr(), C=self.d_z.data_ptr(), M=B, N=d, K=self.Cp,
+                   lda=self.Cp, ldb=self.Cp, ldc=d, epilogue=_lib.EPI_BF16)
+        P.add(L.savit_layernorm_bwd, (self.d_z.data_ptr(), self.x[NL].data_ptr(), pp("lnf_g"), self.fstats[0].data_ptr(),
+                                      self.fstats[1].data_ptr(), None, self.dres.data_ptr(), self.dres_b.data_ptr(), gp("lnf_g"),
+                                      gp("lnf_b"), gp(f"l{NL - 1}.b2"), B, d, N * d, N * d, self.rp, ws, wsb), "lnf.bwd")
+        for l in range(NL - 1, -1, -1):
+            st = self.stats[l]
+            w = lambda n, l=l: self.w[n][l].data_ptr()  # noqa: E731
+            # FFN branch: x_{l+1} = x_mid + gelu(h2 W1 + b1) W2 + b2     (ff.py:26-33, vit.py:26-31)
+            wgrad(f"l{l}.W2.wgrad", self.a[l].data_ptr(), self.dres_b.data_ptr(), gp(f"l{l}.W2"), M, F, d, F, d, d)
+            self._gemm(P, f"l{l}.fc2.dgrad", A=self.dres_b.data_ptr(), Bt=w("W2_n"), C=self.d_u.data_ptr(), aux=self.u[l].data_ptr(),
+                       colsum=gp(f"l{l}.b1"), M=M, N=F, K=d, lda=d, ldb=d, ldc=F, ldaux=F, epilogue=_lib.EPI_DGELU)
+            wgrad(f"l{l}.W1.wgrad", self.h2[l].data_ptr(), self.d_u.data_ptr(), gp(f"l{l}.W1"), M, d, F, d, F, F)
+            self._gemm(P, f"l{l}.fc1.dgrad", A=self.d_u.data_ptr(), Bt=w("W1_n"), C=self.d_h.data_ptr(), M=M, N=d, K=F, lda=F, ldb=F,
+                       ldc=d, epilogue=_lib.EPI_BF16)
+            P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(),
+                                          self.dres.data_ptr(), self.dres.data_ptr(), self.dres_b.data_ptr(), gp(f"l{l}.ln2_g"),
+                                          gp(f"l{l}.ln2_b"), None, M, d, d, d, self.rp, ws, wsb), f"l{l}.ln2.bwd")
+            # attention branch: x_mid = x_l + attn(LN1(x_l)) Wo     (attention.py:21-67, vit.py:19-24)
+            wgrad(f"l{l}.Wo.wgrad", self.o[l].data_ptr(), self.dres_b.data_ptr(), gp(f"l{l}.Wo"), M, d, d, d, d, d)
+            self._gemm(P, f"l{l}.proj.dgrad", A=self.dres_b.data_ptr(), Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=M, N=d, K=d, lda=d, ldb=d,
+                       ldc=d, epilogue=_lib.EPI_BF16)
+            P.add(L.savit_attention_bwd, (self.qkv[l].data_ptr(), self.o[l].data_ptr(), self.d_o.data_ptr(), self.lse[l].data_ptr(),
+                                          self.dqkv.data_ptr(), B, N, H, 64, 3 * d, 1.0 / math.sqrt(cfg.head_dim)), f"l{l}.attn.bwd")
+            wgrad(f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), self.dqkv.data_ptr(), gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d)
+            self._gemm(P, f"l{l}.qkv.dgrad", A=self.dqkv.data_ptr(), Bt=w("Wqkv_n"), C=self.d_h.data_ptr(), M=M, N=d, K=3 * d, lda=3 * d,
+                       ldb=3 * d, ldc=d, epilogue=_lib.EPI_BF16)
+            P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
+                                          self.dres.data_ptr(), self.dres.data_ptr(), self.dres_b.data_ptr(), gp(f"l{l}.ln1_g"),
+                                          gp(f"l{l}.ln1_b"), gp(f"l{l - 1}.b2") if l > 0 else None, M, d, d, d, self.rp, ws, wsb),
+                  f"l{l}.ln1.bwd")
+        # ---- embeddings: dpos, dcls, dWpe   (vit.py:77-85, position_embed.py:56, patch_embed.py:23-25)
+        P.add(L.savit_pos_cls_grad, (self.dres.data_ptr(), gp("pos"), gp("cls"), B, N, d, 1), "pos_cls.grad")
+        wgrad("Wpe.wgrad", self._img_buf.data_ptr(), self.dres_b.data_ptr(), gp("Wpe"), B * cfg.n_patches, cfg.patch_dim, d, 0, d, d,
+              patch=(cfg.patch, cfg.img_size, N, 1))
+        return P
+
+    # ------------------------------------------------------------------------------------ execution
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    def refresh_weights(self):
+        """fp32 master -> bf16 MFMA operands (both layouts).  Call after the parameters change."""
+        if self._cast_plan is None:
+            self._cast_plan = self._build_cast_plan()
+        self._cast_plan.run(self._stream())
+        self.weights_stale = False
+
+    def set_images(self, images: torch.Tensor):
+        """images: [B,S,S,3] NHWC (bf16 or fp32; train.py:81 casts to bf16) or the loader's [S,S,3,B] fp32 layout
+        (train.py:80).  Copied into the engine's bf16 NHWC input buffer."""
+        cfg = self.cfg
+        if not images.is_cuda:
+            raise ValueError("images must be on the GPU")
+        S = cfg.img_size
+        if tuple(images.shape) == (self.B, S, S, 3):
+            if images.dtype == bf16:
+                self._img_buf.copy_(images)
+            elif images.dtype == f32:
+                _lib.check(self.L.savit_cast_bf16(images.contiguous().data_ptr(), self._img_buf.data_ptr(), images.numel(), self._stream()),
+                           "savit_cast_bf16")
+            else:
+                raise ValueError("images must be bf16 or fp32")
+        elif tuple(images.shape) == (S, S, 3, self.B) and images.dtype == f32:
+            _lib.check(self.L.savit_hwcn_to_nhwc_bf16(images.contiguous().data_ptr(), self._img_buf.data_ptr(), S, S, 3, self.B,
+                                                      self._stream()), "savit_hwcn_to_nhwc_bf16")
+        else:
+            raise ValueError(f"images shape {tuple(images.shape)} does not match batch {self.B} / img_size {S}")
+
+    def forward(self, images: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Runs the forward launch sequence; returns the engine-owned fp32 logits [B, C]."""
+        if images is not None:
+            self.set_images(images)
+        if self.weights_stale:
+            self.refresh_weights()
+        if self._fwd_plan is None:
+            self._fwd_plan = self._build_fwd_plan()
+        self._fwd_plan.run(self._stream())
+        return self.logits
+
+    def loss_backward(self, labels: torch.Tensor, label_smoothing: float = 0.1, mix_labels: Optional[torch.Tensor] = None,
+                      ratio: Optional[torch.Tensor] = None, zero_grads: bool = True) -> torch.Tensor:
+        """Loss (train.py:83-90) + full backward into self.grads.  Returns the device scalar loss."""
+        s = self._stream()
+        self.labels.copy_(labels.to(torch.int32))
+        if zero_grads:
+            self.grads.zero_()
+        self.loss.zero_()
+        ml = mr = None
+        if mix_labels is not None:
+            self._mix_labels = mix_labels.to(device=self.dev, dtype=torch.int32).contiguous()
+            self._mix_ratio = ratio.to(device=self.dev, dtype=f32).contiguous()
+            ml, mr = self._mix_labels.data_ptr(), self._mix_ratio.data_ptr()
+        _lib.check(self.L.savit_softmax_xent(self.logits.data_ptr(), self.cfg.num_classes, self.labels.data_ptr(), ml, mr,
+                                             float(label_smoothing), 1.0 / self.B, self.loss_rows.data_ptr(), self.loss.data_ptr(),
+                                             self.dlogits.data_ptr(), self.Cp, self._off_ptr(self.grads, "bh"), self.top1.data_ptr(),
+                                             self.top5.data_ptr(), self.B, self.cfg.num_classes, s), "savit_softmax_xent")
+        self.backward_from_dlogits()
+        return self.loss
+
+    def backward_from_dlogits(self):
+        """Backward from self.dlogits (bf16 [B, Cp], pad columns zero) into self.grads (accumulating)."""
+        s = self._stream()
+        if self._bwd_plan is None:
+            self._bwd_plan = self._build_bwd_plan()
+        self.dres.zero_()
+        self.dres_b.zero_()
+        if not self.bwd_hooks:
+            self._bwd_plan.run(s)
+            return
+        for fn, args, label in self._bwd_plan.calls:
+            rc = fn(*args, s)
+            if rc != 0:
+                _lib.check(rc, label)
+            cb = self.bwd_hooks.get(label)
+            if cb is not None:
+                cb()
+
+    def optimizer_step(self, lr: float, weight_decay: float = 0.0, max_norm: float = 0.0, b1: float = 0.9, b2: float = 0.999,
+                       eps: float = 1e-8, grad_scale: float = 1.0):
+        """Fused AdamW over the flat buffers (train.py:25-27,100) + bf16 operand refresh."""
+        if self.adam_m is None:
+            self.adam_m = torch.zeros_like(self.params)
+            self.adam_v = torch.zeros_like(self.params)
+        s = self._stream()
+        self.step_count += 1
+        ss = None
+        if max_norm and max_norm > 0:
+            self.gnorm_sq.zero_()
+            _lib.check(self.L.savit_sumsq(self.grads.data_ptr(), self.grads.numel(), self.gnorm_sq.data_ptr(), s), "savit_sumsq")
+            ss = self.gnorm_sq.data_ptr()
+        _lib.check(self.L.savit_adamw_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
+                                           self.params.numel(), float(lr), float(b1), float(b2), float(eps), float(weight_decay),
+                                           self.step_count, ss, float(max_norm or 0.0), float(grad_scale), s), "savit_adamw_step")
+        self.refresh_weights()
+
+    def activation_bytes(self) -> int:
+        tot = 0
+        for group in (self.x, self.xmid, self.h1, self.h2, self.qkv, self.o, self.u, self.a, self.stats, self.lse):
+            tot += sum(t.numel() * t.element_size() for t in group)
+        return tot

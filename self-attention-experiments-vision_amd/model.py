@@ -1,0 +1,116 @@
+"""Drop-in boundary: the reference's model factory and module protocol for the hot path.
+
+Mirrors /root/reference/models/create_model.py:6-8 (`create_model(model_name, num_classes=1000, dtype=...)`,
+RuntimeError('Model not found.') on unknown names) and the Flax calling convention its callers use
+(train.py:29-37,82,115; models/vit_test.py:23-26):
+
+    model  = create_model('vit_b_patch16', num_classes=1000, dtype=torch.bfloat16)
+    params = model.init(seed, torch.ones(1, 224, 224, 3), is_training=False)        # {'params': Flax-shaped tree}
+    logits = model.apply(params, images_NHWC, is_training=True)                      # [B, num_classes]
+    logits, params = model.init_with_output(seed, x, is_training=True)               # as in the reference tests
+    logits = model(images_NHWC, is_training)                                         # module(inputs, is_training)
+
+Every tensor lives on the GPU; the arithmetic is the HIP engine (engine.py).  There is no CPU execution path.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .config import ModelConfig, get_config
+from .engine import ViTEngine, _copy_tree
+
+
+def _clone_tree(t):
+    if isinstance(t, dict):
+        return {k: _clone_tree(v) for k, v in t.items()}
+    return t.detach().clone()
+
+
+class ViT:
+    """models/vit.py:61-99 behind the HIP engine.  Stateless w.r.t. parameters in `apply` (the caller owns the
+    tree, as with Flax); `init` / `bind` attach a tree for the `model(images, is_training)` form."""
+
+    def __init__(self, cfg: ModelConfig, dtype=torch.bfloat16):
+        if dtype not in (torch.bfloat16,):
+            raise NotImplementedError("the MI355X path computes in bf16 (MFMA) with fp32 residual/statistics; dtype must be bfloat16")
+        assert cfg.embed_dim % cfg.num_heads == 0  # vit.py:75
+        self.cfg = cfg
+        self.dtype = dtype
+        self._engines: Dict[int, ViTEngine] = {}
+        self._bound_id: Optional[Tuple[int, int]] = None  # (id(tree), version) last loaded into the engines
+
+    # -- engine management: one engine per batch size, sharing parameter / gradient / bf16-weight buffers
+    def engine(self, batch: int) -> ViTEngine:
+        e = self._engines.get(batch)
+        if e is None:
+            e = ViTEngine(self.cfg, batch)
+            if self._engines:
+                first = next(iter(self._engines.values()))
+                e.params, e.grads, e.w = first.params, first.grads, first.w
+                e.adam_m, e.adam_v = first.adam_m, first.adam_v
+                e.weights_stale = first.weights_stale
+            self._engines[batch] = e
+        return e
+
+    def _any_engine(self) -> ViTEngine:
+        if not self._engines:
+            return self.engine(1)
+        return next(iter(self._engines.values()))
+
+    # -- Flax-style protocol
+    def init(self, rng, example_inputs: Optional[torch.Tensor] = None, is_training: bool = False) -> dict:
+        """model.init(rng, ones(1,S,S,3), is_training=False) (train.py:29-31).  `rng` is an int seed.  The example
+        input is used only to check the image size, as Flax uses it only for shapes."""
+        if example_inputs is not None:
+            S = self.cfg.img_size
+            if tuple(example_inputs.shape[1:]) != (S, S, 3):
+                raise ValueError(f"example input must be [B,{S},{S},3] (NHWC)")
+        e = self._any_engine()
+        e.init_params(int(rng))
+        for o in self._engines.values():
+            o.weights_stale = True
+        return _clone_tree(e.param_tree())
+
+    def bind(self, params: dict):
+        """Load a Flax-shaped tree (torch tensors or numpy arrays) into the engine's flat HBM buffer."""
+        e = self._any_engine()
+        e.load_params(params)
+        for o in self._engines.values():
+            o.weights_stale = True
+        return self
+
+    def apply(self, params: dict, images: torch.Tensor, is_training: bool = False, rngs=None) -> torch.Tensor:
+        """TrainState.apply_fn(params, images, is_training=...) (train.py:82,115).  images: NHWC [B,S,S,3] on the GPU,
+        bf16 or fp32 (cast to bf16 like train.py:81).  ViT has no stochastic layer (all dropout rates are 0 in
+        create_model.py:10-37), so is_training only selects nothing here and rngs is ignored."""
+        self.bind(params)
+        return self(images, is_training)
+
+    def init_with_output(self, rng, inputs: torch.Tensor, is_training: bool = True):
+        params = self.init(rng, inputs, is_training)
+        return self(inputs, is_training), params
+
+    def __call__(self, images: torch.Tensor, is_training: bool = False) -> torch.Tensor:
+        if images.dim() != 4:
+            raise ValueError("images must be NHWC [B,S,S,3]")
+        e = self.engine(images.shape[0])
+        logits = e.forward(images)
+        return logits.to(self.dtype)
+
+    # -- training conveniences used by train.py-shaped loops
+    def parameters_tree(self) -> dict:
+        return self._any_engine().param_tree()
+
+    def gradients_tree(self) -> dict:
+        return self._any_engine().grad_tree()
+
+
+def create_model(model_name: str, num_classes: int = 1000, dtype=torch.bfloat16, img_size: int = 224):
+    """models/create_model.py:6-8.  Same names; `vit_ti_patch16` / `vit_s_patch16` added for BASELINE configs 1-2.
+    img_size is an extension (the reference fixes it through the init example; train.py --img_size)."""
+    cfg = get_config(model_name, num_classes=num_classes, img_size=img_size)
+    if cfg.kind == "vit":
+        return ViT(cfg, dtype=dtype)
+    raise NotImplementedError(f"{model_name}: the CaiT family (talking-heads / class-attention kernels) is not built yet")
