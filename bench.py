@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DeiT-B/16 224^2 bf16 TRAIN STEP throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one synthetic batch already resident in HBM:
+  forward (patch-embed, 12 encoder blocks, head) + label-smoothed CE + full backward + gradient all-reduce
+  (RCCL, bucketed, overlapped with backward; N > 1) + fused AdamW + bf16 operand refresh.
+Per-GPU batch is fixed at 128 images (BASELINE config 3: 1024 on 8 GPUs), i.e. weak scaling; `value` is the
+whole-job images/s.  Rank 0 prints ONE JSON line.  Extra objects on that line:
+  roofline      dominant kernel class (the MFMA GEMMs), achieved = algorithmic FLOPs per launch / mean launch duration,
+                measured live with HIP events on the launch stream (one instrumented step after the timed region);
+                peak = dense bf16 MFMA peak of MI355X.  `traffic` is null here (PMC passes are separate rocprofv3 runs;
+                see profiles/ and DESIGN.md).
+  step_roofline whole-step figure of SURVEY.md 8d: images/s/GPU x 105.152 GFLOP per image / peak.
+  cpu_baseline  the CPU restatement (oracle/torch_ref.py, JAX absent: SURVEY 8c) of the same model's train step on this
+                host's cores, bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2516.6  # 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md chip table)
+
+
+def kernel_class(label: str) -> str:
+    if label.endswith(".wgrad") or label == "Wpe.wgrad":
+        return "gemm_wgrad"
+    if label.endswith(".dgrad") or label.split(".")[-1] in ("qkv", "proj", "fc1", "fc2") or label in ("patch_embed", "head"):
+        return "gemm_tn"
+    if "attn" in label:
+        return "attention_bwd" if label.endswith(".bwd") else "attention_fwd"
+    if "ln" in label:
+        return "layernorm_bwd" if label.endswith(".bwd") else "layernorm_fwd"
+    return "other"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="vit_b_patch16", help="workload model (default: DeiT-B/16, the metric's config)")
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--bucket-mb", type=float, default=48.0)
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (WORLD_SIZE is 1)")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU execution path for the product")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import savit_amd  # noqa: F401
+    from savit_amd import ddp
+    from savit_amd.config import get_config, train_flops_per_image
+    from savit_amd.engine import ViTEngine
+
+    cfg = get_config(args.model)
+    B = args.batch
+    eng = ViTEngine(cfg, B)
+    eng.init_params(seed=42)  # train.py:187-189 default seed
+    # the reference zero-initialises the head kernel (vit.py:98); a zero operand would make the first backward
+    # passes run on zeros (higher clocks), so the benchmark gives the head a lecun-normal kernel.
+    g = torch.Generator().manual_seed(7)
+    eng.layout.view(eng.params, "Wh").copy_(torch.randn(cfg.embed_dim, cfg.num_classes, generator=g) * cfg.embed_dim ** -0.5)
+    sync = None
+    if world > 1:
+        ddp.broadcast_params(eng.params)
+        buckets = ddp.plan_buckets(eng.layout.layer_start, eng.layout.final_start, eng.layout.total, int(args.bucket_mb * 2 ** 20 / 4))
+        sync = ddp.GradSync(eng.grads, buckets)
+        eng.bwd_hooks = sync.hooks()
+    eng.refresh_weights()
+
+    # synthetic data, resident in HBM: N(0,1) NHWC images cast to bf16 (train.py:81), uniform labels, seed 42+rank
+    gd = torch.Generator(device="cuda").manual_seed(42 + rank)
+    S = cfg.img_size
+    batches = [(torch.randn(B, S, S, 3, device="cuda", generator=gd).to(torch.bfloat16),
+                torch.randint(0, cfg.num_classes, (B,), device="cuda", generator=gd, dtype=torch.int32)) for _ in range(2)]
+    lr, wd = 5e-4 * (B * world) / 512.0, 1e-4  # train.py:171,214-220 (lr*bs/512), :172-176
+
+    def step(i):
+        img, lab = batches[i & 1]
+        eng.forward(img)
+        eng.loss_backward(lab, label_smoothing=0.1)
+        if sync is not None:
+            sync.wait()
+        eng.optimizer_step(lr=lr, weight_decay=wd, max_norm=1.0, grad_scale=(sync.grad_scale if sync else 1.0))
+
+    for i in range(args.warmup):
+        step(i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(eng.loss.item())
+
+    out = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = B * world * args.steps / elapsed
+        fpi = train_flops_per_image(cfg)
+        per_gpu = value / world
+        out = {
+            "metric": "images/sec DeiT-B/16 224^2 bf16 train step" if args.model == "vit_b_patch16" else f"images/sec {args.model} bf16 train step",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"{args.model} ({'DeiT-B/16' if args.model == 'vit_b_patch16' else args.model}) {S}x{S} train step: "
+                                   "fwd + label-smoothed CE + bwd + grad all-reduce + AdamW",
+                       "images_per_gpu": B, "global_batch": B * world, "seq_len": cfg.seq_len, "parallelism": f"dp{world}",
+                       "final_loss": round(loss, 4)},
+            "step_roofline": {"bound": "mfma", "achieved": round(per_gpu * fpi / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(per_gpu * fpi / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "flops_per_image": fpi},
+        }
+
+    # ---- per-kernel accounting: one instrumented step (HIP events around every launch, on the launch stream)
+    if rank == 0:
+        saved_hooks, eng.bwd_hooks = eng.bwd_hooks, {}
+        times = eng.profile_step(batches[0][1])
+        eng.bwd_hooks = saved_hooks
+        d, F, M = cfg.embed_dim, cfg.hidden, eng.M
+        gemm_flops = {"qkv": 2.0 * M * d * 3 * d, "proj": 2.0 * M * d * d, "fc1": 2.0 * M * d * F, "fc2": 2.0 * M * d * F}
+        cls_ms, cls_n, cls_fl = {}, {}, {}
+        for label, t_ms in times.items():
+            c = kernel_class(label)
+            cls_ms[c] = cls_ms.get(c, 0.0) + t_ms
+            cls_n[c] = cls_n.get(c, 0) + 1
+            fl = 0.0
+            parts = label.split(".")
+            if c in ("gemm_tn", "gemm_wgrad") and len(parts) >= 2 and parts[0].startswith("l"):
+                key = {"Wqkv": "qkv", "Wo": "proj", "W1": "fc1", "W2": "fc2"}.get(parts[1], parts[1])
+                fl = gemm_flops.get(key, 0.0)
+            elif label in ("patch_embed", "Wpe.wgrad"):
+                fl = 2.0 * B * cfg.n_patches * cfg.patch_dim * d
+            elif label.startswith("head"):
+                fl = 2.0 * B * d * cfg.num_classes
+            cls_fl[c] = cls_fl.get(c, 0.0) + fl
+        total_ms = sum(cls_ms.values())
+        dom = max(("gemm_tn", "gemm_wgrad"), key=lambda c: cls_ms.get(c, 0.0))
+        ach = cls_fl[dom] / (cls_ms[dom] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "launches_per_step": cls_n[dom],
+                           "avg_launch_ms": round(cls_ms[dom] / cls_n[dom], 4),
+                           "flops_per_launch": cls_fl[dom] / cls_n[dom], "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
+        out["kernel_breakdown_ms"] = {c: round(v, 3) for c, v in sorted(cls_ms.items(), key=lambda kv: -kv[1])}
+        out["kernel_breakdown_ms"]["sum_fwd_bwd"] = round(total_ms, 3)
+        for c in ("gemm_tn", "gemm_wgrad"):
+            if c != dom and cls_ms.get(c):
+                out.setdefault("other_gemm_tflops", {})[c] = round(cls_fl[c] / (cls_ms[c] * 1e-3) / 1e12, 2)
+
+    # ---- CPU baseline leg (rank 0, N=1 only): the oracle's torch-CPU restatement, bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_ref, vit_ref
+
+        ocfg = vit_ref.get_cfg(args.model)
+        cb = torch_ref.time_train_step(ocfg, batch=8, seconds=args.cpu_seconds)
+        out["cpu_baseline"] = {"value": round(cb["images_per_s"], 3), "unit": "images/s", "cores": cb["cores"], "kind": "port",
+                               "sample": f"{cb['steps']} fp32 train steps (fwd+loss+bwd, no optimizer) of {args.model} at batch 8, "
+                                         f"torch-CPU eager restatement of the reference (JAX absent), {cb['seconds']:.1f} s"}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -154,14 +154,26 @@ def loss_and_grads(params_np: dict, images_np, labels_np, cfg, label_smoothing=0
     return float(loss.detach()), logits.detach().numpy(), gd
 
 
-def time_train_step(cfg, batch: int, seconds: float = 15.0, threads: Optional[int] = None, seed: int = 0):
-    """CPU baseline leg of bench.py: fp32 forward+loss+backward of `cfg` at
-    `batch` on this host's cores with torch eager; returns dict(images_per_s, cores, steps)."""
+def host_cores(cap: int = 16) -> int:
+    """Cores this process may really use: the scheduler affinity, capped (a 1-GPU box exposes 256 logical
+    CPUs but grants a 16-core share; oversubscribing torch's thread pool makes the timing meaningless)."""
     import os
+
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        n = os.cpu_count() or 1
+    return max(1, min(n, cap))
+
+
+def time_train_step(cfg, batch: int, seconds: float = 12.0, threads: Optional[int] = None, seed: int = 0, max_steps: int = 50):
+    """CPU baseline leg of bench.py: fp32 forward+loss+backward of `cfg` at `batch` on this host's
+    cores with torch eager; returns dict(images_per_s, cores, steps, seconds).  Bounded: stops after `seconds`
+    (checked after every step, the first included) or max_steps."""
     import time
     from . import vit_ref
 
-    threads = threads or os.cpu_count() or 1
+    threads = threads or host_cores()
     torch.set_num_threads(threads)
     params = vit_ref.init_params(cfg, seed=seed, randomize=True)
     p = to_torch(params["params"], torch.float32, requires_grad=True)
@@ -174,12 +186,16 @@ def time_train_step(cfg, batch: int, seconds: float = 15.0, threads: Optional[in
         loss = loss_from_logits(forward(p, images, cfg), labels)
         torch.autograd.grad(loss, tensors, allow_unused=True)
 
-    step()  # warm-up
+    t0 = time.perf_counter()
+    step()  # first step doubles as warm-up; it is kept only if the budget is already gone
+    first = time.perf_counter() - t0
+    if first >= seconds:
+        return {"images_per_s": batch / first, "cores": threads, "steps": 1, "seconds": first}
     n, t0 = 0, time.perf_counter()
     while True:
         step()
         n += 1
         el = time.perf_counter() - t0
-        if el >= seconds or n >= 200:
+        if el >= seconds or n >= max_steps:
             break
     return {"images_per_s": n * batch / el, "cores": threads, "steps": n, "seconds": el}

@@ -1,0 +1,83 @@
+"""Data-parallel gradient exchange: the MI355X counterpart of `jax.lax.pmean(grads, 'batch')`
+(/root/reference/train.py:96; replicate/pmap at :228-230).
+
+One process per GPU.  Gradients live in ONE flat fp32 buffer laid out layer-major (engine.ParamLayout), and
+backward finishes layers in reverse order, so a bucket is a contiguous slice [start, end) that becomes final
+right after a known launch of the backward plan.  Each bucket is all-reduced (SUM) with torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for tests) as soon as it is final, asynchronously, so
+the exchange overlaps the remaining backward GEMMs; the 1/world factor is folded into the fused AdamW kernel
+(grad_scale) instead of a separate pass.  Buckets are sized for xGMI's point-to-point links:
+default >= 48 MB so each ring step moves multi-MB chunks per link."""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def plan_buckets(layer_starts: List[int], final_start: int, total: int, min_bucket_elems: int) -> List[Tuple[int, int, str]]:
+    """Buckets in the order backward completes them: [(start, end, trigger_label)].  trigger_label names the
+    backward launch after which the slice is final: 'l{i}.ln1.bwd' closes layer i, 'Wpe.wgrad' closes the
+    embedding block (and everything still open)."""
+    L = len(layer_starts)
+    buckets: List[Tuple[int, int, str]] = []
+    end = total
+    i = L - 1
+    while i >= 0:
+        j = i
+        while j > 0 and end - layer_starts[j] < min_bucket_elems:
+            j -= 1
+        if j == 0:
+            break  # the rest joins the embedding bucket
+        buckets.append((layer_starts[j], end, f"l{j}.ln1.bwd"))
+        end = layer_starts[j]
+        i = j - 1
+    buckets.append((0, end, "Wpe.wgrad"))
+    assert buckets[-1][0] == 0 and sum(e - s for s, e, _ in buckets) == total
+    return buckets
+
+
+class GradSync:
+    def __init__(self, flat_grads: torch.Tensor, buckets: List[Tuple[int, int, str]], group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.flat = flat_grads
+        self.buckets = buckets
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.works: List = []
+        self.launched: List[int] = []
+
+    def hooks(self) -> Dict[str, Callable[[], None]]:
+        return {label: (lambda i=i: self._launch(i)) for i, (_, _, label) in enumerate(self.buckets)}
+
+    def _launch(self, i: int):
+        s, e, _ = self.buckets[i]
+        self.launched.append(i)
+        self.works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        """Block the current stream (GPU) / thread (CPU) until every launched bucket is reduced."""
+        if sorted(self.launched) != list(range(len(self.buckets))):
+            raise RuntimeError(f"gradient buckets launched {self.launched}, expected all {len(self.buckets)}")
+        for w in self.works:
+            w.wait()
+        self.works.clear()
+        self.launched.clear()
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+
+def broadcast_params(flat_params: torch.Tensor, src: int = 0, group=None):
+    """flax.jax_utils.replicate (train.py:228): every rank starts from rank 0's parameters."""
+    dist.broadcast(flat_params, src=src, group=group)
+
+
+def allreduce_scalar_mean(t: torch.Tensor, group=None) -> torch.Tensor:
+    """jax.lax.psum(loss)/n for logging (train.py:119-120)."""
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t /= dist.get_world_size(group)
+    return t

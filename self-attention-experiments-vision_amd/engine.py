@@ -483,6 +483,43 @@ class ViTEngine:
                                            self.step_count, ss, float(max_norm or 0.0), float(grad_scale), s), "savit_adamw_step")
         self.refresh_weights()
 
+    def profile_step(self, labels: torch.Tensor, label_smoothing: float = 0.1) -> Dict[str, float]:
+        """One forward + loss + backward with a HIP event pair around EVERY launch (on the launch stream).
+        Returns {launch label: milliseconds}.  Diagnostic: the events serialise nothing but add host overhead, so
+        use the sum of kernel times, not wall time."""
+        if self.weights_stale:
+            self.refresh_weights()
+        if self._fwd_plan is None:
+            self._fwd_plan = self._build_fwd_plan()
+        if self._bwd_plan is None:
+            self._bwd_plan = self._build_bwd_plan()
+        s = self._stream()
+        self.labels.copy_(labels.to(torch.int32))
+        evs: List[Tuple[str, torch.cuda.Event, torch.cuda.Event]] = []
+
+        def run(plan):
+            for fn, args, label in plan.calls:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                rc = fn(*args, s)
+                b.record()
+                if rc != 0:
+                    _lib.check(rc, label)
+                evs.append((label, a, b))
+
+        run(self._fwd_plan)
+        self.grads.zero_()
+        self.loss.zero_()
+        _lib.check(self.L.savit_softmax_xent(self.logits.data_ptr(), self.cfg.num_classes, self.labels.data_ptr(), None, None,
+                                             float(label_smoothing), 1.0 / self.B, self.loss_rows.data_ptr(), self.loss.data_ptr(),
+                                             self.dlogits.data_ptr(), self.Cp, self._off_ptr(self.grads, "bh"), self.top1.data_ptr(),
+                                             self.top5.data_ptr(), self.B, self.cfg.num_classes, s), "savit_softmax_xent")
+        self.dres.zero_()
+        self.dres_b.zero_()
+        run(self._bwd_plan)
+        torch.cuda.synchronize()
+        return {label: a.elapsed_time(b) for label, a, b in evs}
+
     def activation_bytes(self) -> int:
         tot = 0
         for group in (self.x, self.xmid, self.h1, self.h2, self.qkv, self.o, self.u, self.a, self.stats, self.lse):

@@ -1,0 +1,125 @@
+"""Multi-process (world_size 2, gloo, CPU) tests of the data-parallel gradient exchange (ddp.py): the same
+GradSync / plan_buckets code that bench.py drives over RCCL on the GPUs, here with CPU tensors standing in for
+the engine's flat gradient buffer.  Checks the pmean semantics of /root/reference/train.py:96."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _layout():
+    import savit_amd  # noqa: F401
+    from savit_amd.config import ModelConfig
+    from savit_amd.engine import ParamLayout
+
+    cfg = ModelConfig(kind="vit", num_layers=6, num_heads=2, embed_dim=128, patch=8, num_classes=16, img_size=32)
+    return ParamLayout(cfg)
+
+
+def test_plan_buckets_cover_and_order():
+    from savit_amd import ddp
+
+    lay = _layout()
+    for min_elems in (1, lay.layer_stride, 3 * lay.layer_stride, 10 ** 9):
+        b = ddp.plan_buckets(lay.layer_start, lay.final_start, lay.total, min_elems)
+        # contiguous cover of [0, total), produced from the END of the buffer towards the start
+        assert b[0][1] == lay.total and b[-1][0] == 0 and b[-1][2] == "Wpe.wgrad"
+        for (s0, e0, _), (s1, e1, _) in zip(b, b[1:]):
+            assert s0 == e1 and s0 < e0
+        # a bucket's trigger is the LAST backward launch that writes into it: layer j's ln1.bwd closes layer j
+        for s, e, label in b[:-1]:
+            j = int(label[1:label.index(".")])
+            assert lay.layer_start[j] == s
+        if min_elems == 10 ** 9:
+            assert len(b) == 1
+    # DeiT-B sized layout: 48 MB buckets -> a handful of buckets, each >= 48 MB except possibly the last
+    from savit_amd.config import get_config
+    from savit_amd.engine import ParamLayout
+
+    big = ParamLayout(get_config("vit_b_patch16"))
+    assert big.total >= 86_530_024
+    bb = ddp.plan_buckets(big.layer_start, big.final_start, big.total, 48 * 2 ** 20 // 4)
+    assert 3 <= len(bb) <= 8 and all((e - s) * 4 >= 48 * 2 ** 20 for s, e, _ in bb[:-1])
+
+
+def _worker(rank, world, port, total, buckets, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from savit_amd import ddp
+
+        torch.manual_seed(100 + rank)
+        params = torch.randn(total)
+        ddp.broadcast_params(params)  # replicate (train.py:228)
+        grads = torch.zeros(total)
+        sync = ddp.GradSync(grads, buckets)
+        hooks = sync.hooks()
+        local = torch.randn(total)  # this rank's local-batch gradient
+        # "backward": buckets become final from the end of the buffer; fire each hook right after filling its slice
+        for s, e, label in buckets:
+            grads[s:e] = local[s:e]
+            hooks[label]()
+        sync.wait()
+        mean = grads * sync.grad_scale  # the 1/world factor the fused AdamW kernel applies
+        loss = ddp.allreduce_scalar_mean(torch.tensor([float(rank + 1)]))
+        # second step re-uses the object (works/launched lists must reset)
+        for s, e, label in buckets:
+            grads[s:e] = 1.0
+            hooks[label]()
+        sync.wait()
+        q.put((rank, params.double().sum().item(), local.numpy(), mean.numpy(), float(loss), float(grads.mean())))
+        # a skipped bucket must be reported, not silently ignored
+        hooks[buckets[0][2]]()
+        try:
+            sync.wait()
+            q.put((rank, "no-error"))
+        except RuntimeError:
+            for w in sync.works:
+                w.wait()
+            q.put((rank, "raised"))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_gradsync_gloo_world2():
+    from savit_amd import ddp
+
+    lay = _layout()
+    buckets = ddp.plan_buckets(lay.layer_start, lay.final_start, lay.total, 2 * lay.layer_stride)
+    assert len(buckets) >= 3
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, lay.total, buckets, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res, flags = {}, {}
+    for _ in range(2 * world):
+        item = q.get(timeout=120)
+        if len(item) == 2:
+            flags[item[0]] = item[1]
+        else:
+            res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0]  # parameters replicated from rank 0
+    expect = (res[0][1] + res[1][1]) / 2  # pmean of the local gradients
+    for r in range(world):
+        assert np.allclose(res[r][2], expect, atol=1e-6)
+        assert abs(res[r][3] - 1.5) < 1e-6  # psum(loss)/n
+        assert abs(res[r][4] - 2.0) < 1e-6  # second step: sum of ones over 2 ranks
+        assert flags[r] == "raised"

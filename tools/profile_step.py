@@ -1,0 +1,36 @@
+"""Per-launch timing of one DeiT train step (dev tool)."""
+import sys, os, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import savit_amd
+from savit_amd.config import get_config
+from savit_amd.engine import ViTEngine
+
+model = sys.argv[1] if len(sys.argv) > 1 else "vit_b_patch16"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+cfg = get_config(model)
+eng = ViTEngine(cfg, B)
+eng.init_params(42)
+eng.layout.view(eng.params, "Wh").copy_(torch.randn(cfg.embed_dim, cfg.num_classes) * cfg.embed_dim ** -0.5)
+img = torch.randn(B, 224, 224, 3, device="cuda").to(torch.bfloat16)
+lab = torch.randint(0, 1000, (B,), device="cuda", dtype=torch.int32)
+for _ in range(3):
+    eng.forward(img); eng.loss_backward(lab); eng.optimizer_step(1e-4, 1e-4, 1.0)
+acc = collections.defaultdict(list)
+for _ in range(3):
+    eng.set_images(img)
+    t = eng.profile_step(lab)
+    for k, v in t.items():
+        kk = ".".join(k.split(".")[1:]) if k.startswith("l") and k[1].isdigit() else k
+        acc[kk].append(v)
+d, F, M = cfg.embed_dim, cfg.hidden, eng.M
+fl = {"qkv": 2.0*M*d*3*d, "proj": 2.0*M*d*d, "fc1": 2.0*M*d*F, "fc2": 2.0*M*d*F}
+tot = 0
+for k, v in acc.items():
+    n = len(v) / 3
+    avg = sum(v) / len(v)
+    tot += sum(v) / 3
+    key = {"Wqkv": "qkv", "Wo": "proj", "W1": "fc1", "W2": "fc2"}.get(k.split(".")[0], k.split(".")[0])
+    tf = f"{fl[key]/avg/1e9:7.1f} TF/s" if key in fl else ""
+    print(f"{k:18s} x{n:4.0f}  avg {avg*1e3:8.1f} us  total {sum(v)/3:7.3f} ms  {tf}")
+print("sum", tot)
