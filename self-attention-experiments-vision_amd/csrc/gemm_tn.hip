@@ -16,6 +16,7 @@
 //     share A row-panels.
 #include "common.h"
 #include "savit.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -27,7 +28,20 @@ struct GemmParams {
   int tiles_m, tiles_n;
   int chunks_per_prow;  // PATCH: 16-B chunks per (patch row) = patch*3/8
   int grid_side;        // PATCH: patches per image side
+  int stagger;          // shader cycles the 2nd resident workgroup of each CU sleeps before starting (0 = off)
 };
+
+// De-phase the two workgroups that share a CU.  Both are dispatched at the same instant and would otherwise run their
+// MFMA main loops together and their VALU/store epilogues together for the whole launch (neither pipe overlapped);
+// delaying the second one ONCE by about half a tile period makes one workgroup's epilogue run under the other's main
+// loop, and workgroups dispatched later inherit the offset (they start when a slot frees).  Blocks [256, 512) are the
+// second residents under the observed round-robin dispatch; a different placement only loses the speed-up.
+__device__ __forceinline__ void stagger_start(int cycles) {
+  if (cycles > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)cycles) __builtin_amdgcn_s_sleep(8);
+  }
+}
 
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, f32x4 acc, float (&csum)[4]) {
@@ -102,6 +116,131 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Coalesced epilogue for the bf16-valued epilogues (BF16, BIAS_GELU, RESID, DGELU).
+// The MFMA accumulator layout gives a lane 4 consecutive columns of 16 different rows: stored directly, every wave
+// store instruction touches 16 rows x 32 B - partial cache lines, measured at 1.8-3.9 TB/s effective on the 155 MB
+// outputs of the MLP GEMMs (more than the GELU math).  Instead each wave parks its tile, already rounded to bf16
+// exactly where the reference's bf16 graph rounds (after bias / alpha), in its own slice of the now idle staging LDS
+// (ds_write_b64, 16-B unit XOR-swizzled by row: conflict-free), reads it back row-contiguous (ds_read_b128) and issues
+// 16-B-per-lane loads/stores: one wave instruction = 4 rows x 256 B (or 8 x 128 B) of whole cache lines, for the output
+// AND for the fused operands (fp32 residual, bf16 pre-activation).
+template <int EPI, int WTM, int WTN, int MI, int NI>
+__device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[MI][NI], char* wsm, int row0w, int col0w, int lane) {
+  const savit_gemm_args& a = p.a;
+  constexpr int ROWB = WTN * 2;        // bytes per staged row
+  constexpr int UPR = WTN / 8;         // 16-B units per row (16 or 8)
+  constexpr int RPI = 64 / UPR;        // rows per read instruction
+  const int fr = lane & 15, fq = lane >> 4;
+  // ---- park: lane holds rows 16i+fr, columns 16j + 4fq .. +3
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = col0w + j * 16 + fq * 4;
+    float bb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EPI != SAVIT_EPI_DGELU && a.bias != nullptr && n < a.N) {
+      const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+      bb[0] = b.x; bb[1] = b.y; bb[2] = b.z; bb[3] = b.w;
+      if (a.round_bias_bf16) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bb[k] = round_bf16(bb[k]);
+      }
+    }
+    const float sc = (EPI == SAVIT_EPI_BF16 && n < a.alpha_cols) ? a.alpha : 1.0f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = i * 16 + fr;
+      const int unit = (2 * j + (fq >> 1)) ^ (m & (UPR - 1));
+      const f32x4 v = acc[i][j];
+      float w0 = v[0], w1 = v[1], w2 = v[2], w3 = v[3];
+      if (EPI == SAVIT_EPI_BF16) { w0 *= sc; w1 *= sc; w2 *= sc; w3 *= sc; }
+      *reinterpret_cast<uint2*>(wsm + m * ROWB + unit * 16 + (fq & 1) * 8) =
+          make_uint2(pack_bf16x2(w0 + bb[0], w1 + bb[1]), pack_bf16x2(w2 + bb[2], w3 + bb[3]));
+    }
+  }
+  // ---- drain: row-contiguous, 8 columns (16 B) per lane
+  const int urow = lane / UPR, ucol = lane % UPR;
+  const int n = col0w + ucol * 8;
+  float cs8[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cs8[k] = 0.f;
+  float colscale[8];
+  if (EPI == SAVIT_EPI_RESID) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) colscale[k] = 1.0f;
+    if (a.colscale != nullptr && n < a.N) {
+      const float4 c0 = *reinterpret_cast<const float4*>(a.colscale + n);
+      const float4 c1 = *reinterpret_cast<const float4*>(a.colscale + n + 4);
+      colscale[0] = c0.x; colscale[1] = c0.y; colscale[2] = c0.z; colscale[3] = c0.w;
+      colscale[4] = c1.x; colscale[5] = c1.y; colscale[6] = c1.z; colscale[7] = c1.w;
+    }
+  }
+#pragma unroll 4
+  for (int it = 0; it < WTM / RPI; ++it) {
+    const int ml = it * RPI + urow;
+    const int m = row0w + ml;
+    const uint4 raw = *reinterpret_cast<const uint4*>(wsm + ml * ROWB + ((ucol ^ (ml & (UPR - 1))) << 4));
+    if (m >= a.M || n >= a.N) continue;
+    const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
+    if (EPI == SAVIT_EPI_BF16) {
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n) = raw;
+    } else if (EPI == SAVIT_EPI_BIAS_GELU) {
+      uint32_t g[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float lo = __uint_as_float(rw[k] << 16), hi = __uint_as_float(rw[k] & 0xffff0000u);
+        g[k] = pack_bf16x2(gelu_tanh_f(lo), gelu_tanh_f(hi));
+      }
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n) = raw;
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C2) + (size_t)m * a.ldc + n) = make_uint4(g[0], g[1], g[2], g[3]);
+    } else if (EPI == SAVIT_EPI_RESID) {
+      const float* rp = reinterpret_cast<const float*>(a.aux) + (size_t)m * a.ldaux + n;
+      const float4 r0 = *reinterpret_cast<const float4*>(rp);
+      const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
+      float rs = 1.0f;
+      if (a.rowscale != nullptr) rs = a.rowscale[m / a.rows_per_sample];
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[2 * k] = __uint_as_float(rw[k] << 16);
+        v[2 * k + 1] = __uint_as_float(rw[k] & 0xffff0000u);
+      }
+      float* op = reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + n;
+      *reinterpret_cast<float4*>(op) = make_float4(r0.x + rs * colscale[0] * v[0], r0.y + rs * colscale[1] * v[1],
+                                                   r0.z + rs * colscale[2] * v[2], r0.w + rs * colscale[3] * v[3]);
+      *reinterpret_cast<float4*>(op + 4) = make_float4(r1.x + rs * colscale[4] * v[4], r1.y + rs * colscale[5] * v[5],
+                                                       r1.z + rs * colscale[6] * v[6], r1.w + rs * colscale[7] * v[7]);
+    } else if (EPI == SAVIT_EPI_DGELU) {
+      const uint4 uraw = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.aux) + (size_t)m * a.ldaux + n);
+      const uint32_t uw[4] = {uraw.x, uraw.y, uraw.z, uraw.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dlo = round_bf16(__uint_as_float(rw[k] << 16) * gelu_tanh_grad_f(__uint_as_float(uw[k] << 16)));
+        const float dhi = round_bf16(__uint_as_float(rw[k] & 0xffff0000u) * gelu_tanh_grad_f(__uint_as_float(uw[k] & 0xffff0000u)));
+        cs8[2 * k] += dlo;
+        cs8[2 * k + 1] += dhi;
+        o[k] = pack_bf16x2(dlo, dhi);
+      }
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  if (EPI == SAVIT_EPI_DGELU && a.colsum != nullptr) {
+    // lanes with equal (lane % UPR) own the same 8 columns: fold the RPI row groups, then one atomic per column
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float sdu = cs8[k];
+      if (UPR <= 32) sdu += __shfl_xor(sdu, 32, 64);
+      if (UPR <= 16) sdu += __shfl_xor(sdu, 16, 64);
+      if (UPR <= 8) sdu += __shfl_xor(sdu, 8, 64);
+      if (lane < UPR && n + k < a.N) atomicAdd(a.colsum + n + k, sdu);
+    }
+  }
+}
+
+template <int EPI>
+constexpr bool epi_uses_lds() { return EPI == SAVIT_EPI_BF16 || EPI == SAVIT_EPI_BIAS_GELU || EPI == SAVIT_EPI_RESID || EPI == SAVIT_EPI_DGELU; }
+
 template <int BM, int BN, int WGM, int WGN, int EPI>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(const GemmParams p) {
   constexpr int NW = WGM * WGN;
@@ -113,6 +252,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(const GemmParam
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const savit_gemm_args& a = p.a;
+  stagger_start(p.stagger);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
@@ -220,27 +360,219 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(const GemmParam
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3]
-  const int mrow = row0 + wm * WTM + fr;
-  const int ncol = col0 + wn * WTN + fq * 4;
+  // ---- epilogue
+  if constexpr (epi_uses_lds<EPI>()) {
+    // the staging LDS is idle now (the last K-tile's barrier has passed): each wave parks its tile in its own slice
+    epilogue_lds<EPI, WTM, WTN, MI, NI>(p, acc, smem + wave * (WTM * WTN * 2), row0 + wm * WTM, col0 + wn * WTN, lane);
+  } else {
+    // direct stores: lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3]
+    const int mrow = row0 + wm * WTM + fr;
+    const int ncol = col0 + wn * WTN + fq * 4;
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NI; ++j) {
+      float csum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < MI; ++i) epilogue_store<EPI>(p, mrow + i * 16, ncol + j * 16, acc[i][j], csum);
-    if (EPI == SAVIT_EPI_DGELU && a.colsum != nullptr) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float s = csum[c];
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        s += __shfl_xor(s, 8, 64);
-        const int n = ncol + j * 16 + c;
-        if (fr == 0 && n < a.N) atomicAdd(a.colsum + n, s);
-      }
+      for (int i = 0; i < MI; ++i) epilogue_store<EPI>(p, mrow + i * 16, ncol + j * 16, acc[i][j], csum);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Ring-pipelined variant: K-stages of 32 (64-B LDS rows), S-slot LDS ring filled by LDS-DMA with COUNTED vmcnt
+// (loads stay in flight across the per-stage barrier), and register-prefetched fragments: the fragments of stage
+// kt+1 are read from LDS while the MFMAs of stage kt issue, so MFMAs resume right after each barrier.
+//   slot bytes = (BM + BN) * 64 ; per stage a wave issues G = (BM + BN)/16/NW LDS-DMA instructions.
+//   16-B chunk swizzle for 64-B rows: phys = chunk ^ ((-(row>>2)) & 3)  (conflict-free ds_read_b128, checked per
+//   16-lane read group), applied on the DMA source address and on the fragment read.
+template <int BM, int BN, int WGM, int WGN, int S, int EPI>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const GemmParams p) {
+  constexpr int NW = WGM * WGN;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int MI = WTM / 16, NI = WTN / 16;
+  constexpr int RB = 64;
+  constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_INSTR = BM / 16 / NW, B_INSTR = BN / 16 / NW, G = A_INSTR + B_INSTR;
+  constexpr bool PATCH = (EPI == SAVIT_EPI_PATCH);
+  static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile/wave mismatch");
+  static_assert(G * (S - 2) <= 63, "vmcnt immediate");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const savit_gemm_args& a = p.a;
+  stagger_start(p.stagger);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int tid = xcd_remap(blockIdx.x, nwg);
+  const int tm = tid / p.tiles_n, tn = tid - tm * p.tiles_n;
+  const int row0 = tm * BM, col0 = tn * BN;
+
+  const bf16_t* Abase = reinterpret_cast<const bf16_t*>(a.A);
+  const bf16_t* Bbase = reinterpret_cast<const bf16_t*>(a.Bt) + (size_t)col0 * a.ldb;
+  uint32_t a_bytes, b_bytes;
+  if (PATCH) {
+    const size_t tot = (size_t)(a.M / (p.grid_side * p.grid_side)) * a.img_size * a.img_size * 3 * 2;
+    a_bytes = (uint32_t)(tot > 0xfffffff0ull ? 0xfffffff0ull : tot);
+  } else {
+    Abase += (size_t)row0 * a.lda;
+    const size_t tot = (size_t)(a.M - row0) * a.lda * 2;
+    a_bytes = (uint32_t)(tot > 0xfffffff0ull ? 0xfffffff0ull : tot);
+  }
+  {
+    const size_t tot = (size_t)(a.N - col0) * a.ldb * 2;
+    b_bytes = (uint32_t)(tot > 0xfffffff0ull ? 0xfffffff0ull : tot);
+  }
+  const auto srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Abase), 0, a_bytes, 0x00020000);
+  const auto srdB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bbase), 0, b_bytes, 0x00020000);
+
+  // DMA geometry: one wave-instruction = 16 rows x 64 B; lane -> (row = lane>>2, physical chunk = lane&3)
+  const int lrow = lane >> 2, pch = lane & 3;
+  auto stage = [&](int kt, int slot) {
+    char* sA = smem + slot * STAGE;
+    char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+      const int inst = wave * A_INSTR + i;
+      const int r = inst * 16 + lrow;
+      const int c = pch ^ ((-(r >> 2)) & 3);  // logical 16-B chunk held at this physical slot
+      uint32_t voff;
+      if (PATCH) {
+        const int m = row0 + r;
+        const int ppi = p.grid_side * p.grid_side;
+        const int b = m / ppi, pp = m - b * ppi;
+        const int pi = pp / p.grid_side, pj = pp - pi * p.grid_side;
+        const int kc = kt * 4 + c;
+        const int ph = kc / p.chunks_per_prow, within = kc - ph * p.chunks_per_prow;
+        const size_t pix = ((size_t)b * a.img_size + (size_t)pi * a.patch + ph) * a.img_size + (size_t)pj * a.patch;
+        voff = (m < a.M) ? (uint32_t)(pix * 6 + (size_t)within * 16) : 0xfffffff0u;
+      } else {
+        voff = (uint32_t)r * (uint32_t)(a.lda * 2) + (uint32_t)(kt * RB + c * 16);
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (__attribute__((address_space(3))) void*)(sA + inst * 1024), 16, voff, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+      const int inst = wave * B_INSTR + i;
+      const int r = inst * 16 + lrow;
+      const int c = pch ^ ((-(r >> 2)) & 3);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (__attribute__((address_space(3))) void*)(sB + inst * 1024), 16,
+                                               (uint32_t)r * (uint32_t)(a.ldb * 2) + (uint32_t)(kt * RB + c * 16), 0, 0, 0);
+    }
+  };
+
+  // fragment read offsets inside a slot: row = base16 + (lane&15), logical chunk = lane>>4
+  const int fr = lane & 15, fq = lane >> 4;
+  const int foff = fr * RB + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
+  const int a_frag = (wm * WTM) * RB + foff;
+  const int b_frag = A_BYTES + (wn * WTN) * RB + foff;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int KT = a.K / 32;
+  int slot_issue = 0;
+  const int pre = (S - 1 < KT) ? (S - 1) : KT;
+  for (int s = 0; s < pre; ++s) {
+    stage(s, slot_issue);
+    slot_issue = (slot_issue + 1 == S) ? 0 : slot_issue + 1;
+  }
+  if (pre == S - 1) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (S - 2)) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 af0[MI], af1[MI], bfr[NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) af0[i] = *reinterpret_cast<const bf16x8*>(smem + a_frag + i * 16 * RB);
+#pragma unroll
+  for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(smem + b_frag + j * 16 * RB);
+  int slot_next = (S > 1) ? 1 : 0;  // slot holding stage kt+1
+
+  auto body = [&](bf16x8(&ac)[MI], bf16x8(&an)[MI], int kt) {
+    const bool issue = (kt + S - 1 < KT);
+    if (issue) {
+      stage(kt + S - 1, slot_issue);
+      slot_issue = (slot_issue + 1 == S) ? 0 : slot_issue + 1;
+    }
+    if (issue) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G * (S - 2)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const char* nb = smem + slot_next * STAGE;
+    constexpr int APJ = (MI + NI - 1) / NI;  // A refills per n-tile step
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], ac[i], acc[i][j], 0, 0, 0);
+      // refill in place for stage kt+1 (after the last stage this reads a valid but unused slot: branch-free)
+      bfr[j] = *reinterpret_cast<const bf16x8*>(nb + b_frag + j * 16 * RB);
+#pragma unroll
+      for (int q = 0; q < APJ; ++q) {
+        const int i = j * APJ + q;
+        if (i < MI) an[i] = *reinterpret_cast<const bf16x8*>(nb + a_frag + i * 16 * RB);
+      }
+    }
+    slot_next = (slot_next + 1 == S) ? 0 : slot_next + 1;
+  };
+
+  int kt = 0;
+  for (; kt + 1 < KT; kt += 2) {
+    body(af0, af1, kt);
+    body(af1, af0, kt + 1);
+  }
+  if (kt < KT) body(af0, af1, kt);
+
+  if constexpr (epi_uses_lds<EPI>()) {
+    // all waves must be done reading the ring (the last body's refill reads included) before it is reused
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    epilogue_lds<EPI, WTM, WTN, MI, NI>(p, acc, smem + wave * (WTM * WTN * 2), row0 + wm * WTM, col0 + wn * WTN, lane);
+  } else {
+    const int mrow = row0 + wm * WTM + fr;
+    const int ncol = col0 + wn * WTN + fq * 4;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < MI; ++i) epilogue_store<EPI>(p, mrow + i * 16, ncol + j * 16, acc[i][j], csum);
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, int S>
+int launch_ring(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  p.tiles_m = (p.a.M + BM - 1) / BM;
+  p.tiles_n = (p.a.N + BN - 1) / BN;
+  const dim3 grid(p.tiles_m * p.tiles_n), block(64 * WGM * WGN);
+  const size_t lds = (size_t)S * (BM + BN) * 64;
+#define SAVIT_LAUNCH_EPI(E)                                                                            \
+  case E: {                                                                                            \
+    auto kfn = gemm_tn_ring_kernel<BM, BN, WGM, WGN, S, E>;                                            \
+    if (lds > 48 * 1024) {                                                                             \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return (int)e;                                                              \
+    }                                                                                                  \
+    hipLaunchKernelGGL(kfn, grid, block, lds, s, p);                                                   \
+  } break;
+  switch (p.a.epilogue) {
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_BF16)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_BIAS_GELU)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_RESID)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_DGELU)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_F32)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_PATCH)
+    default: return SAVIT_EINVAL;
+  }
+#undef SAVIT_LAUNCH_EPI
+  SAVIT_LAUNCH_RET();
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -278,10 +610,14 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
   SAVIT_CHECK_ARG(args != nullptr);
   const savit_gemm_args& a = *args;
   SAVIT_CHECK_ARG(a.A && a.Bt && a.C && a.M >= 0 && a.N > 0 && a.K > 0);
-  SAVIT_CHECK_ARG(a.K % BK == 0 && a.N % 4 == 0 && a.ldb >= a.K && a.ldb % 8 == 0 && a.ldc % 4 == 0 && a.ldc >= a.N);
+  SAVIT_CHECK_ARG(a.K % 64 == 0 && a.N % 4 == 0 && (a.epilogue > SAVIT_EPI_DGELU || a.N % 8 == 0) && a.ldb >= a.K && a.ldb % 8 == 0 && a.ldc % 4 == 0 && a.ldc >= a.N);
   SAVIT_CHECK_ARG(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.Bt % 16) == 0 && ((uintptr_t)a.C % 16) == 0);
   GemmParams p{};
   p.a = a;
+  {
+    static const int stagger_env = [] { const char* e = getenv("SAVIT_GEMM_STAGGER"); return e ? atoi(e) : -1; }();
+    p.stagger = stagger_env >= 0 ? stagger_env : 0;
+  }
   if (a.epilogue == SAVIT_EPI_PATCH) {
     SAVIT_CHECK_ARG(a.patch > 0 && a.patch % 8 == 0 && a.img_size % a.patch == 0 && a.K == a.patch * a.patch * 3);
     SAVIT_CHECK_ARG(a.aux != nullptr && a.tokens > 0 && a.token_offset >= 0 && a.ldaux >= a.N && a.ldaux % 4 == 0);
@@ -299,14 +635,18 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   int tile = a.tile;
   if (tile == 0) {
-    // heuristic: big tiles only when they still fill the chip (>= ~2 waves of 256 CUs)
-    const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    tile = (t256 >= 512 && a.N % 256 == 0) ? 2 : 1;
+    // measured on MI355X, cold caches, DeiT-B shapes (tools/bench_gemm2.py): wide outputs (N >= 2048) run best on the
+    // 256x256 ring kernel (half the L2->LDS bytes per flop), narrow ones on the 128x128 ring (more, smaller workgroups)
+    tile = (a.N >= 2048 && a.N % 256 == 0 && a.M >= 2048) ? 7 : 6;
   }
   switch (tile) {
     case 1: return launch_tile<128, 128, 2, 2>(p, s);
     case 2: return launch_tile<256, 256, 2, 4>(p, s);
     case 3: return launch_tile<256, 128, 4, 2>(p, s);
+    case 4: return launch_ring<128, 256, 2, 2, 3>(p, s);
+    case 5: return launch_ring<256, 128, 2, 2, 3>(p, s);
+    case 6: return launch_ring<128, 128, 2, 2, 4>(p, s);
+    case 7: return launch_ring<256, 256, 2, 4, 4>(p, s);
     default: return SAVIT_EINVAL;
   }
 }
