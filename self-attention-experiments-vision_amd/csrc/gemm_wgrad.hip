@@ -16,6 +16,8 @@
 //     fp32 gradient with global_atomic_add_f32 (order-dependent in the last bits, like any atomic sum).
 #include "common.h"
 #include "savit.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -198,6 +200,255 @@ __global__ __launch_bounds__(64 * WGI * WGJ) void gemm_wgrad_kernel(const WgradP
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Ring-pipelined variant: 32-token stages in an S-slot LDS ring filled by LDS-DMA with counted vmcnt (loads stay in
+// flight across the per-stage barrier) and register-prefetched transposed fragments (the fragments of k-step t+1 are
+// read from LDS while the MFMAs of k-step t issue).  One barrier per stage, placed between its two k-steps: every read
+// of a stage's slot is issued before that barrier, so the slot is refilled right after it.
+template <int BI, int BJ, int WGI, int WGJ, int S, bool PATCH>
+__global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_ring_kernel(const WgradParams p) {
+  constexpr int NW = WGI * WGJ;
+  constexpr int TS = 32;  // tokens per stage
+  constexpr int WTI = BI / WGI, WTJ = BJ / WGJ;
+  constexpr int II = WTI / 32, JJ = WTJ / 32;
+  constexpr int XROW = BI * 2, YROW = BJ * 2;
+  constexpr int X_BYTES = TS * XROW, Y_BYTES = TS * YROW, STAGE = X_BYTES + Y_BYTES;
+  constexpr int X_INSTR = X_BYTES / 1024 / NW, Y_INSTR = Y_BYTES / 1024 / NW, G = X_INSTR + Y_INSTR;
+  static_assert(X_BYTES % (1024 * NW) == 0 && Y_BYTES % (1024 * NW) == 0, "tile/wave mismatch");
+  static_assert(G * (S - 1) <= 63, "vmcnt immediate");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wi = wave / WGJ, wj = wave % WGJ;
+  const int tid = blockIdx.x;
+  const int ti = tid / p.tiles_j, tj = tid - ti * p.tiles_j;
+  const int i0 = ti * BI, j0 = tj * BJ;
+  const int st_total = (p.M + TS - 1) / TS;
+  const int st_begin = blockIdx.y * p.tiles_per_split;  // in 32-token stages
+  int st_end = st_begin + p.tiles_per_split;
+  if (st_end > st_total) st_end = st_total;
+  const int NS = st_end - st_begin;
+  if (NS <= 0) return;
+
+  size_t xbytes = PATCH ? (size_t)(p.M / (p.grid_side * p.grid_side)) * p.img_size * p.img_size * 6 : (size_t)p.M * p.ldx * 2;
+  size_t ybytes = PATCH ? (size_t)(p.M / (p.grid_side * p.grid_side)) * p.tokens * p.lddy * 2 : (size_t)p.M * p.lddy * 2;
+  if (xbytes > 0xffffffe0ull) xbytes = 0xffffffe0ull;
+  if (ybytes > 0xffffffe0ull) ybytes = 0xffffffe0ull;
+  const auto srdX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X), 0, (uint32_t)xbytes, 0x00020000);
+  const auto srdY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dY), 0, (uint32_t)ybytes, 0x00020000);
+
+  auto stage = [&](int st, int slot) {
+    char* sX = smem + slot * STAGE;
+    char* sY = sX + X_BYTES;
+    const int m0 = (st_begin + st) * TS;
+    {
+      constexpr int LPR = XROW / 16, RPI = 64 / LPR;
+#pragma unroll
+      for (int i = 0; i < X_INSTR; ++i) {
+        const int inst = wave * X_INSTR + i;
+        const int r = inst * RPI + lane / LPR;
+        const int pc = lane % LPR;
+        const int c = pc ^ ((r & 3) << 2);
+        const int m = m0 + r;
+        uint32_t voff = 0xfffffff0u;
+        if (m < p.M) {
+          if (PATCH) {
+            const int ppi = p.grid_side * p.grid_side;
+            const int b = m / ppi, pp = m - b * ppi;
+            const int pi = pp / p.grid_side, pj = pp - pi * p.grid_side;
+            const int kc = i0 / 8 + c;
+            const int ph = kc / p.chunks_per_prow, within = kc - ph * p.chunks_per_prow;
+            const size_t pix = ((size_t)b * p.img_size + (size_t)pi * p.patch + ph) * p.img_size + (size_t)pj * p.patch;
+            voff = (uint32_t)(pix * 6 + (size_t)within * 16);
+          } else {
+            voff = (uint32_t)((size_t)m * p.ldx * 2 + (size_t)(i0 + c * 8) * 2);
+          }
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdX, (__attribute__((address_space(3))) void*)(sX + inst * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+    {
+      constexpr int LPR = YROW / 16, RPI = 64 / LPR;
+#pragma unroll
+      for (int i = 0; i < Y_INSTR; ++i) {
+        const int inst = wave * Y_INSTR + i;
+        const int r = inst * RPI + lane / LPR;
+        const int pc = lane % LPR;
+        const int c = pc ^ ((r & 3) << 2);
+        const int m = m0 + r;
+        uint32_t voff = 0xfffffff0u;
+        if (m < p.M) {
+          size_t row = m;
+          if (PATCH) {
+            const int ppi = p.grid_side * p.grid_side;
+            const int b = m / ppi, pp = m - b * ppi;
+            row = (size_t)b * p.tokens + p.token_offset + pp;
+          }
+          voff = (uint32_t)(row * p.lddy * 2 + (size_t)(j0 + c * 8) * 2);
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdY, (__attribute__((address_space(3))) void*)(sY + inst * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+  };
+
+  // transposed-fragment addressing (see the 2-stage kernel above): lane -> token q (+8h) of a 4x16 block, columns col..col+3.
+  // The reads are INLINE ASM on purpose: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the
+  // __builtin_amdgcn_ds_read_tr16_b64 builtin whenever an LDS-DMA is in flight (it cannot prove the two do not alias),
+  // which drains the ring every k-step.  The asm form is invisible to that pass; completion is waited for by
+  // `frag_wait` (s_waitcnt lgkmcnt(0) that names every destination "+v", so no consumer or copy can be scheduled above it).
+  const int g = lane >> 4, t = lane & 15;
+  const int q = t >> 2, h = g >> 1;
+  const int colx = wi * WTI + 16 * (g & 1) + 4 * (t & 3);
+  const int coly = wj * WTJ + 16 * (g & 1) + 4 * (t & 3);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  uint32_t offx[II], offy[JJ];  // LDS byte address (slot 0) of token row (8h + q), k-step 0
+#pragma unroll
+  for (int a = 0; a < II; ++a) {
+    const int col = colx + 32 * a;
+    offx[a] = lds0 + (8 * h + q) * XROW + (((col >> 3) ^ (q << 2)) << 4) + ((col & 7) << 1);
+  }
+#pragma unroll
+  for (int b = 0; b < JJ; ++b) {
+    const int col = coly + 32 * b;
+    offy[b] = lds0 + X_BYTES + (8 * h + q) * YROW + (((col >> 3) ^ (q << 2)) << 4) + ((col & 7) << 1);
+  }
+
+  f32x16 acc[II][JJ];
+#pragma unroll
+  for (int a = 0; a < II; ++a)
+#pragma unroll
+    for (int b = 0; b < JJ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  struct Frags {
+    bf16x4 xl[II], xh[II], yl[JJ], yh[JJ];
+  };
+  Frags f0, f1;
+#define SAVIT_TR_READ(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+#define SAVIT_ISSUE_FRAGS(f, slot_off, KS)                                              \
+  do {                                                                                  \
+    _Pragma("unroll") for (int a_ = 0; a_ < II; ++a_) {                                 \
+      SAVIT_TR_READ((f).xl[a_], offx[a_] + (slot_off), (KS) * 16 * XROW);               \
+      SAVIT_TR_READ((f).xh[a_], offx[a_] + (slot_off), (KS) * 16 * XROW + 4 * XROW);    \
+    }                                                                                   \
+    _Pragma("unroll") for (int b_ = 0; b_ < JJ; ++b_) {                                 \
+      SAVIT_TR_READ((f).yl[b_], offy[b_] + (slot_off), (KS) * 16 * YROW);               \
+      SAVIT_TR_READ((f).yh[b_], offy[b_] + (slot_off), (KS) * 16 * YROW + 4 * YROW);    \
+    }                                                                                   \
+  } while (0)
+  auto frag_wait = [&](Frags& f) {
+#pragma unroll
+    for (int a = 0; a < II; ++a) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.xl[a]), "+v"(f.xh[a]));
+#pragma unroll
+    for (int b = 0; b < JJ; ++b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.yl[b]), "+v"(f.yh[b]));
+  };
+  auto mfmas = [&](const Frags& f) {
+    bf16x8 xa[II], yb[JJ];
+#pragma unroll
+    for (int a = 0; a < II; ++a) xa[a] = __builtin_shufflevector(f.xl[a], f.xh[a], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+    for (int b = 0; b < JJ; ++b) yb[b] = __builtin_shufflevector(f.yl[b], f.yh[b], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+    for (int a = 0; a < II; ++a)
+#pragma unroll
+      for (int b = 0; b < JJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[a], yb[b], acc[a][b], 0, 0, 0);
+  };
+
+  const int pre = NS < S ? NS : S;
+  for (int st = 0; st < pre; ++st) stage(st, st);
+  if (pre == S) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (S - 1)) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  SAVIT_ISSUE_FRAGS(f0, 0u, 0);
+
+  int slot = 0;
+  for (int st = 0; st < NS; ++st) {
+    const uint32_t cur_off = (uint32_t)(slot * STAGE);
+    const int nslot = (slot + 1 == S) ? 0 : slot + 1;
+    // k-step 0 of this stage; its fragments were requested one half-step ago
+    frag_wait(f0);
+    SAVIT_ISSUE_FRAGS(f1, cur_off, 1);
+    mfmas(f0);
+    // every read of this slot must be complete before the barrier (the slot is refilled right after it), and
+    // stage st+1 must have landed before its first fragments are requested below
+    frag_wait(f1);
+    if (st + S - 1 < NS) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (S - 2)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (st + S < NS) stage(st + S, slot);
+    // k-step 1, requesting k-step 0 of the next stage (after the last stage: a valid slot, values unused)
+    SAVIT_ISSUE_FRAGS(f0, (uint32_t)(nslot * STAGE), 0);
+    mfmas(f1);
+    slot = nslot;
+  }
+  frag_wait(f0);  // nothing may stay in flight into the epilogue
+#undef SAVIT_ISSUE_FRAGS
+#undef SAVIT_TR_READ
+
+  const int jl = lane & 31, hi5 = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < II; ++a)
+#pragma unroll
+    for (int b = 0; b < JJ; ++b) {
+      const int j = j0 + wj * WTJ + 32 * b + jl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wi * WTI + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi5;
+        if (i < p.Kin && j < p.Nout) atomicAdd(p.dW + (size_t)i * p.lddw + j, acc[a][b][r]);
+      }
+    }
+}
+
+template <int BI, int BJ, int WGI, int WGJ, int S>
+int launch_wgrad_ring(WgradParams p, hipStream_t s, int slots) {
+  constexpr int TS = 32;
+  p.tiles_i = (p.Kin + BI - 1) / BI;
+  p.tiles_j = (p.Nout + BJ - 1) / BJ;
+  const int st_total = (p.M + TS - 1) / TS;
+  int splits = p.splits;
+  if (splits <= 0) {
+    const int tiles = p.tiles_i * p.tiles_j;
+    splits = 1;
+    float best = 0.f;
+    for (int sp = 1; sp <= 24; ++sp) {
+      const int wgs = tiles * sp;
+      const float eff = (float)wgs / (float)(((wgs + slots - 1) / slots) * slots);
+      if (eff > best + 0.02f) { best = eff; splits = sp; }
+      if (eff >= 0.92f) { splits = sp; break; }
+    }
+  }
+  if (splits > st_total) splits = st_total;
+  p.tiles_per_split = (st_total + splits - 1) / splits;
+  p.splits = (st_total + p.tiles_per_split - 1) / p.tiles_per_split;
+  const dim3 grid(p.tiles_i * p.tiles_j, p.splits), block(64 * WGI * WGJ);
+  const size_t lds = (size_t)S * TS * (BI + BJ) * 2;
+  if (p.patch) {
+    auto kfn = gemm_wgrad_ring_kernel<BI, BJ, WGI, WGJ, S, true>;
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kfn, grid, block, lds, s, p);
+  } else {
+    auto kfn = gemm_wgrad_ring_kernel<BI, BJ, WGI, WGJ, S, false>;
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kfn, grid, block, lds, s, p);
+  }
+  SAVIT_LAUNCH_RET();
+}
+
 template <int BI, int BJ, int WGI, int WGJ>
 int launch_wgrad(WgradParams p, hipStream_t s) {
   p.tiles_i = (p.Kin + BI - 1) / BI;
@@ -261,5 +512,20 @@ extern "C" int savit_gemm_bf16_wgrad(const void* X, const void* dY, float* dW, i
     SAVIT_CHECK_ARG(ldx % 8 == 0 && ldx >= Kin);
   }
   if (M == 0) return SAVIT_OK;
-  return launch_wgrad<128, 128, 2, 2>(p, (hipStream_t)stream);
+  // SAVIT_WGRAD_VARIANT (development aid): 0 = auto, 1..4 = ring kernels below, 9 = the 2-stage kernel
+  static const int variant = [] { const char* e = getenv("SAVIT_WGRAD_VARIANT"); return e ? atoi(e) : 0; }();
+  int v = variant;
+  if (v == 0) {
+    // measured on MI355X (tools/bench_wgrad.py, cold caches): big weights run best on 256x256 tiles with one 8-wave
+    // workgroup per CU (fewest L2->LDS bytes per flop and fewest atomic bytes: 4*Kin*Nout*splits); small or ragged ones on
+    // 128x128 tiles, also sized for ONE workgroup per CU so the split count - and with it the atomic traffic - stays low
+    v = (Kin % 256 == 0 && Nout % 256 == 0 && (long)Kin * Nout >= (1 << 20) && !patch) ? 3 : 1;
+  }
+  switch (v) {
+    case 1: return launch_wgrad_ring<128, 128, 2, 2, 4>(p, (hipStream_t)stream, 256);
+    case 2: return launch_wgrad_ring<256, 128, 2, 2, 3>(p, (hipStream_t)stream, 512);
+    case 3: return launch_wgrad_ring<256, 256, 2, 4, 4>(p, (hipStream_t)stream, 256);
+    case 4: return launch_wgrad_ring<128, 128, 2, 2, 3>(p, (hipStream_t)stream, 768);
+    default: return launch_wgrad<128, 128, 2, 2>(p, (hipStream_t)stream);
+  }
 }
