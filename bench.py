@@ -30,6 +30,30 @@ if ROOT not in sys.path:
 MFMA_BF16_PEAK_TFLOPS = 2516.6  # 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md chip table)
 
 
+TN_TILES = {6: "gemm_tn_ring_kernel<128,128,2,2,4,%d>", 7: "gemm_tn_ring_kernel<256,256,2,4,4,%d>"}
+WG_VARIANTS = {1: "gemm_wgrad_ring_kernel<128,128,2,2,4,false>", 3: "gemm_wgrad_ring_kernel<256,256,2,4,4,false>"}
+EPI_OF = {"qkv": 0, "proj": 2, "fc1": 1, "fc2": 2, "fc2.dgrad": 3, "fc1.dgrad": 0, "proj.dgrad": 0, "qkv.dgrad": 0}
+
+
+def kernel_symbol(label: str, lib, M: int, d: int, F: int) -> str:
+    """Launch label of the engine's plan -> the kernel symbol rocprofv3 reports (template arguments as in csrc/)."""
+    parts = label.split(".")
+    op = ".".join(parts[1:]) if parts[0].startswith("l") and parts[0][1:].isdigit() else label
+    shapes = {"qkv": (3 * d, d), "proj": (d, d), "fc1": (F, d), "fc2": (d, F), "fc2.dgrad": (F, d), "fc1.dgrad": (d, F),
+              "proj.dgrad": (d, d), "qkv.dgrad": (d, 3 * d)}
+    if op in shapes:
+        N, K = shapes[op]
+        return TN_TILES[lib.savit_gemm_tn_auto_tile(M, N, K)] % EPI_OF[op]
+    wshapes = {"Wqkv.wgrad": (d, 3 * d), "Wo.wgrad": (d, d), "W1.wgrad": (d, F), "W2.wgrad": (F, d)}
+    if op in wshapes:
+        return WG_VARIANTS[lib.savit_gemm_wgrad_auto_variant(wshapes[op][0], wshapes[op][1], 0)]
+    if "attn" in op:
+        return "attn_bwd_kernel" if op.endswith(".bwd") else "attn_fwd_kernel"
+    if op.startswith("ln"):
+        return "ln_bwd_kernel(+finalize)" if op.endswith(".bwd") else "ln_fwd_kernel"
+    return "other(" + op + ")"
+
+
 def kernel_class(label: str) -> str:
     if label.endswith(".wgrad") or label == "Wpe.wgrad":
         return "gemm_wgrad"
@@ -170,17 +194,25 @@ def main():
                 fl = 2.0 * B * d * cfg.num_classes
             cls_fl[c] = cls_fl.get(c, 0.0) + fl
         total_ms = sum(cls_ms.values())
-        dom = max(("gemm_tn", "gemm_wgrad"), key=lambda c: cls_ms.get(c, 0.0))
-        ach = cls_fl[dom] / (cls_ms[dom] * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "launches_per_step": cls_n[dom],
-                           "avg_launch_ms": round(cls_ms[dom] / cls_n[dom], 4),
-                           "flops_per_launch": cls_fl[dom] / cls_n[dom], "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+        # dominant KERNEL SYMBOL (what rocprofv3 --kernel-trace --stats lists): total time, launches, algorithmic flops
+        sym_ms, sym_n, sym_fl = {}, {}, {}
+        for label, t_ms in times.items():
+            sym = kernel_symbol(label, eng.L, M, d, F)
+            parts = label.split(".")
+            key = {"Wqkv": "qkv", "Wo": "proj", "W1": "fc1", "W2": "fc2"}.get(parts[1], parts[1]) if len(parts) >= 2 else ""
+            fl = gemm_flops.get(key, 0.0) if sym.startswith("gemm") and parts[0].startswith("l") else 0.0
+            sym_ms[sym] = sym_ms.get(sym, 0.0) + t_ms
+            sym_n[sym] = sym_n.get(sym, 0) + 1
+            sym_fl[sym] = sym_fl.get(sym, 0.0) + fl
+        dom = max((k for k in sym_ms if k.startswith("gemm")), key=lambda k: sym_ms[k])
+        ach = sym_fl[dom] / (sym_ms[dom] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "launches_per_step": sym_n[dom],
+                           "avg_launch_ms": round(sym_ms[dom] / sym_n[dom], 4), "share_of_step": round(sym_ms[dom] / total_ms, 3),
+                           "flops_per_launch": sym_fl[dom] / sym_n[dom], "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
         out["kernel_breakdown_ms"] = {c: round(v, 3) for c, v in sorted(cls_ms.items(), key=lambda kv: -kv[1])}
         out["kernel_breakdown_ms"]["sum_fwd_bwd"] = round(total_ms, 3)
-        for c in ("gemm_tn", "gemm_wgrad"):
-            if c != dom and cls_ms.get(c):
-                out.setdefault("other_gemm_tflops", {})[c] = round(cls_fl[c] / (cls_ms[c] * 1e-3) / 1e12, 2)
+        out["gemm_class_tflops"] = {c: round(cls_fl[c] / (cls_ms[c] * 1e-3) / 1e12, 2) for c in ("gemm_tn", "gemm_wgrad") if cls_ms.get(c)}
 
     # ---- CPU baseline leg (rank 0, N=1 only): the oracle's torch-CPU restatement, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

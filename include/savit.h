@@ -85,6 +85,8 @@ typedef struct savit_gemm_args {
 } savit_gemm_args;
 
 int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream);
+/* Tile the auto heuristic (tile == 0) picks for a shape: 6 = 128x128x32 ring (4 waves), 7 = 256x256x32 ring (8 waves). */
+int savit_gemm_tn_auto_tile(int M, int N, int K);
 
 /* Weight-gradient GEMM: dW[Kin, Nout] += X[M, Kin]^T . dY[M, Nout]  (fp32 atomics into dW; caller zeroes).
  * X, dY bf16 row-major; reduction over M is split over `splits` workgroup groups (0 = auto).
@@ -92,6 +94,8 @@ int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream);
  * b*tokens + token_offset + p of the bf16 cotangent buffer [B*tokens, lddy]. */
 int savit_gemm_bf16_wgrad(const void* X, const void* dY, float* dW, int M, int Kin, int Nout, int ldx, int lddy, int lddw,
                           int splits, int patch, int img_size, int tokens, int token_offset, void* stream);
+/* Kernel the wgrad heuristic picks: 1 = 128x128 ring (4 waves), 3 = 256x256 ring (8 waves). */
+int savit_gemm_wgrad_auto_variant(int Kin, int Nout, int patch);
 
 
 /* ---- Fused multi-head self-attention (attention.py:39-58): per (batch, head)

@@ -606,6 +606,13 @@ int launch_tile(const GemmParams& p0, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int savit_gemm_tn_auto_tile(int M, int N, int K) {
+  // measured on MI355X, cold caches, DeiT-B shapes (tools/bench_gemm2.py): wide outputs (N >= 2048) run best on the
+  // 256x256 ring kernel (half the L2->LDS bytes per flop), narrow ones on the 128x128 ring (more, smaller workgroups)
+  (void)K;
+  return (N >= 2048 && N % 256 == 0 && M >= 2048) ? 7 : 6;
+}
+
 extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
   SAVIT_CHECK_ARG(args != nullptr);
   const savit_gemm_args& a = *args;
@@ -634,11 +641,7 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
   if (a.M == 0) return SAVIT_OK;
   hipStream_t s = (hipStream_t)stream;
   int tile = a.tile;
-  if (tile == 0) {
-    // measured on MI355X, cold caches, DeiT-B shapes (tools/bench_gemm2.py): wide outputs (N >= 2048) run best on the
-    // 256x256 ring kernel (half the L2->LDS bytes per flop), narrow ones on the 128x128 ring (more, smaller workgroups)
-    tile = (a.N >= 2048 && a.N % 256 == 0 && a.M >= 2048) ? 7 : 6;
-  }
+  if (tile == 0) tile = savit_gemm_tn_auto_tile(a.M, a.N, a.K);
   switch (tile) {
     case 1: return launch_tile<128, 128, 2, 2>(p, s);
     case 2: return launch_tile<256, 256, 2, 4>(p, s);

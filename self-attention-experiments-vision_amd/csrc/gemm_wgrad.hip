@@ -494,6 +494,13 @@ int launch_wgrad(WgradParams p, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int savit_gemm_wgrad_auto_variant(int Kin, int Nout, int patch) {
+  // measured on MI355X (tools/bench_wgrad.py, cold caches): big weights run best on 256x256 tiles with one 8-wave
+  // workgroup per CU (fewest L2->LDS bytes per flop and fewest atomic bytes: 4*Kin*Nout*splits); small or ragged ones on
+  // 128x128 tiles, also sized for ONE workgroup per CU so the split count - and with it the atomic traffic - stays low
+  return (Kin % 256 == 0 && Nout % 256 == 0 && (long)Kin * Nout >= (1 << 20) && !patch) ? 3 : 1;
+}
+
 extern "C" int savit_gemm_bf16_wgrad(const void* X, const void* dY, float* dW, int M, int Kin, int Nout, int ldx, int lddy,
                                      int lddw, int splits, int patch, int img_size, int tokens, int token_offset, void* stream) {
   SAVIT_CHECK_ARG(X && dY && dW && M >= 0 && Kin > 0 && Nout > 0 && lddw >= Nout);
@@ -515,12 +522,7 @@ extern "C" int savit_gemm_bf16_wgrad(const void* X, const void* dY, float* dW, i
   // SAVIT_WGRAD_VARIANT (development aid): 0 = auto, 1..4 = ring kernels below, 9 = the 2-stage kernel
   static const int variant = [] { const char* e = getenv("SAVIT_WGRAD_VARIANT"); return e ? atoi(e) : 0; }();
   int v = variant;
-  if (v == 0) {
-    // measured on MI355X (tools/bench_wgrad.py, cold caches): big weights run best on 256x256 tiles with one 8-wave
-    // workgroup per CU (fewest L2->LDS bytes per flop and fewest atomic bytes: 4*Kin*Nout*splits); small or ragged ones on
-    // 128x128 tiles, also sized for ONE workgroup per CU so the split count - and with it the atomic traffic - stays low
-    v = (Kin % 256 == 0 && Nout % 256 == 0 && (long)Kin * Nout >= (1 << 20) && !patch) ? 3 : 1;
-  }
+  if (v == 0) v = savit_gemm_wgrad_auto_variant(Kin, Nout, patch);
   switch (v) {
     case 1: return launch_wgrad_ring<128, 128, 2, 2, 4>(p, (hipStream_t)stream, 256);
     case 2: return launch_wgrad_ring<256, 128, 2, 2, 3>(p, (hipStream_t)stream, 512);

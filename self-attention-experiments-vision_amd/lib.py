@@ -37,6 +37,8 @@ _SIGNATURES = {
     "savit_layernorm_bwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_long, c_long, c_int, c_void_p, c_long, c_void_p]),
     "savit_layernorm_bwd_workspace_bytes": (c_long, [c_int, c_int]),
     "savit_gemm_bf16_tn": (c_int, [POINTER(GemmArgs), c_void_p]),
+    "savit_gemm_tn_auto_tile": (c_int, [c_int, c_int, c_int]),
+    "savit_gemm_wgrad_auto_variant": (c_int, [c_int, c_int, c_int]),
     "savit_gemm_bf16_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_void_p]),
     "savit_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
