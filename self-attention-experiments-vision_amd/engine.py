@@ -157,10 +157,10 @@ class ViTEngine:
     def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True):
         if cfg.kind != "vit":
             raise NotImplementedError("ViTEngine handles the ViT family; CaiT uses CaiTEngine")
-        if cfg.head_dim != 64:
-            raise NotImplementedError("attention kernels are built for head_dim 64")
-        if cfg.seq_len > 256:
-            raise NotImplementedError("attention kernels keep the whole head in LDS: seq_len <= 256")
+        if cfg.head_dim not in (48, 64):
+            raise NotImplementedError("attention kernels are built for head_dim 48 and 64")
+        if cfg.seq_len > 608:
+            raise NotImplementedError("attention kernels keep one head's K/V in LDS: seq_len <= 608")
         if cfg.embed_dim % 64 != 0 or cfg.patch % 8 != 0 or cfg.num_classes % 8 != 0:
             raise ValueError("embed_dim % 64, patch % 8 and num_classes % 8 must be 0")
         if not torch.cuda.is_available():
@@ -317,7 +317,7 @@ class ViTEngine:
                                           st[1].data_ptr(), M, d, d, 1e-6, self.rp), f"l{l}.ln1")
             self._gemm(P, f"l{l}.qkv", A=self.h1[l].data_ptr(), Bt=w("Wqkv_t"), C=self.qkv[l].data_ptr(), M=M, N=3 * d, K=d, lda=d, ldb=d,
                        ldc=3 * d, epilogue=_lib.EPI_BF16, alpha=alpha, alpha_cols=d)
-            P.add(L.savit_attention_fwd, (self.qkv[l].data_ptr(), self.o[l].data_ptr(), self.lse[l].data_ptr(), B, N, H, 64, 3 * d),
+            P.add(L.savit_attention_fwd, (self.qkv[l].data_ptr(), self.o[l].data_ptr(), self.lse[l].data_ptr(), B, N, H, cfg.head_dim, 3 * d),
                   f"l{l}.attn")
             self._gemm(P, f"l{l}.proj", A=self.o[l].data_ptr(), Bt=w("Wo_t"), C=self.xmid[l].data_ptr(), aux=x[l].data_ptr(), M=M, N=d, K=d,
                        lda=d, ldb=d, ldc=d, ldaux=d, epilogue=_lib.EPI_RESID)
@@ -369,7 +369,7 @@ class ViTEngine:
             self._gemm(P, f"l{l}.proj.dgrad", A=self.dres_b.data_ptr(), Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=M, N=d, K=d, lda=d, ldb=d,
                        ldc=d, epilogue=_lib.EPI_BF16)
             P.add(L.savit_attention_bwd, (self.qkv[l].data_ptr(), self.o[l].data_ptr(), self.d_o.data_ptr(), self.lse[l].data_ptr(),
-                                          self.dqkv.data_ptr(), B, N, H, 64, 3 * d, 1.0 / math.sqrt(cfg.head_dim)), f"l{l}.attn.bwd")
+                                          self.dqkv.data_ptr(), B, N, H, cfg.head_dim, 3 * d, 1.0 / math.sqrt(cfg.head_dim)), f"l{l}.attn.bwd")
             wgrad(f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), self.dqkv.data_ptr(), gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d)
             self._gemm(P, f"l{l}.qkv.dgrad", A=self.dqkv.data_ptr(), Bt=w("Wqkv_n"), C=self.d_h.data_ptr(), M=M, N=d, K=3 * d, lda=3 * d,
                        ldb=3 * d, ldc=d, epilogue=_lib.EPI_BF16)

@@ -213,11 +213,11 @@ def gemm_wgrad(X: torch.Tensor, dY: torch.Tensor, dW: torch.Tensor, splits: int 
 
 # ---------------------------------------------------------------------------------------------
 def attention_fwd(qkv: torch.Tensor, B: int, N: int, H: int, out: Optional[torch.Tensor] = None,
-                  lse: Optional[torch.Tensor] = None):
-    """Fused softmax attention (attention.py:39-58).  qkv bf16 [B*N, 3*H*64] with pre-scaled queries."""
+                  lse: Optional[torch.Tensor] = None, head_dim: int = 64):
+    """Fused softmax attention (attention.py:39-58).  qkv bf16 [B*N, 3*H*head_dim] with pre-scaled queries."""
     _chk(qkv, bf16, "qkv", 2)
     rows, cols, ld = _rows2d(qkv, "qkv")
-    d = H * 64
+    d = H * head_dim
     if rows < B * N or cols < 3 * d:
         raise ValueError(f"qkv {tuple(qkv.shape)} too small for B={B} N={N} H={H}")
     o = out if out is not None else torch.empty((B * N, d), dtype=bf16, device=qkv.device)
@@ -227,18 +227,18 @@ def attention_fwd(qkv: torch.Tensor, B: int, N: int, H: int, out: Optional[torch
     if not o.is_contiguous() or tuple(o.shape) != (B * N, d) or lse.numel() < B * H * N or not lse.is_contiguous():
         raise ValueError("attention_fwd: bad output buffers")
     L = _lib.load()
-    _lib.check(L.savit_attention_fwd(_p(qkv), _p(o), _p(lse), B, N, H, 64, ld, _stream()), "savit_attention_fwd")
+    _lib.check(L.savit_attention_fwd(_p(qkv), _p(o), _p(lse), B, N, H, head_dim, ld, _stream()), "savit_attention_fwd")
     return o, lse
 
 
 def attention_bwd(qkv: torch.Tensor, o: torch.Tensor, d_o: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int,
-                  dq_scale: float, dqkv: Optional[torch.Tensor] = None):
+                  dq_scale: float, dqkv: Optional[torch.Tensor] = None, head_dim: int = 64):
     _chk(qkv, bf16, "qkv", 2)
     _chk(o, bf16, "o", 2)
     _chk(d_o, bf16, "d_o", 2)
     _chk(lse, f32, "lse")
     rows, cols, ld = _rows2d(qkv, "qkv")
-    d = H * 64
+    d = H * head_dim
     if rows < B * N or cols < 3 * d:
         raise ValueError("qkv too small")
     for name, t in (("o", o), ("d_o", d_o)):
@@ -253,7 +253,7 @@ def attention_bwd(qkv: torch.Tensor, o: torch.Tensor, d_o: torch.Tensor, lse: to
     if r2 < B * N or c2 < 3 * d or ld2 != ld:
         raise ValueError("dqkv must have qkv's shape and row stride")
     L = _lib.load()
-    _lib.check(L.savit_attention_bwd(_p(qkv), _p(o), _p(d_o), _p(lse), _p(dqkv), B, N, H, 64, ld, float(dq_scale), _stream()),
+    _lib.check(L.savit_attention_bwd(_p(qkv), _p(o), _p(d_o), _p(lse), _p(dqkv), B, N, H, head_dim, ld, float(dq_scale), _stream()),
                "savit_attention_bwd")
     return dqkv
 

@@ -21,7 +21,9 @@ d = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 tiles = [int(t) for t in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 4, 5, 7]
 M, F = B * 197, 4 * d
 cases = [("qkv fwd", 3 * d, d, 0), ("proj fwd", d, d, 2), ("fc1 fwd", F, d, 1), ("fc2 fwd", d, F, 2),
-         ("fc2 dgrad", F, d, 3), ("fc1 dgrad", d, F, 0), ("proj dgrad", d, d, 0), ("qkv dgrad", d, 3 * d, 0)]
+         ("fc2 dgrad", F, d, 3), ("fc2 dg-nocs", F, d, 3), ("fc1 dgrad", d, F, 0), ("proj dgrad", d, d, 0), ("qkv dgrad", d, 3 * d, 0)]
+if os.environ.get("ONLY"):
+    cases = [c for c in cases if c[0].startswith(os.environ["ONLY"])]
 # flush buffer to defeat infinity-cache residency between iterations
 flush = torch.empty(512 * 2 ** 20, dtype=torch.uint8, device="cuda")
 for name, N, K, epi in cases:
@@ -36,7 +38,9 @@ for name, N, K, epi in cases:
     if epi == 1:
         kw["C2"] = torch.empty(M, N, device="cuda", dtype=bf16); kw["bias"] = torch.randn(N, device="cuda")
     if epi == 3:
-        kw["aux"] = torch.randn(M, N, device="cuda").to(bf16); kw["colsum"] = torch.zeros(N, device="cuda")
+        kw["aux"] = torch.randn(M, N, device="cuda").to(bf16)
+        if "nocs" not in name:
+            kw["colsum"] = torch.zeros(N, device="cuda")
     fl = 2.0 * M * N * K
     res = []
     for tile in tiles:
