@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="vit_b_patch16", help="workload model (default: DeiT-B/16, the metric's config)")
     ap.add_argument("--batch", type=int, default=128, help="images per GPU")
+    ap.add_argument("--img-size", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--bucket-mb", type=float, default=48.0)
@@ -102,7 +103,7 @@ def main():
     from savit_amd.config import get_config, train_flops_per_image
     from savit_amd.engine import ViTEngine
 
-    cfg = get_config(args.model)
+    cfg = get_config(args.model, img_size=args.img_size)
     B = args.batch
     eng = ViTEngine(cfg, B)
     eng.init_params(seed=42)  # train.py:187-189 default seed
@@ -218,7 +219,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import torch_ref, vit_ref
 
-        ocfg = vit_ref.get_cfg(args.model)
+        ocfg = vit_ref.get_cfg(args.model, img_size=args.img_size)
         cb = torch_ref.time_train_step(ocfg, batch=8, seconds=args.cpu_seconds)
         out["cpu_baseline"] = {"value": round(cb["images_per_s"], 3), "unit": "images/s", "cores": cb["cores"], "kind": "port",
                                "sample": f"{cb['steps']} fp32 train steps (fwd+loss+bwd, no optimizer) of {args.model} at batch 8, "

@@ -175,12 +175,40 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[M
       colscale[4] = c1.x; colscale[5] = c1.y; colscale[6] = c1.z; colscale[7] = c1.w;
     }
   }
-#pragma unroll 4
-  for (int it = 0; it < WTM / RPI; ++it) {
+  // The fused operands (fp32 residual rows / bf16 pre-activation rows) come from HBM at ~2 us latency: ALL of this wave's
+  // loads are issued back to back BEFORE the first use (the accumulators are dead after the park, so the registers are
+  // free); a load-use-load-use loop exposed that latency once per group of rows and made these epilogues latency-bound.
+  constexpr int NIT = WTM / RPI;
+  const bool ncol_ok = n < a.N;
+  [[maybe_unused]] float4 res0[EPI == SAVIT_EPI_RESID ? NIT : 1], res1[EPI == SAVIT_EPI_RESID ? NIT : 1];
+  [[maybe_unused]] uint4 uaux[EPI == SAVIT_EPI_DGELU ? NIT : 1];
+  if (EPI == SAVIT_EPI_RESID) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = row0w + it * RPI + urow;
+      res0[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      res1[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < a.M && ncol_ok) {
+        const float* rp = reinterpret_cast<const float*>(a.aux) + (size_t)m * a.ldaux + n;
+        res0[it] = *reinterpret_cast<const float4*>(rp);
+        res1[it] = *reinterpret_cast<const float4*>(rp + 4);
+      }
+    }
+  }
+  if (EPI == SAVIT_EPI_DGELU) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = row0w + it * RPI + urow;
+      uaux[it] = make_uint4(0u, 0u, 0u, 0u);
+      if (m < a.M && ncol_ok) uaux[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.aux) + (size_t)m * a.ldaux + n);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
     const int ml = it * RPI + urow;
     const int m = row0w + ml;
     const uint4 raw = *reinterpret_cast<const uint4*>(wsm + ml * ROWB + ((ucol ^ (ml & (UPR - 1))) << 4));
-    if (m >= a.M || n >= a.N) continue;
+    if (m >= a.M || !ncol_ok) continue;
     const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
     if (EPI == SAVIT_EPI_BF16) {
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n) = raw;
@@ -194,9 +222,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[M
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n) = raw;
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C2) + (size_t)m * a.ldc + n) = make_uint4(g[0], g[1], g[2], g[3]);
     } else if (EPI == SAVIT_EPI_RESID) {
-      const float* rp = reinterpret_cast<const float*>(a.aux) + (size_t)m * a.ldaux + n;
-      const float4 r0 = *reinterpret_cast<const float4*>(rp);
-      const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
+      const float4 r0 = res0[it], r1 = res1[it];
       float rs = 1.0f;
       if (a.rowscale != nullptr) rs = a.rowscale[m / a.rows_per_sample];
       float v[8];
@@ -211,7 +237,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[M
       *reinterpret_cast<float4*>(op + 4) = make_float4(r1.x + rs * colscale[4] * v[4], r1.y + rs * colscale[5] * v[5],
                                                        r1.z + rs * colscale[6] * v[6], r1.w + rs * colscale[7] * v[7]);
     } else if (EPI == SAVIT_EPI_DGELU) {
-      const uint4 uraw = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.aux) + (size_t)m * a.ldaux + n);
+      const uint4 uraw = uaux[it];
       const uint32_t uw[4] = {uraw.x, uraw.y, uraw.z, uraw.w};
       uint32_t o[4];
 #pragma unroll
@@ -607,10 +633,14 @@ int launch_tile(const GemmParams& p0, hipStream_t s) {
 }  // namespace
 
 extern "C" int savit_gemm_tn_auto_tile(int M, int N, int K) {
-  // measured on MI355X, cold caches, DeiT-B shapes (tools/bench_gemm2.py): wide outputs (N >= 2048) run best on the
-  // 256x256 ring kernel (half the L2->LDS bytes per flop), narrow ones on the 128x128 ring (more, smaller workgroups)
+  // measured on MI355X, cold caches (tools/bench_gemm2.py; DeiT-B, DeiT-S and ViT-L/16-384 shapes): the 256x256 ring
+  // kernel (half the L2->LDS bytes per flop, one 8-wave workgroup per CU) wins once its grid is at least two rounds of
+  // 256 workgroups; smaller problems run better as 128x128 tiles (more, smaller workgroups, 2-3 per CU).
   (void)K;
-  return (N >= 2048 && N % 256 == 0 && M >= 2048) ? 7 : 6;
+  static const int force = [] { const char* e = getenv("SAVIT_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  if (force > 0) return force;
+  const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+  return (t256 >= 512 && N % 128 == 0) ? 7 : 6;
 }
 
 extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
@@ -650,6 +680,8 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
     case 5: return launch_ring<256, 128, 2, 2, 3>(p, s);
     case 6: return launch_ring<128, 128, 2, 2, 4>(p, s);
     case 7: return launch_ring<256, 256, 2, 4, 4>(p, s);
+    case 8: return launch_ring<128, 128, 2, 2, 2>(p, s);
+    case 9: return launch_ring<128, 128, 2, 2, 3>(p, s);
     default: return SAVIT_EINVAL;
   }
 }
