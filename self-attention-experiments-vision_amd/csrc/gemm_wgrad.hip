@@ -222,11 +222,17 @@ __global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_ring_kernel(cons
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wi = wave / WGJ, wj = wave % WGJ;
-  const int tid = blockIdx.x;
+  // 1-D grid, XCD-aware: consecutive remapped ids = the tiles of ONE token range (split), so the workgroups that
+  // stream the same X / dY rows sit on the same XCD and share them through its L2 (measured before the remap: 653 MB
+  // of L2 misses per launch for 194 MB of operands - every XCD re-fetched every token range).
+  const int ntile = p.tiles_i * p.tiles_j;
+  const int wid = xcd_remap(blockIdx.x, ntile * p.splits);
+  const int split = wid / ntile;
+  const int tid = wid - split * ntile;
   const int ti = tid / p.tiles_j, tj = tid - ti * p.tiles_j;
   const int i0 = ti * BI, j0 = tj * BJ;
   const int st_total = (p.M + TS - 1) / TS;
-  const int st_begin = blockIdx.y * p.tiles_per_split;  // in 32-token stages
+  const int st_begin = split * p.tiles_per_split;  // in 32-token stages
   int st_end = st_begin + p.tiles_per_split;
   if (st_end > st_total) st_end = st_total;
   const int NS = st_end - st_begin;
@@ -429,7 +435,7 @@ int launch_wgrad_ring(WgradParams p, hipStream_t s, int slots) {
   if (splits > st_total) splits = st_total;
   p.tiles_per_split = (st_total + splits - 1) / splits;
   p.splits = (st_total + p.tiles_per_split - 1) / p.tiles_per_split;
-  const dim3 grid(p.tiles_i * p.tiles_j, p.splits), block(64 * WGI * WGJ);
+  const dim3 grid(p.tiles_i * p.tiles_j * p.splits), block(64 * WGI * WGJ);
   const size_t lds = (size_t)S * TS * (BI + BJ) * 2;
   if (p.patch) {
     auto kfn = gemm_wgrad_ring_kernel<BI, BJ, WGI, WGJ, S, true>;
