@@ -1,0 +1,45 @@
+"""train.py-shaped loop: schedule on CPU; a short real run with eval + checkpoint save/restore on GPU."""
+import json
+import os
+
+import pytest
+
+import train as train_cli
+from oracle import vit_ref
+
+
+def test_schedule_matches_oracle():
+    for step in (0, 1, 49, 50, 51, 500, 999, 1000):
+        assert abs(train_cli.warmup_cosine(step, 1e-3, 50, 1000) - vit_ref.warmup_cosine_lr(step, 1e-3, 50, 1000)) < 1e-12
+
+
+def test_cli_flag_names_match_reference():
+    """The reference's option names (train.py:130-190)."""
+    src = open(train_cli.__file__).read()
+    for flag in ("--data_dir", "--img_size", "--num_epochs", "--batch_size", "--label_smoothing", "--augmentation", "--model_name",
+                 "--lr", "--weight_decay", "--clip_grad", "--checkpoint_dir", "--seed"):
+        assert f'"{flag}"' in src, flag
+
+
+@pytest.mark.gpu
+def test_short_run_eval_checkpoint_restore(tmp_path, capsys):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ck = str(tmp_path / "ck")
+    common = ["--model_name", "vit_ti_patch16", "--batch_size", "8", "--steps_per_epoch", "3", "--checkpoint_dir", ck, "--clip_grad", "1.0",
+              "--eval_every_epochs", "1", "--save_every_epochs", "1", "--log_every", "1", "--lr", "1e-3"]
+    end = train_cli.main(common + ["--num_epochs", "2"])
+    assert end == 6
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    train = [l for l in lines if "train/loss" in l]
+    evals = [l for l in lines if "eval/loss" in l]
+    assert len(train) == 6 and len(evals) == 2
+    assert abs(train[0]["train/loss"] - 6.9078) < 1e-2  # zero-init head: ln(1000) at step 1 (SURVEY 8c i)
+    assert all(0.0 <= e["eval/top-5-acc"] <= 1.0 for e in evals)
+    assert os.path.exists(os.path.join(ck, "checkpoint_6.pt"))
+    end2 = train_cli.main(common + ["--num_epochs", "3"])  # resumes from step 6
+    assert end2 == 9
+    lines2 = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{") and "train/loss" in l]
+    assert [l["step"] for l in lines2] == [7, 8, 9]
