@@ -109,6 +109,19 @@ int savit_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int 
 int savit_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int N, int H,
                         int head_dim, int ld_qkv, float dq_scale, void* stream);
 
+/* ---- Talking-heads attention (CaiT SA layers: attention.py:41-58 with talking_heads=True, talking_heads.py:9-14)
+ *   S_h = q_h k_h^T ; S'_i = sum_h T1[h,i] S_h ; P_i = softmax_k(S'_i) ; P'_i = sum_h T2[h,i] P_h ; O_i = P'_i v_i
+ * T1/T2 fp32 [H,H] ('h i, b h ... -> b i ...').  H in {2,4,6,8}, head_dim 48 or 64, N <= 256, Np = row pitch of the
+ * score buffers (multiple of 8, >= N).  s_buf / p_buf: bf16 [B,H,N,Np] outputs of forward that backward consumes (S is kept,
+ * p_buf is overwritten with dS); ds_buf: bf16 scratch of the same size; dT1/dT2 fp32 [H,H] are accumulated.
+ * dqkv receives dQ*dq_scale | dK | dV like savit_attention_bwd. */
+int savit_th_attention_fwd(const void* qkv, const float* T1, const float* T2, void* s_buf, void* p_buf, void* o, int B, int N, int H,
+                           int head_dim, int ld_qkv, int Np, void* stream);
+int savit_th_attention_bwd(const void* qkv, const float* T1, const float* T2, const void* s_buf, void* p_buf, const void* d_o, void* ds_buf,
+                           void* dqkv, float* dT1, float* dT2, int B, int N, int H, int head_dim, int ld_qkv, int Np, float dq_scale,
+                           void* workspace, long workspace_bytes, void* stream);
+long savit_th_attention_bwd_workspace_bytes(int B, int N, int H);
+
 /* ---- token assembly (vit.py:81-85, position_embed.py:52-57): x0[b,0,:] = cls + pos[0,:] (patch rows are written by
  * SAVIT_EPI_PATCH); and the backward of both adds: dpos[t,:] += sum_b dx0[b,t,:], dcls += sum_b dx0[b,0,:]. */
 int savit_cls_pos_rows(const float* cls, const float* pos, float* x0, int B, long row_stride, int d, void* stream);

@@ -697,6 +697,402 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Talking-heads attention (CaiT SA layers): attention.py:41-58 with talking_heads=True (talking_heads.py:9-14)
+//   S_h = q_h k_h^T ; S'_i = sum_h T1[h,i] S_h ; P_i = softmax_k(S'_i) ; P'_i = sum_h T2[h,i] P_h ; O_i = P'_i v_i
+// The two H x H mixings couple every head at every (q,k), so a per-head flash kernel cannot fuse them.  Round-1
+// form: S and P' are materialised in HBM as bf16 [B,H,N,Np] (exactly the tensors the reference's XLA graph
+// materialises; S is bf16 there too) and the work is split into three kernels per direction:
+//   th_scores (MFMA, per (b,h))  ->  th_softmax (VALU, one wave per (b,q) row, all heads, fp32)  ->  th_pv (MFMA)
+// and backward th_pv_bwd (dP', dV) -> th_softmax_bwd (dS, dT1, dT2; P recomputed from S) -> th_scores_bwd (dQ, dK).
+// Tile loads/stores use the accumulator layouts of the fused kernels above, so no LDS transposition is needed.
+struct ThParams {
+  const bf16_t* qkv;   // [B*N, ld]
+  bf16_t* sbuf;        // S or dS      [B,H,N,Np]
+  bf16_t* pbuf;        // P' or dP'    [B,H,N,Np]
+  bf16_t* o;           // O  [B*N, d]  (fwd out)      /  dO (bwd in, const)
+  bf16_t* dqkv;        // [B*N, ld]
+  int B, N, H, ld, d, Np, nt, hd;
+  float dq_scale;
+};
+
+// S^T / dP'^T accumulator tile -> buf[q][key]: lane = (q, half); registers 4g..4g+3 = keys kt*32 + 8g + 4*half + 0..3
+__device__ __forceinline__ void store_tile_T(bf16_t* rowp, const f32x16& a, int kt, int half, int Np) {
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const int key = kt * 32 + 8 * g4 + 4 * half;
+    if (key < Np)
+      *reinterpret_cast<uint2*>(rowp + key) = make_uint2(pack_bf16x2(a[4 * g4], a[4 * g4 + 1]), pack_bf16x2(a[4 * g4 + 2], a[4 * g4 + 3]));
+  }
+}
+// B-operand fragment of k-step s2 read from buf[q][.]: elements j <-> key = kt*32 + 16*s2 + 8*(j>>2) + 4*half + (j&3)
+__device__ __forceinline__ bf16x8 load_tile_T_frag(const bf16_t* rowp, bool row_ok, int kt, int s2, int half, int Np) {
+  union { uint2 u[2]; bf16x8 v; } r;
+  r.u[0] = make_uint2(0u, 0u);
+  r.u[1] = make_uint2(0u, 0u);
+  const int k0 = kt * 32 + 16 * s2 + 4 * half;
+  if (row_ok && k0 < Np) r.u[0] = *reinterpret_cast<const uint2*>(rowp + k0);
+  if (row_ok && k0 + 8 < Np) r.u[1] = *reinterpret_cast<const uint2*>(rowp + k0 + 8);
+  return r.v;
+}
+// B-operand fragment with the contraction index on the ROWS of buf (column gather): element j <-> row
+// q = qt*32 + 16*s2 + 8*(j>>2) + 4*half + (j&3), fixed column `key`
+__device__ __forceinline__ bf16x8 load_tile_col_frag(const bf16_t* base, int key, int qt, int s2, int half, int N, int Np) {
+  bf16x8 r = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  if (key < Np) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int q = qt * 32 + 16 * s2 + 8 * (j >> 2) + 4 * half + (j & 3);
+      if (q < N) r[j] = (short)base[(size_t)q * Np + key];
+    }
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(512) void th_scores_kernel(const ThParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NT = p.nt, hd = p.hd;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = blockDim.x >> 6;
+  const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H;
+  const long row_base = (long)b * p.N;
+  size_t bytes = (size_t)p.B * p.N * p.ld * 2;
+  if (bytes > 0xffffffe0ull) bytes = 0xffffffe0ull;
+  const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.qkv), 0, (uint32_t)bytes, 0x00020000);
+  stage_image_rt<0>(smem, srd, row_base, p.N, p.ld, p.d + hh * hd, wave, nwv, lane, NT, hd);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int ql = lane & 31, half = lane >> 5;
+  bf16_t* sb = p.sbuf + ((size_t)b * p.H + hh) * p.N * p.Np;
+  for (int qb = wave; qb < NT; qb += nwv) {
+    const int q = qb * 32 + ql;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      qf[ks] = load_row_frag_global(p.qkv, (size_t)(row_base + q), p.ld, hh * hd + 16 * ks + 8 * half, q < p.N && 16 * ks < hd);
+    for (int kt = 0; kt < NT; ++kt) {
+      f32x16 sa;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        if (16 * ks < hd) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(smem, kt * 32 + ql, 2 * ks + half), qf[ks], sa, 0, 0, 0);
+      if (q < p.N) store_tile_T(sb + (size_t)q * p.Np, sa, kt, half, p.Np);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void th_pv_kernel(const ThParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NT = p.nt, hd = p.hd;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = blockDim.x >> 6;
+  const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H;
+  const long row_base = (long)b * p.N;
+  size_t bytes = (size_t)p.B * p.N * p.ld * 2;
+  if (bytes > 0xffffffe0ull) bytes = 0xffffffe0ull;
+  const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.qkv), 0, (uint32_t)bytes, 0x00020000);
+  stage_image_rt<0>(smem, srd, row_base, p.N, p.ld, 2 * p.d + hh * hd, wave, nwv, lane, NT, hd);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int ql = lane & 31, half = lane >> 5, g = lane >> 4, t = lane & 15;
+  const int trow = 4 * (g >> 1) + (t >> 2), tcol = 16 * (g & 1) + 4 * (t & 3);
+  const bf16_t* pb = p.pbuf + ((size_t)b * p.H + hh) * p.N * p.Np;
+  for (int qb = wave; qb < NT; qb += nwv) {
+    const int q = qb * 32 + ql;
+    f32x16 oacc[2];
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[eb][r] = 0.f;
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = load_tile_T_frag(pb + (size_t)q * p.Np, q < p.N, kt, s2, half, p.Np);
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb)
+          oacc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(smem, kt * 32 + 16 * s2 + trow, 32 * eb + tcol), pf, oacc[eb], 0, 0, 0);
+      }
+    }
+    if (q < p.N) {
+      bf16_t* orow = p.o + (size_t)(row_base + q) * p.d + hh * hd;
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int e = 32 * eb + 8 * g4 + 4 * half;
+          if (e < hd)
+            *reinterpret_cast<uint2*>(orow + e) = make_uint2(pack_bf16x2(oacc[eb][4 * g4], oacc[eb][4 * g4 + 1]),
+                                                             pack_bf16x2(oacc[eb][4 * g4 + 2], oacc[eb][4 * g4 + 3]));
+        }
+    }
+  }
+}
+
+// MODE 0: dP' = dO V^T (pbuf out) and dV = P'^T dO (pbuf in is P' -> sbuf carries P' here); see host wrapper.
+// pass A writes out_t[q][key] = sum_e X[q][e] * IMG_A[key][e]; pass B accumulates G[key][e] = sum_q in_c[q][key] * IMG_B[q][e].
+template <int MODE>  // 0: pv backward (A image = V, X = dO, out = dP';  B image = dO, in = P', G = dV)
+                     // 1: scores backward (pass A: dQ^T[e][q] = sum_key K^T[e][key] dS^T[key][q]; pass B: G = dK, B image = Q, in = dS)
+__global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NT = p.nt, hd = p.hd;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = blockDim.x >> 6;
+  const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H;
+  const long row_base = (long)b * p.N;
+  size_t bytes = (size_t)p.B * p.N * p.ld * 2;
+  if (bytes > 0xffffffe0ull) bytes = 0xffffffe0ull;
+  size_t bytes_o = (size_t)p.B * p.N * p.d * 2;
+  if (bytes_o > 0xffffffe0ull) bytes_o = 0xffffffe0ull;
+  const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.qkv), 0, (uint32_t)bytes, 0x00020000);
+  const auto srdO = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.o), 0, (uint32_t)bytes_o, 0x00020000);
+  const int ql = lane & 31, half = lane >> 5, g = lane >> 4, t = lane & 15;
+  const int trow = 4 * (g >> 1) + (t >> 2), tcol = 16 * (g & 1) + 4 * (t & 3);
+  const size_t bh = ((size_t)b * p.H + hh) * p.N * p.Np;
+  // ---- pass A
+  if (MODE == 0) stage_image_rt<0>(smem, srd, row_base, p.N, p.ld, 2 * p.d + hh * hd, wave, nwv, lane, NT, hd);  // V
+  else           stage_image_rt<0>(smem, srd, row_base, p.N, p.ld, p.d + hh * hd, wave, nwv, lane, NT, hd);      // K
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int qb = wave; qb < NT; qb += nwv) {
+    const int q = qb * 32 + ql;
+    if (MODE == 0) {
+      bf16x8 df[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        df[ks] = load_row_frag_global(p.o, (size_t)(row_base + q), p.d, hh * hd + 16 * ks + 8 * half, q < p.N && 16 * ks < hd);
+      for (int kt = 0; kt < NT; ++kt) {
+        f32x16 da;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) da[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          if (16 * ks < hd) da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(smem, kt * 32 + ql, 2 * ks + half), df[ks], da, 0, 0, 0);
+        if (q < p.N) store_tile_T(p.pbuf + bh + (size_t)q * p.Np, da, kt, half, p.Np);
+      }
+    } else {
+      f32x16 dq[2];
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[eb][r] = 0.f;
+      for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 dsf = load_tile_T_frag(p.sbuf + bh + (size_t)q * p.Np, q < p.N, kt, s2, half, p.Np);
+#pragma unroll
+          for (int eb = 0; eb < 2; ++eb)
+            dq[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(smem, kt * 32 + 16 * s2 + trow, 32 * eb + tcol), dsf, dq[eb], 0, 0, 0);
+        }
+      }
+      if (q < p.N) {
+        bf16_t* drow = p.dqkv + (size_t)(row_base + q) * p.ld + hh * hd;
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int e = 32 * eb + 8 * g4 + 4 * half;
+            if (e < hd)
+              *reinterpret_cast<uint2*>(drow + e) = make_uint2(pack_bf16x2(dq[eb][4 * g4] * p.dq_scale, dq[eb][4 * g4 + 1] * p.dq_scale),
+                                                               pack_bf16x2(dq[eb][4 * g4 + 2] * p.dq_scale, dq[eb][4 * g4 + 3] * p.dq_scale));
+          }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- pass B: G^T[e][key] = sum_q IMG^T[e][q] * in[q][key]
+  if (MODE == 0) stage_image_rt<0>(smem, srdO, row_base, p.N, p.d, hh * hd, wave, nwv, lane, NT, hd);   // dO
+  else           stage_image_rt<0>(smem, srd, row_base, p.N, p.ld, hh * hd, wave, nwv, lane, NT, hd);    // Q
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const bf16_t* inb = p.sbuf + bh;  // MODE 0: P' ; MODE 1: dS
+  for (int kb = wave; kb < NT; kb += nwv) {
+    const int key = kb * 32 + ql;
+    f32x16 acc[2];
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[eb][r] = 0.f;
+    for (int qt = 0; qt < NT; ++qt) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 cf = load_tile_col_frag(inb, key, qt, s2, half, p.N, p.Np);
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb)
+          acc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(smem, qt * 32 + 16 * s2 + trow, 32 * eb + tcol), cf, acc[eb], 0, 0, 0);
+      }
+    }
+    if (key < p.N) {
+      bf16_t* grow = p.dqkv + (size_t)(row_base + key) * p.ld + (MODE == 0 ? 2 : 1) * p.d + hh * hd;
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int e = 32 * eb + 8 * g4 + 4 * half;
+          if (e < hd)
+            *reinterpret_cast<uint2*>(grow + e) = make_uint2(pack_bf16x2(acc[eb][4 * g4], acc[eb][4 * g4 + 1]),
+                                                             pack_bf16x2(acc[eb][4 * g4 + 2], acc[eb][4 * g4 + 3]));
+        }
+    }
+  }
+}
+
+// ---- head mixing + softmax rows: one wave per (b, q) row, all H heads, keys strided over the lanes (<= 4 per lane)
+constexpr int TH_KPL = 4;  // keys per lane: Np <= 256
+template <int H>
+__device__ __forceinline__ void th_row_forward(const float (&s)[H][TH_KPL], const float* T1, int N, int lane, float (&pr)[H][TH_KPL]) {
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    float sp[TH_KPL];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < TH_KPL; ++k) {
+      float a = 0.f;
+#pragma unroll
+      for (int h = 0; h < H; ++h) a += T1[h * H + i] * s[h][k];
+      sp[k] = (lane + 64 * k < N) ? a : -INFINITY;
+      m = fmaxf(m, sp[k]);
+    }
+    m = wave_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int k = 0; k < TH_KPL; ++k) {
+      sp[k] = __builtin_amdgcn_exp2f((sp[k] - m) * LOG2E);
+      l += sp[k];
+    }
+    l = wave_sum(l);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int k = 0; k < TH_KPL; ++k) pr[i][k] = sp[k] * inv;
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void th_softmax_fwd_kernel(const bf16_t* __restrict__ S, bf16_t* __restrict__ Pp, const float* __restrict__ T1g,
+                                                              const float* __restrict__ T2g, int B, int N, int Np) {
+  __shared__ float T1[H * H], T2[H * H];
+  for (int i = threadIdx.x; i < H * H; i += blockDim.x) {
+    T1[i] = T1g[i];
+    T2[i] = T2g[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const long rows = (long)B * N;
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+    const int b = (int)(row / N), q = (int)(row - (long)b * N);
+    float s[H][TH_KPL], pr[H][TH_KPL];
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int k = 0; k < TH_KPL; ++k) {
+        const int key = lane + 64 * k;
+        s[h][k] = (key < N) ? bf16_to_f32(S[(((size_t)b * H + h) * N + q) * Np + key]) : 0.f;
+      }
+    th_row_forward<H>(s, T1, N, lane, pr);
+#pragma unroll
+    for (int i = 0; i < H; ++i)
+#pragma unroll
+      for (int k = 0; k < TH_KPL; ++k) {
+        const int key = lane + 64 * k;
+        float a = 0.f;
+#pragma unroll
+        for (int h = 0; h < H; ++h) a += T2[h * H + i] * pr[h][k];
+        if (key < Np) Pp[(((size_t)b * H + i) * N + q) * Np + key] = f32_to_bf16(key < N ? a : 0.f);
+      }
+  }
+}
+
+// backward of the row op; dT1/dT2 partial sums go to slab[block][2*H*H] (summed by th_dT_finalize_kernel)
+template <int H>
+__global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __restrict__ S, const bf16_t* __restrict__ dPp, bf16_t* __restrict__ dS,
+                                                                 const float* __restrict__ T1g, const float* __restrict__ T2g,
+                                                                 float* __restrict__ slab, int B, int N, int Np) {
+  __shared__ float T1[H * H], T2[H * H];
+  __shared__ float red[4][2 * H * H];
+  for (int i = threadIdx.x; i < H * H; i += blockDim.x) {
+    T1[i] = T1g[i];
+    T2[i] = T2g[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float g1[H][H], g2[H][H];  // per-lane partial dT1[h][i], dT2[h][i]
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      g1[h][i] = 0.f;
+      g2[h][i] = 0.f;
+    }
+  const long rows = (long)B * N;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const int b = (int)(row / N), q = (int)(row - (long)b * N);
+    float s[H][TH_KPL], pr[H][TH_KPL], dpp[H][TH_KPL];
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int k = 0; k < TH_KPL; ++k) {
+        const int key = lane + 64 * k;
+        const size_t off = (((size_t)b * H + h) * N + q) * Np + key;
+        s[h][k] = (key < N) ? bf16_to_f32(S[off]) : 0.f;
+        dpp[h][k] = (key < N) ? bf16_to_f32(dPp[off]) : 0.f;
+      }
+    th_row_forward<H>(s, T1, N, lane, pr);
+    // dT2[h][i] += sum_k P_h dP'_i ;  dP_h = sum_i T2[h][i] dP'_i ; delta_h ; dS'_h = P_h (dP_h - delta_h)   (in place in pr)
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float dp[TH_KPL];
+      float del = 0.f;
+#pragma unroll
+      for (int k = 0; k < TH_KPL; ++k) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+          a += T2[h * H + i] * dpp[i][k];
+          g2[h][i] += pr[h][k] * dpp[i][k];
+        }
+        dp[k] = a;
+        del += pr[h][k] * a;
+      }
+      del = wave_sum(del);
+#pragma unroll
+      for (int k = 0; k < TH_KPL; ++k) pr[h][k] = pr[h][k] * (dp[k] - del);
+    }
+    // dS_h = sum_i T1[h][i] dS'_i ; dT1[h][i] += sum_k S_h dS'_i
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int k = 0; k < TH_KPL; ++k) {
+        const int key = lane + 64 * k;
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+          a += T1[h * H + i] * pr[i][k];
+          g1[h][i] += s[h][k] * pr[i][k];
+        }
+        if (key < Np) dS[(((size_t)b * H + h) * N + q) * Np + key] = f32_to_bf16(key < N ? a : 0.f);
+      }
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      const float a = wave_sum(g1[h][i]), c = wave_sum(g2[h][i]);
+      if (lane == 0) {
+        red[wave][h * H + i] = a;
+        red[wave][H * H + h * H + i] = c;
+      }
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * H * H; i += blockDim.x)
+    slab[(size_t)blockIdx.x * 2 * H * H + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
+__global__ void th_dT_finalize_kernel(const float* __restrict__ slab, int nblk, int hh2, float* __restrict__ dT1, float* __restrict__ dT2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * hh2) return;
+  float a = 0.f;
+  for (int r = 0; r < nblk; ++r) a += slab[(size_t)r * 2 * hh2 + i];
+  if (i < hh2) dT1[i] += a; else dT2[i - hh2] += a;
+}
+
 }  // namespace
 
 static bool attn_force_general() {
@@ -772,3 +1168,82 @@ extern "C" int savit_attention_bwd(const void* qkv, const void* o, const void* d
   ATTN_DISPATCH(attn_bwd_kernel, (size_t)4 * NT * 32 * ROWB + (size_t)2 * NT * 32 * sizeof(float))
   SAVIT_LAUNCH_RET();
 }
+
+// ------------------------------------------------------------------------------------------------------------ talking heads (C ABI)
+static int th_fill(ThParams& p, const void* qkv, int B, int N, int H, int head_dim, int ld_qkv, int Np) {
+  if (!(qkv && B >= 0 && N > 0 && H > 0 && (head_dim == 48 || head_dim == 64) && N <= 256 && Np >= N && Np % 8 == 0 && Np <= 256 &&
+        ld_qkv >= 3 * H * head_dim && ld_qkv % 8 == 0 && ((uintptr_t)qkv % 16) == 0))
+    return SAVIT_EINVAL;
+  p.qkv = (const bf16_t*)qkv; p.B = B; p.N = N; p.H = H; p.ld = ld_qkv; p.d = H * head_dim; p.Np = Np; p.nt = (N + 31) / 32; p.hd = head_dim;
+  return SAVIT_OK;
+}
+#define TH_H_DISPATCH(KERNEL, GRID, ...)                                                                  \
+  switch (H) {                                                                                             \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(GRID), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(GRID), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    case 6: hipLaunchKernelGGL(KERNEL<6>, dim3(GRID), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(GRID), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    default: return SAVIT_EINVAL;                                                                          \
+  }
+
+extern "C" long savit_th_attention_bwd_workspace_bytes(int B, int N, int H) {
+  long rows = (long)B * N, blocks = (rows + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  return blocks * 2 * H * H * (long)sizeof(float);
+}
+
+extern "C" int savit_th_attention_fwd(const void* qkv, const float* T1, const float* T2, void* s_buf, void* p_buf, void* o, int B, int N, int H,
+                                      int head_dim, int ld_qkv, int Np, void* stream) {
+  ThParams p{};
+  int rc = th_fill(p, qkv, B, N, H, head_dim, ld_qkv, Np);
+  if (rc) return rc;
+  SAVIT_CHECK_ARG(T1 && T2 && s_buf && p_buf && o && (H == 2 || H == 4 || H == 6 || H == 8));
+  if (B == 0) return SAVIT_OK;
+  p.sbuf = (bf16_t*)s_buf; p.pbuf = (bf16_t*)p_buf; p.o = (bf16_t*)o;
+  const size_t lds = (size_t)p.nt * 32 * ROWB;
+  const int threads = 64 * (p.nt < 8 ? p.nt : 8);
+  hipError_t e = hipFuncSetAttribute((const void*)th_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  e = hipFuncSetAttribute((const void*)th_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(th_scores_kernel, dim3(B * H), dim3(threads), lds, (hipStream_t)stream, p);
+  long rows = (long)B * N, blocks = (rows + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  TH_H_DISPATCH(th_softmax_fwd_kernel, (unsigned)blocks, (const bf16_t*)s_buf, (bf16_t*)p_buf, T1, T2, B, N, Np)
+  hipLaunchKernelGGL(th_pv_kernel, dim3(B * H), dim3(threads), lds, (hipStream_t)stream, p);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_th_attention_bwd(const void* qkv, const float* T1, const float* T2, const void* s_buf, void* p_buf, const void* d_o,
+                                      void* ds_buf, void* dqkv, float* dT1, float* dT2, int B, int N, int H, int head_dim, int ld_qkv, int Np,
+                                      float dq_scale, void* workspace, long workspace_bytes, void* stream) {
+  ThParams p{};
+  int rc = th_fill(p, qkv, B, N, H, head_dim, ld_qkv, Np);
+  if (rc) return rc;
+  SAVIT_CHECK_ARG(T1 && T2 && s_buf && p_buf && d_o && ds_buf && dqkv && dT1 && dT2 && (H == 2 || H == 4 || H == 6 || H == 8));
+  SAVIT_CHECK_ARG(workspace && workspace_bytes >= savit_th_attention_bwd_workspace_bytes(B, N, H) && ((uintptr_t)workspace % 16) == 0);
+  if (B == 0) return SAVIT_OK;
+  const size_t lds = (size_t)p.nt * 32 * ROWB;
+  const int threads = 64 * (p.nt < 8 ? p.nt : 8);
+  hipError_t e = hipFuncSetAttribute((const void*)th_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  e = hipFuncSetAttribute((const void*)th_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  // 1) dP' (into ds_buf) and dV from P' (p_buf) and dO
+  p.o = (bf16_t*)const_cast<void*>(d_o); p.dqkv = (bf16_t*)dqkv; p.dq_scale = dq_scale;
+  p.sbuf = (bf16_t*)p_buf;   // pass B input: P'
+  p.pbuf = (bf16_t*)ds_buf;  // pass A output: dP'
+  hipLaunchKernelGGL(th_bwd_kernel<0>, dim3(B * H), dim3(threads), lds, (hipStream_t)stream, p);
+  // 2) rows: dS (into p_buf: P' is dead now), dT1, dT2
+  long rows = (long)B * N, blocks = (rows + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  TH_H_DISPATCH(th_softmax_bwd_kernel, (unsigned)blocks, (const bf16_t*)s_buf, (const bf16_t*)ds_buf, (bf16_t*)p_buf, T1, T2, (float*)workspace, B,
+                N, Np)
+  hipLaunchKernelGGL(th_dT_finalize_kernel, dim3((2 * H * H + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, (int)blocks,
+                     H * H, dT1, dT2);
+  // 3) dQ, dK from dS (p_buf)
+  p.sbuf = (bf16_t*)p_buf;
+  hipLaunchKernelGGL(th_bwd_kernel<1>, dim3(B * H), dim3(threads), lds, (hipStream_t)stream, p);
+  SAVIT_LAUNCH_RET();
+}
+

@@ -44,6 +44,9 @@ _SIGNATURES = {
     "savit_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "savit_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                     c_void_p]),
+    "savit_th_attention_fwd": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
+    "savit_th_attention_bwd": (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_float, c_void_p, c_long, c_void_p]),
+    "savit_th_attention_bwd_workspace_bytes": (c_long, [c_int, c_int, c_int]),
     "savit_cls_pos_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p]),
     "savit_pos_cls_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "savit_softmax_xent": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,

@@ -385,3 +385,45 @@ def hwcn_to_nhwc_bf16(src: torch.Tensor, dst: Optional[torch.Tensor] = None):
     L = _lib.load()
     _lib.check(L.savit_hwcn_to_nhwc_bf16(_p(src), _p(dst), H, W, C, N, _stream()), "savit_hwcn_to_nhwc_bf16")
     return dst
+
+
+# ---------------------------------------------------------------------------------------------
+def th_attention_fwd(qkv: torch.Tensor, T1: torch.Tensor, T2: torch.Tensor, B: int, N: int, H: int, head_dim: int = 48):
+    """Talking-heads attention forward (CaiT).  Returns (o bf16 [B*N, d], s_buf, p_buf) - the last two feed backward."""
+    _chk(qkv, bf16, "qkv", 2)
+    _chk(T1, f32, "T1", 2)
+    _chk(T2, f32, "T2", 2)
+    rows, cols, ld = _rows2d(qkv, "qkv")
+    d = H * head_dim
+    if rows < B * N or cols < 3 * d or tuple(T1.shape) != (H, H) or tuple(T2.shape) != (H, H) or not T1.is_contiguous() or not T2.is_contiguous():
+        raise ValueError("th_attention_fwd: bad shapes")
+    Np = (N + 7) // 8 * 8
+    s_buf = torch.empty((B, H, N, Np), dtype=bf16, device=qkv.device)
+    p_buf = torch.empty((B, H, N, Np), dtype=bf16, device=qkv.device)
+    o = torch.empty((B * N, d), dtype=bf16, device=qkv.device)
+    L = _lib.load()
+    _lib.check(L.savit_th_attention_fwd(_p(qkv), _p(T1), _p(T2), _p(s_buf), _p(p_buf), _p(o), B, N, H, head_dim, ld, Np, _stream()),
+               "savit_th_attention_fwd")
+    return o, s_buf, p_buf
+
+
+def th_attention_bwd(qkv, T1, T2, s_buf, p_buf, d_o, dT1, dT2, B: int, N: int, H: int, dq_scale: float, head_dim: int = 48):
+    """Backward of th_attention_fwd; p_buf is overwritten.  dT1/dT2 accumulate.  Returns dqkv bf16 [B*N, ld]."""
+    for name, t, dt in (("qkv", qkv, bf16), ("s_buf", s_buf, bf16), ("p_buf", p_buf, bf16), ("d_o", d_o, bf16), ("T1", T1, f32), ("T2", T2, f32),
+                        ("dT1", dT1, f32), ("dT2", dT2, f32)):
+        _chk(t, dt, name)
+    rows, cols, ld = _rows2d(qkv, "qkv")
+    d = H * head_dim
+    Np = s_buf.shape[-1]
+    if tuple(s_buf.shape) != (B, H, N, Np) or tuple(p_buf.shape) != (B, H, N, Np) or tuple(d_o.shape) != (B * N, d) or not d_o.is_contiguous():
+        raise ValueError("th_attention_bwd: bad shapes")
+    if dT1.numel() != H * H or dT2.numel() != H * H:
+        raise ValueError("dT sizes")
+    ds_buf = torch.empty_like(s_buf)
+    dqkv = torch.empty((rows, cols), dtype=bf16, device=qkv.device)
+    L = _lib.load()
+    need = L.savit_th_attention_bwd_workspace_bytes(B, N, H)
+    ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=qkv.device)
+    _lib.check(L.savit_th_attention_bwd(_p(qkv), _p(T1), _p(T2), _p(s_buf), _p(p_buf), _p(d_o), _p(ds_buf), _p(dqkv), _p(dT1), _p(dT2), B, N, H,
+                                        head_dim, ld, Np, float(dq_scale), _p(ws), ws.numel(), _stream()), "savit_th_attention_bwd")
+    return dqkv

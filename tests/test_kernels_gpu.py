@@ -466,3 +466,42 @@ def test_cast_transpose_and_layout(ops):
     assert np.array_equal(host(y), rb(np.transpose(x, (3, 0, 1, 2))))
     z = rng.standard_normal(1003).astype(np.float32)
     assert np.array_equal(host(ops.cast_bf16(dev(z), torch.empty(1003, dtype=bf16, device="cuda"))), rb(z))
+
+
+# ------------------------------------------------------------------------------------------ talking-heads attention (CaiT)
+@pytest.mark.parametrize("B,N,H,hd", [(2, 196, 8, 48), (1, 196, 4, 48), (2, 50, 6, 48), (1, 33, 2, 64), (1, 197, 8, 48)])
+def test_talking_heads_attention(ops, B, N, H, hd):
+    """attention.py:41-58 with talking_heads=True: fp64 autograd reference incl. dT1/dT2 (talking_heads.py:13)."""
+    rng = np.random.default_rng(B + N + H)
+    d = H * hd
+    qkv = rb(rng.standard_normal((B * N, 3 * d)))
+    qkv[:, :d] = rb(qkv[:, :d] / np.sqrt(hd) * 2.0)
+    T1 = (np.linalg.qr(rng.standard_normal((H, H)))[0] + 0.1 * rng.standard_normal((H, H))).astype(np.float32)
+    T2 = (np.linalg.qr(rng.standard_normal((H, H)))[0] + 0.1 * rng.standard_normal((H, H))).astype(np.float32)
+    d_o = rb(rng.standard_normal((B * N, d)))
+    t = torch.tensor(qkv.astype(np.float64), requires_grad=True)
+    t1 = torch.tensor(T1.astype(np.float64), requires_grad=True)
+    t2 = torch.tensor(T2.astype(np.float64), requires_grad=True)
+    x = t.view(B, N, 3, H, hd)
+    q, k, v = x[:, :, 0].permute(0, 2, 1, 3), x[:, :, 1].permute(0, 2, 1, 3), x[:, :, 2].permute(0, 2, 1, 3)
+    s_raw = q @ k.transpose(-1, -2)
+    # the reference's bf16 graph materialises S in bf16 before the fp32 talking-heads mix (SURVEY A.5): emulate that rounding
+    # (straight-through for the gradient), as the kernel stores S as bf16
+    s_rnd = s_raw + (s_raw.detach().float().bfloat16().double() - s_raw.detach())
+    sc = torch.einsum("hi,bhqk->biqk", t1, s_rnd)
+    w = torch.einsum("hi,bhqk->biqk", t2, torch.softmax(sc, dim=-1))
+    o_t = (w @ v).permute(0, 2, 1, 3).reshape(B * N, d)
+    o_t.backward(torch.tensor(d_o.astype(np.float64)))
+    qkv_d, T1d, T2d = dev(qkv, bf16), dev(T1), dev(T2)
+    o, s_buf, p_buf = ops.th_attention_fwd(qkv_d, T1d, T2d, B, N, H, head_dim=hd)
+    assert np.isfinite(host(o)).all()
+    assert rel(host(o), o_t.detach().numpy()) < 5e-3, rel(host(o), o_t.detach().numpy())  # P' is a bf16 MFMA operand
+    dT1 = torch.zeros((H, H), device="cuda")
+    dT2 = torch.zeros((H, H), device="cuda")
+    dqkv = ops.th_attention_bwd(qkv_d, T1d, T2d, s_buf, p_buf, dev(d_o, bf16), dT1, dT2, B, N, H, dq_scale=1.0, head_dim=hd)
+    out, g = host(dqkv), t.grad.numpy()
+    assert np.isfinite(out).all()
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        assert rel(out[:, sl], g[:, sl]) < 2e-2, (name, rel(out[:, sl], g[:, sl]))
+    assert rel(host(dT1), t1.grad.numpy()) < 2e-2, rel(host(dT1), t1.grad.numpy())
+    assert rel(host(dT2), t2.grad.numpy()) < 2e-2, rel(host(dT2), t2.grad.numpy())
