@@ -46,6 +46,30 @@ int savit_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma,
 /* Scratch the call above needs (per-block partial column sums; 16-B aligned, contents undefined afterwards). */
 long savit_layernorm_bwd_workspace_bytes(int rows, int d);
 
+/* Row-mapped variants for the LayerNorm over concat([cls, x]) of CaiT's token-only layers (cait.py:98-99): logical row r of x is
+ * written to (read from, for dy) row (r / grp) * grp_stride + grp_off + r % grp of the bf16 matrix, so the cls rows and the patch rows
+ * are normalised by two calls into ONE [B*(N+1), d] operand without materialising the fp32 concatenation. */
+int savit_layernorm_fwd_mapped(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean, float* rstd, int rows, int d,
+                               long x_stride, float eps, int round_params_bf16, int grp, int grp_stride, int grp_off, void* stream);
+int savit_layernorm_bwd_mapped(const void* dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
+                               const float* dres_in, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* dcolsum, int rows, int d,
+                               long x_stride, long out_stride, int round_params_bf16, int dy_grp, int dy_grp_stride, int dy_grp_off,
+                               void* workspace, long workspace_bytes, void* stream);
+
+/* ---- LayerScale + StochasticDepth backward (layerscale.py:18-23, stochastic_depth.py:16-27): for out = res + rs*ls*branch
+ *   dbranch = bf16(dres * rs * ls) ; d_layerscale += sum_rows dres*rs*branch ; dbias (nullable) += column sums of dbranch.
+ * branch is the bf16 tensor SAVIT_EPI_RESID stores through C2.  workspace: savit_layernorm_bwd_workspace_bytes(rows, d). */
+int savit_layerscale_bwd(const float* dres, const void* branch_bf16, const float* layerscale, const float* rowscale, int rows_per_sample,
+                         void* dbranch_bf16, float* d_layerscale, float* dbias, int rows, int d, long dres_stride, void* workspace,
+                         long workspace_bytes, void* stream);
+
+/* ---- Class attention (cait.py:10-15): one query per image (cls) against Nk keys.  q bf16 [B, ldq] pre-scaled; kv bf16 [B*Nk, ldkv]
+ * with keys at column h*hd and values at column d + h*hd; o bf16 [B, d]; probs fp32 [B,H,Nk] (saved for backward). */
+int savit_class_attention_fwd(const void* q, long ldq, const void* kv, int ldkv, void* o, float* probs, int B, int Nk, int H, int head_dim,
+                              void* stream);
+int savit_class_attention_bwd(const void* q, long ldq, const void* kv, int ldkv, const float* probs, const void* d_o, void* dq, long lddq,
+                              void* dkv, int B, int Nk, int H, int head_dim, float dq_scale, void* stream);
+
 /* ---- Dense / DenseGeneral GEMMs with fused epilogues (bf16 MFMA, fp32 accumulate).
  * C[M,N] = epilogue( A[M,K] . Bt[N,K]^T ).  A and Bt are bf16, K contiguous ("TN"); K % 64 == 0, N % 4 == 0.
  * Replaces nn.Dense / nn.DenseGeneral at attention.py:29-37,60-63, ff.py:26-31, patch_embed.py:23-25,
@@ -53,7 +77,7 @@ long savit_layernorm_bwd_workspace_bytes(int rows, int d);
 enum savit_epilogue {
   SAVIT_EPI_BF16 = 0,      /* C bf16 = acc (* alpha for columns < alpha_cols: query/sqrt(hd), attention.py:39) (+bias) */
   SAVIT_EPI_BIAS_GELU = 1, /* u = bf16(acc+bias) -> C ; gelu_tanh(u) -> C2   (ff.py:26-28) */
-  SAVIT_EPI_RESID = 2,     /* C fp32 = aux_f32 + rowscale[m/rows_per_sample] * colscale[n] * bf16(acc+bias)
+  SAVIT_EPI_RESID = 2,     /* C fp32 = aux_f32 + rowscale[m/rows_per_sample] * colscale[n] * bf16(acc+bias); C2 (nullable) = that bf16 branch
                               (vit.py:24,31; cait.py:36-40,47-52: LayerScale, StochasticDepth, +residual) */
   SAVIT_EPI_DGELU = 3,     /* C bf16 = acc * gelu_tanh'(aux_bf16[m,n]); colsum[n] += column sums  (backward of ff.py:27) */
   SAVIT_EPI_F32 = 4,       /* C fp32 = acc + bias (rounded through bf16 if round_out_bf16)   (vit.py:95-98) */
@@ -65,7 +89,7 @@ typedef struct savit_gemm_args {
   const void* A;          /* bf16 [M, lda]   (SAVIT_EPI_PATCH: images bf16 [B, img, img, 3]) */
   const void* Bt;         /* bf16 [N, ldb] */
   void* C;                /* see epilogue */
-  void* C2;               /* SAVIT_EPI_BIAS_GELU only */
+  void* C2;               /* SAVIT_EPI_BIAS_GELU: gelu output; SAVIT_EPI_RESID: optional bf16 branch (for LayerScale backward) */
   const float* bias;      /* fp32 [N] or NULL */
   const void* aux;        /* RESID: fp32 [M, ldaux]; DGELU: bf16 [M, ldaux]; PATCH: fp32 pos [tokens, N] */
   const float* colscale;  /* fp32 [N] or NULL  (LayerScale) */

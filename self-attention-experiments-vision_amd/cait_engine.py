@@ -1,0 +1,548 @@
+"""CaiT training engine (models/cait.py:140-183 of the reference): patch-embed -> L x [LN -> talking-heads SA -> LayerScale ->
+StochasticDepth -> +res ; LN -> FF -> LayerScale -> StochasticDepth -> +res] -> 2 x class-attention blocks that update only the
+cls token -> LN -> head.  Same design as engine.ViTEngine: flat fp32 parameter / gradient buffers (layer-major), bf16 MFMA operand
+copies in both layouts, prebuilt launch plans, every tensor operation a C-ABI kernel.
+
+Pieces specific to CaiT
+  * talking-heads attention (attention.py:44-52): savit_th_attention_fwd/bwd; S and P' are bf16 [B,H,N,Np] HBM tensors;
+  * LayerScale + stochastic depth (cait.py:36-40,47-52): fused into the residual GEMM epilogue (colscale / rowscale), which also
+    stores the bf16 branch so that savit_layerscale_bwd can form d(layerscale) and the branch cotangent;
+  * class attention (cait.py:96-122): LayerNorm over [cls; x] is two row-mapped LN calls into one [B*(N+1), d] operand (no fp32
+    concat); q is projected for the cls rows only, K|V for all rows, through ONE fused Wqkv whose q rows see a zero cotangent
+    except at the cls rows; savit_class_attention_fwd/bwd does the 1 x (N+1) softmax per (batch, head);
+  * stochastic-depth masks are drawn per step with torch's generator on the GPU (the JAX 'stochastic_depth' rng stream cannot be
+    reproduced) or supplied by the caller (tests): rowscale = floor(keep + U) / keep per sample and branch.
+The reference runs the SA encoder in fp32 because cait.py:147-154 forgets to forward dtype (defect B8); this engine runs all of
+CaiT in bf16 like the ViT path and is checked against the fp32 oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import lib as _lib
+from .config import ModelConfig
+from .engine import _Plan, _align, _copy_tree
+
+bf16 = torch.bfloat16
+f32 = torch.float32
+
+
+class CaiTLayout:
+    def __init__(self, cfg: ModelConfig):
+        self.cfg = cfg
+        d, F, C, N, H = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.n_patches, cfg.num_heads
+        self.off: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        cur = 0
+
+        def add(name, shape):
+            nonlocal cur
+            n = 1
+            for s in shape:
+                n *= s
+            self.off[name] = (cur, tuple(shape))
+            cur += _align(n, 4)
+
+        add("Wpe", (cfg.patch_dim, d))
+        add("pos", (N, d))
+        cur = _align(cur, 64)
+        self.layer_start: List[int] = []
+        for l in range(cfg.num_layers):
+            self.layer_start.append(cur)
+            for nm, shp in (("ln1_g", (d,)), ("ln1_b", (d,)), ("Wqkv", (d, 3 * d)), ("T1", (H, H)), ("T2", (H, H)), ("Wo", (d, d)), ("ls1", (d,)),
+                            ("ln2_g", (d,)), ("ln2_b", (d,)), ("W1", (d, F)), ("b1", (F,)), ("W2", (F, d)), ("b2", (d,)), ("ls2", (d,))):
+                add(f"l{l}.{nm}", shp)
+            cur = _align(cur, 64)
+        self.layer_stride = (self.layer_start[1] - self.layer_start[0]) if cfg.num_layers > 1 else (cur - self.layer_start[0])
+        self.ca_start: List[int] = []
+        for c in range(cfg.num_layers_token_only):
+            self.ca_start.append(cur)
+            for nm, shp in (("ln1_g", (d,)), ("ln1_b", (d,)), ("Wqkv", (d, 3 * d)), ("Wo", (d, d)), ("ls1", (d,)), ("ln2_g", (d,)), ("ln2_b", (d,)),
+                            ("W1", (d, F)), ("b1", (F,)), ("W2", (F, d)), ("b2", (d,)), ("ls2", (d,))):
+                add(f"c{c}.{nm}", shp)
+            cur = _align(cur, 64)
+        self.ca_stride = (self.ca_start[1] - self.ca_start[0]) if cfg.num_layers_token_only > 1 else (cur - (self.ca_start[0] if self.ca_start else cur))
+        self.final_start = cur
+        add("cls", (d,))
+        add("lnf_g", (d,))
+        add("lnf_b", (d,))
+        add("Wh", (d, C))
+        add("bh", (C,))
+        self.total = _align(cur, 64)
+
+    def view(self, flat, name):
+        o, shape = self.off[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return flat[o:o + n].view(*shape)
+
+    def flax_tree(self, flat) -> dict:
+        """Flax-shaped tree of views (CaiT additions)."""
+        cfg = self.cfg
+        d, H, hd = cfg.embed_dim, cfg.num_heads, cfg.head_dim
+        v = lambda n: self.view(flat, n)  # noqa: E731
+
+        def attn(prefix, talking):
+            w = v(prefix + ".Wqkv")
+            t = {"queries": {"kernel": w[:, 0:d].unflatten(1, (H, hd))}, "keys": {"kernel": w[:, d:2 * d].unflatten(1, (H, hd))},
+                 "values": {"kernel": w[:, 2 * d:3 * d].unflatten(1, (H, hd))}, "DenseGeneral_0": {"kernel": v(prefix + ".Wo").view(H, hd, d)}}
+            if talking:
+                t["TalkingHeadsBlock_0"] = {"talking_heads_transform": v(prefix + ".T1")}
+                t["TalkingHeadsBlock_1"] = {"talking_heads_transform": v(prefix + ".T2")}
+            return t
+
+        def block(prefix, attn_name, talking):
+            return {"LayerNorm_0": {"scale": v(prefix + ".ln1_g"), "bias": v(prefix + ".ln1_b")}, attn_name: attn(prefix, talking),
+                    "LayerScaleBlock_0": {"layerscale": v(prefix + ".ls1")},
+                    "LayerNorm_1": {"scale": v(prefix + ".ln2_g"), "bias": v(prefix + ".ln2_b")},
+                    "FFBlock_0": {"Dense_0": {"kernel": v(prefix + ".W1"), "bias": v(prefix + ".b1")},
+                                  "Dense_1": {"kernel": v(prefix + ".W2"), "bias": v(prefix + ".b2")}},
+                    "LayerScaleBlock_1": {"layerscale": v(prefix + ".ls2")}}
+
+        enc = {"AddAbsPosEmbed_0": {"pos_embed": v("pos").view(1, cfg.n_patches, d)}}
+        for l in range(cfg.num_layers):
+            enc[f"EncoderBlock_{l}"] = block(f"l{l}", "SelfAttentionBlock_0", True)
+        p = {"PatchEmbedBlock_0": {"Dense_0": {"kernel": v("Wpe")}}, "Encoder_0": enc, "cls": v("cls").view(1, 1, d),
+             "LayerNorm_0": {"scale": v("lnf_g"), "bias": v("lnf_b")}, "Dense_0": {"kernel": v("Wh"), "bias": v("bh")}}
+        for c in range(cfg.num_layers_token_only):
+            p[f"CAEncoderBlock_{c}"] = block(f"c{c}", "ClassSelfAttentionBlock_0", False)
+        return {"params": p}
+
+
+class CaiTEngine:
+    def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True):
+        if cfg.kind != "cait":
+            raise ValueError("CaiTEngine needs a CaiT config")
+        if cfg.head_dim not in (48, 64) or cfg.num_heads not in (2, 4, 6, 8):
+            raise NotImplementedError("talking-heads kernels: head_dim 48/64 and 2/4/6/8 heads (cait_m_* has 16 heads)")
+        if cfg.n_patches + 1 > 256:
+            raise NotImplementedError("talking-heads / class-attention kernels: at most 255 patches")
+        if cfg.embed_dim % 32 or cfg.patch % 8 or cfg.num_classes % 8:
+            raise ValueError("embed_dim % 32, patch % 8 and num_classes % 8 must be 0")
+        if not torch.cuda.is_available():
+            raise RuntimeError("CaiTEngine needs a GPU: there is no CPU path")
+        self.L = _lib.load()
+        self.cfg, self.B, self.dev, self.rp = cfg, int(batch), torch.device(device), int(round_like_reference)
+        self.layout = CaiTLayout(cfg)
+        d, F, C, N, NL, NC, H = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.n_patches, cfg.num_layers, cfg.num_layers_token_only, cfg.num_heads
+        B = self.B
+        self.M, self.Mc = B * N, B * (N + 1)
+        self.Cp, self.Np = _align(C, 64), _align(N, 8)
+        z = lambda *s, dt=f32: torch.zeros(*s, dtype=dt, device=self.dev)  # noqa: E731
+        e = lambda *s, dt=f32: torch.empty(*s, dtype=dt, device=self.dev)  # noqa: E731
+        self.params, self.grads = z(self.layout.total), z(self.layout.total)
+        self.adam_m = self.adam_v = None
+        self.step_count = 0
+        self.gnorm_sq = z(1)
+        self.w = {}
+        for pre, n in (("", NL), ("c", NC)):
+            for nm, R, Cc in (("Wqkv", d, 3 * d), ("Wo", d, d), ("W1", d, F), ("W2", F, d)):
+                self.w[pre + nm + "_n"] = e(n, R, Cc, dt=bf16)
+                self.w[pre + nm + "_t"] = e(n, Cc, R, dt=bf16)
+        self.w["Wpe_t"], self.w["Wh_t"], self.w["Wh_n"] = e(d, cfg.patch_dim, dt=bf16), e(C, d, dt=bf16), z(d, self.Cp, dt=bf16)
+        M, Mc = self.M, self.Mc
+        # ---- SA activations
+        self.x = [e(M, d) for _ in range(NL + 1)]
+        self.xmid = [e(M, d) for _ in range(NL)]
+        self.h1, self.h2, self.o = ([e(M, d, dt=bf16) for _ in range(NL)] for _ in range(3))
+        self.br1, self.br2 = ([e(M, d, dt=bf16) for _ in range(NL)] for _ in range(2))
+        self.qkv = [e(M, 3 * d, dt=bf16) for _ in range(NL)]
+        self.sbuf = [e(B, H, N, self.Np, dt=bf16) for _ in range(NL)]
+        self.pbuf = [e(B, H, N, self.Np, dt=bf16) for _ in range(NL)]
+        self.u, self.a = ([e(M, F, dt=bf16) for _ in range(NL)] for _ in range(2))
+        self.stats = [e(4, M) for _ in range(NL)]
+        # ---- CA activations
+        self.cls = [e(B, d) for _ in range(NC + 1)]
+        self.clsmid = [e(B, d) for _ in range(NC)]
+        self.hc = [e(Mc, d, dt=bf16) for _ in range(NC)]
+        self.qkvc = [z(Mc, 3 * d, dt=bf16) for _ in range(NC)]
+        self.oc, self.cbr1, self.cbr2, self.hc2 = ([e(B, d, dt=bf16) for _ in range(NC)] for _ in range(4))
+        self.probs = [e(B, H, N + 1) for _ in range(NC)]
+        self.uc, self.ac = ([e(B, F, dt=bf16) for _ in range(NC)] for _ in range(2))
+        self.cstat_x = [e(2, M) for _ in range(NC)]
+        self.cstat_c = [e(4, B) for _ in range(NC)]
+        self.zero_d = z(d)
+        self.zcls, self.fstats, self.logits = e(B, d, dt=bf16), e(2, B), e(B, C)
+        # ---- stochastic depth scales [(NL + NC) * 2, B]
+        self.sd = torch.ones((NL + NC) * 2, B, dtype=f32, device=self.dev)
+        self.gen = torch.Generator(device=self.dev).manual_seed(0)
+        # ---- backward scratch
+        self.dres, self.dres_b = e(M, d), e(M, d, dt=bf16)
+        self.dbr, self.d_h, self.d_o = e(M, d, dt=bf16), e(M, d, dt=bf16), e(M, d, dt=bf16)
+        self.d_u = e(M, F, dt=bf16)
+        self.dqkv = e(M, 3 * d, dt=bf16)
+        self.dsbuf = e(B, H, N, self.Np, dt=bf16)
+        self.dcls, self.dcls_b = e(B, d), e(B, d, dt=bf16)
+        self.dbr_c, self.d_hc2, self.d_oc = e(B, d, dt=bf16), e(B, d, dt=bf16), e(B, d, dt=bf16)
+        self.d_uc = e(B, F, dt=bf16)
+        self.dqkvc = z(Mc, 3 * d, dt=bf16)
+        self.d_hc = e(Mc, d, dt=bf16)
+        self.dlogits, self.d_z = z(B, self.Cp, dt=bf16), e(B, d, dt=bf16)
+        ws = max(self.L.savit_layernorm_bwd_workspace_bytes(M, d), self.L.savit_th_attention_bwd_workspace_bytes(B, N, H), 16)
+        self.ws = torch.empty(int(ws), dtype=torch.uint8, device=self.dev)
+        self.labels = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        self.loss, self.loss_rows, self.top1, self.top5 = z(1), z(B), z(B), z(B)
+        self._img_buf = e(B, cfg.img_size, cfg.img_size, 3, dt=bf16)
+        self._fwd_plan = self._bwd_plan = self._cast_plan = None
+        self.bwd_hooks: Dict[str, object] = {}
+        self.weights_stale = True
+
+    # ------------------------------------------------------------------------------------ parameters
+    def param_tree(self):
+        return self.layout.flax_tree(self.params)
+
+    def grad_tree(self):
+        return self.layout.flax_tree(self.grads)
+
+    def load_params(self, tree: dict):
+        src = tree["params"] if "params" in tree else tree
+        _copy_tree(self.param_tree()["params"], src)
+        self.weights_stale = True
+
+    def init_params(self, seed: int = 0):
+        """Reference initialisers: lecun-normal Dense, zero biases / cls / head, normal(0.02) pos-embed, LN 1/0, orthogonal
+        talking-heads matrices (talking_heads.py:12), LayerScale = eps (layerscale.py:5-10)."""
+        g = torch.Generator(device="cpu").manual_seed(int(seed))
+        self.params.zero_()
+        lay, cfg = self.layout, self.cfg
+
+        def lecun(name, fan_in):
+            std = math.sqrt(1.0 / fan_in) / 0.87962566103423978
+            t = torch.empty(lay.off[name][1], dtype=f32)
+            torch.nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=g)
+            lay.view(self.params, name).copy_(t)
+
+        lecun("Wpe", cfg.patch_dim)
+        lay.view(self.params, "pos").copy_(torch.randn(lay.off["pos"][1], generator=g) * 0.02)
+        for pre, n in (("l", cfg.num_layers), ("c", cfg.num_layers_token_only)):
+            for i in range(n):
+                for nm in ("ln1_g", "ln2_g"):
+                    lay.view(self.params, f"{pre}{i}.{nm}").fill_(1.0)
+                for nm in ("ls1", "ls2"):
+                    lay.view(self.params, f"{pre}{i}.{nm}").fill_(cfg.layerscale_eps)
+                lecun(f"{pre}{i}.Wqkv", cfg.embed_dim)
+                lecun(f"{pre}{i}.Wo", cfg.embed_dim)
+                lecun(f"{pre}{i}.W1", cfg.embed_dim)
+                lecun(f"{pre}{i}.W2", cfg.hidden)
+                if pre == "l":
+                    for nm in ("T1", "T2"):
+                        q, r = torch.linalg.qr(torch.randn(cfg.num_heads, cfg.num_heads, generator=g))
+                        lay.view(self.params, f"l{i}.{nm}").copy_(q * torch.sign(torch.diagonal(r)))
+        lay.view(self.params, "lnf_g").fill_(1.0)
+        self.weights_stale = True
+
+    # ------------------------------------------------------------------------------------ plan helpers
+    def _off_ptr(self, buf, name):
+        return buf.data_ptr() + self.layout.off[name][0] * 4
+
+    def _gemm(self, plan, label, **kw):
+        a = _lib.GemmArgs()
+        for k, v in kw.items():
+            setattr(a, k, v)
+        if not a.rows_per_sample:
+            a.rows_per_sample = 1
+        a.round_bias_bf16 = self.rp
+        plan.keep.append(a)
+        plan.add(self.L.savit_gemm_bf16_tn, (ctypes.byref(a),), label)
+
+    def _wgrad(self, plan, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0)):
+        plan.add(self.L.savit_gemm_bf16_wgrad, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, 0, patch[0], patch[1], patch[2], patch[3]), label)
+
+    def _build_cast_plan(self):
+        P, L, lay, cfg = _Plan(), self.L, self.layout, self.cfg
+        d, F, C = cfg.embed_dim, cfg.hidden, cfg.num_classes
+        for pre, first, stride, n in (("", "l0", lay.layer_stride, cfg.num_layers), ("c", "c0", lay.ca_stride, cfg.num_layers_token_only)):
+            if n == 0:
+                continue
+            for nm, R, Cc in (("Wqkv", d, 3 * d), ("Wo", d, d), ("W1", d, F), ("W2", F, d)):
+                P.add(L.savit_cast_transpose_bf16, (self._off_ptr(self.params, f"{first}.{nm}"), stride, n, R, Cc, self.w[pre + nm + "_n"].data_ptr(),
+                                                    R * Cc, Cc, self.w[pre + nm + "_t"].data_ptr(), R * Cc, R), f"cast {pre}{nm}")
+        P.add(L.savit_cast_transpose_bf16, (self._off_ptr(self.params, "Wpe"), 0, 1, cfg.patch_dim, d, None, 0, d, self.w["Wpe_t"].data_ptr(), 0,
+                                            cfg.patch_dim), "cast Wpe")
+        P.add(L.savit_cast_transpose_bf16, (self._off_ptr(self.params, "Wh"), 0, 1, d, C, self.w["Wh_n"].data_ptr(), 0, self.Cp,
+                                            self.w["Wh_t"].data_ptr(), 0, d), "cast Wh")
+        return P
+
+    def _build_fwd_plan(self):
+        P, L, cfg = _Plan(), self.L, self.cfg
+        d, F, C, N, NL, NC, H, B, M, Mc = (cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.n_patches, cfg.num_layers, cfg.num_layers_token_only,
+                                           cfg.num_heads, self.B, self.M, self.Mc)
+        hd, Np = cfg.head_dim, self.Np
+        pp = lambda n: self._off_ptr(self.params, n)  # noqa: E731
+        alpha = 1.0 / math.sqrt(hd)
+        x = self.x
+        self._gemm(P, "patch_embed", A=self._img_buf.data_ptr(), Bt=self.w["Wpe_t"].data_ptr(), C=x[0].data_ptr(), aux=pp("pos"), M=M, N=d,
+                   K=cfg.patch_dim, lda=0, ldb=cfg.patch_dim, ldc=d, ldaux=d, epilogue=_lib.EPI_PATCH, img_size=cfg.img_size, patch=cfg.patch,
+                   tokens=N, token_offset=0)
+        for l in range(NL):
+            st = self.stats[l]
+            w = lambda n, l=l: self.w[n][l].data_ptr()  # noqa: E731
+            sd0, sd1 = self.sd[2 * l].data_ptr(), self.sd[2 * l + 1].data_ptr()
+            P.add(L.savit_layernorm_fwd, (x[l].data_ptr(), pp(f"l{l}.ln1_g"), pp(f"l{l}.ln1_b"), self.h1[l].data_ptr(), st[0].data_ptr(),
+                                          st[1].data_ptr(), M, d, d, 1e-6, self.rp), f"l{l}.ln1")
+            self._gemm(P, f"l{l}.qkv", A=self.h1[l].data_ptr(), Bt=w("Wqkv_t"), C=self.qkv[l].data_ptr(), M=M, N=3 * d, K=d, lda=d, ldb=d,
+                       ldc=3 * d, epilogue=_lib.EPI_BF16, alpha=alpha, alpha_cols=d)
+            P.add(L.savit_th_attention_fwd, (self.qkv[l].data_ptr(), pp(f"l{l}.T1"), pp(f"l{l}.T2"), self.sbuf[l].data_ptr(), self.pbuf[l].data_ptr(),
+                                             self.o[l].data_ptr(), B, N, H, hd, 3 * d, Np), f"l{l}.th_attn")
+            self._gemm(P, f"l{l}.proj", A=self.o[l].data_ptr(), Bt=w("Wo_t"), C=self.xmid[l].data_ptr(), C2=self.br1[l].data_ptr(),
+                       aux=x[l].data_ptr(), colscale=pp(f"l{l}.ls1"), rowscale=sd0, rows_per_sample=N, M=M, N=d, K=d, lda=d, ldb=d, ldc=d,
+                       ldaux=d, epilogue=_lib.EPI_RESID)
+            P.add(L.savit_layernorm_fwd, (self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), pp(f"l{l}.ln2_b"), self.h2[l].data_ptr(), st[2].data_ptr(),
+                                          st[3].data_ptr(), M, d, d, 1e-6, self.rp), f"l{l}.ln2")
+            self._gemm(P, f"l{l}.fc1", A=self.h2[l].data_ptr(), Bt=w("W1_t"), C=self.u[l].data_ptr(), C2=self.a[l].data_ptr(), bias=pp(f"l{l}.b1"),
+                       M=M, N=F, K=d, lda=d, ldb=d, ldc=F, epilogue=_lib.EPI_BIAS_GELU)
+            self._gemm(P, f"l{l}.fc2", A=self.a[l].data_ptr(), Bt=w("W2_t"), C=x[l + 1].data_ptr(), C2=self.br2[l].data_ptr(), bias=pp(f"l{l}.b2"),
+                       aux=self.xmid[l].data_ptr(), colscale=pp(f"l{l}.ls2"), rowscale=sd1, rows_per_sample=N, M=M, N=d, K=F, lda=F, ldb=F,
+                       ldc=d, ldaux=d, epilogue=_lib.EPI_RESID)
+        # cls token rows: cls[0][b] = cls parameter (cait.py:157-160)
+        P.add(L.savit_cls_pos_rows, (pp("cls"), self.zero_d.data_ptr(), self.cls[0].data_ptr(), B, d, d), "cls_bcast")
+        for c in range(NC):
+            w = lambda n, c=c: self.w["c" + n][c].data_ptr()  # noqa: E731
+            sd0, sd1 = self.sd[2 * (NL + c)].data_ptr(), self.sd[2 * (NL + c) + 1].data_ptr()
+            cs, cx = self.cstat_c[c], self.cstat_x[c]
+            # LayerNorm over concat([cls, x]) (cait.py:98-99) as two row-mapped calls into hc [B*(N+1), d]
+            P.add(L.savit_layernorm_fwd_mapped, (x[NL].data_ptr(), pp(f"c{c}.ln1_g"), pp(f"c{c}.ln1_b"), self.hc[c].data_ptr(), cx[0].data_ptr(),
+                                                 cx[1].data_ptr(), M, d, d, 1e-6, self.rp, N, N + 1, 1), f"c{c}.ln1x")
+            P.add(L.savit_layernorm_fwd_mapped, (self.cls[c].data_ptr(), pp(f"c{c}.ln1_g"), pp(f"c{c}.ln1_b"), self.hc[c].data_ptr(),
+                                                 cs[0].data_ptr(), cs[1].data_ptr(), B, d, d, 1e-6, self.rp, 1, N + 1, 0), f"c{c}.ln1c")
+            qk = self.qkvc[c].data_ptr()
+            # queries from the cls rows only (cait.py:14), keys / values from every row
+            self._gemm(P, f"c{c}.q", A=self.hc[c].data_ptr(), Bt=w("Wqkv_t"), C=qk, M=B, N=d, K=d, lda=(N + 1) * d, ldb=d, ldc=(N + 1) * 3 * d,
+                       epilogue=_lib.EPI_BF16, alpha=alpha, alpha_cols=d)
+            self._gemm(P, f"c{c}.kv", A=self.hc[c].data_ptr(), Bt=self.w["cWqkv_t"][c].data_ptr() + d * d * 2, C=qk + d * 2, M=Mc, N=2 * d, K=d,
+                       lda=d, ldb=d, ldc=3 * d, epilogue=_lib.EPI_BF16)
+            P.add(L.savit_class_attention_fwd, (qk, (N + 1) * 3 * d, qk + d * 2, 3 * d, self.oc[c].data_ptr(), self.probs[c].data_ptr(), B, N + 1, H,
+                                                hd), f"c{c}.cattn")
+            self._gemm(P, f"c{c}.proj", A=self.oc[c].data_ptr(), Bt=w("Wo_t"), C=self.clsmid[c].data_ptr(), C2=self.cbr1[c].data_ptr(),
+                       aux=self.cls[c].data_ptr(), colscale=pp(f"c{c}.ls1"), rowscale=sd0, rows_per_sample=1, M=B, N=d, K=d, lda=d, ldb=d, ldc=d,
+                       ldaux=d, epilogue=_lib.EPI_RESID)
+            P.add(L.savit_layernorm_fwd, (self.clsmid[c].data_ptr(), pp(f"c{c}.ln2_g"), pp(f"c{c}.ln2_b"), self.hc2[c].data_ptr(), cs[2].data_ptr(),
+                                          cs[3].data_ptr(), B, d, d, 1e-6, self.rp), f"c{c}.ln2")
+            self._gemm(P, f"c{c}.fc1", A=self.hc2[c].data_ptr(), Bt=w("W1_t"), C=self.uc[c].data_ptr(), C2=self.ac[c].data_ptr(),
+                       bias=pp(f"c{c}.b1"), M=B, N=F, K=d, lda=d, ldb=d, ldc=F, epilogue=_lib.EPI_BIAS_GELU)
+            self._gemm(P, f"c{c}.fc2", A=self.ac[c].data_ptr(), Bt=w("W2_t"), C=self.cls[c + 1].data_ptr(), C2=self.cbr2[c].data_ptr(),
+                       bias=pp(f"c{c}.b2"), aux=self.clsmid[c].data_ptr(), colscale=pp(f"c{c}.ls2"), rowscale=sd1, rows_per_sample=1, M=B, N=d,
+                       K=F, lda=F, ldb=F, ldc=d, ldaux=d, epilogue=_lib.EPI_RESID)
+        # final LayerNorm: only the cls row reaches the head (cait.py:175-178)
+        P.add(L.savit_layernorm_fwd, (self.cls[NC].data_ptr(), pp("lnf_g"), pp("lnf_b"), self.zcls.data_ptr(), self.fstats[0].data_ptr(),
+                                      self.fstats[1].data_ptr(), B, d, d, 1e-6, self.rp), "lnf")
+        self._gemm(P, "head", A=self.zcls.data_ptr(), Bt=self.w["Wh_t"].data_ptr(), C=self.logits.data_ptr(), bias=pp("bh"), M=B, N=C, K=d, lda=d,
+                   ldb=d, ldc=C, epilogue=_lib.EPI_F32, round_out_bf16=self.rp)
+        return P
+
+    def _build_bwd_plan(self):
+        P, L, cfg = _Plan(), self.L, self.cfg
+        d, F, C, N, NL, NC, H, B, M, Mc = (cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.n_patches, cfg.num_layers, cfg.num_layers_token_only,
+                                           cfg.num_heads, self.B, self.M, self.Mc)
+        hd, Np = cfg.head_dim, self.Np
+        pp = lambda n: self._off_ptr(self.params, n)  # noqa: E731
+        gp = lambda n: self._off_ptr(self.grads, n)  # noqa: E731
+        ws, wsb = self.ws.data_ptr(), self.ws.numel()
+        dqs = 1.0 / math.sqrt(hd)
+        # ---- head + final LayerNorm -> dcls (gradient of the cls token state)
+        self._wgrad(P, "head.wgrad", self.zcls.data_ptr(), self.dlogits.data_ptr(), gp("Wh"), B, d, C, d, self.Cp, C)
+        self._gemm(P, "head.dgrad", A=self.dlogits.data_ptr(), Bt=self.w["Wh_n"].data_ptr(), C=self.d_z.data_ptr(), M=B, N=d, K=self.Cp, lda=self.Cp,
+                   ldb=self.Cp, ldc=d, epilogue=_lib.EPI_BF16)
+        P.add(L.savit_layernorm_bwd, (self.d_z.data_ptr(), self.cls[NC].data_ptr(), pp("lnf_g"), self.fstats[0].data_ptr(), self.fstats[1].data_ptr(),
+                                      None, self.dcls.data_ptr(), None, gp("lnf_g"), gp("lnf_b"), None, B, d, d, d, self.rp, ws, wsb), "lnf.bwd")
+        # ---- class-attention blocks (reverse); dres accumulates the gradient w.r.t. the patch tokens x[NL] (zeroed by the caller)
+        for c in range(NC - 1, -1, -1):
+            w = lambda n, c=c: self.w["c" + n][c].data_ptr()  # noqa: E731
+            sd0, sd1 = self.sd[2 * (NL + c)].data_ptr(), self.sd[2 * (NL + c) + 1].data_ptr()
+            cs, cx = self.cstat_c[c], self.cstat_x[c]
+            P.add(L.savit_layerscale_bwd, (self.dcls.data_ptr(), self.cbr2[c].data_ptr(), pp(f"c{c}.ls2"), sd1, 1, self.dbr_c.data_ptr(),
+                                           gp(f"c{c}.ls2"), gp(f"c{c}.b2"), B, d, d, ws, wsb), f"c{c}.ls2.bwd")
+            self._wgrad(P, f"c{c}.W2.wgrad", self.ac[c].data_ptr(), self.dbr_c.data_ptr(), gp(f"c{c}.W2"), B, F, d, F, d, d)
+            self._gemm(P, f"c{c}.fc2.dgrad", A=self.dbr_c.data_ptr(), Bt=w("W2_n"), C=self.d_uc.data_ptr(), aux=self.uc[c].data_ptr(),
+                       colsum=gp(f"c{c}.b1"), M=B, N=F, K=d, lda=d, ldb=d, ldc=F, ldaux=F, epilogue=_lib.EPI_DGELU)
+            self._wgrad(P, f"c{c}.W1.wgrad", self.hc2[c].data_ptr(), self.d_uc.data_ptr(), gp(f"c{c}.W1"), B, d, F, d, F, F)
+            self._gemm(P, f"c{c}.fc1.dgrad", A=self.d_uc.data_ptr(), Bt=w("W1_n"), C=self.d_hc2.data_ptr(), M=B, N=d, K=F, lda=F, ldb=F, ldc=d,
+                       epilogue=_lib.EPI_BF16)
+            P.add(L.savit_layernorm_bwd, (self.d_hc2.data_ptr(), self.clsmid[c].data_ptr(), pp(f"c{c}.ln2_g"), cs[2].data_ptr(), cs[3].data_ptr(),
+                                          self.dcls.data_ptr(), self.dcls.data_ptr(), None, gp(f"c{c}.ln2_g"), gp(f"c{c}.ln2_b"), None, B, d, d, d,
+                                          self.rp, ws, wsb), f"c{c}.ln2.bwd")
+            P.add(L.savit_layerscale_bwd, (self.dcls.data_ptr(), self.cbr1[c].data_ptr(), pp(f"c{c}.ls1"), sd0, 1, self.dbr_c.data_ptr(),
+                                           gp(f"c{c}.ls1"), None, B, d, d, ws, wsb), f"c{c}.ls1.bwd")
+            self._wgrad(P, f"c{c}.Wo.wgrad", self.oc[c].data_ptr(), self.dbr_c.data_ptr(), gp(f"c{c}.Wo"), B, d, d, d, d, d)
+            self._gemm(P, f"c{c}.proj.dgrad", A=self.dbr_c.data_ptr(), Bt=w("Wo_n"), C=self.d_oc.data_ptr(), M=B, N=d, K=d, lda=d, ldb=d, ldc=d,
+                       epilogue=_lib.EPI_BF16)
+            qk, dqk = self.qkvc[c].data_ptr(), self.dqkvc.data_ptr()
+            # dqkvc: q columns are zero except at the cls rows (written here); k|v columns are written for every row
+            P.add(L.savit_class_attention_bwd, (qk, (N + 1) * 3 * d, qk + d * 2, 3 * d, self.probs[c].data_ptr(), self.d_oc.data_ptr(), dqk,
+                                                (N + 1) * 3 * d, dqk + d * 2, B, N + 1, H, hd, dqs), f"c{c}.cattn.bwd")
+            self._wgrad(P, f"c{c}.Wqkv.wgrad", self.hc[c].data_ptr(), dqk, gp(f"c{c}.Wqkv"), Mc, d, 3 * d, d, 3 * d, 3 * d)
+            self._gemm(P, f"c{c}.qkv.dgrad", A=dqk, Bt=w("Wqkv_n"), C=self.d_hc.data_ptr(), M=Mc, N=d, K=3 * d, lda=3 * d, ldb=3 * d, ldc=d,
+                       epilogue=_lib.EPI_BF16)
+            P.add(L.savit_layernorm_bwd_mapped, (self.d_hc.data_ptr(), self.x[NL].data_ptr(), pp(f"c{c}.ln1_g"), cx[0].data_ptr(), cx[1].data_ptr(),
+                                                 self.dres.data_ptr(), self.dres.data_ptr(), None, gp(f"c{c}.ln1_g"), gp(f"c{c}.ln1_b"), None, M, d,
+                                                 d, d, self.rp, N, N + 1, 1, ws, wsb), f"c{c}.ln1x.bwd")
+            P.add(L.savit_layernorm_bwd_mapped, (self.d_hc.data_ptr(), self.cls[c].data_ptr(), pp(f"c{c}.ln1_g"), cs[0].data_ptr(), cs[1].data_ptr(),
+                                                 self.dcls.data_ptr(), self.dcls.data_ptr(), None, gp(f"c{c}.ln1_g"), gp(f"c{c}.ln1_b"), None, B, d,
+                                                 d, d, self.rp, 1, N + 1, 0, ws, wsb), f"c{c}.ln1c.bwd")
+        P.add(L.savit_pos_cls_grad, (self.dcls.data_ptr(), gp("cls"), None, B, 1, d, 0), "cls.grad")
+        # ---- SA layers (reverse)
+        for l in range(NL - 1, -1, -1):
+            st = self.stats[l]
+            w = lambda n, l=l: self.w[n][l].data_ptr()  # noqa: E731
+            sd0, sd1 = self.sd[2 * l].data_ptr(), self.sd[2 * l + 1].data_ptr()
+            P.add(L.savit_layerscale_bwd, (self.dres.data_ptr(), self.br2[l].data_ptr(), pp(f"l{l}.ls2"), sd1, N, self.dbr.data_ptr(), gp(f"l{l}.ls2"),
+                                           gp(f"l{l}.b2"), M, d, d, ws, wsb), f"l{l}.ls2.bwd")
+            self._wgrad(P, f"l{l}.W2.wgrad", self.a[l].data_ptr(), self.dbr.data_ptr(), gp(f"l{l}.W2"), M, F, d, F, d, d)
+            self._gemm(P, f"l{l}.fc2.dgrad", A=self.dbr.data_ptr(), Bt=w("W2_n"), C=self.d_u.data_ptr(), aux=self.u[l].data_ptr(),
+                       colsum=gp(f"l{l}.b1"), M=M, N=F, K=d, lda=d, ldb=d, ldc=F, ldaux=F, epilogue=_lib.EPI_DGELU)
+            self._wgrad(P, f"l{l}.W1.wgrad", self.h2[l].data_ptr(), self.d_u.data_ptr(), gp(f"l{l}.W1"), M, d, F, d, F, F)
+            self._gemm(P, f"l{l}.fc1.dgrad", A=self.d_u.data_ptr(), Bt=w("W1_n"), C=self.d_h.data_ptr(), M=M, N=d, K=F, lda=F, ldb=F, ldc=d,
+                       epilogue=_lib.EPI_BF16)
+            P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(),
+                                          self.dres.data_ptr(), self.dres.data_ptr(), None, gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b"), None, M, d, d, d,
+                                          self.rp, ws, wsb), f"l{l}.ln2.bwd")
+            P.add(L.savit_layerscale_bwd, (self.dres.data_ptr(), self.br1[l].data_ptr(), pp(f"l{l}.ls1"), sd0, N, self.dbr.data_ptr(), gp(f"l{l}.ls1"),
+                                           None, M, d, d, ws, wsb), f"l{l}.ls1.bwd")
+            self._wgrad(P, f"l{l}.Wo.wgrad", self.o[l].data_ptr(), self.dbr.data_ptr(), gp(f"l{l}.Wo"), M, d, d, d, d, d)
+            self._gemm(P, f"l{l}.proj.dgrad", A=self.dbr.data_ptr(), Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=M, N=d, K=d, lda=d, ldb=d, ldc=d,
+                       epilogue=_lib.EPI_BF16)
+            P.add(L.savit_th_attention_bwd, (self.qkv[l].data_ptr(), pp(f"l{l}.T1"), pp(f"l{l}.T2"), self.sbuf[l].data_ptr(), self.pbuf[l].data_ptr(),
+                                             self.d_o.data_ptr(), self.dsbuf.data_ptr(), self.dqkv.data_ptr(), gp(f"l{l}.T1"), gp(f"l{l}.T2"), B, N, H,
+                                             hd, 3 * d, Np, dqs, ws, wsb), f"l{l}.th_attn.bwd")
+            self._wgrad(P, f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), self.dqkv.data_ptr(), gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d)
+            self._gemm(P, f"l{l}.qkv.dgrad", A=self.dqkv.data_ptr(), Bt=w("Wqkv_n"), C=self.d_h.data_ptr(), M=M, N=d, K=3 * d, lda=3 * d, ldb=3 * d,
+                       ldc=d, epilogue=_lib.EPI_BF16)
+            P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
+                                          self.dres.data_ptr(), self.dres.data_ptr(), self.dres_b.data_ptr(), gp(f"l{l}.ln1_g"), gp(f"l{l}.ln1_b"),
+                                          None, M, d, d, d, self.rp, ws, wsb), f"l{l}.ln1.bwd")
+        P.add(L.savit_pos_cls_grad, (self.dres.data_ptr(), gp("pos"), None, B, N, d, 0), "pos.grad")
+        self._wgrad(P, "Wpe.wgrad", self._img_buf.data_ptr(), self.dres_b.data_ptr(), gp("Wpe"), M, cfg.patch_dim, d, 0, d, d,
+                    patch=(cfg.patch, cfg.img_size, N, 0))
+        return P
+
+    # ------------------------------------------------------------------------------------ execution
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def refresh_weights(self):
+        if self._cast_plan is None:
+            self._cast_plan = self._build_cast_plan()
+        self._cast_plan.run(self._stream())
+        self.weights_stale = False
+
+    def set_images(self, images: torch.Tensor):
+        S = self.cfg.img_size
+        if not images.is_cuda:
+            raise ValueError("images must be on the GPU")
+        if tuple(images.shape) == (self.B, S, S, 3) and images.dtype == bf16:
+            self._img_buf.copy_(images)
+        elif tuple(images.shape) == (self.B, S, S, 3) and images.dtype == f32:
+            _lib.check(self.L.savit_cast_bf16(images.contiguous().data_ptr(), self._img_buf.data_ptr(), images.numel(), self._stream()), "savit_cast_bf16")
+        elif tuple(images.shape) == (S, S, 3, self.B) and images.dtype == f32:
+            _lib.check(self.L.savit_hwcn_to_nhwc_bf16(images.contiguous().data_ptr(), self._img_buf.data_ptr(), S, S, 3, self.B, self._stream()),
+                       "savit_hwcn_to_nhwc_bf16")
+        else:
+            raise ValueError(f"images shape {tuple(images.shape)} / dtype {images.dtype} not accepted")
+
+    def set_stochastic_depth(self, is_training: bool, keep_masks: Optional[torch.Tensor] = None, seed: Optional[int] = None):
+        """rowscale = mask / keep_prob per (layer, branch, sample) (stochastic_depth.py:16-27); identity in eval or at rate 0.
+        keep_masks [(L+Lc), 2, B] of 0/1 overrides the generator (tests)."""
+        rate = self.cfg.stoch_depth_rate
+        if not is_training or rate == 0.0:
+            self.sd.fill_(1.0)
+            return
+        keep = 1.0 - rate
+        if keep_masks is not None:
+            self.sd.copy_(keep_masks.to(device=self.dev, dtype=f32).reshape(-1, self.B) / keep)
+            return
+        if seed is not None:
+            self.gen.manual_seed(int(seed))
+        u = torch.rand(self.sd.shape, device=self.dev, generator=self.gen)
+        self.sd.copy_(torch.floor(keep + u) / keep)
+
+    def forward(self, images: Optional[torch.Tensor] = None, is_training: bool = False, keep_masks=None) -> torch.Tensor:
+        if images is not None:
+            self.set_images(images)
+        self.set_stochastic_depth(is_training, keep_masks)
+        if self.weights_stale:
+            self.refresh_weights()
+        if self._fwd_plan is None:
+            self._fwd_plan = self._build_fwd_plan()
+        self._fwd_plan.run(self._stream())
+        return self.logits
+
+    def loss_backward(self, labels, label_smoothing: float = 0.1, mix_labels=None, ratio=None, zero_grads: bool = True):
+        s = self._stream()
+        self.labels.copy_(labels.to(torch.int32))
+        if zero_grads:
+            self.grads.zero_()
+        self.loss.zero_()
+        ml = mr = None
+        if mix_labels is not None:
+            self._mix_labels = mix_labels.to(device=self.dev, dtype=torch.int32).contiguous()
+            self._mix_ratio = ratio.to(device=self.dev, dtype=f32).contiguous()
+            ml, mr = self._mix_labels.data_ptr(), self._mix_ratio.data_ptr()
+        _lib.check(self.L.savit_softmax_xent(self.logits.data_ptr(), self.cfg.num_classes, self.labels.data_ptr(), ml, mr, float(label_smoothing),
+                                             1.0 / self.B, self.loss_rows.data_ptr(), self.loss.data_ptr(), self.dlogits.data_ptr(), self.Cp,
+                                             self._off_ptr(self.grads, "bh"), self.top1.data_ptr(), self.top5.data_ptr(), self.B,
+                                             self.cfg.num_classes, s), "savit_softmax_xent")
+        if self._bwd_plan is None:
+            self._bwd_plan = self._build_bwd_plan()
+        self.dres.zero_()
+        for fn, args, label in self._bwd_plan.calls:
+            rc = fn(*args, s)
+            if rc != 0:
+                _lib.check(rc, label)
+            cb = self.bwd_hooks.get(label)
+            if cb is not None:
+                cb()
+        return self.loss
+
+    def optimizer_step(self, lr: float, weight_decay: float = 0.0, max_norm: float = 0.0, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8,
+                       grad_scale: float = 1.0):
+        if self.adam_m is None:
+            self.adam_m, self.adam_v = torch.zeros_like(self.params), torch.zeros_like(self.params)
+        s = self._stream()
+        self.step_count += 1
+        ss = None
+        if max_norm and max_norm > 0:
+            self.gnorm_sq.zero_()
+            _lib.check(self.L.savit_sumsq(self.grads.data_ptr(), self.grads.numel(), self.gnorm_sq.data_ptr(), s), "savit_sumsq")
+            ss = self.gnorm_sq.data_ptr()
+        _lib.check(self.L.savit_adamw_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
+                                           self.params.numel(), float(lr), float(b1), float(b2), float(eps), float(weight_decay), self.step_count, ss,
+                                           float(max_norm or 0.0), float(grad_scale), s), "savit_adamw_step")
+        self.refresh_weights()
+
+    def profile_step(self, labels, label_smoothing: float = 0.1):
+        if self.weights_stale:
+            self.refresh_weights()
+        if self._fwd_plan is None:
+            self._fwd_plan = self._build_fwd_plan()
+        if self._bwd_plan is None:
+            self._bwd_plan = self._build_bwd_plan()
+        s = self._stream()
+        self.labels.copy_(labels.to(torch.int32))
+        evs = []
+
+        def run(plan):
+            for fn, args, label in plan.calls:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                rc = fn(*args, s)
+                b.record()
+                if rc != 0:
+                    _lib.check(rc, label)
+                evs.append((label, a, b))
+
+        run(self._fwd_plan)
+        self.grads.zero_()
+        self.loss.zero_()
+        _lib.check(self.L.savit_softmax_xent(self.logits.data_ptr(), self.cfg.num_classes, self.labels.data_ptr(), None, None, float(label_smoothing),
+                                             1.0 / self.B, self.loss_rows.data_ptr(), self.loss.data_ptr(), self.dlogits.data_ptr(), self.Cp,
+                                             self._off_ptr(self.grads, "bh"), self.top1.data_ptr(), self.top5.data_ptr(), self.B,
+                                             self.cfg.num_classes, s), "savit_softmax_xent")
+        self.dres.zero_()
+        run(self._bwd_plan)
+        torch.cuda.synchronize()
+        return {label: a.elapsed_time(b) for label, a, b in evs}

@@ -1,0 +1,179 @@
+// Class attention (CaiT token-only layers): ClassSelfAttentionBlock at /root/reference/models/cait.py:10-15 -
+// AttentionBlock (attention.py:21-67) with ONE query (the cls token, row 0 of the normalised [cls; x] sequence) against all
+// Nk = N+1 keys.  Per (batch, head) this is a 1 x Nk softmax and two GEMVs: latency-bound, no MFMA.  One 64-lane wave per
+// (batch, head): keys are strided over the lanes (<= 4 per lane), the query / output-cotangent row is broadcast-loaded into
+// every lane, row max / sum / dot products are wave shuffles.  The K and V projections over all tokens - where the FLOPs of a
+// token-only layer are - are ordinary savit_gemm_bf16_tn calls on a fused [d, 2d] weight.
+#include "common.h"
+#include "savit.h"
+
+namespace {
+
+constexpr int CA_KPL = 4;  // keys per lane: Nk <= 256
+
+template <int HDV>
+__device__ __forceinline__ void load_row_f32(const bf16_t* p, float (&out)[HDV]) {
+#pragma unroll
+  for (int c = 0; c < HDV / 8; ++c) {
+    const uint4 v = reinterpret_cast<const uint4*>(p)[c];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      out[8 * c + 2 * k] = __uint_as_float(w[k] << 16);
+      out[8 * c + 2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+    }
+  }
+}
+
+template <int HDV>
+__device__ __forceinline__ void store_row_bf16(bf16_t* p, const float (&v)[HDV]) {
+#pragma unroll
+  for (int c = 0; c < HDV / 8; ++c)
+    reinterpret_cast<uint4*>(p)[c] = make_uint4(pack_bf16x2(v[8 * c], v[8 * c + 1]), pack_bf16x2(v[8 * c + 2], v[8 * c + 3]),
+                                                pack_bf16x2(v[8 * c + 4], v[8 * c + 5]), pack_bf16x2(v[8 * c + 6], v[8 * c + 7]));
+}
+
+// q [B, ldq] (row b, columns h*hd..: already scaled), kv [B*Nk, ldkv]: k at column h*hd, v at column d + h*hd
+template <int HDV>
+__global__ __launch_bounds__(256) void class_attn_fwd_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kv, int ldkv,
+                                                              bf16_t* __restrict__ o, float* __restrict__ probs, int B, int Nk, int H) {
+  const int lane = threadIdx.x & 63;
+  const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bh >= B * H) return;
+  const int b = bh / H, h = bh - b * H, d = H * HDV;
+  float qv[HDV];
+  load_row_f32<HDV>(q + (size_t)b * ldq + h * HDV, qv);
+  float s[CA_KPL], m = -INFINITY;
+#pragma unroll
+  for (int kk = 0; kk < CA_KPL; ++kk) {
+    const int key = lane + 64 * kk;
+    s[kk] = -INFINITY;
+    if (key < Nk) {
+      float kr[HDV];
+      load_row_f32<HDV>(kv + ((size_t)b * Nk + key) * ldkv + h * HDV, kr);
+      float a = 0.f;
+#pragma unroll
+      for (int e = 0; e < HDV; ++e) a += qv[e] * kr[e];
+      s[kk] = round_bf16(a);  // the reference's score tensor is bf16
+    }
+    m = fmaxf(m, s[kk]);
+  }
+  m = wave_max(m);
+  float l = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < CA_KPL; ++kk) {
+    s[kk] = __expf(s[kk] - m);
+    l += s[kk];
+  }
+  l = wave_sum(l);
+  const float inv = 1.0f / l;
+  float acc[HDV];
+#pragma unroll
+  for (int e = 0; e < HDV; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < CA_KPL; ++kk) {
+    const int key = lane + 64 * kk;
+    const float pk = s[kk] * inv;
+    if (key < Nk) {
+      probs[((size_t)b * H + h) * Nk + key] = pk;
+      float vr[HDV];
+      load_row_f32<HDV>(kv + ((size_t)b * Nk + key) * ldkv + d + h * HDV, vr);
+#pragma unroll
+      for (int e = 0; e < HDV; ++e) acc[e] += pk * vr[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < HDV; ++e) acc[e] = wave_sum(acc[e]);
+  if (lane == 0) store_row_bf16<HDV>(o + (size_t)b * d + h * HDV, acc);
+}
+
+template <int HDV>
+__global__ __launch_bounds__(256) void class_attn_bwd_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kv, int ldkv,
+                                                              const float* __restrict__ probs, const bf16_t* __restrict__ d_o,
+                                                              bf16_t* __restrict__ dq, long lddq, bf16_t* __restrict__ dkv, int B, int Nk, int H,
+                                                              float dq_scale) {
+  const int lane = threadIdx.x & 63;
+  const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bh >= B * H) return;
+  const int b = bh / H, h = bh - b * H, d = H * HDV;
+  float qv[HDV], dov[HDV];
+  load_row_f32<HDV>(q + (size_t)b * ldq + h * HDV, qv);
+  load_row_f32<HDV>(d_o + (size_t)b * d + h * HDV, dov);
+  float pk[CA_KPL], dp[CA_KPL], del = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < CA_KPL; ++kk) {
+    const int key = lane + 64 * kk;
+    pk[kk] = 0.f;
+    dp[kk] = 0.f;
+    if (key < Nk) {
+      pk[kk] = probs[((size_t)b * H + h) * Nk + key];
+      float vr[HDV];
+      load_row_f32<HDV>(kv + ((size_t)b * Nk + key) * ldkv + d + h * HDV, vr);
+      float a = 0.f;
+#pragma unroll
+      for (int e = 0; e < HDV; ++e) a += dov[e] * vr[e];
+      dp[kk] = a;
+      del += pk[kk] * a;
+    }
+  }
+  del = wave_sum(del);
+  float dqa[HDV];
+#pragma unroll
+  for (int e = 0; e < HDV; ++e) dqa[e] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < CA_KPL; ++kk) {
+    const int key = lane + 64 * kk;
+    if (key < Nk) {
+      const float ds = pk[kk] * (dp[kk] - del);
+      float kr[HDV], dkr[HDV], dvr[HDV];
+      load_row_f32<HDV>(kv + ((size_t)b * Nk + key) * ldkv + h * HDV, kr);
+#pragma unroll
+      for (int e = 0; e < HDV; ++e) {
+        dqa[e] += ds * kr[e];
+        dkr[e] = ds * qv[e];
+        dvr[e] = pk[kk] * dov[e];
+      }
+      store_row_bf16<HDV>(dkv + ((size_t)b * Nk + key) * ldkv + h * HDV, dkr);
+      store_row_bf16<HDV>(dkv + ((size_t)b * Nk + key) * ldkv + d + h * HDV, dvr);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < HDV; ++e) dqa[e] = wave_sum(dqa[e]) * dq_scale;
+  if (lane == 0) store_row_bf16<HDV>(dq + (size_t)b * lddq + h * HDV, dqa);
+}
+
+}  // namespace
+
+extern "C" int savit_class_attention_fwd(const void* q, long ldq, const void* kv, int ldkv, void* o, float* probs, int B, int Nk, int H,
+                                         int head_dim, void* stream) {
+  SAVIT_CHECK_ARG(q && kv && o && probs && B >= 0 && Nk > 0 && Nk <= 64 * CA_KPL && H > 0 && (head_dim == 48 || head_dim == 64));
+  SAVIT_CHECK_ARG(ldq >= H * head_dim && ldq % 8 == 0 && ldkv >= 2 * H * head_dim && ldkv % 8 == 0);
+  SAVIT_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)kv % 16) == 0 && ((uintptr_t)o % 16) == 0);
+  if (B == 0) return SAVIT_OK;
+  const dim3 grid((B * H + 3) / 4), block(256);
+  if (head_dim == 48)
+    hipLaunchKernelGGL(class_attn_fwd_kernel<48>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)q, ldq, (const bf16_t*)kv, ldkv, (bf16_t*)o,
+                       probs, B, Nk, H);
+  else
+    hipLaunchKernelGGL(class_attn_fwd_kernel<64>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)q, ldq, (const bf16_t*)kv, ldkv, (bf16_t*)o,
+                       probs, B, Nk, H);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_class_attention_bwd(const void* q, long ldq, const void* kv, int ldkv, const float* probs, const void* d_o, void* dq,
+                                         long lddq, void* dkv, int B, int Nk, int H, int head_dim, float dq_scale, void* stream) {
+  SAVIT_CHECK_ARG(lddq >= H * head_dim && lddq % 8 == 0);
+  SAVIT_CHECK_ARG(q && kv && probs && d_o && dq && dkv && B >= 0 && Nk > 0 && Nk <= 64 * CA_KPL && H > 0 && (head_dim == 48 || head_dim == 64));
+  SAVIT_CHECK_ARG(ldq >= H * head_dim && ldq % 8 == 0 && ldkv >= 2 * H * head_dim && ldkv % 8 == 0);
+  SAVIT_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)kv % 16) == 0 && ((uintptr_t)d_o % 16) == 0 && ((uintptr_t)dq % 16) == 0 &&
+                  ((uintptr_t)dkv % 16) == 0);
+  if (B == 0) return SAVIT_OK;
+  const dim3 grid((B * H + 3) / 4), block(256);
+  if (head_dim == 48)
+    hipLaunchKernelGGL(class_attn_bwd_kernel<48>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)q, ldq, (const bf16_t*)kv, ldkv, probs,
+                       (const bf16_t*)d_o, (bf16_t*)dq, lddq, (bf16_t*)dkv, B, Nk, H, dq_scale);
+  else
+    hipLaunchKernelGGL(class_attn_bwd_kernel<64>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)q, ldq, (const bf16_t*)kv, ldkv, probs,
+                       (const bf16_t*)d_o, (bf16_t*)dq, lddq, (bf16_t*)dkv, B, Nk, H, dq_scale);
+  SAVIT_LAUNCH_RET();
+}

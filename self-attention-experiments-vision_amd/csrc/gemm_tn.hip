@@ -231,6 +231,8 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[M
         v[2 * k] = __uint_as_float(rw[k] << 16);
         v[2 * k + 1] = __uint_as_float(rw[k] & 0xffff0000u);
       }
+      if (a.C2 != nullptr)  // the bf16 branch value, needed by the LayerScale gradient (layerscale.py:23)
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C2) + (size_t)m * a.ldc + n) = raw;
       float* op = reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + n;
       *reinterpret_cast<float4*>(op) = make_float4(r0.x + rs * colscale[0] * v[0], r0.y + rs * colscale[1] * v[1],
                                                    r0.z + rs * colscale[2] * v[2], r0.w + rs * colscale[3] * v[3]);
@@ -647,7 +649,7 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
   SAVIT_CHECK_ARG(args != nullptr);
   const savit_gemm_args& a = *args;
   SAVIT_CHECK_ARG(a.A && a.Bt && a.C && a.M >= 0 && a.N > 0 && a.K > 0);
-  SAVIT_CHECK_ARG(a.K % 64 == 0 && a.N % 4 == 0 && (a.epilogue > SAVIT_EPI_DGELU || a.N % 8 == 0) && a.ldb >= a.K && a.ldb % 8 == 0 && a.ldc % 4 == 0 && a.ldc >= a.N);
+  SAVIT_CHECK_ARG(a.K % 32 == 0 && (a.K % 64 == 0 || a.tile == 0 || a.tile >= 4) && a.N % 4 == 0 && (a.epilogue > SAVIT_EPI_DGELU || a.N % 8 == 0) && a.ldb >= a.K && a.ldb % 8 == 0 && a.ldc % 4 == 0 && a.ldc >= a.N);
   SAVIT_CHECK_ARG(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.Bt % 16) == 0 && ((uintptr_t)a.C % 16) == 0);
   GemmParams p{};
   p.a = a;

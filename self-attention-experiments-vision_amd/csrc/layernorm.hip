@@ -20,7 +20,8 @@ template <int CH>  // CH = ceil(d/4/64) chunks per lane
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                             int rows, int d, long x_stride, float eps, int round_params) {
+                                                             int rows, int d, long x_stride, float eps, int round_params, int grp,
+                                                             int grp_stride, int grp_off) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nchunk = d >> 2;
@@ -61,7 +62,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
       if (mean_out) mean_out[row] = mean;
       if (rstd_out) rstd_out[row] = rstd;
     }
-    uint2* yr = reinterpret_cast<uint2*>(y + (size_t)row * d);
+    const size_t yrow = grp > 0 ? (size_t)(row / grp) * grp_stride + grp_off + (row % grp) : (size_t)row;
+    uint2* yr = reinterpret_cast<uint2*>(y + yrow * d);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int ci = lane + 64 * c;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
                                                              const float* __restrict__ rstd_in, const float* __restrict__ dres_in,
                                                              float* __restrict__ dx_out, bf16_t* __restrict__ dx_bf16,
                                                              float* __restrict__ partial, int rows, int d, long x_stride,
-                                                             long out_stride, int round_params) {
+                                                             long out_stride, int round_params, int grp, int grp_stride, int grp_off) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nchunk = d >> 2;
@@ -104,7 +106,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
   const float inv_d = 1.0f / (float)d;
   for (int row = blockIdx.x * LN_WAVES + wave; row < rows; row += gridDim.x * LN_WAVES) {
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * x_stride);
-    const uint2* dyr = reinterpret_cast<const uint2*>(dy + (size_t)row * d);
+    const size_t dyrow = grp > 0 ? (size_t)(row / grp) * grp_stride + grp_off + (row % grp) : (size_t)row;
+    const uint2* dyr = reinterpret_cast<const uint2*>(dy + dyrow * d);
     const float mean = mean_in[row], rstd = rstd_in[row];
     float4 xh[CH], gy[CH];
     float c1 = 0.f, c2 = 0.f;
@@ -198,6 +201,67 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __res
   }
 }
 
+
+// LayerScale (+ stochastic depth) backward: out = res + rs[m/rps] * ls * branch  (layerscale.py:23, stochastic_depth.py:16-27)
+//   dbr[m,:]  = bf16( dres[m,:] * rs * ls )                 cotangent of the bf16 branch (feeds the wgrad / dgrad GEMMs)
+//   d_ls     += sum_m dres[m,:] * rs * branch[m,:]          dbias += sum_m dbr[m,:]   (bias of the Dense that produced the branch)
+// Same wave-per-row / partial-slab structure as ln_bwd_kernel; slab rows are [d_ls | dbias | unused].
+template <int CH>
+__global__ __launch_bounds__(LN_THREADS) void layerscale_bwd_kernel(const float* __restrict__ dres, const bf16_t* __restrict__ branch,
+                                                                     const float* __restrict__ ls, const float* __restrict__ rowscale,
+                                                                     int rows_per_sample, bf16_t* __restrict__ dbr, float* __restrict__ partial,
+                                                                     int rows, int d, long dres_stride) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nchunk = d >> 2;
+  float4 g[CH], dg[CH], db[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ci = lane + 64 * c;
+    g[c] = (ci < nchunk) ? reinterpret_cast<const float4*>(ls)[ci] : make_float4(0, 0, 0, 0);
+    dg[c] = make_float4(0, 0, 0, 0);
+    db[c] = make_float4(0, 0, 0, 0);
+  }
+  for (int row = blockIdx.x * LN_WAVES + wave; row < rows; row += gridDim.x * LN_WAVES) {
+    const float rs = rowscale ? rowscale[row / rows_per_sample] : 1.0f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ci = lane + 64 * c;
+      if (ci < nchunk) {
+        const float4 dr = reinterpret_cast<const float4*>(dres + (size_t)row * dres_stride)[ci];
+        const uint2 bv = reinterpret_cast<const uint2*>(branch + (size_t)row * d)[ci];
+        const float b0 = __uint_as_float(bv.x << 16), b1 = __uint_as_float(bv.x & 0xffff0000u);
+        const float b2 = __uint_as_float(bv.y << 16), b3 = __uint_as_float(bv.y & 0xffff0000u);
+        const float o0 = round_bf16(dr.x * rs * g[c].x), o1 = round_bf16(dr.y * rs * g[c].y);
+        const float o2 = round_bf16(dr.z * rs * g[c].z), o3 = round_bf16(dr.w * rs * g[c].w);
+        reinterpret_cast<uint2*>(dbr + (size_t)row * d)[ci] = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+        dg[c].x += dr.x * rs * b0; dg[c].y += dr.y * rs * b1; dg[c].z += dr.z * rs * b2; dg[c].w += dr.w * rs * b3;
+        db[c].x += o0; db[c].y += o1; db[c].z += o2; db[c].w += o3;
+      }
+    }
+  }
+  __shared__ float4 red[LN_WAVES][64];
+#pragma unroll
+  for (int which = 0; which < 3; ++which) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float4 v = which == 0 ? dg[c] : (which == 1 ? db[c] : make_float4(0, 0, 0, 0));
+      __syncthreads();
+      red[wave][lane] = v;
+      __syncthreads();
+      if (wave == 0) {
+        float4 t = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < LN_WAVES; ++w) {
+          t.x += red[w][lane].x; t.y += red[w][lane].y; t.z += red[w][lane].z; t.w += red[w][lane].w;
+        }
+        const int ci = lane + 64 * c;
+        if (ci < nchunk) reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 3 + which) * d)[ci] = t;
+      }
+    }
+  }
+}
+
 inline int ln_grid(int rows, int cap) {
   int g = (rows + LN_WAVES - 1) / LN_WAVES;
   return g < cap ? (g < 1 ? 1 : g) : cap;
@@ -223,11 +287,28 @@ extern "C" int savit_layernorm_fwd(const float* x, const float* gamma, const flo
   hipStream_t s = (hipStream_t)stream;
   const int ch = (d / 4 + 63) / 64;
   const int grid = ln_grid(rows, 256 * 16);
-  LN_DISPATCH(ch, ln_fwd_kernel, grid, x, gamma, beta, (bf16_t*)y, mean, rstd, rows, d, x_stride, eps, round_params_bf16);
+  LN_DISPATCH(ch, ln_fwd_kernel, grid, x, gamma, beta, (bf16_t*)y, mean, rstd, rows, d, x_stride, eps, round_params_bf16, 0, 0, 0);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_layernorm_fwd_mapped(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows,
+                                          int d, long x_stride, float eps, int round_params_bf16, int grp, int grp_stride, int grp_off,
+                                          void* stream) {
+  SAVIT_CHECK_ARG(x && gamma && beta && y && x_stride >= d && (x_stride % 4) == 0 && rows >= 0 && d > 0 && (d % 4) == 0 && d <= 64 * 4 * LN_MAX_CHUNKS);
+  SAVIT_CHECK_ARG(grp > 0 && grp_stride >= grp && grp_off >= 0 && grp_off + grp <= grp_stride);
+  if (rows == 0) return SAVIT_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int ch = (d / 4 + 63) / 64;
+  const int grid = ln_grid(rows, 256 * 16);
+  LN_DISPATCH(ch, ln_fwd_kernel, grid, x, gamma, beta, (bf16_t*)y, mean, rstd, rows, d, x_stride, eps, round_params_bf16, grp, grp_stride, grp_off);
   SAVIT_LAUNCH_RET();
 }
 
 static int ln_bwd_grid(int rows) { return ln_grid(rows, 256 * 3); }
+extern "C" int savit_layernorm_bwd_mapped(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                          const float* dres_in, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* dcolsum, int rows,
+                                          int d, long x_stride, long out_stride, int round_params_bf16, int dy_grp, int dy_grp_stride,
+                                          int dy_grp_off, void* workspace, long workspace_bytes, void* stream);
 
 extern "C" long savit_layernorm_bwd_workspace_bytes(int rows, int d) {
   if (rows <= 0 || d <= 0) return 0;
@@ -238,6 +319,15 @@ extern "C" int savit_layernorm_bwd(const void* dy, const float* x, const float* 
                                    const float* dres_in, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* dcolsum,
                                    int rows, int d, long x_stride, long out_stride, int round_params_bf16, void* workspace,
                                    long workspace_bytes, void* stream) {
+  return savit_layernorm_bwd_mapped(dy, x, gamma, mean, rstd, dres_in, dx, dx_bf16, dgamma, dbeta, dcolsum, rows, d, x_stride, out_stride,
+                                    round_params_bf16, 0, 0, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int savit_layernorm_bwd_mapped(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                          const float* dres_in, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* dcolsum, int rows,
+                                          int d, long x_stride, long out_stride, int round_params_bf16, int dy_grp, int dy_grp_stride,
+                                          int dy_grp_off, void* workspace, long workspace_bytes, void* stream) {
+  SAVIT_CHECK_ARG(dy_grp == 0 || (dy_grp > 0 && dy_grp_stride >= dy_grp && dy_grp_off >= 0 && dy_grp_off + dy_grp <= dy_grp_stride));
   SAVIT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && x_stride >= d && out_stride >= d && (x_stride % 4) == 0 &&
                   (out_stride % 4) == 0 && rows >= 0 && d > 0 && (d % 4) == 0 && d <= 64 * 4 * LN_MAX_CHUNKS);
   if (rows == 0) return SAVIT_OK;
@@ -248,10 +338,29 @@ extern "C" int savit_layernorm_bwd(const void* dy, const float* x, const float* 
   const int grid = ln_bwd_grid(rows);
   float* partial = (float*)workspace;
   LN_DISPATCH(ch, ln_bwd_kernel, grid, (const bf16_t*)dy, x, gamma, mean, rstd, dres_in, dx, (bf16_t*)dx_bf16, partial, rows, d,
-              x_stride, out_stride, round_params_bf16);
+              x_stride, out_stride, round_params_bf16, dy_grp, dy_grp_stride, dy_grp_off);
   if (dgamma || dbeta || dcolsum) {
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * d + 63) / 64, FIN_SPLIT), dim3(256), 0, s, partial, grid, d, dgamma,
                        dbeta, dcolsum);
   }
   SAVIT_LAUNCH_RET();
 }
+
+extern "C" int savit_layerscale_bwd(const float* dres, const void* branch_bf16, const float* layerscale, const float* rowscale,
+                                    int rows_per_sample, void* dbranch_bf16, float* d_layerscale, float* dbias, int rows, int d,
+                                    long dres_stride, void* workspace, long workspace_bytes, void* stream) {
+  SAVIT_CHECK_ARG(dres && branch_bf16 && layerscale && dbranch_bf16 && d_layerscale && rows >= 0 && d > 0 && (d % 4) == 0 &&
+                  d <= 64 * 4 * LN_MAX_CHUNKS && dres_stride >= d && (dres_stride % 4) == 0 && (rowscale == nullptr || rows_per_sample >= 1));
+  if (rows == 0) return SAVIT_OK;
+  SAVIT_CHECK_ARG(workspace != nullptr && ((uintptr_t)workspace % 16) == 0 && workspace_bytes >= savit_layernorm_bwd_workspace_bytes(rows, d));
+  hipStream_t s = (hipStream_t)stream;
+  const int ch = (d / 4 + 63) / 64;
+  const int grid = ln_bwd_grid(rows);
+  float* partial = (float*)workspace;
+  LN_DISPATCH(ch, layerscale_bwd_kernel, grid, dres, (const bf16_t*)branch_bf16, layerscale, rowscale, rows_per_sample, (bf16_t*)dbranch_bf16,
+              partial, rows, d, dres_stride);
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * d + 63) / 64, FIN_SPLIT), dim3(256), 0, s, partial, grid, d, d_layerscale, dbias,
+                     (float*)nullptr);
+  SAVIT_LAUNCH_RET();
+}
+

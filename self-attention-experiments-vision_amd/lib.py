@@ -36,6 +36,12 @@ _SIGNATURES = {
                                     c_int, c_void_p]),
     "savit_layernorm_bwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_long, c_long, c_int, c_void_p, c_long, c_void_p]),
     "savit_layernorm_bwd_workspace_bytes": (c_long, [c_int, c_int]),
+    "savit_layernorm_fwd_mapped": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_float, c_int, c_int, c_int, c_int, c_void_p]),
+    "savit_layernorm_bwd_mapped": (c_int, [c_void_p] * 11 + [c_int, c_int, c_long, c_long, c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p]),
+    "savit_layerscale_bwd": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_long, c_void_p]),
+    "savit_class_attention_fwd": (c_int, [c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "savit_class_attention_bwd": (c_int, [c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int,
+                                          c_int, c_float, c_void_p]),
     "savit_gemm_bf16_tn": (c_int, [POINTER(GemmArgs), c_void_p]),
     "savit_gemm_tn_auto_tile": (c_int, [c_int, c_int, c_int]),
     "savit_gemm_wgrad_auto_variant": (c_int, [c_int, c_int, c_int]),

@@ -107,10 +107,42 @@ class ViT:
         return self._any_engine().grad_tree()
 
 
+class CaiT(ViT):
+    """models/cait.py:125-183 behind cait_engine.CaiTEngine.  `is_training=True` draws per-sample stochastic-depth masks
+    (stochastic_depth.py:16-27) from the engine's generator; pass `rngs={'stochastic_depth': seed}` to seed it (the reference needs
+    that rng stream too and forgets to pass it, defect B7)."""
+
+    def engine(self, batch: int):
+        from .cait_engine import CaiTEngine
+
+        e = self._engines.get(batch)
+        if e is None:
+            e = CaiTEngine(self.cfg, batch)
+            if self._engines:
+                first = next(iter(self._engines.values()))
+                e.params, e.grads, e.w = first.params, first.grads, first.w
+                e.adam_m, e.adam_v = first.adam_m, first.adam_v
+                e.weights_stale = first.weights_stale
+            self._engines[batch] = e
+        return e
+
+    def apply(self, params: dict, images: torch.Tensor, is_training: bool = False, rngs=None) -> torch.Tensor:
+        self.bind(params)
+        e = self.engine(images.shape[0])
+        if rngs and "stochastic_depth" in rngs:
+            e.gen.manual_seed(int(rngs["stochastic_depth"]))
+        return e.forward(images, is_training=is_training).to(self.dtype)
+
+    def __call__(self, images: torch.Tensor, is_training: bool = False) -> torch.Tensor:
+        if images.dim() != 4:
+            raise ValueError("images must be NHWC [B,S,S,3]")
+        return self.engine(images.shape[0]).forward(images, is_training=is_training).to(self.dtype)
+
+
 def create_model(model_name: str, num_classes: int = 1000, dtype=torch.bfloat16, img_size: int = 224):
     """models/create_model.py:6-8.  Same names; `vit_ti_patch16` / `vit_s_patch16` added for BASELINE configs 1-2.
     img_size is an extension (the reference fixes it through the init example; train.py --img_size)."""
     cfg = get_config(model_name, num_classes=num_classes, img_size=img_size)
     if cfg.kind == "vit":
         return ViT(cfg, dtype=dtype)
-    raise NotImplementedError(f"{model_name}: the CaiT family (talking-heads / class-attention kernels) is not built yet")
+    return CaiT(cfg, dtype=dtype)

@@ -183,3 +183,73 @@ def test_train_steps_track_oracle(pkg):
         kk = k[len("params/"):]
         # Adam's sign-like first steps amplify bf16 gradient noise on near-zero gradients; compare the update direction
         assert rel(got[kk], x) < 6e-2, (kk, rel(got[kk], x))
+
+
+# ------------------------------------------------------------------------------------------ CaiT
+CAIT_CASES = {
+    "tiny_cait": dict(kind="cait", num_layers=2, num_heads=2, embed_dim=128, patch=8, num_classes=16, img_size=32, num_layers_token_only=2,
+                      stoch_depth_rate=0.1, layerscale_eps=1e-5),
+    "xxs2": dict(kind="cait", num_layers=2, num_heads=4, embed_dim=192, patch=16, num_classes=1000, img_size=224, num_layers_token_only=2,
+                 stoch_depth_rate=0.05, layerscale_eps=1e-5),
+}
+
+
+@pytest.mark.parametrize("case,B,training", [("tiny_cait", 3, False), ("tiny_cait", 4, True), ("xxs2", 2, True)])
+def test_cait_forward_backward_parity(pkg, case, B, training):
+    """Talking-heads SA + LayerScale + stochastic depth + class attention end to end vs the fp32 oracle / fp32 autograd.
+    Training mode uses explicit per-sample keep masks (the JAX rng stream cannot be reproduced)."""
+    from savit_amd.cait_engine import CaiTEngine
+    from savit_amd.config import ModelConfig
+
+    kw = CAIT_CASES[case]
+    mc, oc = ModelConfig(**kw), vit_ref.Cfg(**kw)
+    rng = np.random.default_rng(21)
+    params = vit_ref.init_params(oc, seed=6, randomize=True)
+    images = vit_ref.bf16_round(rng.standard_normal((B, oc.img_size, oc.img_size, 3)).astype(np.float32))
+    labels = rng.integers(0, oc.num_classes, B)
+    masks = (rng.random((oc.num_layers + oc.num_layers_token_only, 2, B)) < 0.7).astype(np.float32) if training else None
+    eng = CaiTEngine(mc, B)
+    eng.load_params(params)
+    logits = eng.forward(torch.as_tensor(images).cuda(), is_training=training,
+                         keep_masks=None if masks is None else torch.as_tensor(masks)).float().cpu().numpy()
+    ref32 = vit_ref.forward(params, images, oc, mode="f32", is_training=training, keep_masks=masks)
+    refbf = vit_ref.forward(params, images, oc, mode="bf16", is_training=training, keep_masks=masks)
+    r_us, r_emul = rel(logits, ref32), rel(refbf, ref32)
+    print(f"[{case} train={training}] logits rel-L2 vs fp32 oracle: engine {r_us:.2e}, bf16-emulating oracle {r_emul:.2e}")
+    assert np.isfinite(logits).all()
+    assert r_us < max(2.5 * r_emul, 8e-3)
+    loss = float(eng.loss_backward(torch.as_tensor(labels).cuda(), 0.1))
+    loss_ref, _, grads_ref = torch_ref.loss_and_grads(params, images, labels, oc, 0.1, is_training=training, keep_masks=masks)
+    assert abs(loss - loss_ref) < 2e-2 * max(1.0, abs(loss_ref))
+    got = _flat(eng.grad_tree()["params"])
+    assert set(got) == set(grads_ref)
+    worst, worst_k = 0.0, ""
+    for k, g in grads_ref.items():
+        r = rel(got[k], g)
+        if r > worst:
+            worst, worst_k = r, k
+        assert r < 8e-2, (k, r)
+    print(f"[{case} train={training}] worst parameter-gradient rel-L2 vs fp32 autograd: {worst:.2e} ({worst_k})")
+
+
+def test_cait_reference_shapes_and_known_answers(pkg):
+    """models/cait_test.py:13-40 (logits (2, 1000) on ones for the CaiT sizes; here the smallest and cait_s_24) + SURVEY 8c vi."""
+    from savit_amd.model import create_model
+
+    for name, count in (("cait_xxs_24", None), ("cait_s_24", 46_875_496)):
+        model = create_model(name)
+        logits, params = model.init_with_output(0, torch.ones(2, 224, 224, 3, device="cuda"), is_training=False)
+        assert tuple(logits.shape) == (2, 1000)
+        assert float(logits.float().abs().max()) == 0.0  # zero-init head (cait.py:179-182)
+        p = params["params"]
+        ls = p["Encoder_0"]["EncoderBlock_0"]["LayerScaleBlock_0"]["layerscale"]
+        assert torch.all(ls == model.cfg.layerscale_eps)  # layerscale.py:5-10
+        t = p["Encoder_0"]["EncoderBlock_0"]["SelfAttentionBlock_0"]["TalkingHeadsBlock_0"]["talking_heads_transform"]
+        assert torch.allclose(t @ t.T, torch.eye(t.shape[0], device=t.device), atol=1e-5)  # orthogonal init
+        assert "CAEncoderBlock_1" in p and "ClassSelfAttentionBlock_0" in p["CAEncoderBlock_0"]
+        if count is not None:
+            assert sum(v.numel() for _, v in torch_ref.leaves(p)) == count
+        # training mode runs (stochastic depth masks drawn on the GPU) and differs from eval only through the masks
+        model.bind(params)
+        out_t = model(torch.ones(2, 224, 224, 3, device="cuda"), is_training=True)
+        assert tuple(out_t.shape) == (2, 1000)
