@@ -57,10 +57,12 @@ def kernel_symbol(label: str, lib, M: int, d: int, F: int) -> str:
 def kernel_class(label: str) -> str:
     if label.endswith(".wgrad") or label == "Wpe.wgrad":
         return "gemm_wgrad"
-    if label.endswith(".dgrad") or label.split(".")[-1] in ("qkv", "proj", "fc1", "fc2") or label in ("patch_embed", "head"):
+    if label.endswith(".dgrad") or label.split(".")[-1] in ("qkv", "proj", "fc1", "fc2", "q", "kv") or label in ("patch_embed", "head"):
         return "gemm_tn"
     if "attn" in label:
         return "attention_bwd" if label.endswith(".bwd") else "attention_fwd"
+    if ".ls" in label:
+        return "layerscale_bwd"
     if "ln" in label:
         return "layernorm_bwd" if label.endswith(".bwd") else "layernorm_fwd"
     return "other"
@@ -105,7 +107,12 @@ def main():
 
     cfg = get_config(args.model, img_size=args.img_size)
     B = args.batch
-    eng = ViTEngine(cfg, B)
+    if cfg.kind == "cait":
+        from savit_amd.cait_engine import CaiTEngine
+
+        eng = CaiTEngine(cfg, B)
+    else:
+        eng = ViTEngine(cfg, B)
     eng.init_params(seed=42)  # train.py:187-189 default seed
     # the reference zero-initialises the head kernel (vit.py:98); a zero operand would make the first backward
     # passes run on zeros (higher clocks), so the benchmark gives the head a lecun-normal kernel.
@@ -114,7 +121,7 @@ def main():
     sync = None
     if world > 1:
         ddp.broadcast_params(eng.params)
-        buckets = ddp.plan_buckets(eng.layout.layer_start, eng.layout.final_start, eng.layout.total, int(args.bucket_mb * 2 ** 20 / 4))
+        buckets = ddp.plan_buckets_for(eng.layout, int(args.bucket_mb * 2 ** 20 / 4))
         sync = ddp.GradSync(eng.grads, buckets)
         eng.bwd_hooks = sync.hooks()
     eng.refresh_weights()
@@ -128,7 +135,10 @@ def main():
 
     def step(i):
         img, lab = batches[i & 1]
-        eng.forward(img)
+        if cfg.kind == "cait":
+            eng.forward(img, is_training=True)  # stochastic depth active (cait.py:38,49)
+        else:
+            eng.forward(img)
         eng.loss_backward(lab, label_smoothing=0.1)
         if sync is not None:
             sync.wait()
@@ -198,7 +208,7 @@ def main():
         # dominant KERNEL SYMBOL (what rocprofv3 --kernel-trace --stats lists): total time, launches, algorithmic flops
         sym_ms, sym_n, sym_fl = {}, {}, {}
         for label, t_ms in times.items():
-            sym = kernel_symbol(label, eng.L, M, d, F)
+            sym = kernel_symbol(label, eng.L, M, d, F) if cfg.kind == "vit" else kernel_class(label)
             parts = label.split(".")
             key = {"Wqkv": "qkv", "Wo": "proj", "W1": "fc1", "W2": "fc2"}.get(parts[1], parts[1]) if len(parts) >= 2 else ""
             fl = gemm_flops.get(key, 0.0) if sym.startswith("gemm") and parts[0].startswith("l") else 0.0

@@ -948,7 +948,7 @@ __device__ __forceinline__ void th_row_forward(const float (&s)[H][TH_KPL], cons
       float a = 0.f;
 #pragma unroll
       for (int h = 0; h < H; ++h) a += T1[h * H + i] * s[h][k];
-      sp[k] = (lane + 64 * k < N) ? a : -INFINITY;
+      sp[k] = (4 * lane + k < N) ? a : -INFINITY;
       m = fmaxf(m, sp[k]);
     }
     m = wave_max(m);
@@ -979,118 +979,201 @@ __global__ __launch_bounds__(256) void th_softmax_fwd_kernel(const bf16_t* __res
   for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
     const int b = (int)(row / N), q = (int)(row - (long)b * N);
     float s[H][TH_KPL], pr[H][TH_KPL];
+    // lane owns 4 CONSECUTIVE keys (one 8-byte load per head): strided 2-byte loads made this kernel latency-bound
+    const bool in_row = 4 * lane < Np;
 #pragma unroll
-    for (int h = 0; h < H; ++h)
-#pragma unroll
-      for (int k = 0; k < TH_KPL; ++k) {
-        const int key = lane + 64 * k;
-        s[h][k] = (key < N) ? bf16_to_f32(S[(((size_t)b * H + h) * N + q) * Np + key]) : 0.f;
-      }
+    for (int h = 0; h < H; ++h) {
+      uint2 v = make_uint2(0u, 0u);
+      if (in_row) v = *reinterpret_cast<const uint2*>(S + (((size_t)b * H + h) * N + q) * Np + 4 * lane);
+      s[h][0] = __uint_as_float(v.x << 16); s[h][1] = __uint_as_float(v.x & 0xffff0000u);
+      s[h][2] = __uint_as_float(v.y << 16); s[h][3] = __uint_as_float(v.y & 0xffff0000u);
+    }
     th_row_forward<H>(s, T1, N, lane, pr);
 #pragma unroll
-    for (int i = 0; i < H; ++i)
+    for (int i = 0; i < H; ++i) {
+      float o4[TH_KPL];
 #pragma unroll
       for (int k = 0; k < TH_KPL; ++k) {
-        const int key = lane + 64 * k;
         float a = 0.f;
 #pragma unroll
         for (int h = 0; h < H; ++h) a += T2[h * H + i] * pr[h][k];
-        if (key < Np) Pp[(((size_t)b * H + i) * N + q) * Np + key] = f32_to_bf16(key < N ? a : 0.f);
+        o4[k] = (4 * lane + k < N) ? a : 0.f;
       }
+      if (in_row)
+        *reinterpret_cast<uint2*>(Pp + (((size_t)b * H + i) * N + q) * Np + 4 * lane) = make_uint2(pack_bf16x2(o4[0], o4[1]), pack_bf16x2(o4[2], o4[3]));
+    }
   }
 }
 
-// backward of the row op; dT1/dT2 partial sums go to slab[block][2*H*H] (summed by th_dT_finalize_kernel)
+// backward of the row op; dT1/dT2 partial sums go to slab[block][2*H*H] (summed by th_dT_finalize_kernel).
+// Register plan (H = 8): S and dP' stay PACKED as bf16 pairs (16 + 16 VGPRs), P / dP are fp32 [H][4] (32 + 32), the 2 x H x H
+// per-lane dT partials persist across the rows a wave processes (128); every mixing loop runs key-outer so only 8 + 8 unpacked
+// temporaries are live.  The first version kept everything in fp32 and spilled 580 B/lane to scratch (1.55 ms per layer).
+__device__ __forceinline__ float th_unpack(uint32_t w, int odd) { return odd ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16); }
+
+// Reduce-scatter of 64 per-lane partials over the 64 lanes: after 6 halving exchanges lane l holds sum_lanes g[l].
+// 63 shuffles instead of 64 full wave reductions, and the H x H dT partials need not persist in registers across rows.
+__device__ __forceinline__ float reduce_scatter64(float (&g)[64], int lane) {
+#pragma unroll
+  for (int st = 0; st < 6; ++st) {
+    const int mask = 32 >> st, n2 = 32 >> st;
+    const bool upper = (lane & mask) != 0;
+#pragma unroll
+    for (int j = 0; j < n2; ++j) {
+      const float lo = g[j], hi = g[j + n2];
+      const float send = upper ? lo : hi, keep = upper ? hi : lo;
+      g[j] = keep + __shfl_xor(send, mask, 64);
+    }
+  }
+  return g[0];
+}
+
 template <int H>
 __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __restrict__ S, const bf16_t* __restrict__ dPp, bf16_t* __restrict__ dS,
-                                                                 const float* __restrict__ T1g, const float* __restrict__ T2g,
-                                                                 float* __restrict__ slab, int B, int N, int Np) {
+                                                              const float* __restrict__ T1g, const float* __restrict__ T2g,
+                                                              float* __restrict__ slab, int B, int N, int Np) {
+  static_assert(H <= 8, "dT partials are reduce-scattered as 8x8 tiles");
   __shared__ float T1[H * H], T2[H * H];
-  __shared__ float red[4][2 * H * H];
+  __shared__ float red[4][128];
   for (int i = threadIdx.x; i < H * H; i += blockDim.x) {
     T1[i] = T1g[i];
     T2[i] = T2g[i];
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float g1[H][H], g2[H][H];  // per-lane partial dT1[h][i], dT2[h][i]
-#pragma unroll
-  for (int h = 0; h < H; ++h)
-#pragma unroll
-    for (int i = 0; i < H; ++i) {
-      g1[h][i] = 0.f;
-      g2[h][i] = 0.f;
-    }
+  float acc1 = 0.f, acc2 = 0.f;  // lane l accumulates dT1 / dT2 entry (h = l>>3, i = l&7)
   const long rows = (long)B * N;
   for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
     const int b = (int)(row / N), q = (int)(row - (long)b * N);
-    float s[H][TH_KPL], pr[H][TH_KPL], dpp[H][TH_KPL];
-#pragma unroll
-    for (int h = 0; h < H; ++h)
-#pragma unroll
-      for (int k = 0; k < TH_KPL; ++k) {
-        const int key = lane + 64 * k;
-        const size_t off = (((size_t)b * H + h) * N + q) * Np + key;
-        s[h][k] = (key < N) ? bf16_to_f32(S[off]) : 0.f;
-        dpp[h][k] = (key < N) ? bf16_to_f32(dPp[off]) : 0.f;
-      }
-    th_row_forward<H>(s, T1, N, lane, pr);
-    // dT2[h][i] += sum_k P_h dP'_i ;  dP_h = sum_i T2[h][i] dP'_i ; delta_h ; dS'_h = P_h (dP_h - delta_h)   (in place in pr)
+    uint32_t sp[H][TH_KPL / 2], dq[H][TH_KPL / 2];
+    // lane owns keys 4*lane .. 4*lane+3: one 8-byte load per head and tensor; pair k2 = keys (2*k2, 2*k2+1)
+    const bool in_row = 4 * lane < Np;
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      float dp[TH_KPL];
-      float del = 0.f;
-#pragma unroll
-      for (int k = 0; k < TH_KPL; ++k) {
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < H; ++i) {
-          a += T2[h * H + i] * dpp[i][k];
-          g2[h][i] += pr[h][k] * dpp[i][k];
-        }
-        dp[k] = a;
-        del += pr[h][k] * a;
+      const size_t off = (((size_t)b * H + h) * N + q) * Np + 4 * lane;
+      uint2 sv2 = make_uint2(0u, 0u), dv2 = make_uint2(0u, 0u);
+      if (in_row) {
+        sv2 = *reinterpret_cast<const uint2*>(S + off);
+        dv2 = *reinterpret_cast<const uint2*>(dPp + off);
       }
-      del = wave_sum(del);
-#pragma unroll
-      for (int k = 0; k < TH_KPL; ++k) pr[h][k] = pr[h][k] * (dp[k] - del);
+      sp[h][0] = sv2.x; sp[h][1] = sv2.y;
+      dq[h][0] = dv2.x; dq[h][1] = dv2.y;
     }
-    // dS_h = sum_i T1[h][i] dS'_i ; dT1[h][i] += sum_k S_h dS'_i
+    // ---- forward recompute: P_i = softmax_k(sum_h T1[h][i] S_h)
+    float pr[H][TH_KPL];
 #pragma unroll
-    for (int h = 0; h < H; ++h)
+    for (int k = 0; k < TH_KPL; ++k) {
+      float sv[H];
 #pragma unroll
-      for (int k = 0; k < TH_KPL; ++k) {
-        const int key = lane + 64 * k;
+      for (int h = 0; h < H; ++h) sv[h] = th_unpack(sp[h][k >> 1], k & 1);
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
         float a = 0.f;
 #pragma unroll
-        for (int i = 0; i < H; ++i) {
-          a += T1[h * H + i] * pr[i][k];
-          g1[h][i] += s[h][k] * pr[i][k];
-        }
-        if (key < Np) dS[(((size_t)b * H + h) * N + q) * Np + key] = f32_to_bf16(key < N ? a : 0.f);
+        for (int h = 0; h < H; ++h) a += T1[h * H + i] * sv[h];
+        pr[i][k] = (4 * lane + k < N) ? a : -INFINITY;
       }
-  }
-#pragma unroll
-  for (int h = 0; h < H; ++h)
+    }
 #pragma unroll
     for (int i = 0; i < H; ++i) {
-      const float a = wave_sum(g1[h][i]), c = wave_sum(g2[h][i]);
-      if (lane == 0) {
-        red[wave][h * H + i] = a;
-        red[wave][H * H + h * H + i] = c;
+      float m = fmaxf(fmaxf(pr[i][0], pr[i][1]), fmaxf(pr[i][2], pr[i][3]));
+      m = wave_max(m);
+      float l = 0.f;
+#pragma unroll
+      for (int k = 0; k < TH_KPL; ++k) {
+        pr[i][k] = __builtin_amdgcn_exp2f((pr[i][k] - m) * LOG2E);
+        l += pr[i][k];
       }
+      const float inv = 1.0f / wave_sum(l);
+#pragma unroll
+      for (int k = 0; k < TH_KPL; ++k) pr[i][k] *= inv;
     }
+    // ---- dT2[h][i] += sum_k P_h dP'_i ; dP_h = sum_i T2[h][i] dP'_i ; delta_h = sum_k P_h dP_h
+    float dp[H][TH_KPL], del[H];
+    {
+      float g[64];
+#pragma unroll
+      for (int j = 0; j < 64; ++j) g[j] = 0.f;
+#pragma unroll
+      for (int h = 0; h < H; ++h) del[h] = 0.f;
+#pragma unroll
+      for (int k = 0; k < TH_KPL; ++k) {
+        float dv[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) dv[i] = th_unpack(dq[i][k >> 1], k & 1);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          float a = 0.f;
+#pragma unroll
+          for (int i = 0; i < H; ++i) {
+            a += T2[h * H + i] * dv[i];
+            g[h * 8 + i] += pr[h][k] * dv[i];
+          }
+          dp[h][k] = a;
+          del[h] += pr[h][k] * a;
+        }
+      }
+      acc2 += reduce_scatter64(g, lane);
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) del[h] = wave_sum(del[h]);
+    // ---- dS'_i = P_i (dP_i - delta_i) ; dS_h = sum_i T1[h][i] dS'_i ; dT1[h][i] += sum_k S_h dS'_i
+    {
+      float g[64];
+#pragma unroll
+      for (int j = 0; j < 64; ++j) g[j] = 0.f;
+      float dsv[H][TH_KPL];
+#pragma unroll
+      for (int k = 0; k < TH_KPL; ++k) {
+        float dsp[H], sv[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+          dsp[i] = pr[i][k] * (dp[i][k] - del[i]);
+          sv[i] = th_unpack(sp[i][k >> 1], k & 1);
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          float a = 0.f;
+#pragma unroll
+          for (int i = 0; i < H; ++i) {
+            a += T1[h * H + i] * dsp[i];
+            g[h * 8 + i] += sv[h] * dsp[i];
+          }
+          dsv[h][k] = (4 * lane + k < N) ? a : 0.f;
+        }
+      }
+      if (in_row) {
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+          *reinterpret_cast<uint2*>(dS + (((size_t)b * H + h) * N + q) * Np + 4 * lane) =
+              make_uint2(pack_bf16x2(dsv[h][0], dsv[h][1]), pack_bf16x2(dsv[h][2], dsv[h][3]));
+      }
+      acc1 += reduce_scatter64(g, lane);
+    }
+  }
+  red[wave][lane] = acc1;
+  red[wave][64 + lane] = acc2;
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * H * H; i += blockDim.x)
-    slab[(size_t)blockIdx.x * 2 * H * H + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+  // slab row: [dT1 (H*H) | dT2 (H*H)], entry (h, i) sits in reduce-scatter lane h*8 + i
+  for (int t = threadIdx.x; t < 2 * H * H; t += blockDim.x) {
+    const int which = t / (H * H), e = t - which * H * H;
+    const int src = which * 64 + (e / H) * 8 + (e % H);
+    slab[(size_t)blockIdx.x * 2 * H * H + t] = red[0][src] + red[1][src] + red[2][src] + red[3][src];
+  }
 }
 
-__global__ void th_dT_finalize_kernel(const float* __restrict__ slab, int nblk, int hh2, float* __restrict__ dT1, float* __restrict__ dT2) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per output element: rows of the slab strided over the lanes, wave reduction, one add
+__global__ __launch_bounds__(256) void th_dT_finalize_kernel(const float* __restrict__ slab, int nblk, int hh2, float* __restrict__ dT1,
+                                                              float* __restrict__ dT2) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= 2 * hh2) return;
+  const int lane = threadIdx.x & 63;
   float a = 0.f;
-  for (int r = 0; r < nblk; ++r) a += slab[(size_t)r * 2 * hh2 + i];
-  if (i < hh2) dT1[i] += a; else dT2[i - hh2] += a;
+  for (int r = lane; r < nblk; r += 64) a += slab[(size_t)r * 2 * hh2 + i];
+  a = wave_sum(a);
+  if (lane == 0) {
+    if (i < hh2) dT1[i] += a; else dT2[i - hh2] += a;
+  }
 }
 
 }  // namespace
@@ -1239,7 +1322,7 @@ extern "C" int savit_th_attention_bwd(const void* qkv, const float* T1, const fl
   if (blocks > 2048) blocks = 2048;
   TH_H_DISPATCH(th_softmax_bwd_kernel, (unsigned)blocks, (const bf16_t*)s_buf, (const bf16_t*)ds_buf, (bf16_t*)p_buf, T1, T2, (float*)workspace, B,
                 N, Np)
-  hipLaunchKernelGGL(th_dT_finalize_kernel, dim3((2 * H * H + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, (int)blocks,
+  hipLaunchKernelGGL(th_dT_finalize_kernel, dim3((2 * H * H + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)blocks,
                      H * H, dT1, dT2);
   // 3) dQ, dK from dS (p_buf)
   p.sbuf = (bf16_t*)p_buf;

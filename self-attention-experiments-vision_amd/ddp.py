@@ -38,6 +38,17 @@ def plan_buckets(layer_starts: List[int], final_start: int, total: int, min_buck
     return buckets
 
 
+def plan_buckets_for(layout, min_bucket_elems: int) -> List[Tuple[int, int, str]]:
+    """Buckets for an engine layout (engine.ParamLayout or cait_engine.CaiTLayout).  CaiT: the token-only layers and the final
+    block sit at the end of the buffer and finish first (after 'cls.grad'); the SA layers follow as for ViT."""
+    ca = getattr(layout, "ca_start", None)
+    if ca:
+        tail = (ca[0], layout.total, "cls.grad")
+        rest = plan_buckets(layout.layer_start, ca[0], ca[0], min_bucket_elems)
+        return [tail] + rest
+    return plan_buckets(layout.layer_start, layout.final_start, layout.total, min_bucket_elems)
+
+
 class GradSync:
     def __init__(self, flat_grads: torch.Tensor, buckets: List[Tuple[int, int, str]], group=None):
         if not dist.is_initialized():

@@ -153,7 +153,7 @@ def main(argv=None):
     sync = None
     if world > 1:
         ddp.broadcast_params(eng.params)  # replicate, train.py:228
-        sync = ddp.GradSync(eng.grads, ddp.plan_buckets(eng.layout.layer_start, eng.layout.final_start, eng.layout.total, 48 * 2 ** 20 // 4))
+        sync = ddp.GradSync(eng.grads, ddp.plan_buckets_for(eng.layout, 48 * 2 ** 20 // 4))
         eng.bwd_hooks = sync.hooks()
     eng.refresh_weights()
 
@@ -194,7 +194,10 @@ def main(argv=None):
     for epoch in range(start // spe, args.num_epochs):
         for batch in train_src(epoch):
             lr = warmup_cosine(step, peak, 5 * spe, total)
-            eng.forward(batch["images"])
+            if eng.cfg.kind == "cait":
+                eng.forward(batch["images"], is_training=True)
+            else:
+                eng.forward(batch["images"])
             eng.loss_backward(batch["labels"], args.label_smoothing, batch.get("mix_labels"), batch.get("ratio"))
             if sync is not None:
                 sync.wait()
