@@ -221,6 +221,19 @@ def main():
                            "avg_launch_ms": round(sym_ms[dom] / sym_n[dom], 4), "share_of_step": round(sym_ms[dom] / total_ms, 3),
                            "flops_per_launch": sym_fl[dom] / sym_n[dom], "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
+        # HBM-side traffic of that kernel: PMC passes cannot run inside this process, so the figure is the committed
+        # rocprofv3 --pmc measurement of the same workload (tools/pmc_summary.py -> profiles/*_pmc_traffic.json), when it
+        # covers this kernel and this is the headline workload; null otherwise.
+        try:
+            if args.model == "vit_b_patch16" and B == 128:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(dom)
+                if pm:
+                    out["roofline"]["traffic"] = pm["traffic_bytes"]
+                    out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled)"
+                    out["roofline"]["algorithmic_bytes_per_launch"] = int(sum(2 * M * (a + b_) + 4 * a * b_ for a, b_ in ((d, 3 * d), (d, F), (F, d))) / 3) \
+                        if dom.startswith("gemm_wgrad_ring_kernel<256") else None
+        except (OSError, ValueError, KeyError):
+            pass
         out["kernel_breakdown_ms"] = {c: round(v, 3) for c, v in sorted(cls_ms.items(), key=lambda kv: -kv[1])}
         out["kernel_breakdown_ms"]["sum_fwd_bwd"] = round(total_ms, 3)
         out["gemm_class_tflops"] = {c: round(cls_fl[c] / (cls_ms[c] * 1e-3) / 1e12, 2) for c in ("gemm_tn", "gemm_wgrad") if cls_ms.get(c)}
