@@ -21,6 +21,7 @@ a flat loop of ~260 asynchronous launches with no allocation - and therefore cap
 from __future__ import annotations
 
 import ctypes
+import os
 import math
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -137,20 +138,71 @@ def _copy_tree(dst: dict, src: dict, path: str = ""):
 
 
 class _Plan:
-    """A recorded sequence of kernel launches: (ctypes fn, args-without-stream, label)."""
+    """A recorded sequence of kernel launches: (ctypes fn, args-without-stream, label).
+
+    A launch may be marked `side`: it has no consumer later in the plan (the weight-gradient GEMMs: their only output is
+    the gradient buffer), so `run_overlapped` issues it on a second HIP stream where it fills the CUs that the
+    memory-bound LayerNorm / attention launches of the main chain leave idle.  `reads`/`writes` declare the scratch
+    buffers a side launch reads and a main launch overwrites; the plan turns them into event waits."""
 
     def __init__(self):
         self.calls: List[Tuple[Callable, tuple, str]] = []
         self.keep: List[object] = []  # ctypes structs that must outlive the plan
+        self.side: Dict[int, bool] = {}          # call index -> runs on the side stream
+        self.guard: Dict[int, List[int]] = {}    # main call index -> side call indices that must have finished first
+        self._readers: Dict[int, List[int]] = {}  # buffer address -> side calls reading it (build-time bookkeeping)
+        self._ev_ready: Dict[int, "torch.cuda.Event"] = {}
+        self._ev_done: Dict[int, "torch.cuda.Event"] = {}
 
-    def add(self, fn, args: tuple, label: str):
+    def add(self, fn, args: tuple, label: str, side: bool = False, reads: tuple = (), writes: tuple = ()):
+        i = len(self.calls)
         self.calls.append((fn, args, label))
+        if side:
+            assert not writes
+            self.side[i] = True
+            for r in reads:
+                self._readers.setdefault(r, []).append(i)
+        else:
+            g = [j for w in writes for j in self._readers.pop(w, [])]
+            if g:
+                self.guard[i] = [max(g)]  # the side stream is in-order: the latest reader covers the rest
 
     def run(self, stream: int):
         for fn, args, label in self.calls:
             rc = fn(*args, stream)
             if rc != 0:
                 _lib.check(rc, label)
+
+    def run_overlapped(self, main: "torch.cuda.Stream", side: "torch.cuda.Stream", hooks: Optional[Dict[str, Callable[[], None]]] = None):
+        """Main-chain launches on `main`, side launches on `side`, ordered by events; both streams are joined before every
+        hook (the DDP bucket all-reduce reads gradients written on either stream) and at the end."""
+        mh, sh = main.cuda_stream, side.cuda_stream
+        last_side = None
+        for i, (fn, args, label) in enumerate(self.calls):
+            if i in self.side:
+                ev = self._ev_ready.get(i)
+                if ev is None:
+                    ev = self._ev_ready[i] = torch.cuda.Event()
+                    self._ev_done[i] = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                rc = fn(*args, sh)
+                self._ev_done[i].record(side)
+                last_side = i
+            else:
+                for j in self.guard.get(i, ()):
+                    main.wait_event(self._ev_done[j])
+                rc = fn(*args, mh)
+            if rc != 0:
+                _lib.check(rc, label)
+            if hooks:
+                cb = hooks.get(label)
+                if cb is not None:
+                    if last_side is not None:
+                        main.wait_event(self._ev_done[last_side])
+                    cb()
+        if last_side is not None:
+            main.wait_event(self._ev_done[last_side])
 
 
 class ViTEngine:
@@ -209,11 +261,15 @@ class ViTEngine:
         self.logits = e(self.B, C)
         # ---- backward scratch
         self.dres = e(M, d)
-        self.dres_b = e(M, d, dt=bf16)
-        self.d_u = e(M, F, dt=bf16)
+        # scratch that the side-stream weight-gradient GEMMs read is rotated, so the main chain rarely has to wait for them
+        self.dres_b_ring = [e(M, d, dt=bf16) for _ in range(4)]
+        self.dres_b = self.dres_b_ring[0]
+        self.d_u_ring = [e(M, F, dt=bf16) for _ in range(2)]
+        self.d_u = self.d_u_ring[0]
         self.d_h = e(M, d, dt=bf16)
         self.d_o = e(M, d, dt=bf16)
-        self.dqkv = e(M, 3 * d, dt=bf16)
+        self.dqkv_ring = [e(M, 3 * d, dt=bf16) for _ in range(2)]
+        self.dqkv = self.dqkv_ring[0]
         self.dlogits = z(self.B, self.Cp, dt=bf16)
         self.d_z = e(self.B, d, dt=bf16)
         ws = self.L.savit_layernorm_bwd_workspace_bytes(M, d)
@@ -231,6 +287,9 @@ class ViTEngine:
         self._cast_plan: Optional[_Plan] = None
         self.bwd_hooks: Dict[str, Callable[[], None]] = {}  # label -> callback run right after that launch (DDP buckets)
         self.weights_stale = True
+        # weight-gradient GEMMs on a second stream (SAVIT_OVERLAP_WGRAD=0 keeps every launch on the caller's stream)
+        self.overlap_wgrad = os.environ.get("SAVIT_OVERLAP_WGRAD", "1") != "0"
+        self._side_stream: Optional[torch.cuda.Stream] = None
 
     # ------------------------------------------------------------------------------------ parameters
     def param_tree(self) -> dict:
@@ -276,7 +335,7 @@ class ViTEngine:
     def _off_ptr(self, buf: torch.Tensor, name: str) -> int:
         return buf.data_ptr() + self.layout.off[name][0] * 4
 
-    def _gemm(self, plan: _Plan, label: str, **kw):
+    def _gemm(self, plan: _Plan, label: str, writes: tuple = (), **kw):
         a = _lib.GemmArgs()
         for k, v in kw.items():
             setattr(a, k, v)
@@ -284,7 +343,7 @@ class ViTEngine:
             a.rows_per_sample = 1
         a.round_bias_bf16 = self.rp
         plan.keep.append(a)
-        plan.add(self.L.savit_gemm_bf16_tn, (ctypes.byref(a),), label)
+        plan.add(self.L.savit_gemm_bf16_tn, (ctypes.byref(a),), label, writes=writes)
 
     def _build_cast_plan(self) -> _Plan:
         P, L, lay, cfg = _Plan(), self.L, self.layout, self.cfg
@@ -342,44 +401,51 @@ class ViTEngine:
         ws, wsb = self.ln_ws.data_ptr(), self.ln_ws.numel()
 
         def wgrad(label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0)):
-            P.add(L.savit_gemm_bf16_wgrad, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, 0, patch[0], patch[1], patch[2], patch[3]), label)
+            # no later launch consumes dW: side stream.  X is a saved activation (stable until the next forward), dY is scratch
+            P.add(L.savit_gemm_bf16_wgrad, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, 0, patch[0], patch[1], patch[2], patch[3]), label,
+                  side=True, reads=(dY,))
 
+        ring, ri = [t.data_ptr() for t in self.dres_b_ring], 0
         # ---- head: dWh, d z_cls, final LayerNorm backward into the (zeroed) residual gradient
         wgrad("head.wgrad", self.zcls.data_ptr(), self.dlogits.data_ptr(), gp("Wh"), B, d, C, d, self.Cp, C)
         self._gemm(P, "head.dgrad", A=self.dlogits.data_ptr(), Bt=self.w["Wh_n"].data_ptr(), C=self.d_z.data_ptr(), M=B, N=d, K=self.Cp,
                    lda=self.Cp, ldb=self.Cp, ldc=d, epilogue=_lib.EPI_BF16)
         P.add(L.savit_layernorm_bwd, (self.d_z.data_ptr(), self.x[NL].data_ptr(), pp("lnf_g"), self.fstats[0].data_ptr(),
-                                      self.fstats[1].data_ptr(), None, self.dres.data_ptr(), self.dres_b.data_ptr(), gp("lnf_g"),
-                                      gp("lnf_b"), gp(f"l{NL - 1}.b2"), B, d, N * d, N * d, self.rp, ws, wsb), "lnf.bwd")
+                                      self.fstats[1].data_ptr(), None, self.dres.data_ptr(), ring[0], gp("lnf_g"),
+                                      gp("lnf_b"), gp(f"l{NL - 1}.b2"), B, d, N * d, N * d, self.rp, ws, wsb), "lnf.bwd", writes=(ring[0],))
         for l in range(NL - 1, -1, -1):
             st = self.stats[l]
             w = lambda n, l=l: self.w[n][l].data_ptr()  # noqa: E731
+            d_u, dqkv = self.d_u_ring[l % 2].data_ptr(), self.dqkv_ring[l % 2].data_ptr()
             # FFN branch: x_{l+1} = x_mid + gelu(h2 W1 + b1) W2 + b2     (ff.py:26-33, vit.py:26-31)
-            wgrad(f"l{l}.W2.wgrad", self.a[l].data_ptr(), self.dres_b.data_ptr(), gp(f"l{l}.W2"), M, F, d, F, d, d)
-            self._gemm(P, f"l{l}.fc2.dgrad", A=self.dres_b.data_ptr(), Bt=w("W2_n"), C=self.d_u.data_ptr(), aux=self.u[l].data_ptr(),
+            wgrad(f"l{l}.W2.wgrad", self.a[l].data_ptr(), ring[ri], gp(f"l{l}.W2"), M, F, d, F, d, d)
+            self._gemm(P, f"l{l}.fc2.dgrad", writes=(d_u,), A=ring[ri], Bt=w("W2_n"), C=d_u, aux=self.u[l].data_ptr(),
                        colsum=gp(f"l{l}.b1"), M=M, N=F, K=d, lda=d, ldb=d, ldc=F, ldaux=F, epilogue=_lib.EPI_DGELU)
-            wgrad(f"l{l}.W1.wgrad", self.h2[l].data_ptr(), self.d_u.data_ptr(), gp(f"l{l}.W1"), M, d, F, d, F, F)
-            self._gemm(P, f"l{l}.fc1.dgrad", A=self.d_u.data_ptr(), Bt=w("W1_n"), C=self.d_h.data_ptr(), M=M, N=d, K=F, lda=F, ldb=F,
+            wgrad(f"l{l}.W1.wgrad", self.h2[l].data_ptr(), d_u, gp(f"l{l}.W1"), M, d, F, d, F, F)
+            self._gemm(P, f"l{l}.fc1.dgrad", A=d_u, Bt=w("W1_n"), C=self.d_h.data_ptr(), M=M, N=d, K=F, lda=F, ldb=F,
                        ldc=d, epilogue=_lib.EPI_BF16)
+            ri = (ri + 1) % len(ring)
             P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(),
-                                          self.dres.data_ptr(), self.dres.data_ptr(), self.dres_b.data_ptr(), gp(f"l{l}.ln2_g"),
-                                          gp(f"l{l}.ln2_b"), None, M, d, d, d, self.rp, ws, wsb), f"l{l}.ln2.bwd")
+                                          self.dres.data_ptr(), self.dres.data_ptr(), ring[ri], gp(f"l{l}.ln2_g"),
+                                          gp(f"l{l}.ln2_b"), None, M, d, d, d, self.rp, ws, wsb), f"l{l}.ln2.bwd", writes=(ring[ri],))
             # attention branch: x_mid = x_l + attn(LN1(x_l)) Wo     (attention.py:21-67, vit.py:19-24)
-            wgrad(f"l{l}.Wo.wgrad", self.o[l].data_ptr(), self.dres_b.data_ptr(), gp(f"l{l}.Wo"), M, d, d, d, d, d)
-            self._gemm(P, f"l{l}.proj.dgrad", A=self.dres_b.data_ptr(), Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=M, N=d, K=d, lda=d, ldb=d,
+            wgrad(f"l{l}.Wo.wgrad", self.o[l].data_ptr(), ring[ri], gp(f"l{l}.Wo"), M, d, d, d, d, d)
+            self._gemm(P, f"l{l}.proj.dgrad", A=ring[ri], Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=M, N=d, K=d, lda=d, ldb=d,
                        ldc=d, epilogue=_lib.EPI_BF16)
             P.add(L.savit_attention_bwd, (self.qkv[l].data_ptr(), self.o[l].data_ptr(), self.d_o.data_ptr(), self.lse[l].data_ptr(),
-                                          self.dqkv.data_ptr(), B, N, H, cfg.head_dim, 3 * d, 1.0 / math.sqrt(cfg.head_dim)), f"l{l}.attn.bwd")
-            wgrad(f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), self.dqkv.data_ptr(), gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d)
-            self._gemm(P, f"l{l}.qkv.dgrad", A=self.dqkv.data_ptr(), Bt=w("Wqkv_n"), C=self.d_h.data_ptr(), M=M, N=d, K=3 * d, lda=3 * d,
+                                          dqkv, B, N, H, cfg.head_dim, 3 * d, 1.0 / math.sqrt(cfg.head_dim)), f"l{l}.attn.bwd",
+                  writes=(dqkv,))
+            wgrad(f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), dqkv, gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d)
+            self._gemm(P, f"l{l}.qkv.dgrad", A=dqkv, Bt=w("Wqkv_n"), C=self.d_h.data_ptr(), M=M, N=d, K=3 * d, lda=3 * d,
                        ldb=3 * d, ldc=d, epilogue=_lib.EPI_BF16)
+            ri = (ri + 1) % len(ring)
             P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
-                                          self.dres.data_ptr(), self.dres.data_ptr(), self.dres_b.data_ptr(), gp(f"l{l}.ln1_g"),
+                                          self.dres.data_ptr(), self.dres.data_ptr(), ring[ri], gp(f"l{l}.ln1_g"),
                                           gp(f"l{l}.ln1_b"), gp(f"l{l - 1}.b2") if l > 0 else None, M, d, d, d, self.rp, ws, wsb),
-                  f"l{l}.ln1.bwd")
+                  f"l{l}.ln1.bwd", writes=(ring[ri],))
         # ---- embeddings: dpos, dcls, dWpe   (vit.py:77-85, position_embed.py:56, patch_embed.py:23-25)
         P.add(L.savit_pos_cls_grad, (self.dres.data_ptr(), gp("pos"), gp("cls"), B, N, d, 1), "pos_cls.grad")
-        wgrad("Wpe.wgrad", self._img_buf.data_ptr(), self.dres_b.data_ptr(), gp("Wpe"), B * cfg.n_patches, cfg.patch_dim, d, 0, d, d,
+        wgrad("Wpe.wgrad", self._img_buf.data_ptr(), ring[ri], gp("Wpe"), B * cfg.n_patches, cfg.patch_dim, d, 0, d, d,
               patch=(cfg.patch, cfg.img_size, N, 1))
         return P
 
@@ -453,7 +519,12 @@ class ViTEngine:
         if self._bwd_plan is None:
             self._bwd_plan = self._build_bwd_plan()
         self.dres.zero_()
-        self.dres_b.zero_()
+        self.dres_b.zero_()  # ring slot 0: lnf.bwd fills only the cls rows
+        if self.overlap_wgrad:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=self.dev)
+            self._bwd_plan.run_overlapped(torch.cuda.current_stream(), self._side_stream, self.bwd_hooks)
+            return
         if not self.bwd_hooks:
             self._bwd_plan.run(s)
             return

@@ -280,9 +280,9 @@ def test_wgrad_patch(ops, img, P, d, tok_off):
 
 
 def test_contract_violations_raise(ops):
-    A = torch.zeros((64, 96), dtype=bf16, device="cuda")  # K % 64 != 0
+    A = torch.zeros((64, 80), dtype=bf16, device="cuda")  # K % 32 != 0
     with pytest.raises(ValueError):
-        ops.gemm_tn(A, torch.zeros((64, 96), dtype=bf16, device="cuda"), torch.zeros((64, 64), dtype=bf16, device="cuda"), 0)
+        ops.gemm_tn(A, torch.zeros((64, 80), dtype=bf16, device="cuda"), torch.zeros((64, 64), dtype=bf16, device="cuda"), 0)
     with pytest.raises(ValueError):
         ops.layernorm_fwd(torch.zeros((4, 64)), torch.zeros(64), torch.zeros(64))  # CPU tensors: no CPU path
 

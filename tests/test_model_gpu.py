@@ -253,3 +253,34 @@ def test_cait_reference_shapes_and_known_answers(pkg):
         model.bind(params)
         out_t = model(torch.ones(2, 224, 224, 3, device="cuda"), is_training=True)
         assert tuple(out_t.shape) == (2, 1000)
+
+
+@pytest.mark.gpu
+def test_backward_overlapped_wgrad_matches_single_stream():
+    """The weight-gradient GEMMs run on a second stream (engine._Plan.run_overlapped); the gradients must equal the
+    single-stream schedule's up to fp32 atomic summation order."""
+    import torch
+    from savit_amd.config import get_config
+    from savit_amd.engine import ViTEngine
+
+    cfg = get_config("vit_s_patch16", num_classes=104)
+    B = 16
+    eng = ViTEngine(cfg, B)
+    eng.init_params(3)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    eng.layout.view(eng.params, "Wh").copy_(torch.randn(cfg.embed_dim, cfg.num_classes, device="cuda", generator=g) * 0.05)
+    eng.weights_stale = True
+    img = torch.randn(B, 224, 224, 3, device="cuda", generator=g).to(torch.bfloat16)
+    lab = torch.randint(0, 104, (B,), device="cuda", generator=g, dtype=torch.int32)
+    grads = {}
+    for mode in (False, True, True):
+        eng.overlap_wgrad = mode
+        eng.forward(img)
+        eng.loss_backward(lab)
+        torch.cuda.synchronize()
+        grads.setdefault(mode, []).append(eng.grads.clone())
+    ref = grads[False][0]
+    assert float(ref.abs().max()) > 0
+    for got in grads[True]:
+        err = float((got - ref).abs().max())
+        assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
