@@ -30,7 +30,8 @@ if ROOT not in sys.path:
 MFMA_BF16_PEAK_TFLOPS = 2516.6  # 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md chip table)
 
 
-TN_TILES = {6: "gemm_tn_ring_kernel<128,128,2,2,4,%d>", 7: "gemm_tn_ring_kernel<256,256,2,4,4,%d>"}
+TN_TILES = {6: "gemm_tn_ring_kernel<128,128,2,2,4,%d>", 7: "gemm_tn_ring_kernel<256,256,2,4,4,%d>",
+            12: "gemm_tn_pair_kernel<128,128,2,2,2,%d>", 13: "gemm_tn_pair_kernel<256,256,2,4,2,%d>"}
 WG_VARIANTS = {1: "gemm_wgrad_ring_kernel<128,128,2,2,4,false>", 3: "gemm_wgrad_ring_kernel<256,256,2,4,4,false>"}
 EPI_OF = {"qkv": 0, "proj": 2, "fc1": 1, "fc2": 2, "fc2.dgrad": 3, "fc1.dgrad": 0, "proj.dgrad": 0, "qkv.dgrad": 0}
 

@@ -412,7 +412,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(const GemmParam
 //   slot bytes = (BM + BN) * 64 ; per stage a wave issues G = (BM + BN)/16/NW LDS-DMA instructions.
 //   16-B chunk swizzle for 64-B rows: phys = chunk ^ ((-(row>>2)) & 3)  (conflict-free ds_read_b128, checked per
 //   16-lane read group), applied on the DMA source address and on the fragment read.
-template <int BM, int BN, int WGM, int WGN, int S, int EPI>
+#ifndef SAVIT_AUX_A
+#define SAVIT_AUX_A 0
+#endif
+#ifndef SAVIT_AUX_B
+#define SAVIT_AUX_B 0
+#endif
+#ifndef SAVIT_ABLATE  // experiment builds only (tools/build_variant.sh): 1 no main-loop DMA, 2 no barrier, 4 no fragment refills
+#define SAVIT_ABLATE 0
+#endif
+template <int BM, int BN, int WGM, int WGN, int S, int EPI, bool LATE = false>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const GemmParams p) {
   constexpr int NW = WGM * WGN;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -455,12 +464,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const G
 
   // DMA geometry: one wave-instruction = 16 rows x 64 B; lane -> (row = lane>>2, physical chunk = lane&3)
   const int lrow = lane >> 2, pch = lane & 3;
-  auto stage = [&](int kt, int slot) {
+  // one LDS-DMA wave-instruction of stage kt: piece g < A_INSTR loads A rows, the rest B rows
+  auto stage_piece = [&](int kt, int slot, int g) {
     char* sA = smem + slot * STAGE;
     char* sB = sA + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) {
-      const int inst = wave * A_INSTR + i;
+    if (g < A_INSTR) {
+      const int inst = wave * A_INSTR + g;
       const int r = inst * 16 + lrow;
       const int c = pch ^ ((-(r >> 2)) & 3);  // logical 16-B chunk held at this physical slot
       uint32_t voff;
@@ -473,19 +482,28 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const G
         const int ph = kc / p.chunks_per_prow, within = kc - ph * p.chunks_per_prow;
         const size_t pix = ((size_t)b * a.img_size + (size_t)pi * a.patch + ph) * a.img_size + (size_t)pj * a.patch;
         voff = (m < a.M) ? (uint32_t)(pix * 6 + (size_t)within * 16) : 0xfffffff0u;
+      } else if (SAVIT_ABLATE & 8) {  // experiment: full 128-B lines per row (timing only, results wrong)
+        const int rr = (kt & 1) * (BM / 2) + inst * 8 + (lane >> 3);
+        voff = (uint32_t)rr * (uint32_t)(a.lda * 2) + (uint32_t)((kt >> 1) * 128 + (lane & 7) * 16);
       } else {
         voff = (uint32_t)r * (uint32_t)(a.lda * 2) + (uint32_t)(kt * RB + c * 16);
       }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (__attribute__((address_space(3))) void*)(sA + inst * 1024), 16, voff, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < B_INSTR; ++i) {
-      const int inst = wave * B_INSTR + i;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (__attribute__((address_space(3))) void*)(sA + inst * 1024), 16, voff, 0, 0, SAVIT_AUX_A);
+    } else {
+      const int inst = wave * B_INSTR + (g - A_INSTR);
       const int r = inst * 16 + lrow;
       const int c = pch ^ ((-(r >> 2)) & 3);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (__attribute__((address_space(3))) void*)(sB + inst * 1024), 16,
-                                               (uint32_t)r * (uint32_t)(a.ldb * 2) + (uint32_t)(kt * RB + c * 16), 0, 0, 0);
+      uint32_t voffb = (uint32_t)r * (uint32_t)(a.ldb * 2) + (uint32_t)(kt * RB + c * 16);
+      if (SAVIT_ABLATE & 8) {
+        const int rr = (kt & 1) * (BN / 2) + inst * 8 + (lane >> 3);
+        voffb = (uint32_t)rr * (uint32_t)(a.ldb * 2) + (uint32_t)((kt >> 1) * 128 + (lane & 7) * 16);
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (__attribute__((address_space(3))) void*)(sB + inst * 1024), 16, voffb, 0, 0, SAVIT_AUX_B);
     }
+  };
+  auto stage = [&](int kt, int slot) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) stage_piece(kt, slot, g);
   };
 
   // fragment read offsets inside a slot: row = base16 + (lane&15), logical chunk = lane>>4
@@ -502,13 +520,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const G
 
   const int KT = a.K / 32;
   int slot_issue = 0;
-  const int pre = (S - 1 < KT) ? (S - 1) : KT;
+  // LATE: stage kt+S is issued AFTER the barrier of step kt, interleaved with that step's MFMAs (the slot of stage kt is free
+  // then: its fragments were read during step kt-1).  Otherwise stage kt+S-1 is issued before the barrier.
+  constexpr int PRE = LATE ? S : S - 1;
+  const int pre = (PRE < KT) ? PRE : KT;
   for (int s = 0; s < pre; ++s) {
     stage(s, slot_issue);
     slot_issue = (slot_issue + 1 == S) ? 0 : slot_issue + 1;
   }
-  if (pre == S - 1) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (S - 2)) : "memory");
+  if (pre == PRE) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (PRE - 1)) : "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -522,30 +543,54 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const G
   int slot_next = (S > 1) ? 1 : 0;  // slot holding stage kt+1
 
   auto body = [&](bf16x8(&ac)[MI], bf16x8(&an)[MI], int kt) {
-    const bool issue = (kt + S - 1 < KT);
-    if (issue) {
-      stage(kt + S - 1, slot_issue);
-      slot_issue = (slot_issue + 1 == S) ? 0 : slot_issue + 1;
-    }
-    if (issue) {
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G * (S - 2)) : "memory");
+    bool issue;
+    if constexpr (LATE) {
+      issue = (kt + S < KT) && !(SAVIT_ABLATE & 1);
+      // stages kt+2 .. kt+S-1 may stay in flight; in the tail (nothing left to issue) drain instead of counting
+      if (kt + S - 1 < KT) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G * (S - 2)) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
     } else {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      issue = (kt + S - 1 < KT) && !(SAVIT_ABLATE & 1);
+      if (issue) {
+        stage(kt + S - 1, slot_issue);
+        slot_issue = (slot_issue + 1 == S) ? 0 : slot_issue + 1;
+      }
+      if (issue) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G * (S - 2)) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
     }
-    __builtin_amdgcn_s_barrier();
+    if (!(SAVIT_ABLATE & 2)) __builtin_amdgcn_s_barrier();
     const char* nb = smem + slot_next * STAGE;
     constexpr int APJ = (MI + NI - 1) / NI;  // A refills per n-tile step
+    constexpr int GPJ = (G + NI - 1) / NI;   // LDS-DMA pieces per n-tile step (LATE)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], ac[i], acc[i][j], 0, 0, 0);
       // refill in place for stage kt+1 (after the last stage this reads a valid but unused slot: branch-free)
-      bfr[j] = *reinterpret_cast<const bf16x8*>(nb + b_frag + j * 16 * RB);
+      if (!(SAVIT_ABLATE & 4)) {
+        bfr[j] = *reinterpret_cast<const bf16x8*>(nb + b_frag + j * 16 * RB);
 #pragma unroll
-      for (int q = 0; q < APJ; ++q) {
-        const int i = j * APJ + q;
-        if (i < MI) an[i] = *reinterpret_cast<const bf16x8*>(nb + a_frag + i * 16 * RB);
+        for (int q = 0; q < APJ; ++q) {
+          const int i = j * APJ + q;
+          if (i < MI) an[i] = *reinterpret_cast<const bf16x8*>(nb + a_frag + i * 16 * RB);
+        }
       }
+      if constexpr (LATE) {
+        if (issue) {
+#pragma unroll
+          for (int q = 0; q < GPJ; ++q)
+            if (j * GPJ + q < G) stage_piece(kt + S, slot_issue, j * GPJ + q);
+        }
+      }
+    }
+    if constexpr (LATE) {
+      if (issue) slot_issue = (slot_issue + 1 == S) ? 0 : slot_issue + 1;
     }
     slot_next = (slot_next + 1 == S) ? 0 : slot_next + 1;
   };
@@ -574,7 +619,222 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const G
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int S>
+// ------------------------------------------------------------------------------------------------------------
+// Paired-stage variant.  The ring kernel above stages 64-B row pieces (K = 32), so every LDS-DMA wave-instruction touches
+// 16 HALF cache lines and each 128-B line of A / W is requested twice, one K-step apart: measured on MI355X the L2 -> LDS
+// feed, not the MFMA pipe, bounds that kernel (removing the main-loop DMA: 0.84 -> 1.3 PFLOP/s on the 128x256 tile).
+// Here one wave-instruction fetches 8 rows x 128 B = whole lines, and a ring slot holds a PAIR of K-steps:
+//   slot bytes = (BM + BN) * 128 ; row r at r * 128 ; logical 16-B chunk c (0-3: even K-step, 4-7: odd K-step) stored at
+//   physical chunk c ^ ((r >> 1) & 7)   (conflict-free for ds_read_b128's 16-lane groups, applied on the DMA source side).
+// Schedule per pair p (fragments are register-prefetched one K-step ahead as above):
+//   even step : MFMAs of K-step 2p   | read fragments of 2p+1 (same slot, no barrier: nothing was overwritten)
+//   s_waitcnt vmcnt (slot p+1 landed) ; s_barrier
+//   odd step  : MFMAs of K-step 2p+1 | read fragments of 2p+2 (slot p+1) | issue the DMA of pair p+ND into slot p (free now)
+// i.e. ONE barrier per two K-steps, and the DMA issue is spread between the MFMAs of the odd step.
+template <int BM, int BN, int WGM, int WGN, int ND, int EPI>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_pair_kernel(const GemmParams p) {
+  constexpr int NW = WGM * WGN;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int MI = WTM / 16, NI = WTN / 16;
+  constexpr int RB = 128;
+  constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, SLOT = A_BYTES + B_BYTES;
+  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW, G = A_INSTR + B_INSTR;
+  constexpr bool PATCH = (EPI == SAVIT_EPI_PATCH);
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
+  static_assert(ND >= 2 && G * (ND - 2) <= 63, "ring depth / vmcnt immediate");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const savit_gemm_args& a = p.a;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int tid = xcd_remap(blockIdx.x, nwg);
+  const int tm = tid / p.tiles_n, tn = tid - tm * p.tiles_n;
+  const int row0 = tm * BM, col0 = tn * BN;
+
+  const bf16_t* Abase = reinterpret_cast<const bf16_t*>(a.A);
+  const bf16_t* Bbase = reinterpret_cast<const bf16_t*>(a.Bt) + (size_t)col0 * a.ldb;
+  uint32_t a_bytes, b_bytes;
+  if (PATCH) {
+    const size_t tot = (size_t)(a.M / (p.grid_side * p.grid_side)) * a.img_size * a.img_size * 3 * 2;
+    a_bytes = (uint32_t)(tot > 0xfffffff0ull ? 0xfffffff0ull : tot);
+  } else {
+    Abase += (size_t)row0 * a.lda;
+    const size_t tot = (size_t)(a.M - row0) * a.lda * 2;
+    a_bytes = (uint32_t)(tot > 0xfffffff0ull ? 0xfffffff0ull : tot);
+  }
+  {
+    const size_t tot = (size_t)(a.N - col0) * a.ldb * 2;
+    b_bytes = (uint32_t)(tot > 0xfffffff0ull ? 0xfffffff0ull : tot);
+  }
+  const auto srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Abase), 0, a_bytes, 0x00020000);
+  const auto srdB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bbase), 0, b_bytes, 0x00020000);
+
+  // DMA geometry: one wave-instruction = 8 rows x 128 B; lane -> (row = lane>>3, physical chunk = lane&7)
+  const int lrow = lane >> 3, pch = lane & 7;
+  auto pair_piece = [&](int pp, int slot, int g) {
+    char* sA = smem + slot * SLOT;
+    char* sB = sA + A_BYTES;
+    if (g < A_INSTR) {
+      const int inst = wave * A_INSTR + g;
+      const int r = inst * 8 + lrow;
+      const int c = pch ^ ((r >> 1) & 7);  // logical 16-B chunk held at this physical position
+      uint32_t voff;
+      if (PATCH) {
+        const int m = row0 + r;
+        const int ppi = p.grid_side * p.grid_side;
+        const int b = m / ppi, pq = m - b * ppi;
+        const int pi = pq / p.grid_side, pj = pq - pi * p.grid_side;
+        const int kc = pp * 8 + c;
+        const int ph = kc / p.chunks_per_prow, within = kc - ph * p.chunks_per_prow;
+        const size_t pix = ((size_t)b * a.img_size + (size_t)pi * a.patch + ph) * a.img_size + (size_t)pj * a.patch;
+        voff = (m < a.M) ? (uint32_t)(pix * 6 + (size_t)within * 16) : 0xfffffff0u;
+      } else {
+        voff = (uint32_t)r * (uint32_t)(a.lda * 2) + (uint32_t)(pp * RB + c * 16);
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (__attribute__((address_space(3))) void*)(sA + inst * 1024), 16, voff, 0, 0, 0);
+    } else {
+      const int inst = wave * B_INSTR + (g - A_INSTR);
+      const int r = inst * 8 + lrow;
+      const int c = pch ^ ((r >> 1) & 7);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (__attribute__((address_space(3))) void*)(sB + inst * 1024), 16,
+                                               (uint32_t)r * (uint32_t)(a.ldb * 2) + (uint32_t)(pp * RB + c * 16), 0, 0, 0);
+    }
+  };
+
+  // fragment read offsets inside a slot: row = base16 + (lane&15); logical chunk = (lane>>4) + 4 * (K-step parity)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = (fr >> 1) & 7;
+  const int foff0 = fr * RB + ((fq ^ sw) << 4);
+  const int foff1 = fr * RB + (((fq + 4) ^ sw) << 4);
+  const int a_row = (wm * WTM) * RB, b_row = A_BYTES + (wn * WTN) * RB;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int KP = a.K / 64;
+  const int pre = (ND < KP) ? ND : KP;
+  for (int s = 0; s < pre; ++s) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) pair_piece(s, s, g);
+  }
+  if (pre == ND) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (ND - 1)) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 af0[MI], af1[MI], bfr[NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) af0[i] = *reinterpret_cast<const bf16x8*>(smem + a_row + foff0 + i * 16 * RB);
+#pragma unroll
+  for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(smem + b_row + foff0 + j * 16 * RB);
+
+  constexpr int APJ = (MI + NI - 1) / NI;  // A refills per n-tile step
+  constexpr int GPJ = (G + NI - 1) / NI;   // LDS-DMA pieces per n-tile step (odd steps)
+  int slot = 0;                            // slot of pair pp
+  for (int pp = 0; pp < KP; ++pp) {
+    const int slot_nx = (slot + 1 == ND) ? 0 : slot + 1;
+    // ---- even step: K-step 2pp from af0/bfr; prefetch K-step 2pp+1 (same slot, chunks 4-7) into af1/bfr
+    {
+      const char* nb = smem + slot * SLOT;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af0[i], acc[i][j], 0, 0, 0);
+        bfr[j] = *reinterpret_cast<const bf16x8*>(nb + b_row + foff1 + j * 16 * RB);
+#pragma unroll
+        for (int q = 0; q < APJ; ++q) {
+          const int i = j * APJ + q;
+          if (i < MI) af1[i] = *reinterpret_cast<const bf16x8*>(nb + a_row + foff1 + i * 16 * RB);
+        }
+      }
+    }
+    // pair pp+1 must have landed (pairs pp+2 .. pp+ND-1 may stay in flight); all waves are done reading slot `slot`
+    if (pp + ND - 1 < KP) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G * (ND - 2)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    // ---- odd step: K-step 2pp+1 from af1/bfr; prefetch K-step 2pp+2 (next slot, chunks 0-3); refill slot `slot` with pair pp+ND
+    {
+      const bool issue = (pp + ND < KP);
+      const char* nb = smem + slot_nx * SLOT;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af1[i], acc[i][j], 0, 0, 0);
+        // after the last pair this reads a valid but unused slot: branch-free
+        bfr[j] = *reinterpret_cast<const bf16x8*>(nb + b_row + foff0 + j * 16 * RB);
+#pragma unroll
+        for (int q = 0; q < APJ; ++q) {
+          const int i = j * APJ + q;
+          if (i < MI) af0[i] = *reinterpret_cast<const bf16x8*>(nb + a_row + foff0 + i * 16 * RB);
+        }
+        if (issue) {
+#pragma unroll
+          for (int q = 0; q < GPJ; ++q)
+            if (j * GPJ + q < G) pair_piece(pp + ND, slot, j * GPJ + q);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    slot = slot_nx;
+  }
+
+  if constexpr (epi_uses_lds<EPI>()) {
+    // all waves must be done reading the ring (the last step's refill reads included) before it is reused
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    epilogue_lds<EPI, WTM, WTN, MI, NI>(p, acc, smem + wave * (WTM * WTN * 2), row0 + wm * WTM, col0 + wn * WTN, lane);
+  } else {
+    const int mrow = row0 + wm * WTM + fr;
+    const int ncol = col0 + wn * WTN + fq * 4;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < MI; ++i) epilogue_store<EPI>(p, mrow + i * 16, ncol + j * 16, acc[i][j], csum);
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, int ND>
+int launch_pair(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  p.tiles_m = (p.a.M + BM - 1) / BM;
+  p.tiles_n = (p.a.N + BN - 1) / BN;
+  const dim3 grid(p.tiles_m * p.tiles_n), block(64 * WGM * WGN);
+  const size_t lds = (size_t)ND * (BM + BN) * 128;
+#define SAVIT_LAUNCH_EPI(E)                                                                            \
+  case E: {                                                                                            \
+    auto kfn = gemm_tn_pair_kernel<BM, BN, WGM, WGN, ND, E>;                                           \
+    if (lds > 48 * 1024) {                                                                             \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return (int)e;                                                              \
+    }                                                                                                  \
+    hipLaunchKernelGGL(kfn, grid, block, lds, s, p);                                                   \
+  } break;
+  switch (p.a.epilogue) {
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_BF16)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_BIAS_GELU)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_RESID)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_DGELU)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_F32)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_PATCH)
+    default: return SAVIT_EINVAL;
+  }
+#undef SAVIT_LAUNCH_EPI
+  SAVIT_LAUNCH_RET();
+}
+
+template <int BM, int BN, int WGM, int WGN, int S, bool LATE = false>
 int launch_ring(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
   p.tiles_m = (p.a.M + BM - 1) / BM;
@@ -583,7 +843,7 @@ int launch_ring(const GemmParams& p0, hipStream_t s) {
   const size_t lds = (size_t)S * (BM + BN) * 64;
 #define SAVIT_LAUNCH_EPI(E)                                                                            \
   case E: {                                                                                            \
-    auto kfn = gemm_tn_ring_kernel<BM, BN, WGM, WGN, S, E>;                                            \
+    auto kfn = gemm_tn_ring_kernel<BM, BN, WGM, WGN, S, E, LATE>;                                            \
     if (lds > 48 * 1024) {                                                                             \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return (int)e;                                                              \
@@ -635,14 +895,16 @@ int launch_tile(const GemmParams& p0, hipStream_t s) {
 }  // namespace
 
 extern "C" int savit_gemm_tn_auto_tile(int M, int N, int K) {
-  // measured on MI355X, cold caches (tools/bench_gemm2.py; DeiT-B, DeiT-S and ViT-L/16-384 shapes): the 256x256 ring
-  // kernel (half the L2->LDS bytes per flop, one 8-wave workgroup per CU) wins once its grid is at least two rounds of
-  // 256 workgroups; smaller problems run better as 128x128 tiles (more, smaller workgroups, 2-3 per CU).
-  (void)K;
+  // measured on MI355X, cold caches (tools/gemm_probe.py; DeiT-B, DeiT-S and ViT-L/16-384 shapes): a 256x256 tile (half the
+  // L2->LDS bytes per flop, one 8-wave workgroup per CU) wins once its grid is at least two rounds of 256 workgroups; smaller
+  // problems run better as 128x128 tiles (more, smaller workgroups, 2 per CU).  K % 64 == 0 selects the paired-stage kernels
+  // (whole-cache-line LDS-DMA: +8 % on the 256x256 tile, +4..38 % on the 128x128 tile); other K keep the 64-B-row ring.
   static const int force = [] { const char* e = getenv("SAVIT_GEMM_TILE"); return e ? atoi(e) : 0; }();
   if (force > 0) return force;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  return (t256 >= 512 && N % 128 == 0) ? 7 : 6;
+  const bool big = (t256 >= 512 && N % 128 == 0);
+  if (K % 64 == 0) return big ? 13 : 12;
+  return big ? 7 : 6;
 }
 
 extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
@@ -671,6 +933,9 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
     SAVIT_CHECK_ARG(a.aux != nullptr && a.ldaux >= a.N && a.ldaux % 4 == 0);
   if (a.rowscale != nullptr) SAVIT_CHECK_ARG(a.rows_per_sample >= 1);
   if (a.M == 0) return SAVIT_OK;
+  { static const int probe = [] { const char* e = getenv("SAVIT_PROBE_L2"); return e ? atoi(e) : 0; }();  // TEMP experiment
+    if (probe & 1) p.a.lda = 0;
+    if (probe & 2) p.a.ldb = 0; }
   hipStream_t s = (hipStream_t)stream;
   int tile = a.tile;
   if (tile == 0) tile = savit_gemm_tn_auto_tile(a.M, a.N, a.K);
@@ -684,6 +949,12 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
     case 7: return launch_ring<256, 256, 2, 4, 4>(p, s);
     case 8: return launch_ring<128, 128, 2, 2, 2>(p, s);
     case 9: return launch_ring<128, 128, 2, 2, 3>(p, s);
+    case 10: return launch_ring<256, 256, 2, 4, 4, true>(p, s);
+    case 11: return launch_ring<128, 128, 2, 2, 4, true>(p, s);
+    case 12: return a.K % 64 ? SAVIT_EINVAL : launch_pair<128, 128, 2, 2, 2>(p, s);
+    case 13: return a.K % 64 ? SAVIT_EINVAL : launch_pair<256, 256, 2, 4, 2>(p, s);
+    case 14: return a.K % 64 ? SAVIT_EINVAL : launch_pair<128, 256, 2, 2, 2>(p, s);
+    case 15: return a.K % 64 ? SAVIT_EINVAL : launch_pair<256, 128, 2, 2, 2>(p, s);
     default: return SAVIT_EINVAL;
   }
 }
