@@ -23,11 +23,15 @@ namespace {
 constexpr int BK = 64;           // bf16 elements per K-tile  (128 B per LDS row)
 constexpr int ROW_BYTES = 128;
 
+#ifndef SAVIT_ABLATE  // experiment builds only (tools/build_variant.sh): 1 no main-loop DMA, 2 no barrier, 4 no fragment refills,
+#define SAVIT_ABLATE 0  // 8 whole-line fetch pattern on the 64-B ring, 16 RESID without the residual load, 32 RESID without the store
+#endif
 struct GemmParams {
   savit_gemm_args a;
   int tiles_m, tiles_n;
   int chunks_per_prow;  // PATCH: 16-B chunks per (patch row) = patch*3/8
   int grid_side;        // PATCH: patches per image side
+  int reverse_m;        // 1: row-tiles are visited last-to-first (see savit_gemm_bf16_tn)
   int stagger;          // shader cycles the 2nd resident workgroup of each CU sleeps before starting (0 = off)
 };
 
@@ -164,43 +168,61 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[M
   float cs8[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) cs8[k] = 0.f;
-  float colscale[8];
-  if (EPI == SAVIT_EPI_RESID) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) colscale[k] = 1.0f;
-    if (a.colscale != nullptr && n < a.N) {
-      const float4 c0 = *reinterpret_cast<const float4*>(a.colscale + n);
-      const float4 c1 = *reinterpret_cast<const float4*>(a.colscale + n + 4);
-      colscale[0] = c0.x; colscale[1] = c0.y; colscale[2] = c0.z; colscale[3] = c0.w;
-      colscale[4] = c1.x; colscale[5] = c1.y; colscale[6] = c1.z; colscale[7] = c1.w;
-    }
-  }
   // The fused operands (fp32 residual rows / bf16 pre-activation rows) come from HBM at ~2 us latency: ALL of this wave's
   // loads are issued back to back BEFORE the first use (the accumulators are dead after the park, so the registers are
   // free); a load-use-load-use loop exposed that latency once per group of rows and made these epilogues latency-bound.
   constexpr int NIT = WTM / RPI;
   const bool ncol_ok = n < a.N;
-  [[maybe_unused]] float4 res0[EPI == SAVIT_EPI_RESID ? NIT : 1], res1[EPI == SAVIT_EPI_RESID ? NIT : 1];
   [[maybe_unused]] uint4 uaux[EPI == SAVIT_EPI_DGELU ? NIT : 1];
-  if (EPI == SAVIT_EPI_RESID) {
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int m = row0w + it * RPI + urow;
-      res0[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      res1[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < a.M && ncol_ok) {
-        const float* rp = reinterpret_cast<const float*>(a.aux) + (size_t)m * a.ldaux + n;
-        res0[it] = *reinterpret_cast<const float4*>(rp);
-        res1[it] = *reinterpret_cast<const float4*>(rp + 4);
-      }
+  if constexpr (EPI == SAVIT_EPI_RESID) {
+    // fp32 rows: 4 columns (one float4) per lane, so a wave instruction moves whole 128-B lines (RPR rows x WTN*4 B); the
+    // 8-column mapping of the bf16 epilogues would split every fp32 line between two instructions.
+    constexpr int LPR = WTN / 4;       // lanes per row (16 or 8)
+    constexpr int RPR = 64 / LPR;      // rows per instruction
+    constexpr int NR = WTM / RPR;
+    const int rrow = lane / LPR, rcol = lane % LPR;
+    const int nn = col0w + rcol * 4;
+    const bool nn_ok = nn < a.N;
+    float cscale[4] = {1.f, 1.f, 1.f, 1.f};
+    if (a.colscale != nullptr && nn_ok) {
+      const float4 c0 = *reinterpret_cast<const float4*>(a.colscale + nn);
+      cscale[0] = c0.x; cscale[1] = c0.y; cscale[2] = c0.z; cscale[3] = c0.w;
     }
+    float4 res[NR];
+#pragma unroll
+    for (int it = 0; it < NR; ++it) {
+      const int m = row0w + it * RPR + rrow;
+      res[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < a.M && nn_ok && !(SAVIT_ABLATE & 16))
+        res[it] = nt_load_f4(reinterpret_cast<const float*>(a.aux) + (size_t)m * a.ldaux + nn);  // not read again before backward
+    }
+#pragma unroll
+    for (int it = 0; it < NR; ++it) {
+      const int ml = it * RPR + rrow;
+      const int m = row0w + ml;
+      const uint2 raw = *reinterpret_cast<const uint2*>(wsm + ml * ROWB + (((rcol >> 1) ^ (ml & (UPR - 1))) << 4) + (rcol & 1) * 8);
+      if (m >= a.M || !nn_ok) continue;
+      float rs = 1.0f;
+      if (a.rowscale != nullptr) rs = a.rowscale[m / a.rows_per_sample];
+      if (a.C2 != nullptr)  // the bf16 branch value, needed by the LayerScale gradient (layerscale.py:23)
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.C2) + (size_t)m * a.ldc + nn) = raw;
+      const float4 r = res[it];
+      if ((SAVIT_ABLATE & 32) && r.x != 12345.f) continue;
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + nn) =
+          make_float4(r.x + rs * cscale[0] * __uint_as_float(raw.x << 16), r.y + rs * cscale[1] * __uint_as_float(raw.x & 0xffff0000u),
+                      r.z + rs * cscale[2] * __uint_as_float(raw.y << 16), r.w + rs * cscale[3] * __uint_as_float(raw.y & 0xffff0000u));
+    }
+    return;
   }
   if (EPI == SAVIT_EPI_DGELU) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int m = row0w + it * RPI + urow;
       uaux[it] = make_uint4(0u, 0u, 0u, 0u);
-      if (m < a.M && ncol_ok) uaux[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.aux) + (size_t)m * a.ldaux + n);
+      if (m < a.M && ncol_ok) {
+        const bf16_t* up = reinterpret_cast<const bf16_t*>(a.aux) + (size_t)m * a.ldaux + n;
+        uaux[it] = nt_load_u4(up);  // last use of the saved pre-activation
+      }
     }
   }
 #pragma unroll
@@ -219,25 +241,9 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[M
         const float lo = __uint_as_float(rw[k] << 16), hi = __uint_as_float(rw[k] & 0xffff0000u);
         g[k] = pack_bf16x2(gelu_tanh_f(lo), gelu_tanh_f(hi));
       }
-      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n) = raw;
+      // the pre-activation is only read again in backward: non-temporal, so it does not push the activation out of the cache
+      nt_store_u4(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n, raw);
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C2) + (size_t)m * a.ldc + n) = make_uint4(g[0], g[1], g[2], g[3]);
-    } else if (EPI == SAVIT_EPI_RESID) {
-      const float4 r0 = res0[it], r1 = res1[it];
-      float rs = 1.0f;
-      if (a.rowscale != nullptr) rs = a.rowscale[m / a.rows_per_sample];
-      float v[8];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        v[2 * k] = __uint_as_float(rw[k] << 16);
-        v[2 * k + 1] = __uint_as_float(rw[k] & 0xffff0000u);
-      }
-      if (a.C2 != nullptr)  // the bf16 branch value, needed by the LayerScale gradient (layerscale.py:23)
-        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C2) + (size_t)m * a.ldc + n) = raw;
-      float* op = reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + n;
-      *reinterpret_cast<float4*>(op) = make_float4(r0.x + rs * colscale[0] * v[0], r0.y + rs * colscale[1] * v[1],
-                                                   r0.z + rs * colscale[2] * v[2], r0.w + rs * colscale[3] * v[3]);
-      *reinterpret_cast<float4*>(op + 4) = make_float4(r1.x + rs * colscale[4] * v[4], r1.y + rs * colscale[5] * v[5],
-                                                       r1.z + rs * colscale[6] * v[6], r1.w + rs * colscale[7] * v[7]);
     } else if (EPI == SAVIT_EPI_DGELU) {
       const uint4 uraw = uaux[it];
       const uint32_t uw[4] = {uraw.x, uraw.y, uraw.z, uraw.w};
@@ -418,9 +424,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(const GemmParam
 #ifndef SAVIT_AUX_B
 #define SAVIT_AUX_B 0
 #endif
-#ifndef SAVIT_ABLATE  // experiment builds only (tools/build_variant.sh): 1 no main-loop DMA, 2 no barrier, 4 no fragment refills
-#define SAVIT_ABLATE 0
-#endif
+
 template <int BM, int BN, int WGM, int WGN, int S, int EPI, bool LATE = false>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const GemmParams p) {
   constexpr int NW = WGM * WGN;
@@ -650,7 +654,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_pair_kernel(const G
   const int wm = wave / WGN, wn = wave % WGN;
   const int nwg = p.tiles_m * p.tiles_n;
   const int tid = xcd_remap(blockIdx.x, nwg);
-  const int tm = tid / p.tiles_n, tn = tid - tm * p.tiles_n;
+  int tm = tid / p.tiles_n;
+  const int tn = tid - tm * p.tiles_n;
+  if (p.reverse_m) tm = p.tiles_m - 1 - tm;
   const int row0 = tm * BM, col0 = tn * BN;
 
   const bf16_t* Abase = reinterpret_cast<const bf16_t*>(a.A);
@@ -810,7 +816,7 @@ int launch_pair(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
   p.tiles_m = (p.a.M + BM - 1) / BM;
   p.tiles_n = (p.a.N + BN - 1) / BN;
-  const dim3 grid(p.tiles_m * p.tiles_n), block(64 * WGM * WGN);
+  const dim3 grid(p.tiles_m * p.tiles_n);
   const size_t lds = (size_t)ND * (BM + BN) * 128;
 #define SAVIT_LAUNCH_EPI(E)                                                                            \
   case E: {                                                                                            \
@@ -819,7 +825,7 @@ int launch_pair(const GemmParams& p0, hipStream_t s) {
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return (int)e;                                                              \
     }                                                                                                  \
-    hipLaunchKernelGGL(kfn, grid, block, lds, s, p);                                                   \
+    hipLaunchKernelGGL(kfn, grid, dim3(64 * WGM * WGN), lds, s, p);                                   \
   } break;
   switch (p.a.epilogue) {
     SAVIT_LAUNCH_EPI(SAVIT_EPI_BF16)
@@ -933,9 +939,8 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
     SAVIT_CHECK_ARG(a.aux != nullptr && a.ldaux >= a.N && a.ldaux % 4 == 0);
   if (a.rowscale != nullptr) SAVIT_CHECK_ARG(a.rows_per_sample >= 1);
   if (a.M == 0) return SAVIT_OK;
-  { static const int probe = [] { const char* e = getenv("SAVIT_PROBE_L2"); return e ? atoi(e) : 0; }();  // TEMP experiment
-    if (probe & 1) p.a.lda = 0;
-    if (probe & 2) p.a.ldb = 0; }
+  { static const int rev = [] { const char* e = getenv("SAVIT_GEMM_REV"); return e ? atoi(e) : 0; }();  // TEMP experiment
+    p.reverse_m = (rev >> a.epilogue) & 1; }
   hipStream_t s = (hipStream_t)stream;
   int tile = a.tile;
   if (tile == 0) tile = savit_gemm_tn_auto_tile(a.M, a.N, a.K);

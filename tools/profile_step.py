@@ -3,6 +3,9 @@ import sys, os, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import savit_amd
+from savit_amd import lib as _l
+if os.environ.get("SAVIT_EXP_LIB"):
+    _l.LIB_PATH = os.path.join(os.path.dirname(_l.LIB_PATH), "exp", "libsavit_%s.so" % os.environ["SAVIT_EXP_LIB"])
 from savit_amd.config import get_config
 from savit_amd.engine import ViTEngine
 
