@@ -80,6 +80,22 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   return x * s;
 }
 // d/dx gelu_tanh(x) = s + x s (1 - s) * 2 sqrt(2/pi) (1 + 3*0.044715 x^2),  s = sigmoid(2z)
+// Two elements at a time: the FMAs / multiplies / adds become v_pk_*_f32 (two lanes' worth per issue slot); only v_exp_f32 and
+// v_rcp_f32 stay scalar.  The fused GELU epilogues are VALU-bound (about 18 VALU + 2 transcendental instructions per element
+// over a 256x256 tile per CU), so this is where their time goes.  Same formulas as the scalar forms above.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 unpack_bf16x2(uint32_t w) { return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+__device__ __forceinline__ f32x2 gelu_sigmoid2(f32x2 x) {
+  const f32x2 t = x * (-2.302208198f + -0.1029432397f * x * x);
+  const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+  return f32x2{__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+}
+__device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) { return x * gelu_sigmoid2(x); }
+__device__ __forceinline__ f32x2 gelu_tanh_grad2(f32x2 x) {
+  const f32x2 s = gelu_sigmoid2(x);
+  const f32x2 w = 1.5957691216f + 0.2140610297f * x * x;
+  return s + x * s * (1.0f - s) * w;
+}
 __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
   const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gelu_sigmoid_arg(x)));
   const float w = 1.5957691216f + 0.2140610297f * x * x;  // 2c (1 + 0.134145 x^2)

@@ -23,15 +23,11 @@ namespace {
 constexpr int BK = 64;           // bf16 elements per K-tile  (128 B per LDS row)
 constexpr int ROW_BYTES = 128;
 
-#ifndef SAVIT_ABLATE  // experiment builds only (tools/build_variant.sh): 1 no main-loop DMA, 2 no barrier, 4 no fragment refills,
-#define SAVIT_ABLATE 0  // 8 whole-line fetch pattern on the 64-B ring, 16 RESID without the residual load, 32 RESID without the store
-#endif
 struct GemmParams {
   savit_gemm_args a;
   int tiles_m, tiles_n;
   int chunks_per_prow;  // PATCH: 16-B chunks per (patch row) = patch*3/8
   int grid_side;        // PATCH: patches per image side
-  int reverse_m;        // 1: row-tiles are visited last-to-first (see savit_gemm_bf16_tn)
   int stagger;          // shader cycles the 2nd resident workgroup of each CU sleeps before starting (0 = off)
 };
 
@@ -193,7 +189,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[M
     for (int it = 0; it < NR; ++it) {
       const int m = row0w + it * RPR + rrow;
       res[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < a.M && nn_ok && !(SAVIT_ABLATE & 16))
+      if (m < a.M && nn_ok)
         res[it] = nt_load_f4(reinterpret_cast<const float*>(a.aux) + (size_t)m * a.ldaux + nn);  // not read again before backward
     }
 #pragma unroll
@@ -207,7 +203,6 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[M
       if (a.C2 != nullptr)  // the bf16 branch value, needed by the LayerScale gradient (layerscale.py:23)
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.C2) + (size_t)m * a.ldc + nn) = raw;
       const float4 r = res[it];
-      if ((SAVIT_ABLATE & 32) && r.x != 12345.f) continue;
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + nn) =
           make_float4(r.x + rs * cscale[0] * __uint_as_float(raw.x << 16), r.y + rs * cscale[1] * __uint_as_float(raw.x & 0xffff0000u),
                       r.z + rs * cscale[2] * __uint_as_float(raw.y << 16), r.w + rs * cscale[3] * __uint_as_float(raw.y & 0xffff0000u));
@@ -238,8 +233,8 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[M
       uint32_t g[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float lo = __uint_as_float(rw[k] << 16), hi = __uint_as_float(rw[k] & 0xffff0000u);
-        g[k] = pack_bf16x2(gelu_tanh_f(lo), gelu_tanh_f(hi));
+        const f32x2 gv = gelu_tanh2(unpack_bf16x2(rw[k]));
+        g[k] = pack_bf16x2(gv.x, gv.y);
       }
       // the pre-activation is only read again in backward: non-temporal, so it does not push the activation out of the cache
       nt_store_u4(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n, raw);
@@ -250,11 +245,11 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[M
       uint32_t o[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float dlo = round_bf16(__uint_as_float(rw[k] << 16) * gelu_tanh_grad_f(__uint_as_float(uw[k] << 16)));
-        const float dhi = round_bf16(__uint_as_float(rw[k] & 0xffff0000u) * gelu_tanh_grad_f(__uint_as_float(uw[k] & 0xffff0000u)));
-        cs8[2 * k] += dlo;
-        cs8[2 * k + 1] += dhi;
-        o[k] = pack_bf16x2(dlo, dhi);
+        const f32x2 dv = unpack_bf16x2(rw[k]) * gelu_tanh_grad2(unpack_bf16x2(uw[k]));
+        o[k] = pack_bf16x2(dv.x, dv.y);
+        const f32x2 r = unpack_bf16x2(o[k]);  // the column sum adds the bf16-rounded values, as the stored tensor holds them
+        cs8[2 * k] += r.x;
+        cs8[2 * k + 1] += r.y;
       }
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n) = make_uint4(o[0], o[1], o[2], o[3]);
     }
@@ -418,12 +413,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(const GemmParam
 //   slot bytes = (BM + BN) * 64 ; per stage a wave issues G = (BM + BN)/16/NW LDS-DMA instructions.
 //   16-B chunk swizzle for 64-B rows: phys = chunk ^ ((-(row>>2)) & 3)  (conflict-free ds_read_b128, checked per
 //   16-lane read group), applied on the DMA source address and on the fragment read.
-#ifndef SAVIT_AUX_A
-#define SAVIT_AUX_A 0
-#endif
-#ifndef SAVIT_AUX_B
-#define SAVIT_AUX_B 0
-#endif
 
 template <int BM, int BN, int WGM, int WGN, int S, int EPI, bool LATE = false>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const GemmParams p) {
@@ -486,23 +475,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const G
         const int ph = kc / p.chunks_per_prow, within = kc - ph * p.chunks_per_prow;
         const size_t pix = ((size_t)b * a.img_size + (size_t)pi * a.patch + ph) * a.img_size + (size_t)pj * a.patch;
         voff = (m < a.M) ? (uint32_t)(pix * 6 + (size_t)within * 16) : 0xfffffff0u;
-      } else if (SAVIT_ABLATE & 8) {  // experiment: full 128-B lines per row (timing only, results wrong)
-        const int rr = (kt & 1) * (BM / 2) + inst * 8 + (lane >> 3);
-        voff = (uint32_t)rr * (uint32_t)(a.lda * 2) + (uint32_t)((kt >> 1) * 128 + (lane & 7) * 16);
       } else {
         voff = (uint32_t)r * (uint32_t)(a.lda * 2) + (uint32_t)(kt * RB + c * 16);
       }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (__attribute__((address_space(3))) void*)(sA + inst * 1024), 16, voff, 0, 0, SAVIT_AUX_A);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (__attribute__((address_space(3))) void*)(sA + inst * 1024), 16, voff, 0, 0, 0);
     } else {
       const int inst = wave * B_INSTR + (g - A_INSTR);
       const int r = inst * 16 + lrow;
       const int c = pch ^ ((-(r >> 2)) & 3);
       uint32_t voffb = (uint32_t)r * (uint32_t)(a.ldb * 2) + (uint32_t)(kt * RB + c * 16);
-      if (SAVIT_ABLATE & 8) {
-        const int rr = (kt & 1) * (BN / 2) + inst * 8 + (lane >> 3);
-        voffb = (uint32_t)rr * (uint32_t)(a.ldb * 2) + (uint32_t)((kt >> 1) * 128 + (lane & 7) * 16);
-      }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (__attribute__((address_space(3))) void*)(sB + inst * 1024), 16, voffb, 0, 0, SAVIT_AUX_B);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (__attribute__((address_space(3))) void*)(sB + inst * 1024), 16, voffb, 0, 0, 0);
     }
   };
   auto stage = [&](int kt, int slot) {
@@ -549,7 +531,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const G
   auto body = [&](bf16x8(&ac)[MI], bf16x8(&an)[MI], int kt) {
     bool issue;
     if constexpr (LATE) {
-      issue = (kt + S < KT) && !(SAVIT_ABLATE & 1);
+      issue = (kt + S < KT);
       // stages kt+2 .. kt+S-1 may stay in flight; in the tail (nothing left to issue) drain instead of counting
       if (kt + S - 1 < KT) {
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G * (S - 2)) : "memory");
@@ -557,7 +539,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const G
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
     } else {
-      issue = (kt + S - 1 < KT) && !(SAVIT_ABLATE & 1);
+      issue = (kt + S - 1 < KT);
       if (issue) {
         stage(kt + S - 1, slot_issue);
         slot_issue = (slot_issue + 1 == S) ? 0 : slot_issue + 1;
@@ -568,7 +550,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const G
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
     }
-    if (!(SAVIT_ABLATE & 2)) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     const char* nb = smem + slot_next * STAGE;
     constexpr int APJ = (MI + NI - 1) / NI;  // A refills per n-tile step
     constexpr int GPJ = (G + NI - 1) / NI;   // LDS-DMA pieces per n-tile step (LATE)
@@ -577,13 +559,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const G
 #pragma unroll
       for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], ac[i], acc[i][j], 0, 0, 0);
       // refill in place for stage kt+1 (after the last stage this reads a valid but unused slot: branch-free)
-      if (!(SAVIT_ABLATE & 4)) {
-        bfr[j] = *reinterpret_cast<const bf16x8*>(nb + b_frag + j * 16 * RB);
+      bfr[j] = *reinterpret_cast<const bf16x8*>(nb + b_frag + j * 16 * RB);
 #pragma unroll
-        for (int q = 0; q < APJ; ++q) {
-          const int i = j * APJ + q;
-          if (i < MI) an[i] = *reinterpret_cast<const bf16x8*>(nb + a_frag + i * 16 * RB);
-        }
+      for (int q = 0; q < APJ; ++q) {
+        const int i = j * APJ + q;
+        if (i < MI) an[i] = *reinterpret_cast<const bf16x8*>(nb + a_frag + i * 16 * RB);
       }
       if constexpr (LATE) {
         if (issue) {
@@ -654,9 +634,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_pair_kernel(const G
   const int wm = wave / WGN, wn = wave % WGN;
   const int nwg = p.tiles_m * p.tiles_n;
   const int tid = xcd_remap(blockIdx.x, nwg);
-  int tm = tid / p.tiles_n;
-  const int tn = tid - tm * p.tiles_n;
-  if (p.reverse_m) tm = p.tiles_m - 1 - tm;
+  const int tm = tid / p.tiles_n, tn = tid - tm * p.tiles_n;
   const int row0 = tm * BM, col0 = tn * BN;
 
   const bf16_t* Abase = reinterpret_cast<const bf16_t*>(a.A);
@@ -939,8 +917,6 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
     SAVIT_CHECK_ARG(a.aux != nullptr && a.ldaux >= a.N && a.ldaux % 4 == 0);
   if (a.rowscale != nullptr) SAVIT_CHECK_ARG(a.rows_per_sample >= 1);
   if (a.M == 0) return SAVIT_OK;
-  { static const int rev = [] { const char* e = getenv("SAVIT_GEMM_REV"); return e ? atoi(e) : 0; }();  // TEMP experiment
-    p.reverse_m = (rev >> a.epilogue) & 1; }
   hipStream_t s = (hipStream_t)stream;
   int tile = a.tile;
   if (tile == 0) tile = savit_gemm_tn_auto_tile(a.M, a.N, a.K);
