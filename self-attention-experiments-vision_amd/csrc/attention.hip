@@ -23,6 +23,9 @@
 #include "savit.h"
 #include <stdlib.h>
 
+#ifndef ATT_ABLATE
+#define ATT_ABLATE 0  // experiment builds: 1 no compute loops, 2 no image staging
+#endif
 namespace {
 
 constexpr int HD = 64;              // head dim
@@ -98,8 +101,10 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_kernel(const AttnParams p) {
   size_t bytes = (size_t)p.B * p.N * p.ld * 2;
   if (bytes > 0xffffffe0ull) bytes = 0xffffffe0ull;
   const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.qkv), 0, (uint32_t)bytes, 0x00020000);
+  if (!(ATT_ABLATE & 2)) {
   stage_image<NT, NT>(imgK, srd, row_base, p.N, p.ld, p.d + hh * HD, wave, lane);
   stage_image<NT, NT>(imgV, srd, row_base, p.N, p.ld, 2 * p.d + hh * HD, wave, lane);
+  }
 
   // Q fragments of this wave's 32 queries straight from HBM (B operand: lane = (q, half), 8 consecutive e)
   const int ql = lane & 31, half = lane >> 5;
@@ -119,6 +124,7 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_kernel(const AttnParams p) {
   for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+    if (ATT_ABLATE & 1) continue;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const bf16x8 kf = lds_row_frag(imgK, kt * 32 + ql, 2 * ks + half);
@@ -161,6 +167,7 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_kernel(const AttnParams p) {
   const int tcol = 16 * (g & 1) + 4 * (t & 3);      // + 32*eb
 #pragma unroll
   for (int kt = 0; kt < NT; ++kt) {
+    if (ATT_ABLATE & 1) continue;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const bf16x8 pf = acc_to_frag(s[kt], s2);
@@ -207,10 +214,12 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
   if (bytes_o > 0xffffffe0ull) bytes_o = 0xffffffe0ull;
   const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.qkv), 0, (uint32_t)bytes, 0x00020000);
   const auto srdD = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.d_o), 0, (uint32_t)bytes_o, 0x00020000);
+  if (!(ATT_ABLATE & 2)) {
   stage_image<NT, NT>(imgQ, srd, row_base, p.N, p.ld, hh * HD, wave, lane);
   stage_image<NT, NT>(imgK, srd, row_base, p.N, p.ld, p.d + hh * HD, wave, lane);
   stage_image<NT, NT>(imgV, srd, row_base, p.N, p.ld, 2 * p.d + hh * HD, wave, lane);
   stage_image<NT, NT>(imgD, srdD, row_base, p.N, p.d, hh * HD, wave, lane);
+  }
   for (int i = threadIdx.x; i < NT * 32; i += 64 * NT)
     lse_s[i] = (i < p.N) ? p.lse[((size_t)b * p.H + hh) * p.N + i] : INFINITY;
 
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[eb][r] = 0.f;
 #pragma unroll 1
-    for (int kt = 0; kt < NT; ++kt) {
+    for (int kt = 0; kt < ((ATT_ABLATE & 1) ? 0 : NT); ++kt) {
       f32x16 sa, da;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
         dv[eb][r] = 0.f;
       }
 #pragma unroll 1
-    for (int qt = 0; qt < NT; ++qt) {
+    for (int qt = 0; qt < ((ATT_ABLATE & 1) ? 0 : NT); ++qt) {
       f32x16 sa, da;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -570,7 +579,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[eb][r] = 0.f;
 #pragma unroll 1
-    for (int kt = 0; kt < NT; ++kt) {
+    for (int kt = 0; kt < ((ATT_ABLATE & 1) ? 0 : NT); ++kt) {
       f32x16 sa, da;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -642,7 +651,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
         dv[eb][r] = 0.f;
       }
 #pragma unroll 1
-    for (int qt = 0; qt < NT; ++qt) {
+    for (int qt = 0; qt < ((ATT_ABLATE & 1) ? 0 : NT); ++qt) {
       f32x16 sa, da;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

@@ -13,8 +13,8 @@ def agg(path):
     return d
 
 fdir, wdir, out = sys.argv[1:4]
-f = agg(glob.glob(fdir + "/*/*counter_collection.csv")[0])
-w = agg(glob.glob(wdir + "/*/*counter_collection.csv")[0])
+f = agg((glob.glob(fdir + "/*/*counter_collection.csv") + glob.glob(fdir + "/*counter_collection.csv"))[0])
+w = agg((glob.glob(wdir + "/*/*counter_collection.csv") + glob.glob(wdir + "/*counter_collection.csv"))[0])
 res = {}
 for k in sorted(set(f) | set(w)):
     fk = sum(f.get(k, [0])) / max(1, len(f.get(k, [0])))
