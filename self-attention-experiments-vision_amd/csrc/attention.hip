@@ -88,108 +88,132 @@ struct AttnParams {
 };
 
 // ------------------------------------------------------------------------------------------ forward
+// Persistent: each workgroup walks over (batch, head) items blockIdx.x, += gridDim.x with TWO K/V image pairs in LDS, so the
+// LDS-DMA of the next item runs under the MFMA/softmax work of the current one.  (Measured before: loads + stores alone 34 us,
+// compute alone 54 us, together 63 us per launch - every workgroup of a launch is in the same phase, so co-resident workgroups
+// do not cover each other; two 4-wave workgroups per CU ran in the same 63 us.)
 template <int NT>
 __global__ __launch_bounds__(64 * NT) void attn_fwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int IMG = NT * 32 * ROWB;
-  char* imgK = smem;
-  char* imgV = smem + IMG;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H;
-  const long row_base = (long)b * p.N;
+  const int nitems = p.B * p.H;
   size_t bytes = (size_t)p.B * p.N * p.ld * 2;
   if (bytes > 0xffffffe0ull) bytes = 0xffffffe0ull;
   const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.qkv), 0, (uint32_t)bytes, 0x00020000);
-  if (!(ATT_ABLATE & 2)) {
-  stage_image<NT, NT>(imgK, srd, row_base, p.N, p.ld, p.d + hh * HD, wave, lane);
-  stage_image<NT, NT>(imgV, srd, row_base, p.N, p.ld, 2 * p.d + hh * HD, wave, lane);
-  }
-
-  // Q fragments of this wave's 32 queries straight from HBM (B operand: lane = (q, half), 8 consecutive e)
   const int ql = lane & 31, half = lane >> 5;
   const int q = wave * 32 + ql;
-  bf16x8 qf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    qf[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    if (q < p.N) qf[ks] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)(row_base + q) * p.ld + hh * HD + 16 * ks + 8 * half);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // S^T tiles: rows = keys (registers), column = query (lane)
-  f32x16 s[NT];
-#pragma unroll
-  for (int kt = 0; kt < NT; ++kt) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-    if (ATT_ABLATE & 1) continue;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8 kf = lds_row_frag(imgK, kt * 32 + ql, 2 * ks + half);
-      s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
-    }
-  }
-  // mask keys >= N, row max
-  float m = -INFINITY;
-#pragma unroll
-  for (int kt = 0; kt < NT; ++kt) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (key >= p.N) s[kt][r] = -INFINITY;
-      m = fmaxf(m, s[kt][r]);
-    }
-  }
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
-  const float mb = m * LOG2E;
-  float l = 0.f;
-#pragma unroll
-  for (int kt = 0; kt < NT; ++kt) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float e = __builtin_amdgcn_exp2f(s[kt][r] * LOG2E - mb);
-      s[kt][r] = e;
-      l += e;
-    }
-  }
-  l += __shfl_xor(l, 32, 64);
-
-  // O^T[e][q] = sum_key V^T[e][key] P^T[key][q]
-  f32x16 oacc[2];
-#pragma unroll
-  for (int eb = 0; eb < 2; ++eb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[eb][r] = 0.f;
   const int g = lane >> 4, t = lane & 15;
   const int trow = 4 * (g >> 1) + (t >> 2);        // + 32*kt + 16*s2
   const int tcol = 16 * (g & 1) + 4 * (t & 3);      // + 32*eb
+
+  auto stage_item = [&](int item, char* buf) {
+    const int b = item / p.H, hh = item - b * p.H;
+    const long row_base = (long)b * p.N;
+    stage_image<NT, NT>(buf, srd, row_base, p.N, p.ld, p.d + hh * HD, wave, lane);
+    stage_image<NT, NT>(buf + IMG, srd, row_base, p.N, p.ld, 2 * p.d + hh * HD, wave, lane);
+  };
+  // Q fragments of this wave's 32 queries straight from HBM (B operand: lane = (q, half), 8 consecutive e)
+  bf16x8 qf[4];
+  auto load_q = [&](int item) {
+    const int b = item / p.H, hh = item - b * p.H;
 #pragma unroll
-  for (int kt = 0; kt < NT; ++kt) {
-    if (ATT_ABLATE & 1) continue;
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (q < p.N) qf[ks] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)((long)b * p.N + q) * p.ld + hh * HD + 16 * ks + 8 * half);
+    }
+  };
+
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+  stage_item(item, smem);
+  load_q(item);
+  int cur = 0;
+#pragma unroll 1
+  for (; item < nitems; item += gridDim.x) {
+    // this item's images have landed (every wave's share) and every wave is done reading the other pair
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int nxt = item + gridDim.x;
+    char* imgK = smem + cur * 2 * IMG;
+    char* imgV = imgK + IMG;
+    if (nxt < nitems) stage_item(nxt, smem + (cur ^ 1) * 2 * IMG);
+    const int b = item / p.H, hh = item - b * p.H;
+    const long row_base = (long)b * p.N;
+
+    // S^T tiles: rows = keys (registers), column = query (lane)
+    f32x16 s[NT];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const bf16x8 pf = acc_to_frag(s[kt], s2);
+    for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
-      for (int eb = 0; eb < 2; ++eb) {
-        const bf16x8 vf = lds_tr_frag(imgV, kt * 32 + 16 * s2 + trow, 32 * eb + tcol);
-        oacc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[eb], 0, 0, 0);
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = lds_row_frag(imgK, kt * 32 + ql, 2 * ks + half);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
       }
     }
-  }
-  if (q < p.N) {
-    const float inv = 1.0f / l;
-    bf16_t* orow = p.o + (size_t)(row_base + q) * p.d + hh * HD;
+    if (nxt < nitems) load_q(nxt);  // qf is dead: the next item's queries arrive under the softmax
+    // mask keys >= N, row max
+    // only the last key tile can hold keys >= N (NT = ceil(N / 32))
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (NT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (key >= p.N) s[NT - 1][r] = -INFINITY;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kt][r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float mb = m * LOG2E;
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[kt][r] * LOG2E - mb);
+        s[kt][r] = e;
+        l += e;
+      }
+    }
+    l += __shfl_xor(l, 32, 64);
+
+    // O^T[e][q] = sum_key V^T[e][key] P^T[key][q]
+    f32x16 oacc[2];
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int e = 32 * eb + 8 * g4 + 4 * half;
-        *reinterpret_cast<uint2*>(orow + e) = make_uint2(pack_bf16x2(oacc[eb][4 * g4] * inv, oacc[eb][4 * g4 + 1] * inv),
-                                                         pack_bf16x2(oacc[eb][4 * g4 + 2] * inv, oacc[eb][4 * g4 + 3] * inv));
+      for (int r = 0; r < 16; ++r) oacc[eb][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_to_frag(s[kt], s2);
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) {
+          const bf16x8 vf = lds_tr_frag(imgV, kt * 32 + 16 * s2 + trow, 32 * eb + tcol);
+          oacc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[eb], 0, 0, 0);
+        }
       }
-    if (half == 0 && p.lse != nullptr) p.lse[((size_t)b * p.H + hh) * p.N + q] = m + __logf(l);
+    }
+    if (q < p.N) {
+      const float inv = 1.0f / l;
+      bf16_t* orow = p.o + (size_t)(row_base + q) * p.d + hh * HD;
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int e = 32 * eb + 8 * g4 + 4 * half;
+          *reinterpret_cast<uint2*>(orow + e) = make_uint2(pack_bf16x2(oacc[eb][4 * g4] * inv, oacc[eb][4 * g4 + 1] * inv),
+                                                           pack_bf16x2(oacc[eb][4 * g4 + 2] * inv, oacc[eb][4 * g4 + 3] * inv));
+        }
+      if (half == 0 && p.lse != nullptr) p.lse[((size_t)b * p.H + hh) * p.N + q] = m + __logf(l);
+    }
+    cur ^= 1;
   }
 }
 
@@ -1192,19 +1216,34 @@ static bool attn_force_general() {
   return f;
 }
 
-#define ATTN_DISPATCH(KERNEL, LDS_EXPR)                                                                        \
+// workgroups that can be resident at once: CUs x min(LDS, thread) occupancy (register limits are covered by launch bounds)
+static int persistent_grid(int items, size_t lds_bytes, int threads) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  int per_cu = (int)((160 * 1024) / (lds_bytes ? lds_bytes : 1));
+  const int by_threads = 2048 / threads;
+  if (per_cu > by_threads) per_cu = by_threads;
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 2) per_cu = 2;  // the kernels hold 128-256 VGPRs
+  const long g = (long)cus * per_cu;
+  return (int)(items < g ? items : g);
+}
+#define ATTN_DISPATCH(KERNEL, LDS_EXPR, GRID)                                                                       \
   switch (nt) {                                                                                                \
-    case 1: ATTN_CASE(KERNEL, 1, LDS_EXPR)                                                                     \
-    case 2: ATTN_CASE(KERNEL, 2, LDS_EXPR)                                                                     \
-    case 3: ATTN_CASE(KERNEL, 3, LDS_EXPR)                                                                     \
-    case 4: ATTN_CASE(KERNEL, 4, LDS_EXPR)                                                                     \
-    case 5: ATTN_CASE(KERNEL, 5, LDS_EXPR)                                                                     \
-    case 6: ATTN_CASE(KERNEL, 6, LDS_EXPR)                                                                     \
-    case 7: ATTN_CASE(KERNEL, 7, LDS_EXPR)                                                                     \
-    case 8: ATTN_CASE(KERNEL, 8, LDS_EXPR)                                                                     \
+    case 1: ATTN_CASE(KERNEL, 1, LDS_EXPR, GRID)                                                                   \
+    case 2: ATTN_CASE(KERNEL, 2, LDS_EXPR, GRID)                                                                   \
+    case 3: ATTN_CASE(KERNEL, 3, LDS_EXPR, GRID)                                                                   \
+    case 4: ATTN_CASE(KERNEL, 4, LDS_EXPR, GRID)                                                                   \
+    case 5: ATTN_CASE(KERNEL, 5, LDS_EXPR, GRID)                                                                   \
+    case 6: ATTN_CASE(KERNEL, 6, LDS_EXPR, GRID)                                                                   \
+    case 7: ATTN_CASE(KERNEL, 7, LDS_EXPR, GRID)                                                                   \
+    case 8: ATTN_CASE(KERNEL, 8, LDS_EXPR, GRID)                                                                   \
     default: return SAVIT_EINVAL;                                                                              \
   }
-#define ATTN_CASE(KERNEL, NTV, LDS_EXPR)                                                                       \
+#define ATTN_CASE(KERNEL, NTV, LDS_EXPR, GRID)                                                                    \
   {                                                                                                            \
     constexpr int NT = NTV;                                                                                    \
     const size_t lds = (LDS_EXPR);                                                                             \
@@ -1213,7 +1252,7 @@ static bool attn_force_general() {
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return (int)e;                                                                      \
     }                                                                                                          \
-    hipLaunchKernelGGL(kfn, dim3(B * H), dim3(64 * NTV), lds, (hipStream_t)stream, p);                         \
+    hipLaunchKernelGGL(kfn, dim3(GRID), dim3(64 * NTV), lds, (hipStream_t)stream, p);                          \
   } break;
 
 extern "C" int savit_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int head_dim, int ld_qkv,
@@ -1234,7 +1273,8 @@ extern "C" int savit_attention_fwd(const void* qkv, void* o, float* lse, int B, 
     hipLaunchKernelGGL(attn_fwd2_kernel, dim3(B * H), dim3(64 * (nt < 8 ? nt : 8)), lds, (hipStream_t)stream, pp);
     SAVIT_LAUNCH_RET();
   }
-  ATTN_DISPATCH(attn_fwd_kernel, (size_t)2 * NT * 32 * ROWB)
+  // persistent workgroups: as many as fit the CUs' LDS at once (two K/V image pairs each), every one walking over items
+  ATTN_DISPATCH(attn_fwd_kernel, (size_t)4 * NT * 32 * ROWB, persistent_grid(B * H, (size_t)4 * NT * 32 * ROWB, 64 * NT))
   SAVIT_LAUNCH_RET();
 }
 
@@ -1257,7 +1297,7 @@ extern "C" int savit_attention_bwd(const void* qkv, const void* o, const void* d
     hipLaunchKernelGGL(attn_bwd2_kernel, dim3(B * H), dim3(64 * (nt < 8 ? nt : 8)), lds, (hipStream_t)stream, pp);
     SAVIT_LAUNCH_RET();
   }
-  ATTN_DISPATCH(attn_bwd_kernel, (size_t)4 * NT * 32 * ROWB + (size_t)2 * NT * 32 * sizeof(float))
+  ATTN_DISPATCH(attn_bwd_kernel, (size_t)4 * NT * 32 * ROWB + (size_t)2 * NT * 32 * sizeof(float), B * H)
   SAVIT_LAUNCH_RET();
 }
 

@@ -49,8 +49,12 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return *reinterpret_cast<bf16_t*>(&b);
 }
 
+// both halves in ONE v_cvt_pk_bf16_f32 (two scalar casts cost two converts plus a shift/or to merge them)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  typedef __attribute__((ext_vector_type(2))) float f2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
+  const b2_t r = __builtin_convertvector(f2_t{lo, hi}, b2_t);
+  return __builtin_bit_cast(uint32_t, r);
 }
 
 __device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
