@@ -23,9 +23,6 @@
 #include "savit.h"
 #include <stdlib.h>
 
-#ifndef ATT_ABLATE
-#define ATT_ABLATE 0  // experiment builds: 1 no compute loops, 2 no image staging
-#endif
 namespace {
 
 constexpr int HD = 64;              // head dim
@@ -238,7 +235,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
   if (bytes_o > 0xffffffe0ull) bytes_o = 0xffffffe0ull;
   const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.qkv), 0, (uint32_t)bytes, 0x00020000);
   const auto srdD = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.d_o), 0, (uint32_t)bytes_o, 0x00020000);
-  if (!(ATT_ABLATE & 2)) {
+  {
   stage_image<NT, NT>(imgQ, srd, row_base, p.N, p.ld, hh * HD, wave, lane);
   stage_image<NT, NT>(imgK, srd, row_base, p.N, p.ld, p.d + hh * HD, wave, lane);
   stage_image<NT, NT>(imgV, srd, row_base, p.N, p.ld, 2 * p.d + hh * HD, wave, lane);
@@ -285,7 +282,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[eb][r] = 0.f;
 #pragma unroll 1
-    for (int kt = 0; kt < ((ATT_ABLATE & 1) ? 0 : NT); ++kt) {
+    for (int kt = 0; kt < NT; ++kt) {
       f32x16 sa, da;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -349,7 +346,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
         dv[eb][r] = 0.f;
       }
 #pragma unroll 1
-    for (int qt = 0; qt < ((ATT_ABLATE & 1) ? 0 : NT); ++qt) {
+    for (int qt = 0; qt < NT; ++qt) {
       f32x16 sa, da;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -603,7 +600,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[eb][r] = 0.f;
 #pragma unroll 1
-    for (int kt = 0; kt < ((ATT_ABLATE & 1) ? 0 : NT); ++kt) {
+    for (int kt = 0; kt < NT; ++kt) {
       f32x16 sa, da;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -675,7 +672,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
         dv[eb][r] = 0.f;
       }
 #pragma unroll 1
-    for (int qt = 0; qt < ((ATT_ABLATE & 1) ? 0 : NT); ++qt) {
+    for (int qt = 0; qt < NT; ++qt) {
       f32x16 sa, da;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

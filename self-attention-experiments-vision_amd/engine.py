@@ -141,14 +141,15 @@ class _Plan:
     """A recorded sequence of kernel launches: (ctypes fn, args-without-stream, label).
 
     A launch may be marked `side`: it has no consumer later in the plan (the weight-gradient GEMMs: their only output is
-    the gradient buffer), so `run_overlapped` issues it on a second HIP stream where it fills the CUs that the
-    memory-bound LayerNorm / attention launches of the main chain leave idle.  `reads`/`writes` declare the scratch
-    buffers a side launch reads and a main launch overwrites; the plan turns them into event waits."""
+    the gradient buffer), so `run_overlapped` issues it on one of several extra HIP streams, round-robin, where it runs
+    BESIDE the main chain: those launches are sized for about half the CUs (few K-splits, so also few fp32 atomics), the
+    main chain keeps the rest.  `reads`/`writes` declare the scratch buffers a side launch reads and a main launch
+    overwrites; the plan turns them into event waits."""
 
     def __init__(self):
         self.calls: List[Tuple[Callable, tuple, str]] = []
         self.keep: List[object] = []  # ctypes structs that must outlive the plan
-        self.side: Dict[int, bool] = {}          # call index -> runs on the side stream
+        self.side: Dict[int, int] = {}           # call index -> side-launch ordinal (stream = ordinal % number of side streams)
         self.guard: Dict[int, List[int]] = {}    # main call index -> side call indices that must have finished first
         self._readers: Dict[int, List[int]] = {}  # buffer address -> side calls reading it (build-time bookkeeping)
         self._ev_ready: Dict[int, "torch.cuda.Event"] = {}
@@ -159,13 +160,13 @@ class _Plan:
         self.calls.append((fn, args, label))
         if side:
             assert not writes
-            self.side[i] = True
+            self.side[i] = len(self.side)
             for r in reads:
                 self._readers.setdefault(r, []).append(i)
         else:
-            g = [j for w in writes for j in self._readers.pop(w, [])]
+            g = sorted({j for w in writes for j in self._readers.pop(w, [])})
             if g:
-                self.guard[i] = [max(g)]  # the side stream is in-order: the latest reader covers the rest
+                self.guard[i] = g
 
     def run(self, stream: int):
         for fn, args, label in self.calls:
@@ -173,22 +174,26 @@ class _Plan:
             if rc != 0:
                 _lib.check(rc, label)
 
-    def run_overlapped(self, main: "torch.cuda.Stream", side: "torch.cuda.Stream", hooks: Optional[Dict[str, Callable[[], None]]] = None):
-        """Main-chain launches on `main`, side launches on `side`, ordered by events; both streams are joined before every
-        hook (the DDP bucket all-reduce reads gradients written on either stream) and at the end."""
-        mh, sh = main.cuda_stream, side.cuda_stream
-        last_side = None
+    def run_overlapped(self, main: "torch.cuda.Stream", sides: List["torch.cuda.Stream"],
+                       hooks: Optional[Dict[str, Callable[[], None]]] = None):
+        """Main-chain launches on `main`, side launches round-robin on `sides`, ordered by events; every stream is joined
+        before each hook (the DDP bucket all-reduce reads gradients written on any of them) and at the end."""
+        mh = main.cuda_stream
+        ns = len(sides)
+        last = [None] * ns  # last side call issued per side stream
         for i, (fn, args, label) in enumerate(self.calls):
-            if i in self.side:
+            k = self.side.get(i)
+            if k is not None:
+                st = sides[k % ns]
                 ev = self._ev_ready.get(i)
                 if ev is None:
                     ev = self._ev_ready[i] = torch.cuda.Event()
                     self._ev_done[i] = torch.cuda.Event()
                 ev.record(main)
-                side.wait_event(ev)
-                rc = fn(*args, sh)
-                self._ev_done[i].record(side)
-                last_side = i
+                st.wait_event(ev)
+                rc = fn(*args, st.cuda_stream)
+                self._ev_done[i].record(st)
+                last[k % ns] = i
             else:
                 for j in self.guard.get(i, ()):
                     main.wait_event(self._ev_done[j])
@@ -198,11 +203,13 @@ class _Plan:
             if hooks:
                 cb = hooks.get(label)
                 if cb is not None:
-                    if last_side is not None:
-                        main.wait_event(self._ev_done[last_side])
+                    for j in last:
+                        if j is not None:
+                            main.wait_event(self._ev_done[j])
                     cb()
-        if last_side is not None:
-            main.wait_event(self._ev_done[last_side])
+        for j in last:
+            if j is not None:
+                main.wait_event(self._ev_done[j])
 
 
 class ViTEngine:
@@ -262,13 +269,14 @@ class ViTEngine:
         # ---- backward scratch
         self.dres = e(M, d)
         # scratch that the side-stream weight-gradient GEMMs read is rotated, so the main chain rarely has to wait for them
-        self.dres_b_ring = [e(M, d, dt=bf16) for _ in range(4)]
+        depth = max(2, int(os.environ.get("SAVIT_RING_DEPTH", "2")))  # layers the side streams may lag behind the main chain
+        self.dres_b_ring = [e(M, d, dt=bf16) for _ in range(2 * depth)]
         self.dres_b = self.dres_b_ring[0]
-        self.d_u_ring = [e(M, F, dt=bf16) for _ in range(2)]
+        self.d_u_ring = [e(M, F, dt=bf16) for _ in range(depth)]
         self.d_u = self.d_u_ring[0]
         self.d_h = e(M, d, dt=bf16)
         self.d_o = e(M, d, dt=bf16)
-        self.dqkv_ring = [e(M, 3 * d, dt=bf16) for _ in range(2)]
+        self.dqkv_ring = [e(M, 3 * d, dt=bf16) for _ in range(depth)]
         self.dqkv = self.dqkv_ring[0]
         self.dlogits = z(self.B, self.Cp, dt=bf16)
         self.d_z = e(self.B, d, dt=bf16)
@@ -289,7 +297,12 @@ class ViTEngine:
         self.weights_stale = True
         # weight-gradient GEMMs on a second stream (SAVIT_OVERLAP_WGRAD=0 keeps every launch on the caller's stream)
         self.overlap_wgrad = os.environ.get("SAVIT_OVERLAP_WGRAD", "1") != "0"
-        self._side_stream: Optional[torch.cuda.Stream] = None
+        self.n_side_streams = int(os.environ.get("SAVIT_SIDE_STREAMS", "1"))
+        self.wgrad_cu_share = float(os.environ.get("SAVIT_WGRAD_CU_SHARE", "0.56"))
+        self.n_cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        self._side_streams: List[torch.cuda.Stream] = []
+        self._building_serial = False
+        self._bwd_plan_serial: Optional[_Plan] = None  # every launch sized for the whole chip: profile_step / one-stream runs
 
     # ------------------------------------------------------------------------------------ parameters
     def param_tree(self) -> dict:
@@ -402,8 +415,8 @@ class ViTEngine:
 
         def wgrad(label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0)):
             # no later launch consumes dW: side stream.  X is a saved activation (stable until the next forward), dY is scratch
-            P.add(L.savit_gemm_bf16_wgrad, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, 0, patch[0], patch[1], patch[2], patch[3]), label,
-                  side=True, reads=(dY,))
+            P.add(L.savit_gemm_bf16_wgrad, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, self._wgrad_splits(Kin, Nout, patch[0]),
+                                            patch[0], patch[1], patch[2], patch[3]), label, side=True, reads=(dY,))
 
         ring, ri = [t.data_ptr() for t in self.dres_b_ring], 0
         # ---- head: dWh, d z_cls, final LayerNorm backward into the (zeroed) residual gradient
@@ -416,7 +429,7 @@ class ViTEngine:
         for l in range(NL - 1, -1, -1):
             st = self.stats[l]
             w = lambda n, l=l: self.w[n][l].data_ptr()  # noqa: E731
-            d_u, dqkv = self.d_u_ring[l % 2].data_ptr(), self.dqkv_ring[l % 2].data_ptr()
+            d_u, dqkv = self.d_u_ring[l % len(self.d_u_ring)].data_ptr(), self.dqkv_ring[l % len(self.dqkv_ring)].data_ptr()
             # FFN branch: x_{l+1} = x_mid + gelu(h2 W1 + b1) W2 + b2     (ff.py:26-33, vit.py:26-31)
             wgrad(f"l{l}.W2.wgrad", self.a[l].data_ptr(), ring[ri], gp(f"l{l}.W2"), M, F, d, F, d, d)
             self._gemm(P, f"l{l}.fc2.dgrad", writes=(d_u,), A=ring[ri], Bt=w("W2_n"), C=d_u, aux=self.u[l].data_ptr(),
@@ -448,6 +461,25 @@ class ViTEngine:
         wgrad("Wpe.wgrad", self._img_buf.data_ptr(), ring[ri], gp("Wpe"), B * cfg.n_patches, cfg.patch_dim, d, 0, d, d,
               patch=(cfg.patch, cfg.img_size, N, 1))
         return P
+
+    def _wgrad_splits(self, Kin: int, Nout: int, patch: int) -> int:
+        """K-splits of a weight-gradient GEMM.  On its own a launch wants every CU (0 = the library's choice); beside the
+        main chain it is sized for `wgrad_cu_share` of them: measured on DeiT-B/16 the backward pass takes 14.2 ms with
+        256-workgroup weight-gradient launches (7 splits) and 11.9 ms with 144-workgroup ones (4 splits, 43 % fewer atomics)."""
+        if not self.overlap_wgrad or self._building_serial:
+            return 0
+        tile = 256 if self.L.savit_gemm_wgrad_auto_variant(Kin, Nout, patch) == 3 else 128
+        tiles = -(-Kin // tile) * -(-Nout // tile)
+        return max(1, min(24, round(self.wgrad_cu_share * self.n_cus / tiles)))
+
+    def _serial_bwd_plan(self) -> _Plan:
+        if self._bwd_plan_serial is None:
+            self._building_serial = True
+            try:
+                self._bwd_plan_serial = self._build_bwd_plan()
+            finally:
+                self._building_serial = False
+        return self._bwd_plan_serial
 
     # ------------------------------------------------------------------------------------ execution
     @staticmethod
@@ -515,20 +547,22 @@ class ViTEngine:
 
     def backward_from_dlogits(self):
         """Backward from self.dlogits (bf16 [B, Cp], pad columns zero) into self.grads (accumulating)."""
-        s = self._stream()
-        if self._bwd_plan is None:
-            self._bwd_plan = self._build_bwd_plan()
         self.dres.zero_()
         self.dres_b.zero_()  # ring slot 0: lnf.bwd fills only the cls rows
         if self.overlap_wgrad:
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=self.dev)
-            self._bwd_plan.run_overlapped(torch.cuda.current_stream(), self._side_stream, self.bwd_hooks)
+            if self._bwd_plan is None:
+                self._bwd_plan = self._build_bwd_plan()
+            n = max(1, self.n_side_streams)
+            while len(self._side_streams) < n:
+                self._side_streams.append(torch.cuda.Stream(device=self.dev))
+            self._bwd_plan.run_overlapped(torch.cuda.current_stream(), self._side_streams[:n], self.bwd_hooks)
             return
+        s = self._stream()
+        plan = self._serial_bwd_plan()
         if not self.bwd_hooks:
-            self._bwd_plan.run(s)
+            plan.run(s)
             return
-        for fn, args, label in self._bwd_plan.calls:
+        for fn, args, label in plan.calls:
             rc = fn(*args, s)
             if rc != 0:
                 _lib.check(rc, label)
@@ -562,8 +596,7 @@ class ViTEngine:
             self.refresh_weights()
         if self._fwd_plan is None:
             self._fwd_plan = self._build_fwd_plan()
-        if self._bwd_plan is None:
-            self._bwd_plan = self._build_bwd_plan()
+        bwd_plan = self._serial_bwd_plan()
         s = self._stream()
         self.labels.copy_(labels.to(torch.int32))
         evs: List[Tuple[str, torch.cuda.Event, torch.cuda.Event]] = []
@@ -587,7 +620,7 @@ class ViTEngine:
                                              self.top5.data_ptr(), self.B, self.cfg.num_classes, s), "savit_softmax_xent")
         self.dres.zero_()
         self.dres_b.zero_()
-        run(self._bwd_plan)
+        run(bwd_plan)
         torch.cuda.synchronize()
         return {label: a.elapsed_time(b) for label, a, b in evs}
 
