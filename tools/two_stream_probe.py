@@ -36,18 +36,8 @@ def run(nside, splits):
             ev2 = torch.cuda.Event(); ev2.record(s); main.wait_event(ev2)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / 5 * 1e3
-for nside in (0, 1, 3):
-    for splits in (0, 4):
+for nside in (0, 1):
+    for splits in (0, 4, 2, 1):
         if nside == 0 and splits: continue
         print(f"side streams {nside} splits {splits or 'auto'}: bwd {run(nside, splits):.3f} ms", flush=True)
 
-print("--- through the engine (hazards handled), ring depth", os.environ.get("SAVIT_RING_DEPTH", "2"), "---")
-def run_engine(nside, share):
-    eng.n_side_streams = nside; eng.wgrad_cu_share = share; eng._bwd_plan = None
-    for _ in range(2): eng.loss_backward(lab)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(5): eng.loss_backward(lab)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / 5 * 1e3
-for nside, share in ((1, 1.0), (1, 0.56), (2, 0.56), (3, 0.56), (3, 0.5), (4, 0.56)):
-    print(f"engine: side streams {nside} share {share}: loss+bwd {run_engine(nside, share):.3f} ms", flush=True)
