@@ -128,6 +128,8 @@ def _copy_tree(dst: dict, src: dict, path: str = ""):
         if isinstance(dv, dict):
             _copy_tree(dv, sv, f"{path}/{k}")
         else:
+            if not isinstance(sv, torch.Tensor) and hasattr(sv, "flags") and not sv.flags.writeable:
+                sv = sv.copy()  # e.g. arrays restored from a checkpoint buffer (np.frombuffer views are read-only)
             t = torch.as_tensor(sv) if not isinstance(sv, torch.Tensor) else sv
             if tuple(t.shape) != tuple(dv.shape):
                 raise ValueError(f"{path}/{k}: shape {tuple(t.shape)} != {tuple(dv.shape)}")

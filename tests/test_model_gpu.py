@@ -5,6 +5,7 @@ bf16 graph deviates O(1e-2) from fp32 after a few layers, so the end-to-end bar 
 worse than ~2x the bf16-emulating oracle's own deviation (printed), per-kernel bars are in test_kernels_gpu.py.
 Backward: every parameter gradient vs fp32 autograd of the independent torch composition."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -284,3 +285,47 @@ def test_backward_overlapped_wgrad_matches_single_stream():
     for got in grads[True]:
         err = float((got - ref).abs().max())
         assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["vit_ti_patch16", "cait_xxs_24"])
+def test_flax_checkpoint_roundtrip(tmp_path, name):
+    """Row f-4: a TrainState written in the Flax msgpack format restores into a fresh engine bit for bit (parameters, Adam
+    moments, step) and carries the reference's module tree."""
+    import torch
+    from savit_amd import flax_ckpt
+    from savit_amd.model import create_model
+
+    torch.manual_seed(0)
+    model = create_model(name, num_classes=16)
+    B = 2
+    eng = model.engine(B)
+    eng.init_params(11)
+    eng.params.add_(0.01 * torch.randn_like(eng.params))  # non-trivial head / cls / LayerScale values
+    eng.weights_stale = True
+    img = torch.randn(B, 224, 224, 3, device="cuda").to(torch.bfloat16)
+    lab = torch.randint(0, 16, (B,), device="cuda", dtype=torch.int32)
+    eng.forward(img)
+    eng.loss_backward(lab)
+    eng.optimizer_step(1e-3, 1e-4, 1.0)
+    ref_logits = eng.forward(img).clone()
+    path = flax_ckpt.save_from_engine(eng, str(tmp_path), step=3)
+    assert os.path.basename(path) == "checkpoint_3"
+    state = flax_ckpt.read_train_state(path)
+    assert set(state) == {"step", "params", "opt_state"} and set(state["opt_state"]) == {"0", "1", "2", "3"}
+    assert "Encoder_0" in state["params"]["params"] and "mu" in state["opt_state"]["1"]
+
+    model2 = create_model(name, num_classes=16)
+    eng2 = model2.engine(B)
+    eng2.init_params(99)
+    step = flax_ckpt.load_into_engine(eng2, state)
+    eng2.weights_stale = True
+    assert step == 3 and eng2.step_count == eng.step_count
+    def leaves(t):
+        return [x for v in t.values() for x in leaves(v)] if isinstance(t, dict) else [t]
+
+    # (the flat buffers also hold alignment padding between tensors, which is not part of the tree: compare leaf by leaf)
+    for a_flat, b_flat in ((eng.params, eng2.params), (eng.adam_m, eng2.adam_m), (eng.adam_v, eng2.adam_v)):
+        la, lb = leaves(eng.layout.flax_tree(a_flat)), leaves(eng2.layout.flax_tree(b_flat))
+        assert len(la) == len(lb) and all(torch.equal(x, y) for x, y in zip(la, lb))
+    assert torch.equal(eng2.forward(img), ref_logits)

@@ -38,7 +38,7 @@ def test_short_run_eval_checkpoint_restore(tmp_path, capsys):
     assert len(train) == 6 and len(evals) == 2
     assert abs(train[0]["train/loss"] - 6.9078) < 1e-2  # zero-init head: ln(1000) at step 1 (SURVEY 8c i)
     assert all(0.0 <= e["eval/top-5-acc"] <= 1.0 for e in evals)
-    assert os.path.exists(os.path.join(ck, "checkpoint_6.pt"))
+    assert os.path.exists(os.path.join(ck, "checkpoint_6"))  # the reference's file name (flax.training.checkpoints)
     end2 = train_cli.main(common + ["--num_epochs", "3"])  # resumes from step 6
     assert end2 == 9
     lines2 = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{") and "train/loss" in l]

@@ -75,22 +75,24 @@ class NpzData:
 
 
 def save_checkpoint(eng, ckpt_dir, step, keep=3):
-    import torch
+    """checkpoints.save_checkpoint(dir, train_state, step, keep=3) (reference train.py:123-127): the SAME file name and wire
+    format (msgpack of the TrainState state dict, savit_amd/flax_ckpt.py), so the file restores in Flax and vice versa."""
+    from savit_amd import flax_ckpt
 
-    os.makedirs(ckpt_dir, exist_ok=True)
-    path = os.path.join(ckpt_dir, f"checkpoint_{step}.pt")
-    torch.save({"step": step, "opt_step": eng.step_count, "params": eng.params.cpu(),
-                "m": None if eng.adam_m is None else eng.adam_m.cpu(), "v": None if eng.adam_v is None else eng.adam_v.cpu()}, path + ".tmp")
-    os.replace(path + ".tmp", path)
-    old = sorted(glob.glob(os.path.join(ckpt_dir, "checkpoint_*.pt")), key=lambda p: int(p.rsplit("_", 1)[1][:-3]))
-    for p in old[:-keep]:
-        os.remove(p)
-    return path
+    return flax_ckpt.save_from_engine(eng, ckpt_dir, step, keep=keep)
 
 
 def restore_checkpoint(eng, ckpt_dir):
+    """Latest `checkpoint_<step>` (Flax msgpack; the reference never restores, defect B-list) - or a round-1 `.pt` file."""
     import torch
 
+    from savit_amd import flax_ckpt
+
+    path = flax_ckpt.latest_checkpoint(ckpt_dir)
+    if path is not None:
+        step = flax_ckpt.load_into_engine(eng, flax_ckpt.read_train_state(path))
+        eng.weights_stale = True
+        return step
     files = sorted(glob.glob(os.path.join(ckpt_dir, "checkpoint_*.pt")), key=lambda p: int(p.rsplit("_", 1)[1][:-3]))
     if not files:
         return 0
