@@ -174,6 +174,20 @@ int savit_cast_transpose_bf16(const float* src, long src_batch_stride, int batch
 int savit_cast_bf16(const float* src, void* dst, long n, void* stream);
 int savit_hwcn_to_nhwc_bf16(const float* src, void* dst, int H, int W, int C, int N, void* stream);
 
+/* ---- GPU-side input path: what the reference's TF host pipeline does around train.py:80-81.
+ * normalise: dst[n,h,w,c] = bf16( (src*scale - mean[c]) / std[c] )   (data/preprocess/preprocess.py:176-179; mean/std are HOST
+ *   arrays of C floats, e.g. data/constants.py:7-8; scale = 1/255 for u8 pixels, 1 for [0,1] floats); src_format picks the
+ *   source layout: the loader's [H,W,C,N] fp32 (train.py:80) or [N,H,W,C] fp32 / u8.  C <= 4.
+ * mixup:  out[b] = x[b]*weight[b] + x[index[b]]*(1-weight[b])                    (augment_ops.py:144-181)
+ * cutmix: out[b,y,x,:] = (y0<=y<y1 && x0<=x<x1) ? x[b,y,x,:] : x[index[b],y,x,:]   (augment_ops.py:98-141; box[b] = y0,y1,x0,x1;
+ *   the reference pairs b with B-1-b).  x / out: [B,H,W,C] bf16, out != x; weight / index / box: DEVICE arrays (the random
+ *   draws are the caller's: TF's stateless RNG stream is not reproducible).  elems_per_image % 8 == 0. */
+enum savit_src_format { SAVIT_SRC_HWCN_F32 = 0, SAVIT_SRC_NHWC_F32 = 1, SAVIT_SRC_NHWC_U8 = 2 };
+int savit_normalize_to_nhwc_bf16(const void* src, int src_format, void* dst, int H, int W, int C, int N, float scale,
+                                 const float* mean, const float* std, void* stream);
+int savit_batch_mixup_bf16(const void* x, void* out, const float* weight, const int* index, int B, long elems_per_image, void* stream);
+int savit_batch_cutmix_bf16(const void* x, void* out, const int* box, const int* index, int B, int H, int W, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

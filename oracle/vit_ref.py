@@ -624,3 +624,55 @@ def param_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
     out["params/Dense_0/kernel"] = (d, C)
     out["params/Dense_0/bias"] = (C,)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Input path.  The reference runs these in its TF host pipeline; restated in numpy for the GPU kernels'
+# parity tests.  The random draws are arguments (TF's stateless RNG is not reproducible).
+def normalize_images(x, mean, std, scale=1.0):
+    """image = (image*scale - mean) / std per channel, NHWC  (data/preprocess/preprocess.py:176-179; data/constants.py:7-10)."""
+    x = np.asarray(x, dtype=np.float32) * np.float32(scale)
+    return (x - np.asarray(mean, np.float32)) * (np.float32(1.0) / np.asarray(std, np.float32))
+
+
+def batch_mixup_apply(x, labels_onehot, mix, index):
+    """augment_ops.py:176-181: xmix = x*mix + x[index]*(1-mix); lmix likewise.  x [B,H,W,C], mix [B], index [B]."""
+    x = np.asarray(x, np.float32)
+    m = np.asarray(mix, np.float32)
+    xm = x * m[:, None, None, None] + x[index] * (np.float32(1) - m)[:, None, None, None]
+    lm = labels_onehot * m[:, None] + labels_onehot[index] * (np.float32(1) - m)[:, None]
+    return xm, lm
+
+
+def mixup_weight(u, beta):
+    """augment_ops.py:169-172: mix = u**(1/beta)/2 ; mix = max(mix, 1-mix)."""
+    mix = np.power(np.asarray(u, np.float64), 1.0 / beta) / 2
+    return np.maximum(mix, 1 - mix)
+
+
+def cutmix_box(u, x_shift, y_shift, height, width, beta=1.0):
+    """augment_ops.py:119-131 + _sample_batch_mask :70-93: mix_weight = u**(1/beta)/2 (own-label weight = box area fraction),
+    ratio = sqrt(mix_weight), mask_h = int(ratio*H), mask_w = int(ratio*W), shifts taken modulo (size - mask); the mask is
+    rows [y, y+mask_h) x columns [x, x+mask_w).  Returns (mix_weight, boxes [B,4] = y0,y1,x0,x1)."""
+    w = np.power(np.asarray(u, np.float64), 1.0 / beta) / 2
+    ratio = np.sqrt(w)
+    mh = (ratio * height).astype(np.int64)
+    mw = (ratio * width).astype(np.int64)
+    xs = np.asarray(x_shift, np.int64) % (width - mw)
+    ys = np.asarray(y_shift, np.int64) % (height - mh)
+    return w, np.stack([ys, ys + mh, xs, xs + mw], axis=1)
+
+
+def batch_cutmix_apply(x, labels_onehot, mix_weight, boxes, index=None):
+    """augment_ops.py:136-141: images = where(mask, images, images[::-1]); labels = l*w + l[::-1]*(1-w)."""
+    x = np.asarray(x)
+    B, H, W, _ = x.shape
+    if index is None:
+        index = np.arange(B)[::-1]
+    yy, xx = np.arange(H)[None, :, None], np.arange(W)[None, None, :]
+    b = np.asarray(boxes)
+    mask = (yy >= b[:, 0, None, None]) & (yy < b[:, 1, None, None]) & (xx >= b[:, 2, None, None]) & (xx < b[:, 3, None, None])
+    xo = np.where(mask[..., None], x, x[index])
+    w = np.asarray(mix_weight, np.float32)[:, None]
+    lo = labels_onehot * w + labels_onehot[index] * (np.float32(1) - w)
+    return xo, lo

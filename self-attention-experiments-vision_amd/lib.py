@@ -64,6 +64,10 @@ _SIGNATURES = {
                                           c_void_p]),
     "savit_cast_bf16": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
     "savit_hwcn_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "savit_normalize_to_nhwc_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, ctypes.POINTER(c_float),
+                                             ctypes.POINTER(c_float), c_void_p]),
+    "savit_batch_mixup_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
+    "savit_batch_cutmix_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None

@@ -427,3 +427,87 @@ def th_attention_bwd(qkv, T1, T2, s_buf, p_buf, d_o, dT1, dT2, B: int, N: int, H
     _lib.check(L.savit_th_attention_bwd(_p(qkv), _p(T1), _p(T2), _p(s_buf), _p(p_buf), _p(d_o), _p(ds_buf), _p(dqkv), _p(dT1), _p(dT2), B, N, H,
                                         head_dim, ld, Np, float(dq_scale), _p(ws), ws.numel(), _stream()), "savit_th_attention_bwd")
     return dqkv
+
+
+# --------------------------------------------------------------------------------------------- input path (row f-2)
+IMAGENET_1K_MEAN, IMAGENET_1K_STD = (0.475, 0.452, 0.398), (0.232, 0.228, 0.229)      # data/constants.py:7-8
+IMAGENET_21K_MEAN, IMAGENET_21K_STD = (0.494, 0.473, 0.415), (0.228, 0.224, 0.230)    # data/constants.py:9-10
+
+
+def normalize_to_nhwc_bf16(src: torch.Tensor, mean=IMAGENET_1K_MEAN, std=IMAGENET_1K_STD, scale: Optional[float] = None,
+                           layout: str = "NHWC", dst: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(src*scale - mean)/std -> bf16 [N,H,W,C]  (preprocess.py:176-179 + train.py:80-81).  src: fp32 in the loader's
+    [H,W,C,N] layout (layout='HWCN'), or fp32 / uint8 [N,H,W,C].  scale defaults to 1/255 for uint8 and 1 for floats."""
+    if not src.is_cuda or src.dim() != 4 or not src.is_contiguous():
+        raise ValueError("src must be a contiguous 4-D GPU tensor")
+    if layout == "HWCN":
+        if src.dtype != f32:
+            raise ValueError("the [H,W,C,N] loader layout is fp32")
+        H, W, C, N = src.shape
+        fmt = 0
+    elif layout == "NHWC":
+        N, H, W, C = src.shape
+        if src.dtype == f32:
+            fmt = 1
+        elif src.dtype == torch.uint8:
+            fmt = 2
+        else:
+            raise ValueError("NHWC source must be fp32 or uint8")
+    else:
+        raise ValueError("layout must be 'NHWC' or 'HWCN'")
+    if len(mean) != C or len(std) != C or C > 4:
+        raise ValueError("mean/std must have one entry per channel (C <= 4)")
+    if scale is None:
+        scale = 1.0 / 255.0 if src.dtype == torch.uint8 else 1.0
+    if dst is None:
+        dst = torch.empty((N, H, W, C), dtype=bf16, device=src.device)
+    _chk(dst, bf16, "dst", 4)
+    if tuple(dst.shape) != (N, H, W, C) or not dst.is_contiguous():
+        raise ValueError("dst shape")
+    import ctypes as _ct
+    m = (_ct.c_float * C)(*[float(v) for v in mean])
+    s = (_ct.c_float * C)(*[float(v) for v in std])
+    L = _lib.load()
+    _lib.check(L.savit_normalize_to_nhwc_bf16(_p(src), fmt, _p(dst), H, W, C, N, float(scale), m, s, _stream()), "savit_normalize_to_nhwc_bf16")
+    return dst
+
+
+def batch_mixup(x: torch.Tensor, weight: torch.Tensor, index: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x[b]*weight[b] + x[index[b]]*(1-weight[b])  (augment_ops.py:176-179); x bf16 [B,...], weight fp32 [B], index int32 [B]."""
+    _chk(x, bf16, "x")
+    _chk(weight, f32, "weight", 1)
+    _chk(index, torch.int32, "index", 1)
+    B = x.shape[0]
+    per = x.numel() // max(B, 1)
+    if not x.is_contiguous() or weight.numel() != B or index.numel() != B or per % 8 != 0:
+        raise ValueError("batch_mixup: contiguous x, one weight/index per sample, elements per image % 8 == 0")
+    if B and (int(index.min()) < 0 or int(index.max()) >= B):
+        raise ValueError("index out of range")
+    if out is None:
+        out = torch.empty_like(x)
+    _chk(out, bf16, "out")
+    if out.shape != x.shape or out.data_ptr() == x.data_ptr() or not out.is_contiguous():
+        raise ValueError("out must be a distinct contiguous tensor of x's shape")
+    L = _lib.load()
+    _lib.check(L.savit_batch_mixup_bf16(_p(x), _p(out), _p(weight), _p(index), B, per, _stream()), "savit_batch_mixup_bf16")
+    return out
+
+
+def batch_cutmix(x: torch.Tensor, box: torch.Tensor, index: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """where(inside box[b], x[b], x[index[b]])  (augment_ops.py:136-138); x bf16 [B,H,W,C], box int32 [B,4] = y0,y1,x0,x1."""
+    _chk(x, bf16, "x", 4)
+    _chk(box, torch.int32, "box", 2)
+    _chk(index, torch.int32, "index", 1)
+    B, H, W, C = x.shape
+    if not x.is_contiguous() or tuple(box.shape) != (B, 4) or index.numel() != B or not box.is_contiguous():
+        raise ValueError("batch_cutmix: contiguous x [B,H,W,C], box [B,4], index [B]")
+    if B and (int(index.min()) < 0 or int(index.max()) >= B):
+        raise ValueError("index out of range")
+    if out is None:
+        out = torch.empty_like(x)
+    _chk(out, bf16, "out", 4)
+    if out.shape != x.shape or out.data_ptr() == x.data_ptr() or not out.is_contiguous():
+        raise ValueError("out must be a distinct contiguous tensor of x's shape")
+    L = _lib.load()
+    _lib.check(L.savit_batch_cutmix_bf16(_p(x), _p(out), _p(box), _p(index), B, H, W, C, _stream()), "savit_batch_cutmix_bf16")
+    return out

@@ -1,5 +1,6 @@
 """train.py-shaped loop: schedule on CPU; a short real run with eval + checkpoint save/restore on GPU."""
 import json
+import numpy as np
 import os
 
 import pytest
@@ -43,3 +44,19 @@ def test_short_run_eval_checkpoint_restore(tmp_path, capsys):
     assert end2 == 9
     lines2 = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{") and "train/loss" in l]
     assert [l["step"] for l in lines2] == [7, 8, 9]
+
+
+@pytest.mark.gpu
+def test_short_run_with_gpu_mix_augment(capsys):
+    """Row f-2 in the loop: batch mixup / cutmix on the GPU feed the two-label loss (train.py:83-88); at the zero-init head the
+    mixed loss is still ln(1000)."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    end = train_cli.main(["--model_name", "vit_ti_patch16", "--batch_size", "8", "--steps_per_epoch", "4", "--num_epochs", "1", "--log_every", "1",
+                          "--lr", "1e-3", "--mixup_alpha", "0.8", "--cutmix_alpha", "1.0", "--eval_every_epochs", "100"])
+    assert end == 4
+    train = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{") and "train/loss" in l]
+    assert len(train) == 4 and abs(train[0]["train/loss"] - 6.9078) < 1e-2
+    assert all(np.isfinite(t["train/loss"]) for t in train)

@@ -126,6 +126,10 @@ def main(argv=None):
     ap.add_argument("--eval_every_epochs", type=int, default=5)
     ap.add_argument("--save_every_epochs", type=int, default=10)
     ap.add_argument("--log_every", type=int, default=10)
+    # GPU-side input path (the reference does these in its TF host pipeline: data/preprocess/augment_utils.py:85-136)
+    ap.add_argument("--mixup_alpha", type=float, default=0.0, help="batch mixup Beta parameter (reference pipeline: 0.8); 0 = off")
+    ap.add_argument("--cutmix_alpha", type=float, default=0.0, help="batch cutmix Beta parameter (reference pipeline: 1.0); 0 = off")
+    ap.add_argument("--mix_prob", type=float, default=1.0, help="probability of applying the drawn mix augmentation to a batch")
     args = ap.parse_args(argv)
 
     import torch
@@ -192,14 +196,27 @@ def main(argv=None):
             dist.all_reduce(tot)  # psum, train.py:120
         return (tot[0] / tot[3]).item(), (tot[1] / tot[3]).item(), (tot[2] / tot[3]).item()
 
+    mix_on = args.mixup_alpha > 0 or args.cutmix_alpha > 0
+    mix_gen = torch.Generator(device=dev).manual_seed(args.seed + 7919 * (rank + 1)) if mix_on else None
     step, t0, seen = start, time.perf_counter(), 0
     for epoch in range(start // spe, args.num_epochs):
         for batch in train_src(epoch):
             lr = warmup_cosine(step, peak, 5 * spe, total)
+            images = batch["images"]
+            if mix_on and "mix_labels" not in batch:
+                from savit_amd import augment, ops as _ops
+
+                S = args.img_size
+                nhwc = _ops.hwcn_to_nhwc_bf16(images) if tuple(images.shape) == (S, S, 3, bs) and images.dtype == torch.float32 \
+                    else images.to(torch.bfloat16).contiguous()
+                images, _, ml, ratio = augment.mix_batch(nhwc, batch["labels"].to(torch.int32), args.mixup_alpha, args.cutmix_alpha,
+                                                         args.mix_prob, mix_gen)
+                if ml is not None:
+                    batch = dict(batch, mix_labels=ml, ratio=ratio)
             if eng.cfg.kind == "cait":
-                eng.forward(batch["images"], is_training=True)
+                eng.forward(images, is_training=True)
             else:
-                eng.forward(batch["images"])
+                eng.forward(images)
             eng.loss_backward(batch["labels"], args.label_smoothing, batch.get("mix_labels"), batch.get("ratio"))
             if sync is not None:
                 sync.wait()
