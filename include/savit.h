@@ -94,7 +94,8 @@ typedef struct savit_gemm_args {
   const void* aux;        /* RESID: fp32 [M, ldaux]; DGELU: bf16 [M, ldaux]; PATCH: fp32 pos [tokens, N] */
   const float* colscale;  /* fp32 [N] or NULL  (LayerScale) */
   const float* rowscale;  /* fp32 [M / rows_per_sample] or NULL  (stochastic-depth mask/keep_prob per sample) */
-  float* colsum;          /* fp32 [N] or NULL, accumulated with atomics */
+  float* colsum;          /* fp32 or NULL: [N] accumulated with atomics (colsum_rows == 0), or a [colsum_rows, N] slab of per-
+                             row-tile partial sums written with plain stores (deterministic; reduce with savit_colsum_finalize) */
   int M, N, K;
   int lda, ldb, ldc, ldaux;
   int epilogue;           /* enum savit_epilogue */
@@ -105,10 +106,16 @@ typedef struct savit_gemm_args {
   int round_bias_bf16;    /* round bias to bf16 before adding (reference casts params to dtype) */
   /* SAVIT_EPI_PATCH geometry */
   int img_size, patch, tokens, token_offset;
-  int tile;               /* 0 = auto, 1 = 128x128, 2 = 256x256, 3 = 256x128 (benchmarks / tests) */
+  int tile;               /* 0 = auto; explicit ids select a kernel variant (benchmarks / tests, see gemm_tn.hip) */
+  int colsum_rows;        /* 0, or the slab height savit_gemm_colsum_rows() gives for this shape and tile */
 } savit_gemm_args;
 
 int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream);
+/* Bias-gradient column sums without atomics: ~200 row tiles adding into the same N addresses serialise at the memory side
+ * (16 us of a 180 us launch on the fc2 input-gradient GEMM).  savit_gemm_colsum_rows: partial-sum rows the GEMM writes for
+ * (M, N, K, tile) - one per (row tile, wave row); savit_colsum_finalize: out[n] (+)= sum_r slab[r][n]. */
+int savit_gemm_colsum_rows(int M, int N, int K, int tile);
+int savit_colsum_finalize(const float* slab, int rows, int N, float* out, int accumulate, void* stream);
 /* Tile the auto heuristic (tile == 0) picks for a shape: 6 = 128x128x32 ring (4 waves), 7 = 256x256x32 ring (8 waves). */
 int savit_gemm_tn_auto_tile(int M, int N, int K);
 

@@ -127,7 +127,8 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
 // 16-B-per-lane loads/stores: one wave instruction = 4 rows x 256 B (or 8 x 128 B) of whole cache lines, for the output
 // AND for the fused operands (fp32 residual, bf16 pre-activation).
 template <int EPI, int WTM, int WTN, int MI, int NI>
-__device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[MI][NI], char* wsm, int row0w, int col0w, int lane) {
+__device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[MI][NI], char* wsm, int row0w, int col0w, int lane,
+                                             int slab_row = 0) {
   const savit_gemm_args& a = p.a;
   constexpr int ROWB = WTN * 2;        // bytes per staged row
   constexpr int UPR = WTN / 8;         // 16-B units per row (16 or 8)
@@ -262,7 +263,12 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[M
       if (UPR <= 32) sdu += __shfl_xor(sdu, 32, 64);
       if (UPR <= 16) sdu += __shfl_xor(sdu, 16, 64);
       if (UPR <= 8) sdu += __shfl_xor(sdu, 8, 64);
-      if (lane < UPR && n + k < a.N) atomicAdd(a.colsum + n + k, sdu);
+      if (lane < UPR && n + k < a.N) {
+        if (a.colsum_rows > 0)
+          a.colsum[(size_t)slab_row * a.N + n + k] = sdu;  // this (row tile, wave row)'s partial: no atomics, deterministic
+        else
+          atomicAdd(a.colsum + n + k, sdu);
+      }
     }
   }
 }
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(const GemmParam
   // ---- epilogue
   if constexpr (epi_uses_lds<EPI>()) {
     // the staging LDS is idle now (the last K-tile's barrier has passed): each wave parks its tile in its own slice
-    epilogue_lds<EPI, WTM, WTN, MI, NI>(p, acc, smem + wave * (WTM * WTN * 2), row0 + wm * WTM, col0 + wn * WTN, lane);
+    epilogue_lds<EPI, WTM, WTN, MI, NI>(p, acc, smem + wave * (WTM * WTN * 2), row0 + wm * WTM, col0 + wn * WTN, lane, tm * WGM + wm);
   } else {
     // direct stores: lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3]
     const int mrow = row0 + wm * WTM + fr;
@@ -590,7 +596,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const G
     // all waves must be done reading the ring (the last body's refill reads included) before it is reused
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    epilogue_lds<EPI, WTM, WTN, MI, NI>(p, acc, smem + wave * (WTM * WTN * 2), row0 + wm * WTM, col0 + wn * WTN, lane);
+    epilogue_lds<EPI, WTM, WTN, MI, NI>(p, acc, smem + wave * (WTM * WTN * 2), row0 + wm * WTM, col0 + wn * WTN, lane, tm * WGM + wm);
   } else {
     const int mrow = row0 + wm * WTM + fr;
     const int ncol = col0 + wn * WTN + fq * 4;
@@ -776,7 +782,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_pair_kernel(const G
     // all waves must be done reading the ring (the last step's refill reads included) before it is reused
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    epilogue_lds<EPI, WTM, WTN, MI, NI>(p, acc, smem + wave * (WTM * WTN * 2), row0 + wm * WTM, col0 + wn * WTN, lane);
+    epilogue_lds<EPI, WTM, WTN, MI, NI>(p, acc, smem + wave * (WTM * WTN * 2), row0 + wm * WTM, col0 + wn * WTN, lane, tm * WGM + wm);
   } else {
     const int mrow = row0 + wm * WTM + fr;
     const int ncol = col0 + wn * WTN + fq * 4;
@@ -891,6 +897,63 @@ extern "C" int savit_gemm_tn_auto_tile(int M, int N, int K) {
   return big ? 7 : 6;
 }
 
+namespace {
+// out[n] (+)= sum_r slab[r][n]: a block owns 64 columns (16 lanes x float4) and splits the rows over 16 groups (independent
+// loads, ~rows/16 deep), then an LDS tree; fixed summation order, so the result is reproducible
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ slab, int rows, int N, float* __restrict__ out,
+                                                              int accumulate) {
+  __shared__ float4 part[16][16];
+  const int cx = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cx * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < N) {  // N % 4 == 0
+    for (int r = g; r < rows; r += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)r * N + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  part[g][cx] = s;
+  __syncthreads();
+  if (g == 0 && c < N) {
+    float4 t = part[0][cx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = part[k][cx];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    float4* o = reinterpret_cast<float4*>(out + c);
+    if (accumulate) {
+      const float4 old = *o;
+      t.x += old.x; t.y += old.y; t.z += old.z; t.w += old.w;
+    }
+    *o = t;
+  }
+}
+
+// rows of A per workgroup tile and wave rows per workgroup, by tile id
+inline bool tile_geometry(int tile, int* bm, int* wgm) {
+  switch (tile) {
+    case 1: case 4: case 6: case 8: case 9: case 11: case 12: case 14: *bm = 128; *wgm = 2; return true;
+    case 2: case 5: case 7: case 10: case 13: case 15: *bm = 256; *wgm = 2; return true;
+    case 3: *bm = 256; *wgm = 4; return true;
+    default: return false;
+  }
+}
+}  // namespace
+
+extern "C" int savit_gemm_colsum_rows(int M, int N, int K, int tile) {
+  if (tile == 0) tile = savit_gemm_tn_auto_tile(M, N, K);
+  int bm = 0, wgm = 0;
+  if (!tile_geometry(tile, &bm, &wgm) || M < 0) return -1;
+  return ((M + bm - 1) / bm) * wgm;
+}
+
+extern "C" int savit_colsum_finalize(const float* slab, int rows, int N, float* out, int accumulate, void* stream) {
+  SAVIT_CHECK_ARG(slab && out && rows >= 0 && N > 0 && N % 4 == 0 && ((uintptr_t)slab % 16) == 0 && ((uintptr_t)out % 16) == 0);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, slab, rows, N, out, accumulate);
+  SAVIT_LAUNCH_RET();
+}
+
 extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
   SAVIT_CHECK_ARG(args != nullptr);
   const savit_gemm_args& a = *args;
@@ -920,6 +983,7 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   int tile = a.tile;
   if (tile == 0) tile = savit_gemm_tn_auto_tile(a.M, a.N, a.K);
+  if (a.colsum != nullptr && a.colsum_rows != 0) SAVIT_CHECK_ARG(a.colsum_rows == savit_gemm_colsum_rows(a.M, a.N, a.K, tile));
   switch (tile) {
     case 1: return launch_tile<128, 128, 2, 2>(p, s);
     case 2: return launch_tile<256, 256, 2, 4>(p, s);

@@ -280,6 +280,7 @@ class ViTEngine:
         self.d_o = e(M, d, dt=bf16)
         self.dqkv_ring = [e(M, 3 * d, dt=bf16) for _ in range(depth)]
         self.dqkv = self.dqkv_ring[0]
+        self.colsum_slab = e(max(1, self.L.savit_gemm_colsum_rows(M, F, d, 0)), F)
         self.dlogits = z(self.B, self.Cp, dt=bf16)
         self.d_z = e(self.B, d, dt=bf16)
         ws = self.L.savit_layernorm_bwd_workspace_bytes(M, d)
@@ -434,8 +435,12 @@ class ViTEngine:
             d_u, dqkv = self.d_u_ring[l % len(self.d_u_ring)].data_ptr(), self.dqkv_ring[l % len(self.dqkv_ring)].data_ptr()
             # FFN branch: x_{l+1} = x_mid + gelu(h2 W1 + b1) W2 + b2     (ff.py:26-33, vit.py:26-31)
             wgrad(f"l{l}.W2.wgrad", self.a[l].data_ptr(), ring[ri], gp(f"l{l}.W2"), M, F, d, F, d, d)
+            # db1 = column sums of d_u: per-row-tile partials (plain stores) + a finalize launch; ~200 row tiles adding into the
+            # same F addresses with atomics serialise at the memory side (16 us of this 180 us launch), and this is reproducible
             self._gemm(P, f"l{l}.fc2.dgrad", writes=(d_u,), A=ring[ri], Bt=w("W2_n"), C=d_u, aux=self.u[l].data_ptr(),
-                       colsum=gp(f"l{l}.b1"), M=M, N=F, K=d, lda=d, ldb=d, ldc=F, ldaux=F, epilogue=_lib.EPI_DGELU)
+                       colsum=self.colsum_slab.data_ptr(), colsum_rows=self.colsum_slab.shape[0], M=M, N=F, K=d, lda=d, ldb=d, ldc=F,
+                       ldaux=F, epilogue=_lib.EPI_DGELU)
+            P.add(L.savit_colsum_finalize, (self.colsum_slab.data_ptr(), self.colsum_slab.shape[0], F, gp(f"l{l}.b1"), 1), f"l{l}.b1.grad")
             wgrad(f"l{l}.W1.wgrad", self.h2[l].data_ptr(), d_u, gp(f"l{l}.W1"), M, d, F, d, F, F)
             self._gemm(P, f"l{l}.fc1.dgrad", A=d_u, Bt=w("W1_n"), C=self.d_h.data_ptr(), M=M, N=d, K=F, lda=F, ldb=F,
                        ldc=d, epilogue=_lib.EPI_BF16)

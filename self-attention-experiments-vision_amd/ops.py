@@ -154,11 +154,22 @@ def gemm_tn(A: torch.Tensor, Bt: torch.Tensor, C: torch.Tensor, epilogue: int, *
         min_rows = (patch_geom[2] if epilogue == _lib.EPI_PATCH else need_rows)
         if ar < min_rows or ac < N:
             raise ValueError("aux too small")
-    for name, t, n in (("bias", bias, N), ("colscale", colscale, N), ("colsum", colsum, N)):
+    for name, t, n in (("bias", bias, N), ("colscale", colscale, N)):
         if t is not None:
             _chk(t, f32, name, 1)
             if t.numel() < n:
                 raise ValueError(f"{name} too small")
+    colsum_rows = 0
+    if colsum is not None:
+        if colsum.dim() == 2:  # [rows, N] slab of per-row-tile partial sums (no atomics); rows from gemm_colsum_rows()
+            _chk(colsum, f32, "colsum", 2)
+            colsum_rows = colsum.shape[0]
+            if colsum.shape[1] != N or not colsum.is_contiguous() or colsum_rows != gemm_colsum_rows(Mv, N, K, tile):
+                raise ValueError("colsum slab must be contiguous [gemm_colsum_rows(M, N, K, tile), N]")
+        else:
+            _chk(colsum, f32, "colsum", 1)
+            if colsum.numel() < N:
+                raise ValueError("colsum too small")
     if rowscale is not None:
         _chk(rowscale, f32, "rowscale", 1)
         if rowscale.numel() * rows_per_sample < Mv:
@@ -170,9 +181,29 @@ def gemm_tn(A: torch.Tensor, Bt: torch.Tensor, C: torch.Tensor, epilogue: int, *
     a.epilogue = epilogue
     a.alpha, a.alpha_cols, a.rows_per_sample = float(alpha), int(alpha_cols), int(rows_per_sample)
     a.round_out_bf16, a.round_bias_bf16, a.tile = int(round_out_bf16), int(round_bias_bf16), int(tile)
+    a.colsum_rows = colsum_rows
     L = _lib.load()
     _lib.check(L.savit_gemm_bf16_tn(ctypes.byref(a), _stream()), "savit_gemm_bf16_tn")
     return C
+
+
+def gemm_colsum_rows(M: int, N: int, K: int, tile: int = 0) -> int:
+    """Height of the partial-sum slab `gemm_tn(..., colsum=<2-D>)` writes for this shape (one row per row tile and wave row)."""
+    r = _lib.load().savit_gemm_colsum_rows(int(M), int(N), int(K), int(tile))
+    if r < 0:
+        raise ValueError("unknown tile id")
+    return r
+
+
+def colsum_finalize(slab: torch.Tensor, out: torch.Tensor, accumulate: bool = True) -> torch.Tensor:
+    """out[n] (+)= sum_r slab[r][n]"""
+    _chk(slab, f32, "slab", 2)
+    _chk(out, f32, "out", 1)
+    if not slab.is_contiguous() or out.numel() < slab.shape[1]:
+        raise ValueError("colsum_finalize: contiguous slab [rows, N], out [>= N]")
+    L = _lib.load()
+    _lib.check(L.savit_colsum_finalize(_p(slab), slab.shape[0], slab.shape[1], _p(out), int(accumulate), _stream()), "savit_colsum_finalize")
+    return out
 
 
 def gemm_wgrad(X: torch.Tensor, dY: torch.Tensor, dW: torch.Tensor, splits: int = 0, M: Optional[int] = None,

@@ -36,8 +36,8 @@ def test_header_symbols_exported(built):
 
 
 def test_gemm_args_struct_layout(built):
-    """ctypes mirror must match the C struct: 9 pointers then 18 4-byte scalars (+ padding to 8)."""
-    assert ctypes.sizeof(built.lib.GemmArgs) == 9 * 8 + 18 * 4
+    """ctypes mirror must match the C struct: 9 pointers then 19 4-byte scalars (+ padding to 8)."""
+    assert ctypes.sizeof(built.lib.GemmArgs) == 9 * 8 + 19 * 4 + 4
     assert built.lib.GemmArgs.M.offset == 72 and built.lib.GemmArgs.tile.offset == 72 + 17 * 4
 
 

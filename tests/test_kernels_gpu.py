@@ -206,6 +206,33 @@ def test_gemm_dgelu_and_colsum(ops):
     assert rel(host(cs), host(dU).astype(np.float64).sum(0)) < 1e-4
 
 
+@pytest.mark.parametrize("tile", [0, 12, 13, 3])
+def test_gemm_dgelu_colsum_slab_is_deterministic(ops, tile):
+    """colsum as a [rows, N] slab of per-row-tile partials + savit_colsum_finalize: same sums as the atomic form, and bitwise
+    reproducible (no atomics)."""
+    rng = np.random.default_rng(18)
+    M, d, F = 197 * 3 + 11, 192, 768
+    dy, W2, u = _mk(rng, M, d), _mk(rng, F, d, 1 / np.sqrt(d)), _mk(rng, M, F)
+    rows = ops.gemm_colsum_rows(M, F, d, tile)
+    assert rows >= 2 * ((M + 255) // 256)
+    outs = []
+    for _ in range(2):
+        dU = torch.zeros((M, F), dtype=bf16, device="cuda")
+        slab = torch.full((rows, F), float("nan"), device="cuda")
+        ops.gemm_tn(dev(dy, bf16), dev(W2, bf16), dU, 3, aux=dev(u, bf16), colsum=slab, tile=tile)
+        assert torch.isfinite(slab).all()  # every slab entry is written
+        cs = torch.full((F,), 2.0, device="cuda")
+        ops.colsum_finalize(slab, cs, accumulate=True)
+        outs.append(cs.clone())
+        assert rel(host(cs) - 2.0, host(dU).astype(np.float64).sum(0)) < 1e-4
+    assert torch.equal(outs[0], outs[1])
+    cs0 = torch.full((F,), 7.0, device="cuda")
+    ops.colsum_finalize(slab, cs0, accumulate=False)
+    assert torch.equal(cs0, outs[0] - 2.0) or rel(host(cs0), host(outs[0]) - 2.0) < 1e-6
+    with pytest.raises(ValueError):
+        ops.gemm_tn(dev(dy, bf16), dev(W2, bf16), dU, 3, aux=dev(u, bf16), colsum=slab[:-1], tile=tile)
+
+
 def test_gemm_f32_head(ops):
     rng = np.random.default_rng(9)
     B, d, C = 37, 192, 1000
