@@ -93,13 +93,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU execution path for the product")
+    # one rank per GPU (RCCL).  SAVIT_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: the ranks then
+    # share devices (local_rank modulo the device count) and the exchange goes through gloo - same hooks, same bucket plan.
+    backend = os.environ.get("SAVIT_DIST_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     import savit_amd  # noqa: F401
     from savit_amd import ddp
