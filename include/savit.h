@@ -116,7 +116,8 @@ int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream);
  * (M, N, K, tile) - one per (row tile, wave row); savit_colsum_finalize: out[n] (+)= sum_r slab[r][n]. */
 int savit_gemm_colsum_rows(int M, int N, int K, int tile);
 int savit_colsum_finalize(const float* slab, int rows, int N, float* out, int accumulate, void* stream);
-/* Tile the auto heuristic (tile == 0) picks for a shape: 6 = 128x128x32 ring (4 waves), 7 = 256x256x32 ring (8 waves). */
+/* Tile the auto heuristic (tile == 0) picks for a shape.  K % 64 == 0: 12 = 128x128 (4 waves, two workgroups per CU) or
+ * 13 = 256x256 (8 waves) paired-stage kernels; otherwise 6 / 7 = the same tiles on the 32-deep ring. */
 int savit_gemm_tn_auto_tile(int M, int N, int K);
 
 /* Weight-gradient GEMM: dW[Kin, Nout] += X[M, Kin]^T . dY[M, Nout]  (fp32 atomics into dW; caller zeroes).
