@@ -172,9 +172,12 @@ class CaiTEngine:
         self.gen = torch.Generator(device=self.dev).manual_seed(0)
         # ---- backward scratch
         self.dres, self.dres_b = e(M, d), e(M, d, dt=bf16)
-        self.dbr, self.d_h, self.d_o = e(M, d, dt=bf16), e(M, d, dt=bf16), e(M, d, dt=bf16)
-        self.d_u = e(M, F, dt=bf16)
-        self.dqkv = e(M, 3 * d, dt=bf16)
+        self.d_h, self.d_o = e(M, d, dt=bf16), e(M, d, dt=bf16)
+        # scratch the side-stream weight-gradient GEMMs read is rotated, so the main chain rarely waits for them
+        self.dbr_ring = [e(M, d, dt=bf16) for _ in range(4)]
+        self.d_u_ring = [e(M, F, dt=bf16) for _ in range(2)]
+        self.dqkv_ring = [e(M, 3 * d, dt=bf16) for _ in range(2)]
+        self.dbr, self.d_u, self.dqkv = self.dbr_ring[0], self.d_u_ring[0], self.dqkv_ring[0]
         self.dsbuf = e(B, H, N, self.Np, dt=bf16)
         self.dcls, self.dcls_b = e(B, d), e(B, d, dt=bf16)
         self.dbr_c, self.d_hc2, self.d_oc = e(B, d, dt=bf16), e(B, d, dt=bf16), e(B, d, dt=bf16)
@@ -190,6 +193,14 @@ class CaiTEngine:
         self._fwd_plan = self._bwd_plan = self._cast_plan = None
         self.bwd_hooks: Dict[str, object] = {}
         self.weights_stale = True
+        import os as _os
+        self.overlap_wgrad = _os.environ.get("SAVIT_OVERLAP_WGRAD", "1") != "0"
+        self.n_side_streams = int(_os.environ.get("SAVIT_SIDE_STREAMS", "1"))
+        self.wgrad_cu_share = float(_os.environ.get("SAVIT_WGRAD_CU_SHARE", "0.56"))
+        self.n_cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        self._side_streams = []
+        self._building_serial = False
+        self._bwd_plan_serial = None
 
     # ------------------------------------------------------------------------------------ parameters
     def param_tree(self):
@@ -239,7 +250,7 @@ class CaiTEngine:
     def _off_ptr(self, buf, name):
         return buf.data_ptr() + self.layout.off[name][0] * 4
 
-    def _gemm(self, plan, label, **kw):
+    def _gemm(self, plan, label, writes=(), **kw):
         a = _lib.GemmArgs()
         for k, v in kw.items():
             setattr(a, k, v)
@@ -247,10 +258,18 @@ class CaiTEngine:
             a.rows_per_sample = 1
         a.round_bias_bf16 = self.rp
         plan.keep.append(a)
-        plan.add(self.L.savit_gemm_bf16_tn, (ctypes.byref(a),), label)
+        plan.add(self.L.savit_gemm_bf16_tn, (ctypes.byref(a),), label, writes=writes)
 
-    def _wgrad(self, plan, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0)):
-        plan.add(self.L.savit_gemm_bf16_wgrad, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, 0, patch[0], patch[1], patch[2], patch[3]), label)
+    def _wgrad(self, plan, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0), side=False):
+        """side=True (the big SA-layer weight gradients): no later launch consumes dW, so `_Plan.run_overlapped` issues it on a
+        second stream, sized for about half the CUs (engine.ViTEngine._wgrad_splits has the measurements)."""
+        splits = 0
+        if side and self.overlap_wgrad and not self._building_serial:
+            tile = 256 if self.L.savit_gemm_wgrad_auto_variant(Kin, Nout, patch[0]) == 3 else 128
+            tiles = -(-Kin // tile) * -(-Nout // tile)
+            splits = max(1, min(24, round(self.wgrad_cu_share * self.n_cus / tiles)))
+        plan.add(self.L.savit_gemm_bf16_wgrad, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, splits, patch[0], patch[1], patch[2], patch[3]), label,
+                 side=side, reads=(dY,) if side else ())
 
     def _build_cast_plan(self):
         P, L, lay, cfg = _Plan(), self.L, self.layout, self.cfg
@@ -384,32 +403,36 @@ class CaiTEngine:
                                                  self.dcls.data_ptr(), self.dcls.data_ptr(), None, gp(f"c{c}.ln1_g"), gp(f"c{c}.ln1_b"), None, B, d,
                                                  d, d, self.rp, 1, N + 1, 0, ws, wsb), f"c{c}.ln1c.bwd")
         P.add(L.savit_pos_cls_grad, (self.dcls.data_ptr(), gp("cls"), None, B, 1, d, 0), "cls.grad")
-        # ---- SA layers (reverse)
+        # ---- SA layers (reverse).  Their weight-gradient GEMMs go to the side stream; dbr / d_u / dqkv rotate through small rings.
+        ring, ri = [t.data_ptr() for t in self.dbr_ring], 0
         for l in range(NL - 1, -1, -1):
             st = self.stats[l]
             w = lambda n, l=l: self.w[n][l].data_ptr()  # noqa: E731
             sd0, sd1 = self.sd[2 * l].data_ptr(), self.sd[2 * l + 1].data_ptr()
-            P.add(L.savit_layerscale_bwd, (self.dres.data_ptr(), self.br2[l].data_ptr(), pp(f"l{l}.ls2"), sd1, N, self.dbr.data_ptr(), gp(f"l{l}.ls2"),
-                                           gp(f"l{l}.b2"), M, d, d, ws, wsb), f"l{l}.ls2.bwd")
-            self._wgrad(P, f"l{l}.W2.wgrad", self.a[l].data_ptr(), self.dbr.data_ptr(), gp(f"l{l}.W2"), M, F, d, F, d, d)
-            self._gemm(P, f"l{l}.fc2.dgrad", A=self.dbr.data_ptr(), Bt=w("W2_n"), C=self.d_u.data_ptr(), aux=self.u[l].data_ptr(),
+            d_u, dqkv = self.d_u_ring[l % 2].data_ptr(), self.dqkv_ring[l % 2].data_ptr()
+            ri = (ri + 1) % len(ring)
+            P.add(L.savit_layerscale_bwd, (self.dres.data_ptr(), self.br2[l].data_ptr(), pp(f"l{l}.ls2"), sd1, N, ring[ri], gp(f"l{l}.ls2"),
+                                           gp(f"l{l}.b2"), M, d, d, ws, wsb), f"l{l}.ls2.bwd", writes=(ring[ri],))
+            self._wgrad(P, f"l{l}.W2.wgrad", self.a[l].data_ptr(), ring[ri], gp(f"l{l}.W2"), M, F, d, F, d, d, side=True)
+            self._gemm(P, f"l{l}.fc2.dgrad", writes=(d_u,), A=ring[ri], Bt=w("W2_n"), C=d_u, aux=self.u[l].data_ptr(),
                        colsum=gp(f"l{l}.b1"), M=M, N=F, K=d, lda=d, ldb=d, ldc=F, ldaux=F, epilogue=_lib.EPI_DGELU)
-            self._wgrad(P, f"l{l}.W1.wgrad", self.h2[l].data_ptr(), self.d_u.data_ptr(), gp(f"l{l}.W1"), M, d, F, d, F, F)
-            self._gemm(P, f"l{l}.fc1.dgrad", A=self.d_u.data_ptr(), Bt=w("W1_n"), C=self.d_h.data_ptr(), M=M, N=d, K=F, lda=F, ldb=F, ldc=d,
+            self._wgrad(P, f"l{l}.W1.wgrad", self.h2[l].data_ptr(), d_u, gp(f"l{l}.W1"), M, d, F, d, F, F, side=True)
+            self._gemm(P, f"l{l}.fc1.dgrad", A=d_u, Bt=w("W1_n"), C=self.d_h.data_ptr(), M=M, N=d, K=F, lda=F, ldb=F, ldc=d,
                        epilogue=_lib.EPI_BF16)
             P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(),
                                           self.dres.data_ptr(), self.dres.data_ptr(), None, gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b"), None, M, d, d, d,
                                           self.rp, ws, wsb), f"l{l}.ln2.bwd")
-            P.add(L.savit_layerscale_bwd, (self.dres.data_ptr(), self.br1[l].data_ptr(), pp(f"l{l}.ls1"), sd0, N, self.dbr.data_ptr(), gp(f"l{l}.ls1"),
-                                           None, M, d, d, ws, wsb), f"l{l}.ls1.bwd")
-            self._wgrad(P, f"l{l}.Wo.wgrad", self.o[l].data_ptr(), self.dbr.data_ptr(), gp(f"l{l}.Wo"), M, d, d, d, d, d)
-            self._gemm(P, f"l{l}.proj.dgrad", A=self.dbr.data_ptr(), Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=M, N=d, K=d, lda=d, ldb=d, ldc=d,
+            ri = (ri + 1) % len(ring)
+            P.add(L.savit_layerscale_bwd, (self.dres.data_ptr(), self.br1[l].data_ptr(), pp(f"l{l}.ls1"), sd0, N, ring[ri], gp(f"l{l}.ls1"),
+                                           None, M, d, d, ws, wsb), f"l{l}.ls1.bwd", writes=(ring[ri],))
+            self._wgrad(P, f"l{l}.Wo.wgrad", self.o[l].data_ptr(), ring[ri], gp(f"l{l}.Wo"), M, d, d, d, d, d, side=True)
+            self._gemm(P, f"l{l}.proj.dgrad", A=ring[ri], Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=M, N=d, K=d, lda=d, ldb=d, ldc=d,
                        epilogue=_lib.EPI_BF16)
             P.add(L.savit_th_attention_bwd, (self.qkv[l].data_ptr(), pp(f"l{l}.T1"), pp(f"l{l}.T2"), self.sbuf[l].data_ptr(), self.pbuf[l].data_ptr(),
-                                             self.d_o.data_ptr(), self.dsbuf.data_ptr(), self.dqkv.data_ptr(), gp(f"l{l}.T1"), gp(f"l{l}.T2"), B, N, H,
-                                             hd, 3 * d, Np, dqs, ws, wsb), f"l{l}.th_attn.bwd")
-            self._wgrad(P, f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), self.dqkv.data_ptr(), gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d)
-            self._gemm(P, f"l{l}.qkv.dgrad", A=self.dqkv.data_ptr(), Bt=w("Wqkv_n"), C=self.d_h.data_ptr(), M=M, N=d, K=3 * d, lda=3 * d, ldb=3 * d,
+                                             self.d_o.data_ptr(), self.dsbuf.data_ptr(), dqkv, gp(f"l{l}.T1"), gp(f"l{l}.T2"), B, N, H,
+                                             hd, 3 * d, Np, dqs, ws, wsb), f"l{l}.th_attn.bwd", writes=(dqkv,))
+            self._wgrad(P, f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), dqkv, gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d, side=True)
+            self._gemm(P, f"l{l}.qkv.dgrad", A=dqkv, Bt=w("Wqkv_n"), C=self.d_h.data_ptr(), M=M, N=d, K=3 * d, lda=3 * d, ldb=3 * d,
                        ldc=d, epilogue=_lib.EPI_BF16)
             P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
                                           self.dres.data_ptr(), self.dres.data_ptr(), self.dres_b.data_ptr(), gp(f"l{l}.ln1_g"), gp(f"l{l}.ln1_b"),
@@ -486,10 +509,16 @@ class CaiTEngine:
                                              1.0 / self.B, self.loss_rows.data_ptr(), self.loss.data_ptr(), self.dlogits.data_ptr(), self.Cp,
                                              self._off_ptr(self.grads, "bh"), self.top1.data_ptr(), self.top5.data_ptr(), self.B,
                                              self.cfg.num_classes, s), "savit_softmax_xent")
-        if self._bwd_plan is None:
-            self._bwd_plan = self._build_bwd_plan()
         self.dres.zero_()
-        for fn, args, label in self._bwd_plan.calls:
+        if self.overlap_wgrad:
+            if self._bwd_plan is None:
+                self._bwd_plan = self._build_bwd_plan()
+            n = max(1, self.n_side_streams)
+            while len(self._side_streams) < n:
+                self._side_streams.append(torch.cuda.Stream(device=self.dev))
+            self._bwd_plan.run_overlapped(torch.cuda.current_stream(), self._side_streams[:n], self.bwd_hooks)
+            return self.loss
+        for fn, args, label in self._serial_bwd_plan().calls:
             rc = fn(*args, s)
             if rc != 0:
                 _lib.check(rc, label)
@@ -497,6 +526,15 @@ class CaiTEngine:
             if cb is not None:
                 cb()
         return self.loss
+
+    def _serial_bwd_plan(self):
+        if self._bwd_plan_serial is None:
+            self._building_serial = True
+            try:
+                self._bwd_plan_serial = self._build_bwd_plan()
+            finally:
+                self._building_serial = False
+        return self._bwd_plan_serial
 
     def optimizer_step(self, lr: float, weight_decay: float = 0.0, max_norm: float = 0.0, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8,
                        grad_scale: float = 1.0):
@@ -519,8 +557,7 @@ class CaiTEngine:
             self.refresh_weights()
         if self._fwd_plan is None:
             self._fwd_plan = self._build_fwd_plan()
-        if self._bwd_plan is None:
-            self._bwd_plan = self._build_bwd_plan()
+        bwd_plan = self._serial_bwd_plan()
         s = self._stream()
         self.labels.copy_(labels.to(torch.int32))
         evs = []
@@ -543,6 +580,6 @@ class CaiTEngine:
                                              self._off_ptr(self.grads, "bh"), self.top1.data_ptr(), self.top5.data_ptr(), self.B,
                                              self.cfg.num_classes, s), "savit_softmax_xent")
         self.dres.zero_()
-        run(self._bwd_plan)
+        run(bwd_plan)
         torch.cuda.synchronize()
         return {label: a.elapsed_time(b) for label, a, b in evs}
