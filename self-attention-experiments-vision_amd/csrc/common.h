@@ -59,15 +59,43 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 
 __device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 
+// Wave-wide all-reduce without the LDS crossbar: __shfl_xor lowers to ds_bpermute_b32 (six dependent ~100-cycle hops per
+// reduction).  Here lanes 1, 2 apart exchange by DPP quad_perm, 4 and 8 apart by row_half_mirror / row_mirror (after the quad steps
+// every quad is uniform, so mirroring reaches "the other quad / the other half row"), 16 and 32 apart by gfx950's
+// v_permlane16_swap / v_permlane32_swap on two copies of the value (a' + b' then holds both partners everywhere).  The swaps are
+// inline asm: ROCm 7.2's __builtin_amdgcn_permlane{16,32}_swap returns its first result twice.  hipcc does not see the hazards
+// of inline-asm instructions: without wait states between the VALU write of the operands and the swap (and before the results
+// are read) the swap exchanges stale rows (measured, tools/scratch/wave_reduce_test.hip), hence the s_nops.
+#define SAVIT_PERMLANE_SWAP(OP, a, b) asm volatile("s_nop 3\n " OP " %0, %1\n s_nop 3" : "+v"(a), "+v"(b))
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  float a = v, b = v;
+  SAVIT_PERMLANE_SWAP("v_permlane16_swap_b32", a, b);
+  v = a + b;
+  a = v;
+  b = v;
+  SAVIT_PERMLANE_SWAP("v_permlane32_swap_b32", a, b);
+  return a + b;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  float a = v, b = v;
+  SAVIT_PERMLANE_SWAP("v_permlane16_swap_b32", a, b);
+  v = fmaxf(a, b);
+  a = v;
+  b = v;
+  SAVIT_PERMLANE_SWAP("v_permlane32_swap_b32", a, b);
+  return fmaxf(a, b);
 }
 
 // jax.nn.gelu(approximate=True): 0.5 x (1 + tanh(z)), z = sqrt(2/pi) (x + 0.044715 x^3).
