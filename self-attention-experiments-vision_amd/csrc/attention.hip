@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kt][r]);
     }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = half_max(m);
     const float mb = m * LOG2E;
     float l = 0.f;
 #pragma unroll
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_kernel(const AttnParams p) {
         l += e;
       }
     }
-    l += __shfl_xor(l, 32, 64);
+    l = half_sum(l);
 
     // O^T[e][q] = sum_key V^T[e][key] P^T[key][q]
     f32x16 oacc[2];
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
       for (int j = 0; j < 8; ++j) delta += bf16_to_f32((bf16_t)ov[j]) * bf16_to_f32((bf16_t)dv[j]);
     }
   }
-  delta += __shfl_xor(delta, 32, 64);
+  delta = half_sum(delta);
   if (half == 0) del_s[q] = delta;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const AttnParams2 pp) {
           }
         }
       }
-      cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+      cmax = half_max(cmax);
       const float m_new = fmaxf(m, cmax);  // finite: every chunk holds at least one valid key
       const float alpha = __builtin_amdgcn_exp2f((m - m_new) * LOG2E);
       const float mb = m_new * LOG2E;
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const AttnParams2 pp) {
       }
       m = m_new;
     }
-    l += __shfl_xor(l, 32, 64);
+    l = half_sum(l);
     if (q < p.N) {
       const float inv = 1.0f / l;
       bf16_t* orow = p.o + (size_t)(row_base + q) * p.d + hh * hd;
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) delta += bf16_to_f32((bf16_t)ov[j]) * bf16_to_f32((bf16_t)df[ks][j]);
     }
-    delta += __shfl_xor(delta, 32, 64);
+    delta = half_sum(delta);
     if (half == 0) del_s[q] = delta;
     const float nlse = -lse_s[q];
     f32x16 dq[2];

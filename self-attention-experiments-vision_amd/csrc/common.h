@@ -71,6 +71,17 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
+// v(l) (+ / max) v(l ^ 32): the two halves of a wave, e.g. the two key halves of a 32x32 MFMA accumulator column
+__device__ __forceinline__ float half_sum(float v) {
+  float a = v, b = v;
+  SAVIT_PERMLANE_SWAP("v_permlane32_swap_b32", a, b);
+  return a + b;
+}
+__device__ __forceinline__ float half_max(float v) {
+  float a = v, b = v;
+  SAVIT_PERMLANE_SWAP("v_permlane32_swap_b32", a, b);
+  return fmaxf(a, b);
+}
 __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
   v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
