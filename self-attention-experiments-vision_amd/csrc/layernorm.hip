@@ -104,19 +104,52 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
     dc[c] = make_float4(0, 0, 0, 0);
   }
   const float inv_d = 1.0f / (float)d;
-  for (int row = blockIdx.x * LN_WAVES + wave; row < rows; row += gridDim.x * LN_WAVES) {
+  // two-deep software pipeline over this wave's rows: the loads of the NEXT row (x, dy, residual gradient, statistics) are in
+  // flight while this row is reduced and written, so a wave always has a row's worth of HBM requests outstanding.  (The residual
+  // gradient used to be loaded after the two row reductions: a second, exposed, HBM round trip per row.)
+  float4 xv_n[CH], rs_n[CH];
+  uint2 dv_n[CH];
+  float mean_n = 0.f, rstd_n = 0.f;
+  auto load_row = [&](int row) {
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * x_stride);
     const size_t dyrow = grp > 0 ? (size_t)(row / grp) * grp_stride + grp_off + (row % grp) : (size_t)row;
     const uint2* dyr = reinterpret_cast<const uint2*>(dy + dyrow * d);
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    float4 xh[CH], gy[CH];
+    mean_n = mean_in[row];
+    rstd_n = rstd_in[row];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ci = lane + 64 * c;
+      xv_n[c] = make_float4(0, 0, 0, 0);
+      rs_n[c] = make_float4(0, 0, 0, 0);
+      dv_n[c] = make_uint2(0u, 0u);
+      if (ci < nchunk) {
+        xv_n[c] = xr[ci];
+        dv_n[c] = dyr[ci];
+        if (dres_in) rs_n[c] = reinterpret_cast<const float4*>(dres_in + (size_t)row * out_stride)[ci];
+      }
+    }
+  };
+  const int row_step = gridDim.x * LN_WAVES;
+  int row = blockIdx.x * LN_WAVES + wave;
+  if (row < rows) load_row(row);
+  for (; row < rows; row += row_step) {
+    const float mean = mean_n, rstd = rstd_n;
+    float4 xh[CH], gy[CH], rs[CH];
+    uint2 dvc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      xh[c] = xv_n[c];
+      rs[c] = rs_n[c];
+      dvc[c] = dv_n[c];
+    }
+    if (row + row_step < rows) load_row(row + row_step);
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int ci = lane + 64 * c;
       if (ci < nchunk) {
-        const float4 xv = xr[ci];
-        const uint2 dv = dyr[ci];
+        const float4 xv = xh[c];
+        const uint2 dv = dvc[c];
         const float d0 = __uint_as_float(dv.x << 16), d1 = __uint_as_float(dv.x & 0xffff0000u);
         const float d2 = __uint_as_float(dv.y << 16), d3 = __uint_as_float(dv.y & 0xffff0000u);
         xh[c] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
@@ -138,10 +171,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
       if (ci < nchunk) {
         float4 o = make_float4(rstd * (gy[c].x - c1 - xh[c].x * c2), rstd * (gy[c].y - c1 - xh[c].y * c2),
                                rstd * (gy[c].z - c1 - xh[c].z * c2), rstd * (gy[c].w - c1 - xh[c].w * c2));
-        if (dres_in) {
-          const float4 r = reinterpret_cast<const float4*>(dres_in + (size_t)row * out_stride)[ci];
-          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-        }
+        o.x += rs[c].x; o.y += rs[c].y; o.z += rs[c].z; o.w += rs[c].w;
         reinterpret_cast<float4*>(dx_out + (size_t)row * out_stride)[ci] = o;
         if (dx_bf16)
           reinterpret_cast<uint2*>(dx_bf16 + (size_t)row * out_stride)[ci] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
