@@ -241,8 +241,9 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
   stage_image<NT, NT>(imgV, srd, row_base, p.N, p.ld, 2 * p.d + hh * HD, wave, lane);
   stage_image<NT, NT>(imgD, srdD, row_base, p.N, p.d, hh * HD, wave, lane);
   }
+  // lse_s holds -LSE * log2(e), so P = exp2(fma(S, log2 e, lse_s)); rows q >= N hold -inf (P = 0)
   for (int i = threadIdx.x; i < NT * 32; i += 64 * NT)
-    lse_s[i] = (i < p.N) ? p.lse[((size_t)b * p.H + hh) * p.N + i] : INFINITY;
+    lse_s[i] = (i < p.N) ? -LOG2E * p.lse[((size_t)b * p.H + hh) * p.N + i] : -INFINITY;
 
   const int ql = lane & 31, half = lane >> 5;
   const int g = lane >> 4, t = lane & 15;
@@ -275,7 +276,8 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
       qf[ks] = lds_row_frag(imgQ, wave * 32 + ql, 2 * ks + half);
       df[ks] = lds_row_frag(imgD, wave * 32 + ql, 2 * ks + half);
     }
-    const float nlse = -lse_s[q];  // +inf rows (q >= N) give p = 0
+    const float nlse2 = lse_s[q];  // -LSE * log2 e; -inf for rows q >= N (P = 0)
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 dq[2];
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb)
@@ -283,12 +285,9 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
       for (int r = 0; r < 16; ++r) dq[eb][r] = 0.f;
 #pragma unroll 1
     for (int kt = 0; kt < NT; ++kt) {
-      f32x16 sa, da;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        sa[r] = nlse;
-        da[r] = -delta;
-      }
+      // accumulators start from the MFMA's inline-constant zero C operand (no per-tile register initialisation); the LSE /
+      // delta offsets fold into the exp argument and the dS product: this loop is VALU-bound, every instruction per score counts
+      f32x16 sa = zero16, da = zero16;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 kf = lds_row_frag(imgK, kt * 32 + ql, 2 * ks + half);
@@ -298,10 +297,15 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float pr = __builtin_amdgcn_exp2f(sa[r] * LOG2E);
-        if (key >= p.N) pr = 0.f;
-        sa[r] = pr * da[r];  // dS^T
+        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], LOG2E, nlse2));
+        sa[r] = pr * (da[r] - delta);  // dS^T
+      }
+      if (kt == NT - 1) {  // only the last key tile can hold keys >= N
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (key >= p.N) sa[r] = 0.f;
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -337,6 +341,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
       kf[ks] = lds_row_frag(imgK, key, 2 * ks + half);
       vf[ks] = lds_row_frag(imgV, key, 2 * ks + half);
     }
+    const f32x16 zero16b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb)
@@ -347,12 +352,13 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
       }
 #pragma unroll 1
     for (int qt = 0; qt < NT; ++qt) {
-      f32x16 sa, da;
+      f32x16 sa = zero16b, da = zero16b;
+      // -LSE*log2e and delta of this tile's queries: register r holds query qt*32 + 8*(r>>2) + 4*half + (r&3): four 16-byte reads each
+      float4 nl4[4], dl4[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        sa[r] = -lse_s[qq];
-        da[r] = -del_s[qq];
+      for (int g4 = 0; g4 < 4; ++g4) {
+        nl4[g4] = *reinterpret_cast<const float4*>(lse_s + qt * 32 + 8 * g4 + 4 * half);
+        dl4[g4] = *reinterpret_cast<const float4*>(del_s + qt * 32 + 8 * g4 + 4 * half);
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -362,10 +368,16 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
         da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr, vf[ks], da, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pr = __builtin_amdgcn_exp2f(sa[r] * LOG2E);  // rows q >= N: lse = +inf -> 0
-        sa[r] = pr;
-        da[r] = pr * da[r];
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float nl[4] = {nl4[g4].x, nl4[g4].y, nl4[g4].z, nl4[g4].w};
+        const float dl[4] = {dl4[g4].x, dl4[g4].y, dl4[g4].z, dl4[g4].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g4 + j;
+          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], LOG2E, nl[j]));  // rows q >= N: -inf -> 0
+          sa[r] = pr;
+          da[r] = pr * (da[r] - dl[j]);
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
