@@ -72,8 +72,8 @@ def kernel_class(label: str) -> str:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)  # 20 warm-up + >= 50 timed steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--model", default="vit_b_patch16", help="workload model (default: DeiT-B/16, the metric's config)")
     ap.add_argument("--batch", type=int, default=128, help="images per GPU")
     ap.add_argument("--img-size", type=int, default=224)
