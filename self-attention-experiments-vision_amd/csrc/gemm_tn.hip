@@ -28,20 +28,7 @@ struct GemmParams {
   int tiles_m, tiles_n;
   int chunks_per_prow;  // PATCH: 16-B chunks per (patch row) = patch*3/8
   int grid_side;        // PATCH: patches per image side
-  int stagger;          // shader cycles the 2nd resident workgroup of each CU sleeps before starting (0 = off)
 };
-
-// De-phase the two workgroups that share a CU.  Both are dispatched at the same instant and would otherwise run their
-// MFMA main loops together and their VALU/store epilogues together for the whole launch (neither pipe overlapped);
-// delaying the second one ONCE by about half a tile period makes one workgroup's epilogue run under the other's main
-// loop, and workgroups dispatched later inherit the offset (they start when a slot frees).  Blocks [256, 512) are the
-// second residents under the observed round-robin dispatch; a different placement only loses the speed-up.
-__device__ __forceinline__ void stagger_start(int cycles) {
-  if (cycles > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)cycles) __builtin_amdgcn_s_sleep(8);
-  }
-}
 
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, f32x4 acc, float (&csum)[4]) {
@@ -287,7 +274,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(const GemmParam
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const savit_gemm_args& a = p.a;
-  stagger_start(p.stagger);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
@@ -434,7 +420,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const G
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const savit_gemm_args& a = p.a;
-  stagger_start(p.stagger);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
@@ -962,10 +947,6 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
   SAVIT_CHECK_ARG(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.Bt % 16) == 0 && ((uintptr_t)a.C % 16) == 0);
   GemmParams p{};
   p.a = a;
-  {
-    static const int stagger_env = [] { const char* e = getenv("SAVIT_GEMM_STAGGER"); return e ? atoi(e) : -1; }();
-    p.stagger = stagger_env >= 0 ? stagger_env : 0;
-  }
   if (a.epilogue == SAVIT_EPI_PATCH) {
     SAVIT_CHECK_ARG(a.patch > 0 && a.patch % 8 == 0 && a.img_size % a.patch == 0 && a.K == a.patch * a.patch * 3);
     SAVIT_CHECK_ARG(a.aux != nullptr && a.tokens > 0 && a.token_offset >= 0 && a.ldaux >= a.N && a.ldaux % 4 == 0);
