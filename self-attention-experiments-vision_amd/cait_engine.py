@@ -265,9 +265,9 @@ class CaiTEngine:
         second stream, sized for about half the CUs (engine.ViTEngine._wgrad_splits has the measurements)."""
         splits = 0
         if side and self.overlap_wgrad and not self._building_serial:
-            tile = 256 if self.L.savit_gemm_wgrad_auto_variant(Kin, Nout, patch[0]) == 3 else 128
-            tiles = -(-Kin // tile) * -(-Nout // tile)
-            splits = max(1, min(24, round(self.wgrad_cu_share * self.n_cus / tiles)))
+            if self.L.savit_gemm_wgrad_auto_variant(Kin, Nout, patch[0]) == 3:  # big weights only (see ViTEngine._wgrad_splits)
+                tiles = -(-Kin // 256) * -(-Nout // 256)
+                splits = max(1, min(24, round(self.wgrad_cu_share * self.n_cus / tiles)))
         plan.add(self.L.savit_gemm_bf16_wgrad, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, splits, patch[0], patch[1], patch[2], patch[3]), label,
                  side=side, reads=(dY,) if side else ())
 
