@@ -116,9 +116,11 @@ int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream);
  * (M, N, K, tile) - one per (row tile, wave row); savit_colsum_finalize: out[n] (+)= sum_r slab[r][n]. */
 int savit_gemm_colsum_rows(int M, int N, int K, int tile);
 int savit_colsum_finalize(const float* slab, int rows, int N, float* out, int accumulate, void* stream);
-/* Tile the auto heuristic (tile == 0) picks for a shape.  K % 64 == 0: 12 = 128x128 (4 waves, two workgroups per CU) or
- * 13 = 256x256 (8 waves) paired-stage kernels; otherwise 6 / 7 = the same tiles on the 32-deep ring. */
+/* Tile the auto heuristic (tile == 0) picks for a shape and epilogue.  K % 64 == 0: paired-stage kernels 17 = 192x128 (4 waves, two
+ * workgroups per CU; the default), 13 = 256x256 (8 waves; GELU-forward on large grids), 12 = 128x128 (small / ragged problems);
+ * otherwise 6 / 7 = 128x128 / 256x256 on the 32-deep ring.  savit_gemm_tn_auto_tile = the SAVIT_EPI_BF16 choice. */
 int savit_gemm_tn_auto_tile(int M, int N, int K);
+int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue);
 
 /* Weight-gradient GEMM: dW[Kin, Nout] += X[M, Kin]^T . dY[M, Nout]  (fp32 atomics into dW; caller zeroes).
  * X, dY bf16 row-major; reduction over M is split over `splits` workgroup groups (0 = auto).

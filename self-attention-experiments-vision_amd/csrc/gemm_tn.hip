@@ -869,18 +869,27 @@ int launch_tile(const GemmParams& p0, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int savit_gemm_tn_auto_tile(int M, int N, int K) {
-  // measured on MI355X, cold caches (tools/gemm_probe.py; DeiT-B, DeiT-S and ViT-L/16-384 shapes): a 256x256 tile (half the
-  // L2->LDS bytes per flop, one 8-wave workgroup per CU) wins once its grid is at least two rounds of 256 workgroups; smaller
-  // problems run better as 128x128 tiles (more, smaller workgroups, 2 per CU).  K % 64 == 0 selects the paired-stage kernels
-  // (whole-cache-line LDS-DMA: +8 % on the 256x256 tile, +4..38 % on the 128x128 tile); other K keep the 64-B-row ring.
+extern "C" int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue) {
+  // measured on MI355X in the training pipeline (tools/profile_step.py, tools/gemm_probe.py; DeiT-B, DeiT-S, ViT-L/16-384 shapes).
+  // K % 64 == 0 selects the paired-stage kernels (whole-cache-line LDS-DMA), other K the 64-B-row ring.
+  //  * 192x128, two 4-wave workgroups per CU (80 KB of LDS each): the default.  Against 128x128 it needs 19 % fewer L2->LDS bytes per
+  //    flop (the feed bounds these kernels) and keeps the co-resident workgroup that covers prologue and epilogue: fc2 167 -> 148 us,
+  //    fc1/qkv input gradients -8..-10 %.
+  //  * 256x256, one 8-wave workgroup per CU (half the feed again, nothing to overlap with): where its per-tile fixed costs are
+  //    amortised - grids of at least two rounds with K >= 1024 (ViT-L: every product 5-20 % faster than 192x128), or the
+  //    GELU-forward epilogue (two outputs).
+  //  * 128x128: small or ragged problems (few rows, N not a multiple of 128).
   static const int force = [] { const char* e = getenv("SAVIT_GEMM_TILE"); return e ? atoi(e) : 0; }();
   if (force > 0) return force;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
   const bool big = (t256 >= 512 && N % 128 == 0);
-  if (K % 64 == 0) return big ? 13 : 12;
-  return big ? 7 : 6;
+  if (K % 64 != 0) return big ? 7 : 6;
+  if (big && (epilogue == SAVIT_EPI_BIAS_GELU || K >= 1024)) return 13;
+  if (N % 128 == 0 && M >= 1536 && epilogue != SAVIT_EPI_PATCH) return 17;
+  return big ? 13 : 12;
 }
+
+extern "C" int savit_gemm_tn_auto_tile(int M, int N, int K) { return savit_gemm_tn_auto_tile_epi(M, N, K, SAVIT_EPI_BF16); }
 
 namespace {
 // out[n] (+)= sum_r slab[r][n]: a block owns 64 columns (16 lanes x float4) and splits the rows over 16 groups (independent
@@ -921,13 +930,14 @@ inline bool tile_geometry(int tile, int* bm, int* wgm) {
     case 1: case 4: case 6: case 8: case 9: case 11: case 12: case 14: *bm = 128; *wgm = 2; return true;
     case 2: case 5: case 7: case 10: case 13: case 15: *bm = 256; *wgm = 2; return true;
     case 3: *bm = 256; *wgm = 4; return true;
+    case 17: *bm = 192; *wgm = 2; return true;
     default: return false;
   }
 }
 }  // namespace
 
 extern "C" int savit_gemm_colsum_rows(int M, int N, int K, int tile) {
-  if (tile == 0) tile = savit_gemm_tn_auto_tile(M, N, K);
+  if (tile == 0) tile = savit_gemm_tn_auto_tile_epi(M, N, K, SAVIT_EPI_DGELU);  // the only epilogue with column sums
   int bm = 0, wgm = 0;
   if (!tile_geometry(tile, &bm, &wgm) || M < 0) return -1;
   return ((M + bm - 1) / bm) * wgm;
@@ -963,7 +973,7 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
   if (a.M == 0) return SAVIT_OK;
   hipStream_t s = (hipStream_t)stream;
   int tile = a.tile;
-  if (tile == 0) tile = savit_gemm_tn_auto_tile(a.M, a.N, a.K);
+  if (tile == 0) tile = savit_gemm_tn_auto_tile_epi(a.M, a.N, a.K, a.epilogue);
   if (a.colsum != nullptr && a.colsum_rows != 0) SAVIT_CHECK_ARG(a.colsum_rows == savit_gemm_colsum_rows(a.M, a.N, a.K, tile));
   switch (tile) {
     case 1: return launch_tile<128, 128, 2, 2>(p, s);
@@ -981,6 +991,7 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
     case 13: return a.K % 64 ? SAVIT_EINVAL : launch_pair<256, 256, 2, 4, 2>(p, s);
     case 14: return a.K % 64 ? SAVIT_EINVAL : launch_pair<128, 256, 2, 2, 2>(p, s);
     case 15: return a.K % 64 ? SAVIT_EINVAL : launch_pair<256, 128, 2, 2, 2>(p, s);
+    case 17: return a.K % 64 ? SAVIT_EINVAL : launch_pair<192, 128, 2, 2, 2>(p, s);
     default: return SAVIT_EINVAL;
   }
 }

@@ -44,6 +44,7 @@ _SIGNATURES = {
                                           c_int, c_float, c_void_p]),
     "savit_gemm_bf16_tn": (c_int, [POINTER(GemmArgs), c_void_p]),
     "savit_gemm_tn_auto_tile": (c_int, [c_int, c_int, c_int]),
+    "savit_gemm_tn_auto_tile_epi": (c_int, [c_int, c_int, c_int, c_int]),
     "savit_gemm_colsum_rows": (c_int, [c_int, c_int, c_int, c_int]),
     "savit_colsum_finalize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "savit_gemm_wgrad_auto_variant": (c_int, [c_int, c_int, c_int]),

@@ -107,7 +107,7 @@ def _mk(rng, M, K, scale=1.0):
     return rb(rng.standard_normal((M, K)) * scale)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 13, 14, 15, 17])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 256, 128), (197 * 2, 192 * 3, 192), (591, 768, 768), (1000, 384, 1536),
                                    (37, 1000, 192), (300, 64, 128)])
 def test_gemm_bf16_plain(ops, tile, M, N, K):
@@ -149,7 +149,7 @@ def test_gemm_qkv_alpha_and_strided_views(ops):
     assert float(Cw[:, :d].abs().max()) == 0 and float(Cw[:, 2 * d:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("tile", [1, 2, 4, 7, 10, 11, 12, 13])
+@pytest.mark.parametrize("tile", [1, 2, 4, 7, 10, 11, 12, 13, 17])
 def test_gemm_bias_gelu(ops, tile):
     rng = np.random.default_rng(6)
     M, d, F = 197 * 3, 192, 768
@@ -166,7 +166,7 @@ def test_gemm_bias_gelu(ops, tile):
     assert np.abs(host(Aact) - a_ref).max() <= 2 ** -7 * max(1.0, np.abs(a_ref).max())
 
 
-@pytest.mark.parametrize("tile", [1, 2, 4, 7, 10, 11, 12, 13])
+@pytest.mark.parametrize("tile", [1, 2, 4, 7, 10, 11, 12, 13, 17])
 def test_gemm_residual_layerscale_stochdepth(ops, tile):
     rng = np.random.default_rng(7)
     B, N, d, F = 3, 197, 192, 768

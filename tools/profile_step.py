@@ -11,11 +11,12 @@ from savit_amd.engine import ViTEngine
 
 model = sys.argv[1] if len(sys.argv) > 1 else "vit_b_patch16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-cfg = get_config(model)
+IMG = int(sys.argv[3]) if len(sys.argv) > 3 else 224
+cfg = get_config(model, img_size=IMG)
 eng = ViTEngine(cfg, B)
 eng.init_params(42)
 eng.layout.view(eng.params, "Wh").copy_(torch.randn(cfg.embed_dim, cfg.num_classes) * cfg.embed_dim ** -0.5)
-img = torch.randn(B, 224, 224, 3, device="cuda").to(torch.bfloat16)
+img = torch.randn(B, IMG, IMG, 3, device="cuda").to(torch.bfloat16)
 lab = torch.randint(0, 1000, (B,), device="cuda", dtype=torch.int32)
 for _ in range(3):
     eng.forward(img); eng.loss_backward(lab); eng.optimizer_step(1e-4, 1e-4, 1.0)
