@@ -206,7 +206,7 @@ def test_gemm_dgelu_and_colsum(ops):
     assert rel(host(cs), host(dU).astype(np.float64).sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("tile", [0, 12, 13, 3])
+@pytest.mark.parametrize("tile", [0, 12, 13, 17, 3])
 def test_gemm_dgelu_colsum_slab_is_deterministic(ops, tile):
     """colsum as a [rows, N] slab of per-row-tile partials + savit_colsum_finalize: same sums as the atomic form, and bitwise
     reproducible (no atomics)."""
