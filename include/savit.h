@@ -78,11 +78,13 @@ enum savit_epilogue {
   SAVIT_EPI_BF16 = 0,      /* C bf16 = acc (* alpha for columns < alpha_cols: query/sqrt(hd), attention.py:39) (+bias) */
   SAVIT_EPI_BIAS_GELU = 1, /* u = bf16(acc+bias) -> C ; gelu_tanh(u) -> C2   (ff.py:26-28) */
   SAVIT_EPI_RESID = 2,     /* C fp32 = aux_f32 + rowscale[m/rows_per_sample] * colscale[n] * bf16(acc+bias); C2 (nullable) = that bf16 branch
-                              (vit.py:24,31; cait.py:36-40,47-52: LayerScale, StochasticDepth, +residual) */
+                              (vit.py:24,31; cait.py:36-40,47-52: LayerScale, StochasticDepth, +residual).  round_out_bf16: the sum
+                              is rounded through bf16 (mlp_mixer.py:24,30: a residual stream that stays in the module dtype) */
   SAVIT_EPI_DGELU = 3,     /* C bf16 = acc * gelu_tanh'(aux_bf16[m,n]); colsum[n] += column sums  (backward of ff.py:27) */
   SAVIT_EPI_F32 = 4,       /* C fp32 = acc + bias (rounded through bf16 if round_out_bf16)   (vit.py:95-98) */
   SAVIT_EPI_PATCH = 5      /* A is gathered from NHWC bf16 images (patch_embed.py:19-22); C fp32 row
-                              b*tokens + token_offset + p = bf16(acc) + pos[token_offset+p]  (vit.py:85, position_embed.py:56) */
+                              b*tokens + token_offset + p = bf16(acc (+bias)) + pos[token_offset+p]  (vit.py:85, position_embed.py:56);
+                              aux (pos) may be NULL (mlp_mixer.py:46-49: use_bias=True, no position embedding) */
 };
 
 typedef struct savit_gemm_args {
@@ -102,7 +104,7 @@ typedef struct savit_gemm_args {
   float alpha;            /* scale for columns [0, alpha_cols) */
   int alpha_cols;
   int rows_per_sample;    /* tokens per image for rowscale (>=1) */
-  int round_out_bf16;     /* EPI_F32: round the result through bf16 (reference logits are bf16) */
+  int round_out_bf16;     /* EPI_F32 / EPI_RESID: round the result through bf16 (reference logits are bf16) */
   int round_bias_bf16;    /* round bias to bf16 before adding (reference casts params to dtype) */
   /* SAVIT_EPI_PATCH geometry */
   int img_size, patch, tokens, token_offset;
@@ -160,6 +162,19 @@ long savit_th_attention_bwd_workspace_bytes(int B, int N, int H);
  * SAVIT_EPI_PATCH); and the backward of both adds: dpos[t,:] += sum_b dx0[b,t,:], dcls += sum_b dx0[b,0,:]. */
 int savit_cls_pos_rows(const float* cls, const float* pos, float* x0, int B, long row_stride, int d, void* stream);
 int savit_pos_cls_grad(const float* dx0, float* dpos, float* dcls, int B, int N, int d, int has_cls, void* stream);
+
+/* ---- MLP-Mixer glue (mlp_mixer.py:17-31,61-63).
+ * savit_transpose_bf16: B matrices src[b] = bf16 [R, Cc] (row pitch ld_src, batch stride src_batch_stride elements) are transposed:
+ *   dst_bf16[b][c][r] = src[b][r][c]   (nullable; row pitch ld_dst >= R, batch stride dst_batch_stride; columns >= R are not written)
+ *   out_f32[b][c][r]  = resid[b][c][r] + src[b][r][c], rounded through bf16 if round_out_bf16   (nullable pair; fp32 [B, Cc, ld_dst])
+ *   rowsum[r]        += sum over b, c of src[b][r][c]   (nullable; fp32 atomics)
+ * i.e. rearrange '... l d -> ... d l' (:19), the way back fused with `x = x + inputs` (:23-24), and the bias gradient of
+ * the second token Dense.  Pitches and strides are multiples of 8 elements, pointers 16-B aligned.
+ * savit_token_mean_fwd: z[b, :] = bf16(mean over the L tokens of h[b, :, :])  (jnp.mean(x, axis=1), :62); _bwd: dh[b, l, :] = bf16(dz[b, :] / L). */
+int savit_transpose_bf16(const void* src, long src_batch_stride, int ld_src, void* dst_bf16, long dst_batch_stride, int ld_dst, int B, int R,
+                         int Cc, const float* resid, float* out_f32, int round_out_bf16, float* rowsum, void* stream);
+int savit_token_mean_fwd(const void* h_bf16, void* z_bf16, int B, int L, int d, void* stream);
+int savit_token_mean_bwd(const void* dz_bf16, void* dh_bf16, int B, int L, int d, void* stream);
 
 /* ---- loss (train.py:83-90): one_hot -> optional mix (ratio*y + (1-ratio)*y1) -> optax.smooth_labels ->
  * optax.softmax_cross_entropy -> mean.  logits fp32 [B, ld]; labels int32 [B].  Outputs (each nullable):

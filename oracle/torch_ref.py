@@ -124,9 +124,27 @@ def cait_forward(p, images, cfg, is_training=False, keep_masks=None):
     return F.linear(z[:, 0], p["Dense_0"]["kernel"].t(), p["Dense_0"]["bias"])
 
 
+def mixer_forward(p, images, cfg, taps: Optional[dict] = None):
+    """mlp_mixer.py:44-64 (MixerBlock :17-31): token mixing = FFBlock on the transposed activation."""
+    pe = p["PatchEmbedBlock_0"]["Dense_0"]
+    x = F.linear(_patchify(images, cfg.patch), pe["kernel"].t(), pe["bias"])
+    if taps is not None:
+        taps["x0"] = x
+    for l in range(cfg.num_layers):
+        b = p[f"MixerBlock_{l}"]
+        x = x + _ff(b["FFBlock_0"], _ln(x, b["LayerNorm_0"]).transpose(1, 2)).transpose(1, 2)
+        x = x + _ff(b["FFBlock_1"], _ln(x, b["LayerNorm_1"]))
+        if taps is not None:
+            taps[f"x{l + 1}"] = x
+    z = _ln(x, p["LayerNorm_0"]).mean(dim=1)
+    return F.linear(z, p["Dense_0"]["kernel"].t(), p["Dense_0"]["bias"])
+
+
 def forward(p, images, cfg, is_training=False, keep_masks=None, taps=None):
     if cfg.kind == "vit":
         return vit_forward(p, images, cfg, taps)
+    if cfg.kind == "mixer":
+        return mixer_forward(p, images, cfg, taps)
     return cait_forward(p, images, cfg, is_training, keep_masks)
 
 

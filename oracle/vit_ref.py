@@ -39,7 +39,7 @@ import numpy as np
 
 @dataclass(frozen=True)
 class Cfg:
-    kind: str  # 'vit' | 'cait'
+    kind: str  # 'vit' | 'cait' | 'mixer'
     num_layers: int
     num_heads: int
     embed_dim: int
@@ -51,10 +51,16 @@ class Cfg:
     num_layers_token_only: int = 0
     stoch_depth_rate: float = 0.0
     layerscale_eps: float = 0.0
+    # MLP-Mixer only (ref: models/mlp_mixer.py:39)
+    tokens_expand_ratio: float = 0.5
 
     @property
     def n_patches(self) -> int:
         return (self.img_size // self.patch) ** 2
+
+    @property
+    def tokens_hidden(self) -> int:  # FFBlock over the token axis: ff.py:24 with in_ch = number of patches
+        return max(1, int(self.tokens_expand_ratio * self.n_patches))
 
     @property
     def seq_len(self) -> int:  # tokens seen by the SA encoder
@@ -74,7 +80,19 @@ def _cait(L, H, d, sd, eps):
                 num_layers_token_only=2, stoch_depth_rate=sd, layerscale_eps=eps)
 
 
+def _mixer(L, d, p):
+    return dict(kind="mixer", num_layers=L, num_heads=1, embed_dim=d, patch=p)
+
+
 MODEL_ZOO: Dict[str, dict] = {
+    # ref: models/create_model.py:184-213.  The branch at :199-203 repeats the name 'mixer_s_patch32' (unreachable); its
+    # arguments are Mixer-B/16, registered here under the name it was meant to have.
+    "mixer_s_patch32": _mixer(8, 512, 32),
+    "mixer_s_patch16": _mixer(8, 512, 16),
+    "mixer_b_patch32": _mixer(12, 768, 32),
+    "mixer_b_patch16": _mixer(12, 768, 16),
+    "mixer_l_patch32": _mixer(24, 1024, 32),
+    "mixer_l_patch16": _mixer(32, 1024, 16),
     # ref: models/create_model.py:10-37
     "vit_b_patch32": _vit(12, 12, 768, 32),
     "vit_b_patch16": _vit(12, 12, 768, 16),
@@ -334,9 +352,42 @@ def cait_forward(params: dict, images, cfg: Cfg, mode: str = "f32", is_training:
     return dense(pol, x[:, 0], p["Dense_0"]["kernel"], p["Dense_0"]["bias"])
 
 
+def mixer_block(pol: Policy, p: dict, inputs):
+    """MixerBlock.__call__  (models/mlp_mixer.py:17-31).  Every tensor is in the module dtype: there is no fp32 parameter
+    added to the stream (no cls / pos-embed), so with dtype=bfloat16 the residual sums are bf16 too."""
+    x = layer_norm(pol, inputs, p["LayerNorm_0"]["scale"], p["LayerNorm_0"]["bias"])
+    x = np.swapaxes(x, -1, -2)  # '... l d -> ... d l'  (:19)
+    x = ff_block(pol, p["FFBlock_0"], x)  # over the token axis, hidden = int(0.5 * l)  (:20-22, ff.py:24)
+    x = np.swapaxes(x, -1, -2)  # (:23)
+    x = pol.lo(pol.hi(x) + pol.hi(inputs))  # (:24)
+    y = layer_norm(pol, x, p["LayerNorm_1"]["scale"], p["LayerNorm_1"]["bias"])
+    y = ff_block(pol, p["FFBlock_1"], y)  # over channels, expand 4  (:27-29)
+    return pol.lo(pol.hi(x) + pol.hi(y))  # (:30)
+
+
+def mixer_forward(params: dict, images, cfg: Cfg, mode: str = "f32", is_training: bool = False, return_tokens: bool = False):
+    """MLPMixer.__call__  (models/mlp_mixer.py:44-64).  is_training only reaches FFBlock's dropouts, whose rate is 0."""
+    pol = Policy(mode)
+    p = params["params"] if "params" in params else params
+    x = patchify(pol.lo(images), cfg.patch, cfg.patch)
+    pe = p["PatchEmbedBlock_0"]["Dense_0"]
+    x = dense(pol, x, pe["kernel"], pe["bias"])  # use_bias=True  (:46-49)
+    for l in range(cfg.num_layers):
+        x = mixer_block(pol, p[f"MixerBlock_{l}"], x)
+    tokens = x
+    x = layer_norm(pol, x, p["LayerNorm_0"]["scale"], p["LayerNorm_0"]["bias"])  # (:61)
+    x = pol.lo(pol.hi(x).mean(axis=1))  # jnp.mean(x, axis=1): fp32 accumulation, result in dtype  (:62)
+    logits = dense(pol, x, p["Dense_0"]["kernel"], p["Dense_0"]["bias"])  # (:63)
+    if return_tokens:
+        return logits, tokens
+    return logits
+
+
 def forward(params, images, cfg: Cfg, mode="f32", is_training=False, keep_masks=None):
     if cfg.kind == "vit":
         return vit_forward(params, images, cfg, mode, is_training)
+    if cfg.kind == "mixer":
+        return mixer_forward(params, images, cfg, mode, is_training)
     return cait_forward(params, images, cfg, mode, is_training, keep_masks)
 
 
@@ -492,6 +543,18 @@ def init_params(cfg: Cfg, seed: int = 0, randomize: bool = False) -> dict:
     d, H, F = cfg.embed_dim, cfg.num_heads, cfg.hidden
     pdim = cfg.patch * cfg.patch * 3
     N = cfg.seq_len
+    if cfg.kind == "mixer":
+        # mlp_mixer.py: every Dense keeps flax's defaults (lecun-normal kernel, zero bias) - the head too (:63)
+        n, Ft = cfg.n_patches, cfg.tokens_hidden
+        bpe = (0.02 * rng.standard_normal(d)).astype(np.float32) if randomize else np.zeros(d, np.float32)
+        p = {"PatchEmbedBlock_0": {"Dense_0": {"kernel": _lecun_normal(rng, (pdim, d), pdim), "bias": bpe}}}
+        for l in range(cfg.num_layers):
+            p[f"MixerBlock_{l}"] = {"LayerNorm_0": _ln_params(rng, d, randomize), "FFBlock_0": _ff_params(rng, n, Ft, randomize),
+                                    "LayerNorm_1": _ln_params(rng, d, randomize), "FFBlock_1": _ff_params(rng, d, F, randomize)}
+        p["LayerNorm_0"] = _ln_params(rng, d, randomize)
+        hb = (0.02 * rng.standard_normal(cfg.num_classes)).astype(np.float32) if randomize else np.zeros(cfg.num_classes, np.float32)
+        p["Dense_0"] = {"kernel": _lecun_normal(rng, (d, cfg.num_classes), d), "bias": hb}
+        return {"params": p}
     p: dict = {"PatchEmbedBlock_0": {"Dense_0": {"kernel": _lecun_normal(rng, (pdim, d), pdim)}}}
     p["cls"] = ((0.02 * rng.standard_normal((1, 1, d))).astype(np.float32) if randomize
                 else np.zeros((1, 1, d), np.float32))
@@ -567,6 +630,9 @@ def train_flops_per_image(cfg: Cfg) -> float:
         N = n + 1
         layer = 24.0 * N * d * d + 4.0 * N * N * d
         return 3.0 * (cfg.num_layers * layer + 2.0 * d * C) + 2.0 * pe
+    if cfg.kind == "mixer":  # per layer: token FF 2 * (2 d n Ft) + channel FF 2 * (2 n d F)
+        layer = 4.0 * d * n * cfg.tokens_hidden + 4.0 * n * d * cfg.hidden
+        return 3.0 * (cfg.num_layers * layer + 2.0 * d * C) + 2.0 * pe
     H = cfg.num_heads
     sa = 24.0 * n * d * d + 4.0 * n * n * d + 4.0 * H * H * n * n
     ca = 20.0 * d * d + 4.0 * (n + 1) * d * d + 4.0 * (n + 1) * d
@@ -598,6 +664,22 @@ def param_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
         out[f"{prefix}/Dense_1/bias"] = (d,)
 
     out["params/PatchEmbedBlock_0/Dense_0/kernel"] = (cfg.patch * cfg.patch * 3, d)
+    if cfg.kind == "mixer":
+        n, Ft = cfg.n_patches, cfg.tokens_hidden
+        out["params/PatchEmbedBlock_0/Dense_0/bias"] = (d,)
+        for l in range(cfg.num_layers):
+            b = f"params/MixerBlock_{l}"
+            ln(f"{b}/LayerNorm_0")
+            out[f"{b}/FFBlock_0/Dense_0/kernel"] = (n, Ft)
+            out[f"{b}/FFBlock_0/Dense_0/bias"] = (Ft,)
+            out[f"{b}/FFBlock_0/Dense_1/kernel"] = (Ft, n)
+            out[f"{b}/FFBlock_0/Dense_1/bias"] = (n,)
+            ln(f"{b}/LayerNorm_1")
+            ff(f"{b}/FFBlock_1")
+        ln("params/LayerNorm_0")
+        out["params/Dense_0/kernel"] = (d, C)
+        out["params/Dense_0/bias"] = (C,)
+        return out
     out["params/cls"] = (1, 1, d)
     out["params/Encoder_0/AddAbsPosEmbed_0/pos_embed"] = (1, cfg.seq_len, d)
     for l in range(cfg.num_layers):

@@ -8,7 +8,7 @@ from typing import Dict
 
 @dataclass(frozen=True)
 class ModelConfig:
-    kind: str  # 'vit' | 'cait'
+    kind: str  # 'vit' | 'cait' | 'mixer'
     num_layers: int
     num_heads: int
     embed_dim: int
@@ -19,10 +19,16 @@ class ModelConfig:
     num_layers_token_only: int = 0  # CaiT class-attention layers (cait.py:162)
     stoch_depth_rate: float = 0.0
     layerscale_eps: float = 0.0
+    tokens_expand_ratio: float = 0.5  # MLP-Mixer token-mixing FFBlock (mlp_mixer.py:39)
 
     @property
     def n_patches(self) -> int:
         return (self.img_size // self.patch) ** 2
+
+    @property
+    def tokens_hidden(self) -> int:
+        """hidden width of the token-mixing FFBlock: ff.py:24 with in_ch = number of patches."""
+        return max(1, int(self.tokens_expand_ratio * self.n_patches))
 
     @property
     def seq_len(self) -> int:
@@ -52,7 +58,19 @@ def _cait(L, H, d, sd, eps):
                 stoch_depth_rate=sd, layerscale_eps=eps)
 
 
+def _mixer(L, d, p):
+    return dict(kind="mixer", num_layers=L, num_heads=1, embed_dim=d, patch=p)
+
+
 MODEL_ZOO: Dict[str, dict] = {
+    # create_model.py:184-213; the branch at :199-203 repeats 'mixer_s_patch32' (unreachable) with Mixer-B/16 arguments and is
+    # registered under the name it was meant to have
+    "mixer_s_patch32": _mixer(8, 512, 32),
+    "mixer_s_patch16": _mixer(8, 512, 16),
+    "mixer_b_patch32": _mixer(12, 768, 32),
+    "mixer_b_patch16": _mixer(12, 768, 16),
+    "mixer_l_patch32": _mixer(24, 1024, 32),
+    "mixer_l_patch16": _mixer(32, 1024, 16),
     "vit_b_patch32": _vit(12, 12, 768, 32),   # create_model.py:10-16
     "vit_b_patch16": _vit(12, 12, 768, 16),   # :17-23  (== DeiT-B/16, BASELINE config 3)
     "vit_l_patch32": _vit(24, 16, 1024, 32),  # :24-30
@@ -85,6 +103,9 @@ def train_flops_per_image(cfg: ModelConfig) -> float:
     if cfg.kind == "vit":
         N = n + 1
         layer = 24.0 * N * d * d + 4.0 * N * N * d
+        return 3.0 * (cfg.num_layers * layer + 2.0 * d * C) + 2.0 * pe
+    if cfg.kind == "mixer":  # token FF 2 x (2 d n Ft) + channel FF 2 x (2 n d F) per layer
+        layer = 4.0 * d * n * cfg.tokens_hidden + 4.0 * n * d * cfg.hidden
         return 3.0 * (cfg.num_layers * layer + 2.0 * d * C) + 2.0 * pe
     H = cfg.num_heads
     sa = 24.0 * n * d * d + 4.0 * n * n * d + 4.0 * H * H * n * n

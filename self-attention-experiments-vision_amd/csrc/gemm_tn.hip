@@ -75,6 +75,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
     o.y = r.y + rs * cs[1] * round_bf16(v[1]);
     o.z = r.z + rs * cs[2] * round_bf16(v[2]);
     o.w = r.w + rs * cs[3] * round_bf16(v[3]);
+    if (a.round_out_bf16) o = make_float4(round_bf16(o.x), round_bf16(o.y), round_bf16(o.z), round_bf16(o.w));
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + n) = o;
   } else if (EPI == SAVIT_EPI_DGELU) {
     const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.aux) + (size_t)m * a.ldaux + n);
@@ -97,7 +98,8 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
     const int ppi = p.grid_side * p.grid_side;
     const int b = m / ppi, pp = m - b * ppi;
     const int tok = a.token_offset + pp;
-    const float4 pos = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.aux) + (size_t)tok * a.ldaux + n);
+    float4 pos = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.aux != nullptr) pos = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.aux) + (size_t)tok * a.ldaux + n);
     float4 o = make_float4(round_bf16(v[0]) + pos.x, round_bf16(v[1]) + pos.y, round_bf16(v[2]) + pos.z, round_bf16(v[3]) + pos.w);
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + ((size_t)b * a.tokens + tok) * a.ldc + n) = o;
   }
@@ -191,9 +193,10 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[M
       if (a.C2 != nullptr)  // the bf16 branch value, needed by the LayerScale gradient (layerscale.py:23)
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.C2) + (size_t)m * a.ldc + nn) = raw;
       const float4 r = res[it];
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + nn) =
-          make_float4(r.x + rs * cscale[0] * __uint_as_float(raw.x << 16), r.y + rs * cscale[1] * __uint_as_float(raw.x & 0xffff0000u),
-                      r.z + rs * cscale[2] * __uint_as_float(raw.y << 16), r.w + rs * cscale[3] * __uint_as_float(raw.y & 0xffff0000u));
+      float4 o = make_float4(r.x + rs * cscale[0] * __uint_as_float(raw.x << 16), r.y + rs * cscale[1] * __uint_as_float(raw.x & 0xffff0000u),
+                             r.z + rs * cscale[2] * __uint_as_float(raw.y << 16), r.w + rs * cscale[3] * __uint_as_float(raw.y & 0xffff0000u));
+      if (a.round_out_bf16) o = make_float4(round_bf16(o.x), round_bf16(o.y), round_bf16(o.z), round_bf16(o.w));  // bf16 residual stream
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + nn) = o;
     }
     return;
   }
@@ -959,7 +962,7 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
   p.a = a;
   if (a.epilogue == SAVIT_EPI_PATCH) {
     SAVIT_CHECK_ARG(a.patch > 0 && a.patch % 8 == 0 && a.img_size % a.patch == 0 && a.K == a.patch * a.patch * 3);
-    SAVIT_CHECK_ARG(a.aux != nullptr && a.tokens > 0 && a.token_offset >= 0 && a.ldaux >= a.N && a.ldaux % 4 == 0);
+    SAVIT_CHECK_ARG(a.tokens > 0 && a.token_offset >= 0 && (a.aux == nullptr || (a.ldaux >= a.N && a.ldaux % 4 == 0)));
     p.grid_side = a.img_size / a.patch;
     p.chunks_per_prow = a.patch * 3 / 8;
     SAVIT_CHECK_ARG(a.M % (p.grid_side * p.grid_side) == 0 && a.token_offset + p.grid_side * p.grid_side <= a.tokens);

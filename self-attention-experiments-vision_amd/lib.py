@@ -58,6 +58,10 @@ _SIGNATURES = {
     "savit_th_attention_bwd_workspace_bytes": (c_long, [c_int, c_int, c_int]),
     "savit_cls_pos_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p]),
     "savit_pos_cls_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "savit_transpose_bf16": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_void_p]),
+    "savit_token_mean_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "savit_token_mean_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "savit_softmax_xent": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                    c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "savit_sumsq": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),

@@ -139,10 +139,30 @@ class CaiT(ViT):
         return self.engine(images.shape[0]).forward(images, is_training=is_training).to(self.dtype)
 
 
+class MLPMixer(ViT):
+    """models/mlp_mixer.py:34-64 behind mixer_engine.MixerEngine.  No stochastic layer: is_training selects nothing."""
+
+    def engine(self, batch: int):
+        from .mixer_engine import MixerEngine
+
+        e = self._engines.get(batch)
+        if e is None:
+            e = MixerEngine(self.cfg, batch)
+            if self._engines:
+                first = next(iter(self._engines.values()))
+                e.params, e.grads, e.w = first.params, first.grads, first.w
+                e.adam_m, e.adam_v = first.adam_m, first.adam_v
+                e.weights_stale = first.weights_stale
+            self._engines[batch] = e
+        return e
+
+
 def create_model(model_name: str, num_classes: int = 1000, dtype=torch.bfloat16, img_size: int = 224):
     """models/create_model.py:6-8.  Same names; `vit_ti_patch16` / `vit_s_patch16` added for BASELINE configs 1-2.
     img_size is an extension (the reference fixes it through the init example; train.py --img_size)."""
     cfg = get_config(model_name, num_classes=num_classes, img_size=img_size)
     if cfg.kind == "vit":
         return ViT(cfg, dtype=dtype)
+    if cfg.kind == "mixer":
+        return MLPMixer(cfg, dtype=dtype)
     return CaiT(cfg, dtype=dtype)

@@ -542,3 +542,63 @@ def batch_cutmix(x: torch.Tensor, box: torch.Tensor, index: torch.Tensor, out: O
     L = _lib.load()
     _lib.check(L.savit_batch_cutmix_bf16(_p(x), _p(out), _p(box), _p(index), B, H, W, C, _stream()), "savit_batch_cutmix_bf16")
     return out
+
+
+# --------------------------------------------------------------------------------------------- MLP-Mixer glue
+def transpose_bf16(src: torch.Tensor, dst: Optional[torch.Tensor], R: int, Cc: int, resid: Optional[torch.Tensor] = None,
+                   out_f32: Optional[torch.Tensor] = None, round_out_bf16: bool = False, rowsum: Optional[torch.Tensor] = None):
+    """Per-image transpose (mlp_mixer.py:19,23): src bf16 [B, >=R, ld_src], of which rows < R and columns < Cc are read;
+    dst bf16 [B, >=Cc, ld_dst >= R] receives dst[b, c, r] = src[b, r, c]; out_f32 [B, Cc, R] = resid + that transpose
+    (mlp_mixer.py:24), optionally rounded through bf16; rowsum fp32 [R] += sums over images and columns."""
+    _chk(src, bf16, "src", 3)
+    if not src.is_contiguous() or src.shape[1] < R or src.shape[2] < Cc:
+        raise ValueError("transpose_bf16: src must be contiguous [B, >=R, >=Cc]")
+    B = src.shape[0]
+    ld_dst, dst_bs = R, 0
+    if dst is not None:
+        _chk(dst, bf16, "dst", 3)
+        if not dst.is_contiguous() or dst.shape[0] != B or dst.shape[1] < Cc or dst.shape[2] < R:
+            raise ValueError("transpose_bf16: dst must be contiguous [B, >=Cc, >=R]")
+        ld_dst, dst_bs = dst.shape[2], dst.shape[1] * dst.shape[2]
+    if (resid is None) != (out_f32 is None):
+        raise ValueError("transpose_bf16: resid and out_f32 come together")
+    if out_f32 is not None:
+        _chk(resid, f32, "resid", 3)
+        _chk(out_f32, f32, "out_f32", 3)
+        if tuple(resid.shape) != (B, Cc, R) or tuple(out_f32.shape) != (B, Cc, R) or not resid.is_contiguous() or not out_f32.is_contiguous():
+            raise ValueError("transpose_bf16: resid / out_f32 must be contiguous [B, Cc, R]")
+        if dst is not None and ld_dst != R:
+            raise ValueError("transpose_bf16: with both outputs the bf16 pitch must equal R")
+        ld_dst = R
+    if dst is None and out_f32 is None:
+        raise ValueError("transpose_bf16: no output")
+    if rowsum is not None:
+        _chk(rowsum, f32, "rowsum", 1)
+        if rowsum.numel() < R:
+            raise ValueError("transpose_bf16: rowsum too small")
+    L = _lib.load()
+    _lib.check(L.savit_transpose_bf16(_p(src), src.shape[1] * src.shape[2], src.shape[2], _p(dst), dst_bs, ld_dst, B, R, Cc, _p(resid),
+                                      _p(out_f32), int(round_out_bf16), _p(rowsum), _stream()), "savit_transpose_bf16")
+    return dst if dst is not None else out_f32
+
+
+def token_mean_fwd(h: torch.Tensor) -> torch.Tensor:
+    """jnp.mean(x, axis=1) (mlp_mixer.py:62): h bf16 [B, L, d] -> bf16 [B, d], fp32 accumulation."""
+    _chk(h, bf16, "h", 3)
+    if not h.is_contiguous():
+        raise ValueError("token_mean_fwd: h must be contiguous")
+    B, Ltok, d = h.shape
+    z = torch.empty((B, d), dtype=bf16, device=h.device)
+    _lib.check(_lib.load().savit_token_mean_fwd(_p(h), _p(z), B, Ltok, d, _stream()), "savit_token_mean_fwd")
+    return z
+
+
+def token_mean_bwd(dz: torch.Tensor, Ltok: int) -> torch.Tensor:
+    """Backward of the token mean: dh[b, l, :] = bf16(dz[b, :] / L)."""
+    _chk(dz, bf16, "dz", 2)
+    if not dz.is_contiguous():
+        raise ValueError("token_mean_bwd: dz must be contiguous")
+    B, d = dz.shape
+    dh = torch.empty((B, int(Ltok), d), dtype=bf16, device=dz.device)
+    _lib.check(_lib.load().savit_token_mean_bwd(_p(dz), _p(dh), B, int(Ltok), d, _stream()), "savit_token_mean_bwd")
+    return dh

@@ -26,7 +26,7 @@ def main():
         Bt = (torch.randn(N, K, device="cuda") / K ** 0.5).to(bf16)
         C = torch.empty(M_, N, device="cuda", dtype=bf16)
         fl = 2.0 * M_ * N * K
-        for tile in (1, 2, 3, 4, 5, 6, 7):
+        for tile in (7, 12, 13, 17):
             t = timeit(lambda: ops.gemm_tn(A, Bt, C, 0, tile=tile))
             print(f"fwd  {name:5s} M={M_} N={N} K={K} tile={tile}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s")
         # torch (hipBLASLt) reference for context
