@@ -65,6 +65,8 @@ def kernel_class(label: str) -> str:
         return "attention_bwd" if label.endswith(".bwd") else "attention_fwd"
     if ".ls" in label:
         return "layerscale_bwd"
+    if ".tok.T" in label or ".tok.dT" in label:
+        return "token_transpose"
     if "ln" in label:
         return "layernorm_bwd" if label.endswith(".bwd") else "layernorm_fwd"
     return "other"
@@ -120,6 +122,10 @@ def main():
         from savit_amd.cait_engine import CaiTEngine
 
         eng = CaiTEngine(cfg, B)
+    elif cfg.kind == "mixer":
+        from savit_amd.mixer_engine import MixerEngine
+
+        eng = MixerEngine(cfg, B)
     else:
         eng = ViTEngine(cfg, B)
     eng.init_params(seed=42)  # train.py:187-189 default seed
@@ -197,7 +203,8 @@ def main():
         times = eng.profile_step(batches[0][1])
         eng.bwd_hooks = saved_hooks
         d, F, M = cfg.embed_dim, cfg.hidden, eng.M
-        gemm_flops = {"qkv": 2.0 * M * d * 3 * d, "proj": 2.0 * M * d * d, "fc1": 2.0 * M * d * F, "fc2": 2.0 * M * d * F}
+        gemm_flops = {"qkv": 2.0 * M * d * 3 * d, "proj": 2.0 * M * d * d, "fc1": 2.0 * M * d * F, "fc2": 2.0 * M * d * F,
+                      "tok": 2.0 * B * d * cfg.n_patches * cfg.tokens_hidden}  # MLP-Mixer token-mixing GEMMs (unpadded, algorithmic)
         cls_ms, cls_n, cls_fl = {}, {}, {}
         for label, t_ms in times.items():
             c = kernel_class(label)
@@ -206,7 +213,7 @@ def main():
             fl = 0.0
             parts = label.split(".")
             if c in ("gemm_tn", "gemm_wgrad") and len(parts) >= 2 and parts[0].startswith("l"):
-                key = {"Wqkv": "qkv", "Wo": "proj", "W1": "fc1", "W2": "fc2"}.get(parts[1], parts[1])
+                key = {"Wqkv": "qkv", "Wo": "proj", "W1": "fc1", "W2": "fc2", "tW1": "tok", "tW2": "tok"}.get(parts[1], parts[1])
                 fl = gemm_flops.get(key, 0.0)
             elif label in ("patch_embed", "Wpe.wgrad"):
                 fl = 2.0 * B * cfg.n_patches * cfg.patch_dim * d
@@ -219,7 +226,7 @@ def main():
         for label, t_ms in times.items():
             sym = kernel_symbol(label, eng.L, M, d, F) if cfg.kind == "vit" else kernel_class(label)
             parts = label.split(".")
-            key = {"Wqkv": "qkv", "Wo": "proj", "W1": "fc1", "W2": "fc2"}.get(parts[1], parts[1]) if len(parts) >= 2 else ""
+            key = {"Wqkv": "qkv", "Wo": "proj", "W1": "fc1", "W2": "fc2", "tW1": "tok", "tW2": "tok"}.get(parts[1], parts[1]) if len(parts) >= 2 else ""
             fl = gemm_flops.get(key, 0.0) if sym.startswith("gemm") and parts[0].startswith("l") else 0.0
             sym_ms[sym] = sym_ms.get(sym, 0.0) + t_ms
             sym_n[sym] = sym_n.get(sym, 0) + 1

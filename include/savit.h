@@ -115,7 +115,8 @@ typedef struct savit_gemm_args {
 int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream);
 /* Bias-gradient column sums without atomics: ~200 row tiles adding into the same N addresses serialise at the memory side
  * (16 us of a 180 us launch on the fc2 input-gradient GEMM).  savit_gemm_colsum_rows: partial-sum rows the GEMM writes for
- * (M, N, K, tile) - one per (row tile, wave row); savit_colsum_finalize: out[n] (+)= sum_r slab[r][n]. */
+ * (M, N, K, tile) - one per (row tile, wave row); savit_colsum_finalize: out[n] (+)= sum_r slab[r][n] (fixed summation order
+ * below 512 rows; taller slabs in accumulate mode are reduced in row chunks that add with fp32 atomics). */
 int savit_gemm_colsum_rows(int M, int N, int K, int tile);
 int savit_colsum_finalize(const float* slab, int rows, int N, float* out, int accumulate, void* stream);
 /* Tile the auto heuristic (tile == 0) picks for a shape and epilogue.  K % 64 == 0: paired-stage kernels 17 = 192x128 (4 waves, two
@@ -167,12 +168,14 @@ int savit_pos_cls_grad(const float* dx0, float* dpos, float* dcls, int B, int N,
  * savit_transpose_bf16: B matrices src[b] = bf16 [R, Cc] (row pitch ld_src, batch stride src_batch_stride elements) are transposed:
  *   dst_bf16[b][c][r] = src[b][r][c]   (nullable; row pitch ld_dst >= R, batch stride dst_batch_stride; columns >= R are not written)
  *   out_f32[b][c][r]  = resid[b][c][r] + src[b][r][c], rounded through bf16 if round_out_bf16   (nullable pair; fp32 [B, Cc, ld_dst])
- *   rowsum[r]        += sum over b, c of src[b][r][c]   (nullable; fp32 atomics)
+ *   rowsum_slab[k][r] = partial sums over column tiles: sum_k rowsum_slab[k][r] = sum over b, c of src[b][r][c]   (nullable; fp32
+ *                       [savit_transpose_rowsum_rows(B, Cc), rowsum_ld >= R], plain stores; reduce with savit_colsum_finalize)
  * i.e. rearrange '... l d -> ... d l' (:19), the way back fused with `x = x + inputs` (:23-24), and the bias gradient of
  * the second token Dense.  Pitches and strides are multiples of 8 elements, pointers 16-B aligned.
  * savit_token_mean_fwd: z[b, :] = bf16(mean over the L tokens of h[b, :, :])  (jnp.mean(x, axis=1), :62); _bwd: dh[b, l, :] = bf16(dz[b, :] / L). */
 int savit_transpose_bf16(const void* src, long src_batch_stride, int ld_src, void* dst_bf16, long dst_batch_stride, int ld_dst, int B, int R,
-                         int Cc, const float* resid, float* out_f32, int round_out_bf16, float* rowsum, void* stream);
+                         int Cc, const float* resid, float* out_f32, int round_out_bf16, float* rowsum_slab, int rowsum_ld, void* stream);
+int savit_transpose_rowsum_rows(int B, int Cc);
 int savit_token_mean_fwd(const void* h_bf16, void* z_bf16, int B, int L, int d, void* stream);
 int savit_token_mean_bwd(const void* dz_bf16, void* dh_bf16, int B, int L, int d, void* stream);
 

@@ -896,15 +896,20 @@ extern "C" int savit_gemm_tn_auto_tile(int M, int N, int K) { return savit_gemm_
 
 namespace {
 // out[n] (+)= sum_r slab[r][n]: a block owns 64 columns (16 lanes x float4) and splits the rows over 16 groups (independent
-// loads, ~rows/16 deep), then an LDS tree; fixed summation order, so the result is reproducible
+// loads, ~rows/16 deep), then an LDS tree; fixed summation order, so the result is reproducible.  Tall slabs (the MLP-Mixer
+// token GEMMs: >= 1024 rows of 64..256 columns, 28 us on 4 workgroups) are cut into gridDim.y row chunks that add their partial
+// with fp32 atomics - launched only in accumulate mode.
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ slab, int rows, int N, float* __restrict__ out,
                                                               int accumulate) {
   __shared__ float4 part[16][16];
   const int cx = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + cx * 4;
+  const int chunk = (rows + gridDim.y - 1) / gridDim.y;
+  const int rbeg = blockIdx.y * chunk;
+  rows = min(rows, rbeg + chunk);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < N) {  // N % 4 == 0
-    for (int r = g; r < rows; r += 16) {
+    for (int r = rbeg + g; r < rows; r += 16) {
       const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)r * N + c);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -917,6 +922,13 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     for (int k = 1; k < 16; ++k) {
       const float4 v = part[k][cx];
       t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    if (gridDim.y > 1) {
+      atomicAdd(out + c, t.x);
+      atomicAdd(out + c + 1, t.y);
+      atomicAdd(out + c + 2, t.z);
+      atomicAdd(out + c + 3, t.w);
+      return;
     }
     float4* o = reinterpret_cast<float4*>(out + c);
     if (accumulate) {
@@ -948,7 +960,8 @@ extern "C" int savit_gemm_colsum_rows(int M, int N, int K, int tile) {
 
 extern "C" int savit_colsum_finalize(const float* slab, int rows, int N, float* out, int accumulate, void* stream) {
   SAVIT_CHECK_ARG(slab && out && rows >= 0 && N > 0 && N % 4 == 0 && ((uintptr_t)slab % 16) == 0 && ((uintptr_t)out % 16) == 0);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, slab, rows, N, out, accumulate);
+  const int split = (accumulate && rows >= 512) ? (rows / 256 < 32 ? rows / 256 : 32) : 1;  // <= 263 rows on the ViT shapes: one chunk
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 63) / 64, split), dim3(256), 0, (hipStream_t)stream, slab, rows, N, out, accumulate);
   SAVIT_LAUNCH_RET();
 }
 

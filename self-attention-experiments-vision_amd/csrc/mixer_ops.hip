@@ -17,10 +17,13 @@ constexpr int TPITCH = TT + 2;  // bf16 elements per LDS row: 33 dwords, so the 
 // src: B matrices [R, Cc] bf16 (row pitch ld_src) -> their transposes [Cc, R] (row pitch ld_dst):
 //   dst_bf16[b][c][r] = src[b][r][c]                                   (if dst_bf16)
 //   out_f32[b][c][r]  = (round_bf16)(resid[b][c][r] + src[b][r][c])    (if out_f32; resid / out_f32 fp32 with pitch ld_dst)
-//   rowsum[r]        += sum_{b,c} src[b][r][c]                         (if rowsum; one atomic per (tile, row))
+//   rowsum[b * gridDim.x + tile_c][r] = sum over the tile's 64 columns of src[b][r][c]   (if rowsum: a slab of partial sums with
+//     pitch rowsum_ld, reduced by savit_colsum_finalize; atomics on the R result addresses cost 60 us per launch at B*d/64 = 1536
+//     adds per address)
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, long src_bs, int ld_src, bf16_t* __restrict__ dst,
                                                               long dst_bs, int ld_dst, int R, int Cc, const float* __restrict__ resid,
-                                                              float* __restrict__ out_f32, int round_out, float* __restrict__ rowsum) {
+                                                              float* __restrict__ out_f32, int round_out, float* __restrict__ rowsum,
+                                                              int rowsum_ld) {
   __shared__ bf16_t tile[TT][TPITCH];
   const int b = blockIdx.z;
   const int r0 = blockIdx.y * TT, c0 = blockIdx.x * TT;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
         ps += dpp_mov<0xB1>(ps);
         ps += dpp_mov<0x4E>(ps);
         ps += dpp_mov<0x141>(ps);
-        if ((t & 7) == 0 && r < R) atomicAdd(rowsum + r, ps);
+        if ((t & 7) == 0 && r < R) rowsum[((size_t)b * gridDim.x + blockIdx.x) * rowsum_ld + r] = ps;
       }
     }
   }
@@ -144,19 +147,22 @@ __global__ __launch_bounds__(256) void token_mean_bwd_kernel(const bf16_t* __res
 }  // namespace
 
 extern "C" int savit_transpose_bf16(const void* src, long src_batch_stride, int ld_src, void* dst_bf16, long dst_batch_stride, int ld_dst,
-                                    int B, int R, int Cc, const float* resid, float* out_f32, int round_out_bf16, float* rowsum,
-                                    void* stream) {
+                                    int B, int R, int Cc, const float* resid, float* out_f32, int round_out_bf16, float* rowsum_slab,
+                                    int rowsum_ld, void* stream) {
   SAVIT_CHECK_ARG(src && (dst_bf16 || out_f32) && B >= 0 && R > 0 && Cc > 0 && ld_src >= Cc && ld_dst >= R && (ld_src % 8) == 0 &&
                   (ld_dst % 8) == 0 && (src_batch_stride % 8) == 0 && (dst_batch_stride % 8) == 0 && B <= 65535);
   SAVIT_CHECK_ARG(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst_bf16 % 16) == 0 && ((uintptr_t)resid % 16) == 0 && ((uintptr_t)out_f32 % 16) == 0);
   SAVIT_CHECK_ARG((out_f32 == nullptr) == (resid == nullptr));
+  SAVIT_CHECK_ARG(rowsum_slab == nullptr || rowsum_ld >= R);
   if (B == 0) return SAVIT_OK;
   const dim3 grid((Cc + TT - 1) / TT, (R + TT - 1) / TT, B);
   SAVIT_CHECK_ARG(grid.y <= 65535);
   hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, src_batch_stride, ld_src,
-                     (bf16_t*)dst_bf16, dst_batch_stride, ld_dst, R, Cc, resid, out_f32, round_out_bf16, rowsum);
+                     (bf16_t*)dst_bf16, dst_batch_stride, ld_dst, R, Cc, resid, out_f32, round_out_bf16, rowsum_slab, rowsum_ld);
   SAVIT_LAUNCH_RET();
 }
+
+extern "C" int savit_transpose_rowsum_rows(int B, int Cc) { return (B <= 0 || Cc <= 0) ? 0 : B * ((Cc + TT - 1) / TT); }
 
 extern "C" int savit_token_mean_fwd(const void* h, void* z, int B, int L, int d, void* stream) {
   SAVIT_CHECK_ARG(h && z && B >= 0 && L > 0 && d > 0 && (d % 8) == 0 && B <= 65535);

@@ -59,7 +59,8 @@ _SIGNATURES = {
     "savit_cls_pos_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p]),
     "savit_pos_cls_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "savit_transpose_bf16": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
-                                     c_void_p, c_void_p]),
+                                     c_void_p, c_int, c_void_p]),
+    "savit_transpose_rowsum_rows": (c_int, [c_int, c_int]),
     "savit_token_mean_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "savit_token_mean_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "savit_softmax_xent": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,

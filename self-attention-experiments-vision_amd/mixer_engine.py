@@ -173,6 +173,7 @@ class MixerEngine(ViTEngine):
         self.d_h = e(M, d, dt=bf16)
         self.colsum_slab = e(max(1, self.L.savit_gemm_colsum_rows(M, F, d, 0)), F)
         self.tcolsum_slab = e(max(1, self.L.savit_gemm_colsum_rows(Md, Fp, Lp, 0)), Fp)
+        self.trowsum_slab = z(max(1, self.L.savit_transpose_rowsum_rows(self.B, d)), Lp)  # pad columns stay zero
         self.dlogits = z(self.B, self.Cp, dt=bf16)
         self.d_z = e(self.B, d, dt=bf16)
         ws = self.L.savit_layernorm_bwd_workspace_bytes(M, d)
@@ -258,14 +259,14 @@ class MixerEngine(ViTEngine):
             # token mixing (mlp_mixer.py:18-24)
             P.add(L.savit_layernorm_fwd, (x[l].data_ptr(), pp(f"l{l}.ln1_g"), pp(f"l{l}.ln1_b"), self.h1.data_ptr(), st[0].data_ptr(),
                                           st[1].data_ptr(), M, d, d, 1e-6, self.rp), f"l{l}.ln1")
-            P.add(L.savit_transpose_bf16, (self.h1.data_ptr(), n * d, d, self.h1T[l].data_ptr(), d * Lp, Lp, B, n, d, None, None, 0, None),
+            P.add(L.savit_transpose_bf16, (self.h1.data_ptr(), n * d, d, self.h1T[l].data_ptr(), d * Lp, Lp, B, n, d, None, None, 0, None, 0),
                   f"l{l}.tok.T")
             self._gemm(P, f"l{l}.tok.fc1", A=self.h1T[l].data_ptr(), Bt=w("tW1_t"), C=self.tu[l].data_ptr(), C2=self.ta[l].data_ptr(),
                        bias=pp(f"l{l}.tb1"), M=Md, N=Fp, K=Lp, lda=Lp, ldb=Lp, ldc=Fp, epilogue=_lib.EPI_BIAS_GELU)
             self._gemm(P, f"l{l}.tok.fc2", A=self.ta[l].data_ptr(), Bt=w("tW2_t"), C=self.yT.data_ptr(), bias=pp(f"l{l}.tb2"), M=Md, N=Lp,
                        K=Fp, lda=Fp, ldb=Fp, ldc=Lp, epilogue=_lib.EPI_BF16)
             P.add(L.savit_transpose_bf16, (self.yT.data_ptr(), d * Lp, Lp, None, 0, d, B, d, n, x[l].data_ptr(), self.xmid[l].data_ptr(),
-                                           self.rp, None), f"l{l}.tok.T+res")
+                                           self.rp, None, 0), f"l{l}.tok.T+res")
             # channel mixing (mlp_mixer.py:26-30)
             P.add(L.savit_layernorm_fwd, (self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), pp(f"l{l}.ln2_b"), self.h2[l].data_ptr(),
                                           st[2].data_ptr(), st[3].data_ptr(), M, d, d, 1e-6, self.rp), f"l{l}.ln2")
@@ -323,8 +324,10 @@ class MixerEngine(ViTEngine):
                                           M, d, d, d, self.rp, ws, wsb), f"l{l}.ln2.bwd", writes=(ring[ri],))
             # token mixing backward: cotangent of x_mid transposed per image; its row sums are the gradient of the second
             # token Dense's bias (one value per token, summed over images and channels)
-            P.add(L.savit_transpose_bf16, (ring[ri], n * d, d, dyT, d * Lp, Lp, B, n, d, None, None, 0, gp(f"l{l}.tb2")), f"l{l}.tok.dT",
+            rs = self.trowsum_slab
+            P.add(L.savit_transpose_bf16, (ring[ri], n * d, d, dyT, d * Lp, Lp, B, n, d, None, None, 0, rs.data_ptr(), Lp), f"l{l}.tok.dT",
                   writes=(dyT,))
+            P.add(L.savit_colsum_finalize, (rs.data_ptr(), rs.shape[0], Lp, gp(f"l{l}.tb2"), 1), f"l{l}.tb2.grad")
             wgrad(f"l{l}.tW2.wgrad", self.ta[l].data_ptr(), dyT, gp(f"l{l}.tW2"), Md, Fp, Lp, Fp, Lp, Lp)
             self._gemm(P, f"l{l}.tok.fc2.dgrad", writes=(d_tu,), A=dyT, Bt=w("tW2_n"), C=d_tu, aux=self.tu[l].data_ptr(),
                        colsum=self.tcolsum_slab.data_ptr(), colsum_rows=self.tcolsum_slab.shape[0], M=Md, N=Fp, K=Lp, lda=Lp, ldb=Lp,
@@ -334,7 +337,7 @@ class MixerEngine(ViTEngine):
             wgrad(f"l{l}.tW1.wgrad", self.h1T[l].data_ptr(), d_tu, gp(f"l{l}.tW1"), Md, Lp, Fp, Lp, Fp, Fp)
             self._gemm(P, f"l{l}.tok.fc1.dgrad", A=d_tu, Bt=w("tW1_n"), C=self.dhT.data_ptr(), M=Md, N=Lp, K=Fp, lda=Fp, ldb=Fp, ldc=Lp,
                        epilogue=_lib.EPI_BF16)
-            P.add(L.savit_transpose_bf16, (self.dhT.data_ptr(), d * Lp, Lp, self.d_h.data_ptr(), n * d, d, B, d, n, None, None, 0, None),
+            P.add(L.savit_transpose_bf16, (self.dhT.data_ptr(), d * Lp, Lp, self.d_h.data_ptr(), n * d, d, B, d, n, None, None, 0, None, 0),
                   f"l{l}.tok.dT.back")
             ri = (ri + 1) % len(ring)
             P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),

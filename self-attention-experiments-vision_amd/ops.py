@@ -549,7 +549,8 @@ def transpose_bf16(src: torch.Tensor, dst: Optional[torch.Tensor], R: int, Cc: i
                    out_f32: Optional[torch.Tensor] = None, round_out_bf16: bool = False, rowsum: Optional[torch.Tensor] = None):
     """Per-image transpose (mlp_mixer.py:19,23): src bf16 [B, >=R, ld_src], of which rows < R and columns < Cc are read;
     dst bf16 [B, >=Cc, ld_dst >= R] receives dst[b, c, r] = src[b, r, c]; out_f32 [B, Cc, R] = resid + that transpose
-    (mlp_mixer.py:24), optionally rounded through bf16; rowsum fp32 [R] += sums over images and columns."""
+    (mlp_mixer.py:24), optionally rounded through bf16; rowsum fp32 [R] += sums over images and columns (R % 4 == 0 here: the
+    partial sums go through a slab and savit_colsum_finalize)."""
     _chk(src, bf16, "src", 3)
     if not src.is_contiguous() or src.shape[1] < R or src.shape[2] < Cc:
         raise ValueError("transpose_bf16: src must be contiguous [B, >=R, >=Cc]")
@@ -572,13 +573,17 @@ def transpose_bf16(src: torch.Tensor, dst: Optional[torch.Tensor], R: int, Cc: i
         ld_dst = R
     if dst is None and out_f32 is None:
         raise ValueError("transpose_bf16: no output")
+    L = _lib.load()
+    slab = None
     if rowsum is not None:
         _chk(rowsum, f32, "rowsum", 1)
-        if rowsum.numel() < R:
-            raise ValueError("transpose_bf16: rowsum too small")
-    L = _lib.load()
+        if rowsum.numel() < R or R % 4:
+            raise ValueError("transpose_bf16: rowsum needs >= R elements and R % 4 == 0")
+        slab = torch.empty((L.savit_transpose_rowsum_rows(B, Cc), R), dtype=f32, device=src.device)
     _lib.check(L.savit_transpose_bf16(_p(src), src.shape[1] * src.shape[2], src.shape[2], _p(dst), dst_bs, ld_dst, B, R, Cc, _p(resid),
-                                      _p(out_f32), int(round_out_bf16), _p(rowsum), _stream()), "savit_transpose_bf16")
+                                      _p(out_f32), int(round_out_bf16), _p(slab), R, _stream()), "savit_transpose_bf16")
+    if slab is not None:
+        colsum_finalize(slab, rowsum, accumulate=True)
     return dst if dst is not None else out_f32
 
 

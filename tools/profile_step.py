@@ -13,7 +13,11 @@ model = sys.argv[1] if len(sys.argv) > 1 else "vit_b_patch16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 IMG = int(sys.argv[3]) if len(sys.argv) > 3 else 224
 cfg = get_config(model, img_size=IMG)
-eng = ViTEngine(cfg, B)
+if cfg.kind == "mixer":
+    from savit_amd.mixer_engine import MixerEngine
+    eng = MixerEngine(cfg, B)
+else:
+    eng = ViTEngine(cfg, B)
 eng.init_params(42)
 eng.layout.view(eng.params, "Wh").copy_(torch.randn(cfg.embed_dim, cfg.num_classes) * cfg.embed_dim ** -0.5)
 img = torch.randn(B, IMG, IMG, 3, device="cuda").to(torch.bfloat16)
