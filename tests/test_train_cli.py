@@ -60,3 +60,24 @@ def test_short_run_with_gpu_mix_augment(capsys):
     train = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{") and "train/loss" in l]
     assert len(train) == 4 and abs(train[0]["train/loss"] - 6.9078) < 1e-2
     assert all(np.isfinite(t["train/loss"]) for t in train)
+
+
+@pytest.mark.gpu
+def test_short_run_mlp_mixer(tmp_path, capsys):
+    """The same loop drives the MLP-Mixer family: train, eval, Flax-format checkpoint, resume."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ck = str(tmp_path / "ck")
+    common = ["--model_name", "mixer_s_patch32", "--batch_size", "8", "--steps_per_epoch", "3", "--checkpoint_dir", ck, "--clip_grad", "1.0",
+              "--eval_every_epochs", "1", "--save_every_epochs", "1", "--log_every", "1", "--lr", "1e-3"]
+    assert train_cli.main(common + ["--num_epochs", "1"]) == 3
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    train = [l for l in lines if "train/loss" in l]
+    assert len(train) == 3 and all(np.isfinite(t["train/loss"]) for t in train)
+    assert 5.5 < train[0]["train/loss"] < 8.5  # lecun-normal head (mlp_mixer.py:63): near, not at, ln(1000)
+    assert os.path.exists(os.path.join(ck, "checkpoint_3"))
+    assert train_cli.main(common + ["--num_epochs", "2"]) == 6  # resumes from step 3
+    steps = [json.loads(l)["step"] for l in capsys.readouterr().out.splitlines() if l.startswith("{") and "train/loss" in l]
+    assert steps == [4, 5, 6]
