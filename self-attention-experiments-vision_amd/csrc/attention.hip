@@ -749,6 +749,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
 //   th_scores (MFMA, per (b,h))  ->  th_softmax (VALU, one wave per (b,q) row, all heads, fp32)  ->  th_pv (MFMA)
 // and backward th_pv_bwd (dP', dV) -> th_softmax_bwd (dS, dT1, dT2; P recomputed from S) -> th_scores_bwd (dQ, dK).
 // Tile loads/stores use the accumulator layouts of the fused kernels above, so no LDS transposition is needed.
+constexpr int TH_MAX_NT = 8;  // 32-row tiles per image: N <= 255 patches (checked by the host wrappers)
 struct ThParams {
   const bf16_t* qkv;   // [B*N, ld]
   bf16_t* sbuf;        // S or dS      [B,H,N,Np]
@@ -846,14 +847,21 @@ __global__ __launch_bounds__(512) void th_pv_kernel(const ThParams p) {
     for (int eb = 0; eb < 2; ++eb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[eb][r] = 0.f;
-    for (int kt = 0; kt < NT; ++kt) {
+    // every P' fragment of this query block is requested before the first MFMA: a load -> MFMA loop exposed the HBM latency
+    // once per key tile (7 times per block; these kernels were latency-, not bandwidth-bound).  NT <= TH_MAX_NT.
+    bf16x8 pf[TH_MAX_NT][2];
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pf = load_tile_T_frag(pb + (size_t)q * p.Np, q < p.N, kt, s2, half, p.Np);
+    for (int kt = 0; kt < TH_MAX_NT; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) pf[kt][s2] = load_tile_T_frag(pb + (size_t)q * p.Np, q < p.N && kt < NT, kt, s2, half, p.Np);
+#pragma unroll
+    for (int kt = 0; kt < TH_MAX_NT; ++kt) {
+      if (kt >= NT) break;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb)
-          oacc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(smem, kt * 32 + 16 * s2 + trow, 32 * eb + tcol), pf, oacc[eb], 0, 0, 0);
-      }
+          oacc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(smem, kt * 32 + 16 * s2 + trow, 32 * eb + tcol), pf[kt][s2], oacc[eb], 0, 0, 0);
     }
     if (q < p.N) {
       bf16_t* orow = p.o + (size_t)(row_base + q) * p.d + hh * hd;
@@ -945,7 +953,14 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
   else           stage_image_rt<0>(smem, srd, row_base, p.N, p.ld, hh * hd, wave, nwv, lane, NT, hd);    // Q
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // The contraction index q is the ROW index of in[q][key].  Gathering the column strips from HBM with two-byte loads (8 per
+  // fragment) made this pass 125 of the kernel's 230 us; instead every 32 x 32 tile is read row-contiguous (two 16-B loads per
+  // lane, all tiles of the strip requested up front), parked in a 4 KB image private to the wave (same 128-B rows and chunk
+  // swizzle as the staged images: 32 keys fill half of each row) and read back transposed by ds_read_b64_tr_b16.  The LDS pipe
+  // serves a wave's operations in order, so the next tile's stores cannot overtake this tile's reads: no barrier.
   const bf16_t* inb = p.sbuf + bh;  // MODE 0: P' ; MODE 1: dS
+  char* tile = smem + (size_t)NT * 32 * ROWB + (size_t)wave * (32 * ROWB);
+  const int lr = lane >> 2, lc = lane & 3;
   for (int kb = wave; kb < NT; kb += nwv) {
     const int key = kb * 32 + ql;
     f32x16 acc[2];
@@ -953,10 +968,27 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
     for (int eb = 0; eb < 2; ++eb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[eb][r] = 0.f;
-    for (int qt = 0; qt < NT; ++qt) {
+    const int kcol = kb * 32 + 8 * lc;  // Np % 8 == 0: a 16-B chunk is entirely inside or outside the row
+    uint4 raw[TH_MAX_NT][2];
+#pragma unroll
+    for (int qt = 0; qt < TH_MAX_NT; ++qt)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = qt * 32 + lr + 16 * i;
+        raw[qt][i] = make_uint4(0u, 0u, 0u, 0u);
+        if (qt < NT && q < p.N && kcol < p.Np) raw[qt][i] = *reinterpret_cast<const uint4*>(inb + (size_t)q * p.Np + kcol);
+      }
+#pragma unroll
+    for (int qt = 0; qt < TH_MAX_NT; ++qt) {
+      if (qt >= NT) break;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = lr + 16 * i;
+        *reinterpret_cast<uint4*>(tile + row * ROWB + ((lc ^ rot3(row)) << 4)) = raw[qt][i];
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 cf = load_tile_col_frag(inb, key, qt, s2, half, p.N, p.Np);
+        const bf16x8 cf = lds_tr_frag(tile, 16 * s2 + trow, tcol);
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb)
           acc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(smem, qt * 32 + 16 * s2 + trow, 32 * eb + tcol), cf, acc[eb], 0, 0, 0);
@@ -1364,8 +1396,8 @@ extern "C" int savit_th_attention_bwd(const void* qkv, const float* T1, const fl
   SAVIT_CHECK_ARG(T1 && T2 && s_buf && p_buf && d_o && ds_buf && dqkv && dT1 && dT2 && (H == 2 || H == 4 || H == 6 || H == 8));
   SAVIT_CHECK_ARG(workspace && workspace_bytes >= savit_th_attention_bwd_workspace_bytes(B, N, H) && ((uintptr_t)workspace % 16) == 0);
   if (B == 0) return SAVIT_OK;
-  const size_t lds = (size_t)p.nt * 32 * ROWB;
   const int threads = 64 * (p.nt < 8 ? p.nt : 8);
+  const size_t lds = (size_t)p.nt * 32 * ROWB + (size_t)(threads / 64) * 32 * ROWB;  // staged image + one 32-row tile per wave
   hipError_t e = hipFuncSetAttribute((const void*)th_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   e = hipFuncSetAttribute((const void*)th_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
