@@ -897,18 +897,29 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
   const int ql = lane & 31, half = lane >> 5, g = lane >> 4, t = lane & 15;
   const int trow = 4 * (g >> 1) + (t >> 2), tcol = 16 * (g & 1) + 4 * (t & 3);
   const size_t bh = ((size_t)b * p.H + hh) * p.N * p.Np;
+  // One wave owns one 32-row block in each pass (the launch uses NT waves).  Everything a pass reads from HBM into registers
+  // is requested BEFORE the wait for the staged image, so a workgroup exposes the HBM latency twice (once per pass) instead of
+  // once per staging plus once per key tile.
+  const int qb = wave, q = qb * 32 + ql;
   // ---- pass A
   if (MODE == 0) stage_image_rt<0>(smem, srd, row_base, p.N, p.ld, 2 * p.d + hh * hd, wave, nwv, lane, NT, hd);  // V
   else           stage_image_rt<0>(smem, srd, row_base, p.N, p.ld, p.d + hh * hd, wave, nwv, lane, NT, hd);      // K
+  bf16x8 df[4];                    // MODE 0: dO row fragments
+  bf16x8 dsf[TH_MAX_NT][2];        // MODE 1: dS row fragments of every key tile
+  if (MODE == 0) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      df[ks] = load_row_frag_global(p.o, (size_t)(row_base + q), p.d, hh * hd + 16 * ks + 8 * half, q < p.N && 16 * ks < hd);
+  } else {
+#pragma unroll
+    for (int kt = 0; kt < TH_MAX_NT; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) dsf[kt][s2] = load_tile_T_frag(p.sbuf + bh + (size_t)q * p.Np, q < p.N && kt < NT, kt, s2, half, p.Np);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int qb = wave; qb < NT; qb += nwv) {
-    const int q = qb * 32 + ql;
+  if (qb < NT) {
     if (MODE == 0) {
-      bf16x8 df[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        df[ks] = load_row_frag_global(p.o, (size_t)(row_base + q), p.d, hh * hd + 16 * ks + 8 * half, q < p.N && 16 * ks < hd);
       for (int kt = 0; kt < NT; ++kt) {
         f32x16 da;
 #pragma unroll
@@ -924,14 +935,14 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
       for (int eb = 0; eb < 2; ++eb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[eb][r] = 0.f;
-      for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8 dsf = load_tile_T_frag(p.sbuf + bh + (size_t)q * p.Np, q < p.N, kt, s2, half, p.Np);
+      for (int kt = 0; kt < TH_MAX_NT; ++kt) {
+        if (kt >= NT) break;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
           for (int eb = 0; eb < 2; ++eb)
-            dq[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(smem, kt * 32 + 16 * s2 + trow, 32 * eb + tcol), dsf, dq[eb], 0, 0, 0);
-        }
+            dq[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(smem, kt * 32 + 16 * s2 + trow, 32 * eb + tcol), dsf[kt][s2], dq[eb], 0, 0, 0);
       }
       if (q < p.N) {
         bf16_t* drow = p.dqkv + (size_t)(row_base + q) * p.ld + hh * hd;
@@ -947,12 +958,7 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
       }
     }
   }
-  __syncthreads();
   // ---- pass B: G^T[e][key] = sum_q IMG^T[e][q] * in[q][key]
-  if (MODE == 0) stage_image_rt<0>(smem, srdO, row_base, p.N, p.d, hh * hd, wave, nwv, lane, NT, hd);   // dO
-  else           stage_image_rt<0>(smem, srd, row_base, p.N, p.ld, hh * hd, wave, nwv, lane, NT, hd);    // Q
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
   // The contraction index q is the ROW index of in[q][key].  Gathering the column strips from HBM with two-byte loads (8 per
   // fragment) made this pass 125 of the kernel's 230 us; instead every 32 x 32 tile is read row-contiguous (two 16-B loads per
   // lane, all tiles of the strip requested up front), parked in a 4 KB image private to the wave (same 128-B rows and chunk
@@ -961,23 +967,28 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
   const bf16_t* inb = p.sbuf + bh;  // MODE 0: P' ; MODE 1: dS
   char* tile = smem + (size_t)NT * 32 * ROWB + (size_t)wave * (32 * ROWB);
   const int lr = lane >> 2, lc = lane & 3;
-  for (int kb = wave; kb < NT; kb += nwv) {
-    const int key = kb * 32 + ql;
+  const int kb = wave, key = kb * 32 + ql;
+  const int kcol = kb * 32 + 8 * lc;  // Np % 8 == 0: a 16-B chunk is entirely inside or outside the row
+  uint4 raw[TH_MAX_NT][2];
+#pragma unroll
+  for (int qt = 0; qt < TH_MAX_NT; ++qt)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int qq = qt * 32 + lr + 16 * i;
+      raw[qt][i] = make_uint4(0u, 0u, 0u, 0u);
+      if (qt < NT && qq < p.N && kcol < p.Np) raw[qt][i] = *reinterpret_cast<const uint4*>(inb + (size_t)qq * p.Np + kcol);
+    }
+  __syncthreads();  // every wave is done with the pass-A image
+  if (MODE == 0) stage_image_rt<0>(smem, srdO, row_base, p.N, p.d, hh * hd, wave, nwv, lane, NT, hd);   // dO
+  else           stage_image_rt<0>(smem, srd, row_base, p.N, p.ld, hh * hd, wave, nwv, lane, NT, hd);    // Q
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (kb < NT) {
     f32x16 acc[2];
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[eb][r] = 0.f;
-    const int kcol = kb * 32 + 8 * lc;  // Np % 8 == 0: a 16-B chunk is entirely inside or outside the row
-    uint4 raw[TH_MAX_NT][2];
-#pragma unroll
-    for (int qt = 0; qt < TH_MAX_NT; ++qt)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int q = qt * 32 + lr + 16 * i;
-        raw[qt][i] = make_uint4(0u, 0u, 0u, 0u);
-        if (qt < NT && q < p.N && kcol < p.Np) raw[qt][i] = *reinterpret_cast<const uint4*>(inb + (size_t)q * p.Np + kcol);
-      }
 #pragma unroll
     for (int qt = 0; qt < TH_MAX_NT; ++qt) {
       if (qt >= NT) break;
@@ -1087,9 +1098,28 @@ __device__ __forceinline__ float th_unpack(uint32_t w, int odd) { return odd ? _
 
 // Reduce-scatter of 64 per-lane partials over the 64 lanes: after 6 halving exchanges lane l holds sum_lanes g[l].
 // 63 shuffles instead of 64 full wave reductions, and the H x H dT partials need not persist in registers across rows.
+// The two widest exchanges (lanes 32 and 16 apart: 48 of the 63) are gfx950's v_permlane32_swap / v_permlane16_swap: swapping
+// the upper half (odd rows) of g[j] with the lower half (even rows) of g[j + n2] leaves exactly "kept + received" in the two
+// registers, so one swap + one add replaces two selects, a ds_bpermute and an add (126 bpermutes per row kept the LDS pipe busy
+// for a third of this kernel).  Four swaps share one pair of hazard nops (common.h: SAVIT_PERMLANE_SWAP).
+#define TH_SWAP4(OP, a0, b0, a1, b1, a2, b2, a3, b3)                                                                        \
+  asm volatile("s_nop 3\n " OP " %0, %1\n " OP " %2, %3\n " OP " %4, %5\n " OP " %6, %7\n s_nop 3"                          \
+               : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3))
 __device__ __forceinline__ float reduce_scatter64(float (&g)[64], int lane) {
 #pragma unroll
-  for (int st = 0; st < 6; ++st) {
+  for (int j = 0; j < 32; j += 4) {
+    TH_SWAP4("v_permlane32_swap_b32", g[j], g[j + 32], g[j + 1], g[j + 33], g[j + 2], g[j + 34], g[j + 3], g[j + 35]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[j + k] += g[j + k + 32];
+  }
+#pragma unroll
+  for (int j = 0; j < 16; j += 4) {
+    TH_SWAP4("v_permlane16_swap_b32", g[j], g[j + 16], g[j + 1], g[j + 17], g[j + 2], g[j + 18], g[j + 3], g[j + 19]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[j + k] += g[j + k + 16];
+  }
+#pragma unroll
+  for (int st = 2; st < 6; ++st) {
     const int mask = 32 >> st, n2 = 32 >> st;
     const bool upper = (lane & mask) != 0;
 #pragma unroll
