@@ -24,12 +24,13 @@ def plan_buckets(layer_starts: List[int], final_start: int, total: int, min_buck
     buckets: List[Tuple[int, int, str]] = []
     end = total
     i = L - 1
-    while i >= 0:
+    # The LAST bucket's exchange has no backward work left to hide behind, so it is kept as small as the layout allows:
+    # the embedding block plus layer 0 only.  Whatever is still open above layer 0 closes as its own (possibly short)
+    # bucket at 'l1.ln1.bwd' and overlaps layer 0's backward.
+    while i >= 1:
         j = i
-        while j > 0 and end - layer_starts[j] < min_bucket_elems:
+        while j > 1 and end - layer_starts[j] < min_bucket_elems:
             j -= 1
-        if j == 0:
-            break  # the rest joins the embedding bucket
         buckets.append((layer_starts[j], end, f"l{j}.ln1.bwd"))
         end = layer_starts[j]
         i = j - 1
