@@ -88,7 +88,9 @@ enum savit_epilogue {
 };
 
 typedef struct savit_gemm_args {
-  const void* A;          /* bf16 [M, lda]   (SAVIT_EPI_PATCH: images bf16 [B, img, img, 3]) */
+  const void* A;          /* bf16 [M, lda]   (SAVIT_EPI_PATCH: images bf16 [B, img, img, 3]).  lda < K is allowed for operands whose
+                             true width w <= lda is not a multiple of the 32-deep K-step: columns [lda, K) of a row then alias the next
+                             row (zeros past the end), and Bt must hold ZEROS in columns [w, K) */
   const void* Bt;         /* bf16 [N, ldb] */
   void* C;                /* see epilogue */
   void* C2;               /* SAVIT_EPI_BIAS_GELU: gelu output; SAVIT_EPI_RESID: optional bf16 branch (for LayerScale backward) */
@@ -136,7 +138,7 @@ int savit_gemm_wgrad_auto_variant(int Kin, int Nout, int patch);
 
 
 /* ---- Fused multi-head self-attention (attention.py:39-58): per (batch, head)
- *   S = (q/sqrt(hd)) k^T ; P = softmax_k(S) ; O = P v.      head_dim must be 64, N <= 256.
+ *   S = (q/sqrt(hd)) k^T ; P = softmax_k(S) ; O = P v.      head_dim 16, 32, 48 or 64; N <= 608.
  * qkv bf16 [B*N, ld_qkv]: columns [0,d) = queries ALREADY scaled by 1/sqrt(hd) (SAVIT_EPI_BF16 alpha), [d,2d) keys,
  * [2d,3d) values, head-major (h*64+e) inside each (the DenseGeneral (H,hd) feature order, attention.py:29-33).
  * o bf16 [B*N, d]; lse fp32 [B,H,N] = log-sum-exp of each score row (saved for backward; nullable). */
@@ -178,6 +180,25 @@ int savit_transpose_bf16(const void* src, long src_batch_stride, int ld_src, voi
 int savit_transpose_rowsum_rows(int B, int Cc);
 int savit_token_mean_fwd(const void* h_bf16, void* z_bf16, int B, int L, int d, void* stream);
 int savit_token_mean_bwd(const void* dz_bf16, void* dh_bf16, int B, int L, int d, void* stream);
+
+/* ---- TNT glue (tnt.py:17-33,40-51,166-193).
+ * savit_tnt_pixel_gather: PixelEmbedBlock's rearranges - out bf16 [B*(S/P)^2*(P/t)^2, ld_out], row = (image, patch, pixel token),
+ *   columns c*t*t + t1*t + t2 (channel slowest) of images bf16 NHWC [B, S, S, C]; columns >= C*t*t are left untouched.
+ * savit_add_rows_periodic: x[r, :] += pos[r mod period, :] (AddAbsPosEmbed on the pixel stream).
+ * savit_tnt_inner2outer_add: out[b, 0] = patch[b, 0]; out[b, 1+p] = patch[b, 1+p] + y[b*(N-1)+p]  (jnp.pad + add, tnt.py:49-50).
+ * savit_tnt_inner2outer_split: its backward - dres += dt on every row; dy[b*(N-1)+p] = bf16(dt[b, 1+p]); dbias (nullable) +=
+ *   column sums of dy (the bias gradient of the Inner2Outer Dense).  d <= 1024.
+ * savit_cast_colsum: dst_bf16 (nullable) = bf16(src) for fp32 [rows, d]; colsum (nullable) += column sums of src.  d <= 1024.
+ *   (A residual-stream cotangent that was completed by something other than a LayerNorm backward - which would have produced both.)
+ * savit_gather_rows_bf16 / savit_scatter_rows: the head reads row 0 of every image without a LayerNorm (tnt.py:187):
+ *   dst[b] = bf16(src[b*row_stride ...]);  backward writes the bf16 cotangent rows back as fp32 (and optionally bf16) rows. */
+int savit_tnt_pixel_gather(const void* images_bf16, void* out_bf16, int B, int img_size, int patch, int t, int C, int ld_out, void* stream);
+int savit_add_rows_periodic(float* x, const float* pos, long rows, int period, int d, void* stream);
+int savit_tnt_inner2outer_add(const float* patch, const void* y_bf16, float* out, int B, int N, int d, void* stream);
+int savit_tnt_inner2outer_split(const float* dt, float* dres, void* dy_bf16, float* dbias, int B, int N, int d, void* stream);
+int savit_cast_colsum(const float* src, void* dst_bf16, float* colsum, long rows, int d, void* stream);
+int savit_gather_rows_bf16(const float* src, long row_stride, void* dst_bf16, int B, int d, void* stream);
+int savit_scatter_rows(const void* src_bf16, float* dst, void* dst_bf16, long row_stride, int B, int d, void* stream);
 
 /* ---- loss (train.py:83-90): one_hot -> optional mix (ratio*y + (1-ratio)*y1) -> optax.smooth_labels ->
  * optax.softmax_cross_entropy -> mean.  logits fp32 [B, ld]; labels int32 [B].  Outputs (each nullable):

@@ -140,9 +140,37 @@ def mixer_forward(p, images, cfg, taps: Optional[dict] = None):
     return F.linear(z, p["Dense_0"]["kernel"].t(), p["Dense_0"]["bias"])
 
 
+def tnt_forward(p, images, cfg, taps: Optional[dict] = None):
+    """tnt.py:150-193 (EncoderBlock :66-93, Inner2OuterBlock :40-51, PixelEmbedBlock :17-33)."""
+    B, S, _, C = images.shape
+    P, t = cfg.patch, cfg.transformed_patch
+    g, s = S // P, P // t
+    px = images.view(B, g, s, t, g, s, t, C).permute(0, 1, 4, 2, 5, 7, 3, 6).reshape(B * g * g, s * s, C * t * t)
+    pe, pa = p["PixelEmbedBlock_0"]["Dense_0"], p["PatchEmbedBlock_0"]["Dense_0"]
+    pixels = F.linear(px, pe["kernel"].t(), pe["bias"]) + p["AddAbsPosEmbed_0"]["pos_embed"]
+    patches = F.linear(_patchify(images, P), pa["kernel"].t(), pa["bias"])
+    patches = torch.cat([p["cls"].expand(B, -1, -1), patches], dim=1) + p["AddAbsPosEmbed_1"]["pos_embed"]
+    for l in range(cfg.num_layers):
+        b = p["Encoder_0"][f"EncoderBlock_{l}"]
+        h = _ln(pixels, b["LayerNorm_0"])
+        pixels = pixels + _attn(b["SelfAttentionBlock_0"], h, h, cfg.inner_num_heads)
+        pixels = pixels + _ff(b["FFBlock_0"], _ln(pixels, b["LayerNorm_1"]))
+        i2o = b["Inner2OuterBlock_0"]["Dense_0"]
+        z = F.linear(pixels.reshape(pixels.shape[0], -1), i2o["kernel"].t(), i2o["bias"]).view(B, -1, patches.shape[-1])
+        outer = F.pad(z, (0, 0, 1, 0)) + patches
+        h = _ln(outer, b["LayerNorm_2"])
+        x = patches + _attn(b["SelfAttentionBlock_1"], h, h, cfg.num_heads)  # tnt.py:86: the skip is patch_inputs
+        patches = x + _ff(b["FFBlock_1"], _ln(x, b["LayerNorm_3"]))
+        if taps is not None:
+            taps[f"x{l + 1}"] = patches
+    return F.linear(patches[:, 0], p["Dense_0"]["kernel"].t(), p["Dense_0"]["bias"])
+
+
 def forward(p, images, cfg, is_training=False, keep_masks=None, taps=None):
     if cfg.kind == "vit":
         return vit_forward(p, images, cfg, taps)
+    if cfg.kind == "tnt":
+        return tnt_forward(p, images, cfg, taps)
     if cfg.kind == "mixer":
         return mixer_forward(p, images, cfg, taps)
     return cait_forward(p, images, cfg, is_training, keep_masks)

@@ -54,10 +54,18 @@ class Cfg:
     layerscale_eps: float = 0.0
     # MLP-Mixer only (ref: models/mlp_mixer.py:39)
     tokens_expand_ratio: float = 0.5
+    # TNT only (ref: models/tnt.py:139-147): num_heads / embed_dim are the OUTER transformer's
+    inner_num_heads: int = 0
+    inner_embed_dim: int = 0
+    transformed_patch: int = 4
 
     @property
     def n_patches(self) -> int:
         return (self.img_size // self.patch) ** 2
+
+    @property
+    def n_pixels(self) -> int:  # TNT: pixel tokens per patch, (patch / transformed_patch)^2  (tnt.py:24-29)
+        return (self.patch // self.transformed_patch) ** 2
 
     @property
     def tokens_hidden(self) -> int:  # FFBlock over the token axis: ff.py:24 with in_ch = number of patches
@@ -65,7 +73,7 @@ class Cfg:
 
     @property
     def seq_len(self) -> int:  # tokens seen by the SA encoder
-        return self.n_patches + (1 if self.kind == "vit" else 0)
+        return self.n_patches + (1 if self.kind in ("vit", "tnt") else 0)
 
     @property
     def hidden(self) -> int:  # ref: models/layers/feedforwards/ff.py:24
@@ -85,7 +93,14 @@ def _mixer(L, d, p):
     return dict(kind="mixer", num_layers=L, num_heads=1, embed_dim=d, patch=p)
 
 
+def _tnt(L, Hi, Ho, di, do):
+    return dict(kind="tnt", num_layers=L, num_heads=Ho, embed_dim=do, patch=16, inner_num_heads=Hi, inner_embed_dim=di)
+
+
 MODEL_ZOO: Dict[str, dict] = {
+    # ref: models/create_model.py:50-63
+    "tnt_s_patch16": _tnt(12, 4, 10, 40, 640),
+    "tnt_b_patch16": _tnt(12, 4, 6, 24, 384),
     # ref: models/create_model.py:184-213.  The branch at :199-203 repeats the name 'mixer_s_patch32' (unreachable); its
     # arguments are Mixer-B/16, registered here under the name it was meant to have.
     "mixer_s_patch32": _mixer(8, 512, 32),
@@ -384,9 +399,61 @@ def mixer_forward(params: dict, images, cfg: Cfg, mode: str = "f32", is_training
     return logits
 
 
+def pixelify(images, patch: int, t: int):
+    """PixelEmbedBlock's two rearranges (models/tnt.py:21-29): 'b (h p1) (w p2) c -> (b h w) p1 p2 c' then
+    'n (p1 t1) (p2 t2) c -> n (p1 p2) (c t1 t2)': per patch a sequence of (patch/t)^2 pixel tokens of c*t*t features, c slowest."""
+    B, S, _, C = images.shape
+    g, s = S // patch, patch // t
+    x = images.reshape(B, g, s, t, g, s, t, C)          # b h p1 t1 w p2 t2 c
+    x = x.transpose(0, 1, 4, 2, 5, 7, 3, 6)              # b h w p1 p2 c t1 t2
+    return x.reshape(B * g * g, s * s, C * t * t)
+
+
+def tnt_encoder_block(pol: Policy, p: dict, patch_in, pixel_in, cfg: Cfg):
+    """EncoderBlock.__call__  (models/tnt.py:66-93).  NOTE the outer residual adds `patch_inputs`, not the Inner2Outer sum (:86)."""
+    x = layer_norm(pol, pixel_in, p["LayerNorm_0"]["scale"], p["LayerNorm_0"]["bias"])
+    x = attention_block(pol, p["SelfAttentionBlock_0"], x, x, cfg.inner_num_heads)
+    inner_x = pol.hi(x) + pol.hi(pixel_in)
+    y = layer_norm(pol, inner_x, p["LayerNorm_1"]["scale"], p["LayerNorm_1"]["bias"])
+    inner_out = inner_x + pol.hi(ff_block(pol, p["FFBlock_0"], y))
+    # Inner2OuterBlock (tnt.py:40-51): flatten a patch's pixel tokens, Dense to the outer width, zero row for cls, add
+    B = patch_in.shape[0]
+    i2o = p["Inner2OuterBlock_0"]["Dense_0"]
+    z = dense(pol, inner_out.reshape(inner_out.shape[0], -1), i2o["kernel"], i2o["bias"]).reshape(B, -1, patch_in.shape[-1])
+    z = np.pad(pol.hi(z), ((0, 0), (1, 0), (0, 0)))
+    outer = z + pol.hi(patch_in)
+    o = layer_norm(pol, outer, p["LayerNorm_2"]["scale"], p["LayerNorm_2"]["bias"])
+    o = attention_block(pol, p["SelfAttentionBlock_1"], o, o, cfg.num_heads)
+    outer_x = pol.hi(o) + pol.hi(patch_in)  # tnt.py:86
+    oy = layer_norm(pol, outer_x, p["LayerNorm_3"]["scale"], p["LayerNorm_3"]["bias"])
+    return outer_x + pol.hi(ff_block(pol, p["FFBlock_1"], oy)), inner_out
+
+
+def tnt_forward(params: dict, images, cfg: Cfg, mode: str = "f32", is_training: bool = False):
+    """TNT.__call__  (models/tnt.py:150-193): pixel + patch embeddings (both with bias), cls + position embeddings on both streams,
+    the encoder, Dense head (zero-init kernel) on the cls row - there is NO final LayerNorm.  Dropout rates are 0."""
+    pol = Policy(mode)
+    p = params["params"] if "params" in params else params
+    img = pol.lo(images)
+    pe = p["PixelEmbedBlock_0"]["Dense_0"]
+    pixels = dense(pol, pixelify(img, cfg.patch, cfg.transformed_patch), pe["kernel"], pe["bias"])
+    pa = p["PatchEmbedBlock_0"]["Dense_0"]
+    patches = dense(pol, patchify(img, cfg.patch, cfg.patch), pa["kernel"], pa["bias"])
+    B = patches.shape[0]
+    patches = np.concatenate([np.tile(pol.hi(p["cls"]), (B, 1, 1)), pol.hi(patches)], axis=1)
+    pixels = pol.hi(pixels) + pol.hi(p["AddAbsPosEmbed_0"]["pos_embed"])
+    patches = patches + pol.hi(p["AddAbsPosEmbed_1"]["pos_embed"])
+    enc = p["Encoder_0"]
+    for l in range(cfg.num_layers):
+        patches, pixels = tnt_encoder_block(pol, enc[f"EncoderBlock_{l}"], patches, pixels, cfg)
+    return dense(pol, patches[:, 0], p["Dense_0"]["kernel"], p["Dense_0"]["bias"])
+
+
 def forward(params, images, cfg: Cfg, mode="f32", is_training=False, keep_masks=None):
     if cfg.kind == "vit":
         return vit_forward(params, images, cfg, mode, is_training)
+    if cfg.kind == "tnt":
+        return tnt_forward(params, images, cfg, mode, is_training)
     if cfg.kind == "mixer":
         return mixer_forward(params, images, cfg, mode, is_training)
     return cait_forward(params, images, cfg, mode, is_training, keep_masks)
@@ -544,6 +611,30 @@ def init_params(cfg: Cfg, seed: int = 0, randomize: bool = False) -> dict:
     d, H, F = cfg.embed_dim, cfg.num_heads, cfg.hidden
     pdim = cfg.patch * cfg.patch * 3
     N = cfg.seq_len
+    if cfg.kind == "tnt":
+        di, Hi, n, npx = cfg.inner_embed_dim, cfg.inner_num_heads, cfg.n_patches, cfg.n_pixels
+        fin = 3 * cfg.transformed_patch ** 2
+
+        def bias(k):
+            return (0.02 * rng.standard_normal(k)).astype(np.float32) if randomize else np.zeros(k, np.float32)
+
+        p = {"PixelEmbedBlock_0": {"Dense_0": {"kernel": _lecun_normal(rng, (fin, di), fin), "bias": bias(di)}},
+             "PatchEmbedBlock_0": {"Dense_0": {"kernel": _lecun_normal(rng, (pdim, d), pdim), "bias": bias(d)}},
+             "cls": ((0.02 * rng.standard_normal((1, 1, d))).astype(np.float32) if randomize else np.zeros((1, 1, d), np.float32)),
+             "AddAbsPosEmbed_0": {"pos_embed": (0.02 * rng.standard_normal((1, npx, di))).astype(np.float32)},
+             "AddAbsPosEmbed_1": {"pos_embed": (0.02 * rng.standard_normal((1, n + 1, d))).astype(np.float32)}}
+        enc = {}
+        for l in range(cfg.num_layers):
+            enc[f"EncoderBlock_{l}"] = {
+                "LayerNorm_0": _ln_params(rng, di, randomize), "SelfAttentionBlock_0": _attn_params(rng, di, Hi, False, randomize),
+                "LayerNorm_1": _ln_params(rng, di, randomize), "FFBlock_0": _ff_params(rng, di, max(1, int(4 * di)), randomize),
+                "Inner2OuterBlock_0": {"Dense_0": {"kernel": _lecun_normal(rng, (npx * di, d), npx * di), "bias": bias(d)}},
+                "LayerNorm_2": _ln_params(rng, d, randomize), "SelfAttentionBlock_1": _attn_params(rng, d, H, False, randomize),
+                "LayerNorm_3": _ln_params(rng, d, randomize), "FFBlock_1": _ff_params(rng, d, F, randomize)}
+        p["Encoder_0"] = enc
+        hk = _lecun_normal(rng, (d, cfg.num_classes), d) if randomize else np.zeros((d, cfg.num_classes), np.float32)
+        p["Dense_0"] = {"kernel": hk, "bias": bias(cfg.num_classes)}
+        return {"params": p}
     if cfg.kind == "mixer":
         # mlp_mixer.py: every Dense keeps flax's defaults (lecun-normal kernel, zero bias) - the head too (:63)
         n, Ft = cfg.n_patches, cfg.tokens_hidden
@@ -631,6 +722,13 @@ def train_flops_per_image(cfg: Cfg) -> float:
         N = n + 1
         layer = 24.0 * N * d * d + 4.0 * N * N * d
         return 3.0 * (cfg.num_layers * layer + 2.0 * d * C) + 2.0 * pe
+    if cfg.kind == "tnt":
+        di, npx, N = cfg.inner_embed_dim, cfg.n_pixels, n + 1
+        inner = n * (24.0 * npx * di * di + 4.0 * npx * npx * di)          # per image: n sequences of npx pixel tokens
+        i2o = 2.0 * n * (npx * di) * d
+        outer = 24.0 * N * d * d + 4.0 * N * N * d
+        pix = 2.0 * n * npx * (3 * cfg.transformed_patch ** 2) * di
+        return 3.0 * (cfg.num_layers * (inner + i2o + outer) + 2.0 * d * C) + 2.0 * (pe + pix)
     if cfg.kind == "mixer":  # per layer: token FF 2 * (2 d n Ft) + channel FF 2 * (2 n d F)
         layer = 4.0 * d * n * cfg.tokens_hidden + 4.0 * n * d * cfg.hidden
         return 3.0 * (cfg.num_layers * layer + 2.0 * d * C) + 2.0 * pe
@@ -665,6 +763,34 @@ def param_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
         out[f"{prefix}/Dense_1/bias"] = (d,)
 
     out["params/PatchEmbedBlock_0/Dense_0/kernel"] = (cfg.patch * cfg.patch * 3, d)
+    if cfg.kind == "tnt":
+        di, Hi, npx = cfg.inner_embed_dim, cfg.inner_num_heads, cfg.n_pixels
+        out["params/PatchEmbedBlock_0/Dense_0/bias"] = (d,)
+        out["params/PixelEmbedBlock_0/Dense_0/kernel"] = (3 * cfg.transformed_patch ** 2, di)
+        out["params/PixelEmbedBlock_0/Dense_0/bias"] = (di,)
+        out["params/cls"] = (1, 1, d)
+        out["params/AddAbsPosEmbed_0/pos_embed"] = (1, npx, di)
+        out["params/AddAbsPosEmbed_1/pos_embed"] = (1, cfg.n_patches + 1, d)
+        for l in range(cfg.num_layers):
+            b = f"params/Encoder_0/EncoderBlock_{l}"
+            for i, (w, hh) in enumerate(((di, Hi), (d, H))):
+                out[f"{b}/LayerNorm_{2 * i}/scale"] = (w,)
+                out[f"{b}/LayerNorm_{2 * i}/bias"] = (w,)
+                for nme in ("queries", "keys", "values"):
+                    out[f"{b}/SelfAttentionBlock_{i}/{nme}/kernel"] = (w, hh, w // hh)
+                out[f"{b}/SelfAttentionBlock_{i}/DenseGeneral_0/kernel"] = (hh, w // hh, w)
+                out[f"{b}/LayerNorm_{2 * i + 1}/scale"] = (w,)
+                out[f"{b}/LayerNorm_{2 * i + 1}/bias"] = (w,)
+                f = max(1, int(4 * w))
+                out[f"{b}/FFBlock_{i}/Dense_0/kernel"] = (w, f)
+                out[f"{b}/FFBlock_{i}/Dense_0/bias"] = (f,)
+                out[f"{b}/FFBlock_{i}/Dense_1/kernel"] = (f, w)
+                out[f"{b}/FFBlock_{i}/Dense_1/bias"] = (w,)
+            out[f"{b}/Inner2OuterBlock_0/Dense_0/kernel"] = (npx * di, d)
+            out[f"{b}/Inner2OuterBlock_0/Dense_0/bias"] = (d,)
+        out["params/Dense_0/kernel"] = (d, C)
+        out["params/Dense_0/bias"] = (C,)
+        return out
     if cfg.kind == "mixer":
         n, Ft = cfg.n_patches, cfg.tokens_hidden
         out["params/PatchEmbedBlock_0/Dense_0/bias"] = (d,)

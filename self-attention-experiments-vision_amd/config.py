@@ -8,7 +8,7 @@ from typing import Dict
 
 @dataclass(frozen=True)
 class ModelConfig:
-    kind: str  # 'vit' | 'cait' | 'mixer'
+    kind: str  # 'vit' | 'cait' | 'mixer' | 'tnt'
     num_layers: int
     num_heads: int
     embed_dim: int
@@ -20,10 +20,19 @@ class ModelConfig:
     stoch_depth_rate: float = 0.0
     layerscale_eps: float = 0.0
     tokens_expand_ratio: float = 0.5  # MLP-Mixer token-mixing FFBlock (mlp_mixer.py:39)
+    # TNT (tnt.py:139-147): num_heads / embed_dim describe the OUTER transformer
+    inner_num_heads: int = 0
+    inner_embed_dim: int = 0
+    transformed_patch: int = 4
 
     @property
     def n_patches(self) -> int:
         return (self.img_size // self.patch) ** 2
+
+    @property
+    def n_pixels(self) -> int:
+        """TNT: pixel tokens per patch = (patch / transformed_patch)^2 (tnt.py:24-29)."""
+        return (self.patch // self.transformed_patch) ** 2
 
     @property
     def tokens_hidden(self) -> int:
@@ -33,7 +42,7 @@ class ModelConfig:
     @property
     def seq_len(self) -> int:
         """tokens in the self-attention encoder: patches (+ cls for ViT: vit.py:85)."""
-        return self.n_patches + (1 if self.kind == "vit" else 0)
+        return self.n_patches + (1 if self.kind in ("vit", "tnt") else 0)
 
     @property
     def hidden(self) -> int:
@@ -62,7 +71,13 @@ def _mixer(L, d, p):
     return dict(kind="mixer", num_layers=L, num_heads=1, embed_dim=d, patch=p)
 
 
+def _tnt(L, Hi, Ho, di, do):
+    return dict(kind="tnt", num_layers=L, num_heads=Ho, embed_dim=do, patch=16, inner_num_heads=Hi, inner_embed_dim=di)
+
+
 MODEL_ZOO: Dict[str, dict] = {
+    "tnt_s_patch16": _tnt(12, 4, 10, 40, 640),  # create_model.py:50-56
+    "tnt_b_patch16": _tnt(12, 4, 6, 24, 384),   # :57-63
     # create_model.py:184-213; the branch at :199-203 repeats 'mixer_s_patch32' (unreachable) with Mixer-B/16 arguments and is
     # registered under the name it was meant to have
     "mixer_s_patch32": _mixer(8, 512, 32),
@@ -104,6 +119,13 @@ def train_flops_per_image(cfg: ModelConfig) -> float:
         N = n + 1
         layer = 24.0 * N * d * d + 4.0 * N * N * d
         return 3.0 * (cfg.num_layers * layer + 2.0 * d * C) + 2.0 * pe
+    if cfg.kind == "tnt":
+        di, npx, N = cfg.inner_embed_dim, cfg.n_pixels, n + 1
+        inner = n * (24.0 * npx * di * di + 4.0 * npx * npx * di)
+        i2o = 2.0 * n * (npx * di) * d
+        outer = 24.0 * N * d * d + 4.0 * N * N * d
+        pix = 2.0 * n * npx * (3 * cfg.transformed_patch ** 2) * di
+        return 3.0 * (cfg.num_layers * (inner + i2o + outer) + 2.0 * d * C) + 2.0 * (pe + pix)
     if cfg.kind == "mixer":  # token FF 2 x (2 d n Ft) + channel FF 2 x (2 n d F) per layer
         layer = 4.0 * d * n * cfg.tokens_hidden + 4.0 * n * d * cfg.hidden
         return 3.0 * (cfg.num_layers * layer + 2.0 * d * C) + 2.0 * pe

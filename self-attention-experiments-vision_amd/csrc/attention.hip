@@ -1329,7 +1329,7 @@ static int persistent_grid(int items, size_t lds_bytes, int threads) {
 extern "C" int savit_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int head_dim, int ld_qkv,
                                    void* stream) {
   SAVIT_CHECK_ARG(qkv && o && B >= 0 && N > 0 && H > 0);
-  SAVIT_CHECK_ARG((head_dim == 64 || head_dim == 48) && N <= 608 && ld_qkv >= 3 * H * head_dim && ld_qkv % 8 == 0);
+  SAVIT_CHECK_ARG((head_dim == 64 || head_dim == 48 || head_dim == 32 || head_dim == 16) && N <= 608 && ld_qkv >= 3 * H * head_dim && ld_qkv % 8 == 0);
   SAVIT_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)o % 16) == 0);
   if (B == 0) return SAVIT_OK;
   AttnParams p{};
@@ -1352,7 +1352,7 @@ extern "C" int savit_attention_fwd(const void* qkv, void* o, float* lse, int B, 
 extern "C" int savit_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int N,
                                    int H, int head_dim, int ld_qkv, float dq_scale, void* stream) {
   SAVIT_CHECK_ARG(qkv && o && d_o && lse && dqkv && B >= 0 && N > 0 && H > 0);
-  SAVIT_CHECK_ARG((head_dim == 64 || head_dim == 48) && N <= 608 && ld_qkv >= 3 * H * head_dim && ld_qkv % 8 == 0);
+  SAVIT_CHECK_ARG((head_dim == 64 || head_dim == 48 || head_dim == 32 || head_dim == 16) && N <= 608 && ld_qkv >= 3 * H * head_dim && ld_qkv % 8 == 0);
   SAVIT_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)o % 16) == 0 && ((uintptr_t)d_o % 16) == 0 && ((uintptr_t)dqkv % 16) == 0);
   if (B == 0) return SAVIT_OK;
   AttnParams p{};

@@ -980,7 +980,9 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
     p.chunks_per_prow = a.patch * 3 / 8;
     SAVIT_CHECK_ARG(a.M % (p.grid_side * p.grid_side) == 0 && a.token_offset + p.grid_side * p.grid_side <= a.tokens);
   } else {
-    SAVIT_CHECK_ARG(a.lda >= a.K && a.lda % 8 == 0);
+    // lda < K is allowed: columns [lda, K) of row m then alias the head of row m + 1 (zero beyond the last row: buffer descriptor),
+    // for operands whose true width is not a multiple of the 32-deep K-step - Bt must hold zeros in those K columns
+    SAVIT_CHECK_ARG(a.lda > 0 && a.lda % 8 == 0);
   }
   if (a.epilogue == SAVIT_EPI_BIAS_GELU) SAVIT_CHECK_ARG(a.C2 != nullptr && a.bias != nullptr);
   if (a.epilogue == SAVIT_EPI_RESID || a.epilogue == SAVIT_EPI_DGELU)

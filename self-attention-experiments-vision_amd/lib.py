@@ -63,6 +63,13 @@ _SIGNATURES = {
     "savit_transpose_rowsum_rows": (c_int, [c_int, c_int]),
     "savit_token_mean_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "savit_token_mean_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "savit_tnt_pixel_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "savit_add_rows_periodic": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "savit_tnt_inner2outer_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "savit_tnt_inner2outer_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "savit_cast_colsum": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    "savit_gather_rows_bf16": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_void_p]),
+    "savit_scatter_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
     "savit_softmax_xent": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                    c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "savit_sumsq": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),

@@ -157,6 +157,24 @@ class MLPMixer(ViT):
         return e
 
 
+class TNT(ViT):
+    """models/tnt.py:136-193 behind tnt_engine.TNTEngine.  Every dropout rate is 0: is_training selects nothing."""
+
+    def engine(self, batch: int):
+        from .tnt_engine import TNTEngine
+
+        e = self._engines.get(batch)
+        if e is None:
+            e = TNTEngine(self.cfg, batch)
+            if self._engines:
+                first = next(iter(self._engines.values()))
+                e.params, e.grads, e.w = first.params, first.grads, first.w
+                e.adam_m, e.adam_v = first.adam_m, first.adam_v
+                e.weights_stale = first.weights_stale
+            self._engines[batch] = e
+        return e
+
+
 def create_model(model_name: str, num_classes: int = 1000, dtype=torch.bfloat16, img_size: int = 224):
     """models/create_model.py:6-8.  Same names; `vit_ti_patch16` / `vit_s_patch16` added for BASELINE configs 1-2.
     img_size is an extension (the reference fixes it through the init example; train.py --img_size)."""
@@ -165,4 +183,6 @@ def create_model(model_name: str, num_classes: int = 1000, dtype=torch.bfloat16,
         return ViT(cfg, dtype=dtype)
     if cfg.kind == "mixer":
         return MLPMixer(cfg, dtype=dtype)
+    if cfg.kind == "tnt":
+        return TNT(cfg, dtype=dtype)
     return CaiT(cfg, dtype=dtype)

@@ -607,3 +607,77 @@ def token_mean_bwd(dz: torch.Tensor, Ltok: int) -> torch.Tensor:
     dh = torch.empty((B, int(Ltok), d), dtype=bf16, device=dz.device)
     _lib.check(_lib.load().savit_token_mean_bwd(_p(dz), _p(dh), B, int(Ltok), d, _stream()), "savit_token_mean_bwd")
     return dh
+
+
+# --------------------------------------------------------------------------------------------- TNT glue
+def tnt_pixel_gather(images: torch.Tensor, patch: int, t: int, ld_out: Optional[int] = None) -> torch.Tensor:
+    """PixelEmbedBlock's rearranges (tnt.py:21-29): images bf16 NHWC -> bf16 [B*(S/P)^2*(P/t)^2, ld_out] (zero beyond C*t*t)."""
+    _chk(images, bf16, "images", 4)
+    if not images.is_contiguous():
+        raise ValueError("tnt_pixel_gather: images must be contiguous NHWC")
+    B, S, S2, C = images.shape
+    if S != S2 or S % patch or patch % t:
+        raise ValueError("tnt_pixel_gather: bad geometry")
+    F = C * t * t
+    ld = ld_out or F
+    out = torch.zeros((B * (S // patch) ** 2 * (patch // t) ** 2, ld), dtype=bf16, device=images.device)
+    _lib.check(_lib.load().savit_tnt_pixel_gather(_p(images), _p(out), B, S, patch, t, C, ld, _stream()), "savit_tnt_pixel_gather")
+    return out
+
+
+def add_rows_periodic(x: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+    """x[r, :] += pos[r mod period, :] in place (AddAbsPosEmbed on TNT's pixel stream, tnt.py:170)."""
+    _chk(x, f32, "x", 2)
+    _chk(pos, f32, "pos", 2)
+    if not x.is_contiguous() or not pos.is_contiguous() or x.shape[1] != pos.shape[1]:
+        raise ValueError("add_rows_periodic: contiguous [rows, d] and [period, d]")
+    _lib.check(_lib.load().savit_add_rows_periodic(_p(x), _p(pos), x.shape[0], pos.shape[0], x.shape[1], _stream()), "savit_add_rows_periodic")
+    return x
+
+
+def tnt_inner2outer_add(patch: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """out[b, 0] = patch[b, 0]; out[b, 1+p] = patch[b, 1+p] + y[b, p]  (tnt.py:49-50).  patch fp32 [B, N, d], y bf16 [B, N-1, d]."""
+    _chk(patch, f32, "patch", 3)
+    _chk(y, bf16, "y", 3)
+    B, N, d = patch.shape
+    if tuple(y.shape) != (B, N - 1, d) or not patch.is_contiguous() or not y.is_contiguous():
+        raise ValueError("tnt_inner2outer_add: shapes")
+    out = torch.empty_like(patch)
+    _lib.check(_lib.load().savit_tnt_inner2outer_add(_p(patch), _p(y), _p(out), B, N, d, _stream()), "savit_tnt_inner2outer_add")
+    return out
+
+
+def cast_colsum(src: torch.Tensor, colsum: Optional[torch.Tensor] = None, want_bf16: bool = True):
+    """bf16 copy of fp32 [rows, d] and / or colsum[:] += column sums of src."""
+    _chk(src, f32, "src", 2)
+    if not src.is_contiguous():
+        raise ValueError("cast_colsum: src must be contiguous")
+    dst = torch.empty(src.shape, dtype=bf16, device=src.device) if want_bf16 else None
+    _lib.check(_lib.load().savit_cast_colsum(_p(src), _p(dst), _p(colsum), src.shape[0], src.shape[1], _stream()), "savit_cast_colsum")
+    return dst
+
+
+def tnt_inner2outer_split(dt: torch.Tensor, dres: torch.Tensor, dbias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dres += dt in place; returns dy bf16 [B, N-1, d] = dt[:, 1:]; dbias += column sums of dy."""
+    _chk(dt, f32, "dt", 3)
+    _chk(dres, f32, "dres", 3)
+    B, N, d = dt.shape
+    if dres.shape != dt.shape or not dt.is_contiguous() or not dres.is_contiguous():
+        raise ValueError("tnt_inner2outer_split: shapes")
+    dy = torch.empty((B, N - 1, d), dtype=bf16, device=dt.device)
+    _lib.check(_lib.load().savit_tnt_inner2outer_split(_p(dt), _p(dres), _p(dy), _p(dbias), B, N, d, _stream()), "savit_tnt_inner2outer_split")
+    return dy
+
+
+def gather_rows_bf16(src: torch.Tensor, row_stride: int, B: int, d: int) -> torch.Tensor:
+    _chk(src, f32, "src")
+    dst = torch.empty((B, d), dtype=bf16, device=src.device)
+    _lib.check(_lib.load().savit_gather_rows_bf16(_p(src), row_stride, _p(dst), B, d, _stream()), "savit_gather_rows_bf16")
+    return dst
+
+
+def scatter_rows(src: torch.Tensor, dst: torch.Tensor, row_stride: int, dst_bf16: Optional[torch.Tensor] = None):
+    _chk(src, bf16, "src", 2)
+    _chk(dst, f32, "dst")
+    _lib.check(_lib.load().savit_scatter_rows(_p(src), _p(dst), _p(dst_bf16), row_stride, src.shape[0], src.shape[1], _stream()), "savit_scatter_rows")
+    return dst

@@ -357,7 +357,8 @@ def test_attention_fwd_spike(ops):
     assert abs(host(lse)[0, 0, 5] - lse_ref[0, 0, 5]) < 1e-2
 
 
-@pytest.mark.parametrize("B,N,H,hd", [(2, 197, 3, 48), (1, 196, 8, 48), (1, 577, 2, 64), (1, 300, 1, 48), (2, 17, 2, 48), (1, 608, 1, 64)])
+@pytest.mark.parametrize("B,N,H,hd", [(2, 197, 3, 48), (1, 196, 8, 48), (1, 577, 2, 64), (1, 300, 1, 48), (2, 17, 2, 48), (1, 608, 1, 64),
+                                      (392, 16, 4, 16), (5, 16, 4, 32), (2, 50, 2, 16)])  # TNT's inner transformer: 16 pixel tokens, padded heads
 def test_attention_general_fwd_bwd(ops, B, N, H, hd):
     """General kernels: head_dim 48 (every CaiT size) and N > 256 (ViT-L/16 at 384^2: N = 577), online softmax."""
     rng = np.random.default_rng(B * 7 + N + hd)

@@ -1,0 +1,152 @@
+"""TNT through the HIP engine (/root/reference/models/tnt.py) vs the oracle (GPU): glue kernels bit-exact against
+numpy, then the same model-level bars as tests/test_model_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref, vit_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import savit_amd
+    from savit_amd import config, model, ops  # noqa: F401
+
+    return savit_amd
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def _flat(tree):
+    return {k: v.detach().float().cpu().numpy() for k, v in torch_ref.leaves(tree)}
+
+
+def _bf(x):
+    return torch.as_tensor(vit_ref.bf16_round(np.asarray(x, np.float32))).cuda().to(torch.bfloat16)
+
+
+def test_pixel_gather_matches_the_rearranges(pkg):
+    from savit_amd import ops
+
+    rng = np.random.default_rng(0)
+    img = vit_ref.bf16_round(rng.standard_normal((3, 32, 32, 3)).astype(np.float32))
+    want = vit_ref.pixelify(img, 16, 4).reshape(-1, 48)
+    got = ops.tnt_pixel_gather(_bf(img), 16, 4, ld_out=64).float().cpu().numpy()
+    assert got.shape == (3 * 4 * 16, 64)
+    assert np.array_equal(got[:, :48], want) and np.all(got[:, 48:] == 0)
+
+
+def test_stream_glue(pkg):
+    from savit_amd import ops
+
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((5 * 16, 24)).astype(np.float32)
+    pos = rng.standard_normal((16, 24)).astype(np.float32)
+    got = ops.add_rows_periodic(torch.as_tensor(x).cuda(), torch.as_tensor(pos).cuda()).cpu().numpy()
+    assert np.array_equal(got, x + np.tile(pos, (5, 1)))
+    B, N, d = 3, 5, 64
+    patch = rng.standard_normal((B, N, d)).astype(np.float32)
+    y = vit_ref.bf16_round(rng.standard_normal((B, N - 1, d)).astype(np.float32))
+    out = ops.tnt_inner2outer_add(torch.as_tensor(patch).cuda(), _bf(y)).cpu().numpy()
+    assert np.array_equal(out, patch + np.pad(y, ((0, 0), (1, 0), (0, 0))))
+    dt = rng.standard_normal((B, N, d)).astype(np.float32)
+    dres = rng.standard_normal((B, N, d)).astype(np.float32)
+    dres_d = torch.as_tensor(dres).cuda()
+    dbias = torch.full((d,), 0.25, device="cuda")
+    dy = ops.tnt_inner2outer_split(torch.as_tensor(dt).cuda(), dres_d, dbias).float().cpu().numpy()
+    assert np.array_equal(dres_d.cpu().numpy(), dres + dt) and np.array_equal(dy, vit_ref.bf16_round(dt[:, 1:]))
+    assert np.allclose(dbias.cpu().numpy(), 0.25 + dy.astype(np.float64).sum(axis=(0, 1)), rtol=1e-5, atol=1e-5)
+    for rows, dd in ((1000, 24), (333, 40), (500, 384), (77, 640)):
+        src = rng.standard_normal((rows, dd)).astype(np.float32)
+        cs = torch.full((dd,), -1.0, device="cuda")
+        b16 = ops.cast_colsum(torch.as_tensor(src).cuda(), cs).float().cpu().numpy()
+        assert np.array_equal(b16, vit_ref.bf16_round(src))
+        assert np.allclose(cs.cpu().numpy(), -1.0 + src.astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
+    z = ops.gather_rows_bf16(torch.as_tensor(patch).cuda(), N * d, B, d).float().cpu().numpy()
+    assert np.array_equal(z, vit_ref.bf16_round(patch[:, 0]))
+    back = torch.zeros(B, N, d, device="cuda")
+    ops.scatter_rows(_bf(z), back, N * d)
+    assert np.array_equal(back.cpu().numpy()[:, 0], vit_ref.bf16_round(patch[:, 0])) and float(back[:, 1:].abs().max()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ model
+CASES = {
+    # inner width 24 (heads 6 wide, K rounded 24 -> 32), 4 patches per image
+    "tiny24": dict(kind="tnt", num_layers=2, num_heads=2, embed_dim=128, patch=16, num_classes=16, img_size=32, inner_num_heads=4, inner_embed_dim=24),
+    # inner width 40 (heads 10 wide, K rounded 40 -> 64)
+    "tiny40": dict(kind="tnt", num_layers=2, num_heads=2, embed_dim=128, patch=16, num_classes=16, img_size=32, inner_num_heads=4, inner_embed_dim=40),
+    # create_model's tnt_b geometry (196 patches, outer 384 / 6 heads) with one layer
+    "b1": dict(kind="tnt", num_layers=1, num_heads=6, embed_dim=384, patch=16, num_classes=1000, img_size=224, inner_num_heads=4, inner_embed_dim=24),
+}
+
+
+def _cfgs(**kw):
+    from savit_amd.config import ModelConfig
+
+    return ModelConfig(**kw), vit_ref.Cfg(**kw)
+
+
+@pytest.mark.parametrize("case,B", [("tiny24", 3), ("tiny40", 2), ("b1", 2)])
+def test_forward_backward_parity(pkg, case, B):
+    from savit_amd.tnt_engine import TNTEngine
+
+    mc, oc = _cfgs(**CASES[case])
+    rng = np.random.default_rng(31)
+    params = vit_ref.init_params(oc, seed=8, randomize=True)
+    images = vit_ref.bf16_round(rng.standard_normal((B, oc.img_size, oc.img_size, 3)).astype(np.float32))
+    labels = rng.integers(0, oc.num_classes, B)
+    eng = TNTEngine(mc, B)
+    eng.load_params(params)
+    logits = eng.forward(torch.as_tensor(images).cuda()).float().cpu().numpy()
+    ref32 = vit_ref.forward(params, images, oc, mode="f32")
+    refbf = vit_ref.forward(params, images, oc, mode="bf16")
+    r_us, r_emul = rel(logits, ref32), rel(refbf, ref32)
+    print(f"[tnt {case}] logits rel-L2 vs fp32 oracle: engine {r_us:.2e}, bf16-emulating oracle {r_emul:.2e}")
+    assert np.isfinite(logits).all()
+    assert r_us < max(2.5 * r_emul, 5e-3)
+    loss = float(eng.loss_backward(torch.as_tensor(labels).cuda(), 0.1))
+    loss_ref, _, grads_ref = torch_ref.loss_and_grads(params, images, labels, oc, 0.1)
+    assert abs(loss - loss_ref) < 2e-2 * max(1.0, abs(loss_ref))
+    got = _flat(eng.grad_tree()["params"])
+    assert set(got) == set(grads_ref)
+    worst = 0.0
+    for k, g in grads_ref.items():
+        assert got[k].shape == g.shape, k
+        r = rel(got[k], g)
+        worst = max(worst, r)
+        assert r < 6e-2, (k, r)
+    print(f"[tnt {case}] worst parameter-gradient rel-L2 vs fp32 autograd: {worst:.2e}")
+    # the head padding of the inner attention kernels holds zeros and receives exactly zero gradient
+    lay = eng.layout
+    for flat in (eng.params, eng.grads):
+        w = lay.view(flat, "l0.iWqkv").view(mc.inner_embed_dim, 3, mc.inner_num_heads, 16)
+        assert float(w[..., mc.inner_embed_dim // mc.inner_num_heads:].abs().max()) == 0.0
+        wo = lay.view(flat, "l0.iWo").view(mc.inner_num_heads, 16, mc.inner_embed_dim)
+        assert float(wo[:, mc.inner_embed_dim // mc.inner_num_heads:, :].abs().max()) == 0.0
+
+
+def test_create_model_known_answers(pkg):
+    """create_model names (create_model.py:50-63); zero head => logits == 0 and loss == ln(1000); published TNT sizes."""
+    import math
+
+    from savit_amd.model import create_model
+
+    model = create_model("tnt_b_patch16")
+    x = torch.randn(2, 224, 224, 3, device="cuda")
+    logits, params = model.init_with_output(0, x, is_training=True)
+    assert tuple(logits.shape) == (2, 1000) and float(logits.float().abs().max()) == 0.0
+    p = params["params"]
+    assert {"params/" + k: tuple(v.shape) for k, v in torch_ref.leaves(p)} == vit_ref.param_shapes(vit_ref.get_cfg("tnt_b_patch16"))
+    assert sum(v.numel() for _, v in torch_ref.leaves(p)) == 23_892_640
+    eng = model.engine(2)
+    loss = float(eng.loss_backward(torch.tensor([3, 7], device="cuda"), 0.1))
+    assert abs(loss - math.log(1000.0)) < 1e-5
+    assert create_model("tnt_s_patch16").cfg.embed_dim == 640
