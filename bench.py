@@ -61,7 +61,8 @@ def kernel_symbol(label: str, lib, M: int, d: int, F: int) -> str:
 def kernel_class(label: str) -> str:
     if label.endswith(".wgrad") or label == "Wpe.wgrad":
         return "gemm_wgrad"
-    if label.endswith(".dgrad") or label.split(".")[-1] in ("qkv", "proj", "fc1", "fc2", "q", "kv") or label in ("patch_embed", "head"):
+    if label.endswith(".dgrad") or label.split(".")[-1] in ("qkv", "proj", "fc1", "fc2", "q", "kv", "iqkv", "iproj", "ifc1", "ifc2", "fc") \
+            or label in ("patch_embed", "pixel_embed", "head"):
         return "gemm_tn"
     if "attn" in label:
         return "attention_bwd" if label.endswith(".bwd") else "attention_fwd"
@@ -128,6 +129,10 @@ def main():
         from savit_amd.mixer_engine import MixerEngine
 
         eng = MixerEngine(cfg, B)
+    elif cfg.kind == "tnt":
+        from savit_amd.tnt_engine import TNTEngine
+
+        eng = TNTEngine(cfg, B)
     else:
         eng = ViTEngine(cfg, B)
     eng.init_params(seed=42)  # train.py:187-189 default seed

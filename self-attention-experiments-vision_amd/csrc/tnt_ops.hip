@@ -178,7 +178,7 @@ extern "C" int savit_tnt_inner2outer_split(const float* dt, float* dres, void* d
   if (B == 0) return SAVIT_OK;
   const int q = d / 4, threads = (256 / q) * q;  // a multiple of q: every thread keeps one column group (see block_colsum_flush)
   long blocks = ((long)B * N * q + threads - 1) / threads;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 512) blocks = 512;  // each block ends with d atomics onto the same d addresses: keep them few
   hipLaunchKernelGGL(inner2outer_split_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, dt, dres, (bf16_t*)dy_bf16, dbias, B, N,
                      d);
   SAVIT_LAUNCH_RET();
@@ -190,7 +190,7 @@ extern "C" int savit_cast_colsum(const float* src, void* dst_bf16, float* colsum
   if (rows == 0) return SAVIT_OK;
   const int q = d / 4, threads = (256 / q) * q;
   long blocks = (rows * q + threads - 1) / threads;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 512) blocks = 512;  // each block ends with d atomics onto the same d addresses: keep them few
   hipLaunchKernelGGL(cast_colsum_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, src, (bf16_t*)dst_bf16, colsum, rows, d);
   SAVIT_LAUNCH_RET();
 }

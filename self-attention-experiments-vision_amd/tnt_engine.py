@@ -395,8 +395,16 @@ class TNTEngine(ViTEngine):
         gp = lambda nme: self._off_ptr(self.grads, nme)  # noqa: E731
         ws, wsb = self.ln_ws.data_ptr(), self.ln_ws.numel()
 
+        # The pixel-stream weight gradients reduce B*n*16 rows into one or two 128x128 output tiles: the library's default of 24
+        # K-splits leaves them at 166 us each (4 per layer: the longest item of the step); SAVIT_TNT_INNER_SPLITS sizes them.
+        inner_splits = int(os.environ.get("SAVIT_TNT_INNER_SPLITS", "160"))
+
         def wgrad(label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0)):
-            P.add(L.savit_gemm_bf16_wgrad, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, self._wgrad_splits(Kin, Nout, patch[0]),
+            sp = self._wgrad_splits(Kin, Nout, patch[0])
+            if Mr == Mi and not patch[0]:
+                tiles = -(-Kin // 128) * -(-Nout // 128)
+                sp = max(1, inner_splits // tiles)
+            P.add(L.savit_gemm_bf16_wgrad, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, sp,
                                             patch[0], patch[1], patch[2], patch[3]), label, side=True, reads=(dY,))
 
         ring, ri = [t.data_ptr() for t in self.dres_b_ring], 0

@@ -16,6 +16,9 @@ cfg = get_config(model, img_size=IMG)
 if cfg.kind == "mixer":
     from savit_amd.mixer_engine import MixerEngine
     eng = MixerEngine(cfg, B)
+elif cfg.kind == "tnt":
+    from savit_amd.tnt_engine import TNTEngine
+    eng = TNTEngine(cfg, B)
 else:
     eng = ViTEngine(cfg, B)
 eng.init_params(42)
