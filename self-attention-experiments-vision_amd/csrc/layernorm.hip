@@ -204,6 +204,123 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Narrow rows (d <= 64: TNT's pixel stream, 24 / 40 channels).  One 64-lane wave per row would keep 6 - 10 lanes busy; here a
+// row is owned by one DPP row of 16 lanes (a lane holds one float4), i.e. 4 rows per wave and 16 per workgroup, and the row
+// reductions are the four DPP steps that stay inside 16 lanes.  Same arithmetic, statistics and outputs as the kernels above.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return v;
+}
+
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_narrow_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                                    float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, int d,
+                                                                    long x_stride, float eps, int round_params) {
+  const int sub = threadIdx.x >> 4, ci = threadIdx.x & 15;  // 16 row slots per workgroup
+  const bool on = ci < (d >> 2);
+  float4 g = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0);
+  if (on) {
+    g = reinterpret_cast<const float4*>(gamma)[ci];
+    b = reinterpret_cast<const float4*>(beta)[ci];
+    if (round_params) {
+      g = make_float4(round_bf16(g.x), round_bf16(g.y), round_bf16(g.z), round_bf16(g.w));
+      b = make_float4(round_bf16(b.x), round_bf16(b.y), round_bf16(b.z), round_bf16(b.w));
+    }
+  }
+  const float inv_d = 1.0f / (float)d;
+  const int step = gridDim.x * 16;
+  for (int row0 = blockIdx.x * 16; row0 < rows; row0 += step) {  // uniform trip count: the DPP steps need every lane
+    const int row = row0 + sub;
+    const bool live = on && row < rows;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (live) v = reinterpret_cast<const float4*>(x + (size_t)row * x_stride)[ci];
+    const float s = row16_sum((v.x + v.y) + (v.z + v.w));
+    const float s2 = row16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+    const float mean = s * inv_d;
+    const float rstd = rsqrtf(fmaxf(s2 * inv_d - mean * mean, 0.f) + eps);
+    if (ci == 0 && row < rows) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+    if (live) {
+      const float o0 = (v.x - mean) * (rstd * g.x) + b.x, o1 = (v.y - mean) * (rstd * g.y) + b.y;
+      const float o2 = (v.z - mean) * (rstd * g.z) + b.z, o3 = (v.w - mean) * (rstd * g.w) + b.w;
+      reinterpret_cast<uint2*>(y + (size_t)row * d)[ci] = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+    }
+  }
+}
+
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_narrow_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                                    const float* __restrict__ rstd_in, const float* __restrict__ dres_in,
+                                                                    float* __restrict__ dx_out, bf16_t* __restrict__ dx_bf16,
+                                                                    float* __restrict__ partial, int rows, int d, long x_stride, long out_stride,
+                                                                    int round_params) {
+  const int sub = threadIdx.x >> 4, ci = threadIdx.x & 15;
+  const bool on = ci < (d >> 2);
+  float4 g = make_float4(0, 0, 0, 0);
+  if (on) {
+    g = reinterpret_cast<const float4*>(gamma)[ci];
+    if (round_params) g = make_float4(round_bf16(g.x), round_bf16(g.y), round_bf16(g.z), round_bf16(g.w));
+  }
+  float4 dg = make_float4(0, 0, 0, 0), db = make_float4(0, 0, 0, 0), dc = make_float4(0, 0, 0, 0);
+  const float inv_d = 1.0f / (float)d;
+  const int step = gridDim.x * 16;
+  for (int row0 = blockIdx.x * 16; row0 < rows; row0 += step) {
+    const int row = row0 + sub;
+    const bool live = on && row < rows;
+    float4 xv = make_float4(0, 0, 0, 0), rs = make_float4(0, 0, 0, 0);
+    uint2 dv = make_uint2(0u, 0u);
+    float mean = 0.f, rstd = 0.f;
+    if (live) {
+      xv = reinterpret_cast<const float4*>(x + (size_t)row * x_stride)[ci];
+      dv = reinterpret_cast<const uint2*>(dy + (size_t)row * d)[ci];
+      if (dres_in) rs = reinterpret_cast<const float4*>(dres_in + (size_t)row * out_stride)[ci];
+      mean = mean_in[row];
+      rstd = rstd_in[row];
+    }
+    const float d0 = __uint_as_float(dv.x << 16), d1 = __uint_as_float(dv.x & 0xffff0000u);
+    const float d2 = __uint_as_float(dv.y << 16), d3 = __uint_as_float(dv.y & 0xffff0000u);
+    const float4 xh = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+    const float4 gy = make_float4(d0 * g.x, d1 * g.y, d2 * g.z, d3 * g.w);
+    float c1 = (gy.x + gy.y) + (gy.z + gy.w);
+    float c2 = (gy.x * xh.x + gy.y * xh.y) + (gy.z * xh.z + gy.w * xh.w);
+    c1 = row16_sum(live ? c1 : 0.f) * inv_d;
+    c2 = row16_sum(live ? c2 : 0.f) * inv_d;
+    if (live) {
+      dg.x += d0 * xh.x; dg.y += d1 * xh.y; dg.z += d2 * xh.z; dg.w += d3 * xh.w;
+      db.x += d0; db.y += d1; db.z += d2; db.w += d3;
+      float4 o = make_float4(rstd * (gy.x - c1 - xh.x * c2), rstd * (gy.y - c1 - xh.y * c2), rstd * (gy.z - c1 - xh.z * c2),
+                             rstd * (gy.w - c1 - xh.w * c2));
+      o.x += rs.x; o.y += rs.y; o.z += rs.z; o.w += rs.w;
+      reinterpret_cast<float4*>(dx_out + (size_t)row * out_stride)[ci] = o;
+      if (dx_bf16) reinterpret_cast<uint2*>(dx_bf16 + (size_t)row * out_stride)[ci] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+      dc.x += o.x; dc.y += o.y; dc.z += o.z; dc.w += o.w;
+    }
+  }
+  // the 16 row slots of the workgroup fold through LDS; one plain store per (block, column) into partial[block][which][d]
+  __shared__ float4 red[16][16];
+#pragma unroll
+  for (int which = 0; which < 3; ++which) {
+    const float4 v = which == 0 ? dg : (which == 1 ? db : dc);
+    __syncthreads();
+    red[sub][ci] = v;
+    __syncthreads();
+    if (sub == 0 && on) {
+      float4 t = red[0][ci];
+#pragma unroll
+      for (int w = 1; w < 16; ++w) {
+        t.x += red[w][ci].x; t.y += red[w][ci].y; t.z += red[w][ci].z; t.w += red[w][ci].w;
+      }
+      reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 3 + which) * d)[ci] = t;
+    }
+  }
+}
+
 // Sums the partial slab [nblk][3][d] over blocks: grid (ceil(3d/64), FIN_SPLIT); a block handles 64 columns x
 // its share of slab rows with 4 row-lanes per column, reduces in LDS and issues one atomic per column
 // (FIN_SPLIT adders per address).
@@ -315,6 +432,12 @@ extern "C" int savit_layernorm_fwd(const float* x, const float* gamma, const flo
   SAVIT_CHECK_ARG(x && gamma && beta && y && x_stride >= d && (x_stride % 4) == 0 && rows >= 0 && d > 0 && (d % 4) == 0 && d <= 64 * 4 * LN_MAX_CHUNKS);
   if (rows == 0) return SAVIT_OK;
   hipStream_t s = (hipStream_t)stream;
+  if (d <= 64) {  // narrow rows: 16 lanes per row, 16 rows per workgroup
+    const int g16 = (rows + 15) / 16;
+    hipLaunchKernelGGL(ln_fwd_narrow_kernel, dim3(g16 < 256 * 16 ? g16 : 256 * 16), dim3(LN_THREADS), 0, s, x, gamma, beta, (bf16_t*)y, mean, rstd,
+                       rows, d, x_stride, eps, round_params_bf16);
+    SAVIT_LAUNCH_RET();
+  }
   const int ch = (d / 4 + 63) / 64;
   const int grid = ln_grid(rows, 256 * 16);
   LN_DISPATCH(ch, ln_fwd_kernel, grid, x, gamma, beta, (bf16_t*)y, mean, rstd, rows, d, x_stride, eps, round_params_bf16, 0, 0, 0);
@@ -365,8 +488,17 @@ extern "C" int savit_layernorm_bwd_mapped(const void* dy, const float* x, const 
                   workspace_bytes >= savit_layernorm_bwd_workspace_bytes(rows, d));
   hipStream_t s = (hipStream_t)stream;
   const int ch = (d / 4 + 63) / 64;
-  const int grid = ln_bwd_grid(rows);
   float* partial = (float*)workspace;
+  if (d <= 64 && dy_grp == 0) {  // narrow rows; its grid never exceeds ln_bwd_grid(rows), which sized the workspace
+    const int g16 = (rows + 15) / 16, cap = ln_bwd_grid(rows);
+    const int ngrid = g16 < cap ? g16 : cap;
+    hipLaunchKernelGGL(ln_bwd_narrow_kernel, dim3(ngrid), dim3(LN_THREADS), 0, s, (const bf16_t*)dy, x, gamma, mean, rstd, dres_in, dx,
+                       (bf16_t*)dx_bf16, partial, rows, d, x_stride, out_stride, round_params_bf16);
+    if (dgamma || dbeta || dcolsum)
+      hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * d + 63) / 64, FIN_SPLIT), dim3(256), 0, s, partial, ngrid, d, dgamma, dbeta, dcolsum);
+    SAVIT_LAUNCH_RET();
+  }
+  const int grid = ln_bwd_grid(rows);
   LN_DISPATCH(ch, ln_bwd_kernel, grid, (const bf16_t*)dy, x, gamma, mean, rstd, dres_in, dx, (bf16_t*)dx_bf16, partial, rows, d,
               x_stride, out_stride, round_params_bf16, dy_grp, dy_grp_stride, dy_grp_off);
   if (dgamma || dbeta || dcolsum) {

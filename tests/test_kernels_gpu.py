@@ -45,7 +45,8 @@ def rb(x):  # bf16-rounded fp32 numpy
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm
-@pytest.mark.parametrize("rows,d", [(1, 192), (5, 192), (197 * 3, 384), (394, 768), (131, 1024), (64, 288), (7, 32)])
+@pytest.mark.parametrize("rows,d", [(1, 192), (5, 192), (197 * 3, 384), (394, 768), (131, 1024), (64, 288), (7, 32),
+                                    (16 * 196 * 3 + 5, 24), (1000, 40), (33, 64), (3, 24)])  # d <= 64: the narrow-row kernels (TNT pixels)
 def test_layernorm_fwd(ops, rows, d):
     rng = np.random.default_rng(rows * 1000 + d)
     x = (rng.standard_normal((rows, d)) * 2 + 0.3).astype(np.float32)
@@ -73,7 +74,8 @@ def test_layernorm_fwd_strided_rows(ops):
     assert rel(host(y), ref) < 1e-3
 
 
-@pytest.mark.parametrize("rows,d,with_res", [(5, 192, False), (197 * 4, 384, True), (394, 768, True), (33, 1024, True)])
+@pytest.mark.parametrize("rows,d,with_res", [(5, 192, False), (197 * 4, 384, True), (394, 768, True), (33, 1024, True),
+                                             (16 * 196 * 3 + 5, 24, True), (1000, 40, True), (37, 64, False), (3, 24, True)])
 def test_layernorm_bwd(ops, rows, d, with_res):
     rng = np.random.default_rng(rows + d)
     x = (rng.standard_normal((rows, d)) * 1.5 + 0.2).astype(np.float32)
