@@ -81,3 +81,18 @@ def test_short_run_mlp_mixer(tmp_path, capsys):
     assert train_cli.main(common + ["--num_epochs", "2"]) == 6  # resumes from step 3
     steps = [json.loads(l)["step"] for l in capsys.readouterr().out.splitlines() if l.startswith("{") and "train/loss" in l]
     assert steps == [4, 5, 6]
+
+
+@pytest.mark.gpu
+def test_short_run_tnt(capsys):
+    """... and the TNT family: zero-init head => ln(1000) at step 1, finite afterwards."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    end = train_cli.main(["--model_name", "tnt_b_patch16", "--batch_size", "8", "--steps_per_epoch", "3", "--num_epochs", "1", "--log_every", "1",
+                          "--lr", "1e-3", "--clip_grad", "1.0", "--eval_every_epochs", "100"])
+    assert end == 3
+    train = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{") and "train/loss" in l]
+    assert len(train) == 3 and abs(train[0]["train/loss"] - 6.9078) < 1e-2
+    assert all(np.isfinite(t["train/loss"]) for t in train)
