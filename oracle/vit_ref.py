@@ -1,4 +1,4 @@
-"""CPU oracle for the ViT / CaiT attention+MLP training path (and the MLP-Mixer family).
+"""CPU oracle for the ViT / CaiT attention+MLP training path (and the MLP-Mixer and TNT families).
 TEST INFRASTRUCTURE ONLY.
 
 This file is a NumPy restatement of the reference's algorithm for the hot path named in
