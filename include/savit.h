@@ -148,6 +148,14 @@ int savit_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int 
 int savit_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int N, int H,
                         int head_dim, int ld_qkv, float dq_scale, void* stream);
 
+/* Very short sequences (TNT's inner transformer, tnt.py:68-76: 16 pixel tokens, 4 heads padded to 16 columns): one wave per
+ * sequence, scores / softmax / outputs in registers.  Same tensor layout and scaling conventions as savit_attention_fwd/bwd with
+ * B = nseq, N = 16, H = 4, head_dim = 16, ld_qkv = 192 - the only geometry accepted (SAVIT_EINVAL otherwise; the tiled kernels
+ * cover the rest).  Backward recomputes P: no lse. */
+int savit_seq16_attention_fwd(const void* qkv, void* o, long nseq, int tokens, int heads, int head_dim_padded, int ld_qkv, void* stream);
+int savit_seq16_attention_bwd(const void* qkv, const void* d_o, void* dqkv, long nseq, int tokens, int heads, int head_dim_padded, int ld_qkv,
+                              float dq_scale, void* stream);
+
 /* ---- Talking-heads attention (CaiT SA layers: attention.py:41-58 with talking_heads=True, talking_heads.py:9-14)
  *   S_h = q_h k_h^T ; S'_i = sum_h T1[h,i] S_h ; P_i = softmax_k(S'_i) ; P'_i = sum_h T2[h,i] P_h ; O_i = P'_i v_i
  * T1/T2 fp32 [H,H] ('h i, b h ... -> b i ...').  H in {2,4,6,8}, head_dim 48 or 64, N <= 256, Np = row pitch of the

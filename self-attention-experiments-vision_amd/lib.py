@@ -63,6 +63,8 @@ _SIGNATURES = {
     "savit_transpose_rowsum_rows": (c_int, [c_int, c_int]),
     "savit_token_mean_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "savit_token_mean_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "savit_seq16_attention_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p]),
+    "savit_seq16_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "savit_tnt_pixel_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "savit_add_rows_periodic": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
     "savit_tnt_inner2outer_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

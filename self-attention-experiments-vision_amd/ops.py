@@ -681,3 +681,24 @@ def scatter_rows(src: torch.Tensor, dst: torch.Tensor, row_stride: int, dst_bf16
     _chk(dst, f32, "dst")
     _lib.check(_lib.load().savit_scatter_rows(_p(src), _p(dst), _p(dst_bf16), row_stride, src.shape[0], src.shape[1], _stream()), "savit_scatter_rows")
     return dst
+
+
+def seq16_attention_fwd(qkv: torch.Tensor, nseq: int) -> torch.Tensor:
+    """One wave per 16-token, 4-head (padded to 16 columns) sequence: qkv bf16 [nseq*16, 192] -> o bf16 [nseq*16, 64]."""
+    _chk(qkv, bf16, "qkv", 2)
+    if tuple(qkv.shape) != (nseq * 16, 192) or not qkv.is_contiguous():
+        raise ValueError("seq16_attention_fwd: qkv must be contiguous [nseq*16, 192]")
+    o = torch.empty((nseq * 16, 64), dtype=bf16, device=qkv.device)
+    _lib.check(_lib.load().savit_seq16_attention_fwd(_p(qkv), _p(o), nseq, 16, 4, 16, 192, _stream()), "savit_seq16_attention_fwd")
+    return o
+
+
+def seq16_attention_bwd(qkv: torch.Tensor, d_o: torch.Tensor, nseq: int, dq_scale: float) -> torch.Tensor:
+    _chk(qkv, bf16, "qkv", 2)
+    _chk(d_o, bf16, "d_o", 2)
+    if tuple(qkv.shape) != (nseq * 16, 192) or tuple(d_o.shape) != (nseq * 16, 64) or not qkv.is_contiguous() or not d_o.is_contiguous():
+        raise ValueError("seq16_attention_bwd: shapes")
+    dqkv = torch.empty_like(qkv)
+    _lib.check(_lib.load().savit_seq16_attention_bwd(_p(qkv), _p(d_o), _p(dqkv), nseq, 16, 4, 16, 192, float(dq_scale), _stream()),
+               "savit_seq16_attention_bwd")
+    return dqkv

@@ -154,6 +154,8 @@ class TNTEngine(ViTEngine):
         self.layout = lay = TNTLayout(cfg)
         do, Fo, C, N, NL, n, npx = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers, cfg.n_patches, cfg.n_pixels
         Fi, dap = lay.Fi, lay.dap
+        # 16 pixel tokens x 4 heads = one 64-lane wave per sequence; other geometries go through the tiled attention kernels
+        self.seq16 = cfg.n_pixels == 16 and Hi == 4 and os.environ.get("SAVIT_TNT_SEQ16", "1") != "0"
         self.Kpi = Kpi = _align(di, 32)            # GEMM K for operands of width di
         self.Kpx = Kpx = _align(lay.pix_in, 64)    # pixel-embedding operand pitch
         self.M = Mo = self.B * N                   # patch-stream rows (name shared with the ViT engine)
@@ -350,8 +352,11 @@ class TNTEngine(ViTEngine):
                                           ist[1].data_ptr(), Mi, di, di, 1e-6, self.rp), p + "iln1")
             self._gemm(P, p + "iqkv", A=self.ih1[l].data_ptr(), Bt=w("iWqkv_t"), C=self.iqkv[l].data_ptr(), M=Mi, N=3 * dap, K=Kpi, lda=di, ldb=Kpi,
                        ldc=3 * dap, epilogue=_lib.EPI_BF16, alpha=ialpha, alpha_cols=dap)
-            P.add(L.savit_attention_fwd, (self.iqkv[l].data_ptr(), self.io[l].data_ptr(), self.ilse[l].data_ptr(), Ms, npx, Hi, HDP, 3 * dap),
-                  p + "iattn")
+            if self.seq16:  # one wave per pixel sequence (seq16_attention.hip)
+                P.add(L.savit_seq16_attention_fwd, (self.iqkv[l].data_ptr(), self.io[l].data_ptr(), Ms, npx, Hi, HDP, 3 * dap), p + "iattn")
+            else:
+                P.add(L.savit_attention_fwd, (self.iqkv[l].data_ptr(), self.io[l].data_ptr(), self.ilse[l].data_ptr(), Ms, npx, Hi, HDP, 3 * dap),
+                      p + "iattn")
             self._gemm(P, p + "iproj", A=self.io[l].data_ptr(), Bt=w("iWo_t"), C=self.ximid[l].data_ptr(), aux=xi[l].data_ptr(), M=Mi, N=di, K=dap,
                        lda=dap, ldb=dap, ldc=di, ldaux=di, epilogue=_lib.EPI_RESID)
             P.add(L.savit_layernorm_fwd, (self.ximid[l].data_ptr(), pp(p + "iln2_g"), pp(p + "iln2_b"), self.ih2[l].data_ptr(), ist[2].data_ptr(),
@@ -469,8 +474,12 @@ class TNTEngine(ViTEngine):
             wgrad(p + "iWo.wgrad", self.io[l].data_ptr(), iring[iri], gp(p + "iWo"), Mi, dap, di, dap, di, di)
             self._gemm(P, p + "iproj.dgrad", A=iring[iri], Bt=w("iWo_n"), C=self.id_o.data_ptr(), M=Mi, N=dap, K=Kpi, lda=di, ldb=Kpi, ldc=dap,
                        epilogue=_lib.EPI_BF16)
-            P.add(L.savit_attention_bwd, (self.iqkv[l].data_ptr(), self.io[l].data_ptr(), self.id_o.data_ptr(), self.ilse[l].data_ptr(), idqkv,
-                                          Ms, npx, Hi, HDP, 3 * dap, 1.0 / math.sqrt(di // Hi)), p + "iattn.bwd", writes=(idqkv,))
+            if self.seq16:
+                P.add(L.savit_seq16_attention_bwd, (self.iqkv[l].data_ptr(), self.id_o.data_ptr(), idqkv, Ms, npx, Hi, HDP, 3 * dap,
+                                                    1.0 / math.sqrt(di // Hi)), p + "iattn.bwd", writes=(idqkv,))
+            else:
+                P.add(L.savit_attention_bwd, (self.iqkv[l].data_ptr(), self.io[l].data_ptr(), self.id_o.data_ptr(), self.ilse[l].data_ptr(), idqkv,
+                                              Ms, npx, Hi, HDP, 3 * dap, 1.0 / math.sqrt(di // Hi)), p + "iattn.bwd", writes=(idqkv,))
             wgrad(p + "iWqkv.wgrad", self.ih1[l].data_ptr(), idqkv, gp(p + "iWqkv"), Mi, di, 3 * dap, di, 3 * dap, 3 * dap)
             self._gemm(P, p + "iqkv.dgrad", A=idqkv, Bt=w("iWqkv_n"), C=self.id_h.data_ptr(), M=Mi, N=di, K=3 * dap, lda=3 * dap, ldb=3 * dap,
                        ldc=di, epilogue=_lib.EPI_BF16)

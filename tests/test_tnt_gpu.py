@@ -77,6 +77,36 @@ def test_stream_glue(pkg):
     assert np.array_equal(back.cpu().numpy()[:, 0], vit_ref.bf16_round(patch[:, 0])) and float(back[:, 1:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("nseq,hd", [(1, 6), (7, 10), (392, 6), (1025, 16)])
+def test_seq16_attention(pkg, nseq, hd):
+    """One-wave-per-sequence attention vs fp64 autograd; pad columns (hd..15 of every head) are zero in, zero out."""
+    from savit_amd import ops
+
+    rng = np.random.default_rng(nseq + hd)
+    qkv = np.zeros((nseq * 16, 3, 4, 16), np.float32)
+    qkv[..., :hd] = vit_ref.bf16_round(rng.standard_normal((nseq * 16, 3, 4, hd)).astype(np.float32))
+    qkv[:, 0] = vit_ref.bf16_round(qkv[:, 0] / np.sqrt(hd) * 2.0)  # pre-scaled queries
+    d_o = np.zeros((nseq * 16, 4, 16), np.float32)
+    d_o[..., :hd] = vit_ref.bf16_round(rng.standard_normal((nseq * 16, 4, hd)).astype(np.float32))
+    t = torch.tensor(qkv.astype(np.float64), requires_grad=True)
+    x = t.view(nseq, 16, 3, 4, 16)
+    q, k, v = x[:, :, 0].permute(0, 2, 1, 3), x[:, :, 1].permute(0, 2, 1, 3), x[:, :, 2].permute(0, 2, 1, 3)
+    o_ref = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(nseq * 16, 4, 16)
+    o_ref.backward(torch.tensor(d_o.astype(np.float64)))
+    g = t.grad.numpy().reshape(nseq * 16, 3, 4, 16)
+    qkv_d = _bf(qkv.reshape(nseq * 16, 192))
+    o = ops.seq16_attention_fwd(qkv_d, nseq).float().cpu().numpy().reshape(nseq * 16, 4, 16)
+    assert np.isfinite(o).all() and rel(o, o_ref.detach().numpy()) < 4e-3
+    assert np.all(o[..., hd:] == 0)
+    dqkv = ops.seq16_attention_bwd(qkv_d, _bf(d_o.reshape(nseq * 16, 64)), nseq, 1.0).float().cpu().numpy().reshape(nseq * 16, 3, 4, 16)
+    assert np.isfinite(dqkv).all() and np.all(dqkv[..., hd:] == 0)
+    for i, nme in enumerate(("dq", "dk", "dv")):
+        assert rel(dqkv[:, i], g[:, i]) < 1.2e-2, (nme, rel(dqkv[:, i], g[:, i]))
+    # and against the tiled kernels the engine used before
+    o2, lse = ops.attention_fwd(qkv_d, nseq, 16, 4, head_dim=16)
+    assert rel(o.reshape(-1, 64), o2.float().cpu().numpy()) < 4e-3
+
+
 # ------------------------------------------------------------------------------------------------ model
 CASES = {
     # inner width 24 (heads 6 wide, K rounded 24 -> 32), 4 patches per image
