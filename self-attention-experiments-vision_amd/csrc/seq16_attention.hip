@@ -10,6 +10,9 @@
 //   (205 MB forward, 360 MB backward at the TNT-B shapes), which is what bounds these kernels.
 // (The LDS regions are private to a wave, yet replacing the workgroup barriers by wave-level hand-offs measured 45 % SLOWER: with
 // the barriers the four waves issue their tile loads together.)
+// Register note: the fully unrolled key loops let hipcc keep every k / v row of a sequence in registers (256 VGPRs, one wave per
+// SIMD, no spills).  Capping the registers with launch bounds, alone or with a scheduling fence per key, made it spill 100-500
+// VGPRs instead (7x slower): the SLP vectoriser pairs iterations across keys before any fence applies.  Left as compiled.
 // Layout as for the tiled kernels: qkv bf16 [S*16, ld] = q (pre-scaled) | k | v, head-major, heads padded to 16 columns (zeros);
 // o bf16 [S*16, 64]; dqkv receives dQ * dq_scale | dK | dV.  P is rounded to bf16 before P.V like an MFMA operand would be.
 #include "common.h"
