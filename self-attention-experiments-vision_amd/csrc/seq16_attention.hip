@@ -10,9 +10,10 @@
 //   (205 MB forward, 360 MB backward at the TNT-B shapes), which is what bounds these kernels.
 // (The LDS regions are private to a wave, yet replacing the workgroup barriers by wave-level hand-offs measured 45 % SLOWER: with
 // the barriers the four waves issue their tile loads together.)
-// Register note: the fully unrolled key loops let hipcc keep every k / v row of a sequence in registers (256 VGPRs, one wave per
-// SIMD, no spills).  Capping the registers with launch bounds, alone or with a scheduling fence per key, made it spill 100-500
-// VGPRs instead (7x slower): the SLP vectoriser pairs iterations across keys before any fence applies.  Left as compiled.
+// Register note: with the key loops fully unrolled hipcc's SLP vectoriser pairs iterations across keys and keeps every k / v row of
+// the sequence live (256 VGPRs, one wave per SIMD; a register cap only made it spill 100-500 VGPRs).  This file is therefore
+// compiled with -fno-slp-vectorize (csrc/Makefile) and backward re-reads its rows after a compiler memory barrier between
+// phases instead of keeping them: 69 VGPRs forward, 132 backward, no spills.
 // Layout as for the tiled kernels: qkv bf16 [S*16, ld] = q (pre-scaled) | k | v, head-major, heads padded to 16 columns (zeros);
 // o bf16 [S*16, 64]; dqkv receives dQ * dq_scale | dK | dV.  P is rounded to bf16 before P.V like an MFMA operand would be.
 #include "common.h"
@@ -64,7 +65,7 @@ __device__ __forceinline__ void row_softmax(const bf16_t* tile, int h, const flo
   for (int key = 0; key < T; ++key) p[key] *= inv;
 }
 
-__global__ __launch_bounds__(256) void seq16_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, long nseq) {
+__global__ __launch_bounds__(256, 4) void seq16_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, long nseq) {
   __shared__ __attribute__((aligned(16))) bf16_t tiles[4][T * 3 * W];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 4, q = lane & 15;
@@ -97,11 +98,11 @@ __global__ __launch_bounds__(256) void seq16_fwd_kernel(const bf16_t* __restrict
   }
 }
 
-__global__ __launch_bounds__(256) void seq16_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o, bf16_t* __restrict__ dqkv,
+__global__ __launch_bounds__(256, 2) void seq16_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o, bf16_t* __restrict__ dqkv,
                                                          long nseq, float dq_scale) {
   __shared__ __attribute__((aligned(16))) bf16_t tiles[4][T * 3 * W];
   __shared__ __attribute__((aligned(16))) bf16_t dots[4][T * W];
-  __shared__ __attribute__((aligned(16))) float pm[4][H * T * T], dsm[4][H * T * T];  // [h][key][q]
+  __shared__ __attribute__((aligned(16))) bf16_t pm[4][H * T * T], dsm[4][H * T * T];  // [h][key][q]; bf16-rounded values
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 4, q = lane & 15;
   bf16_t* tile = tiles[wave];
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(256) void seq16_bwd_kernel(const bf16_t* __restrict
       float qv[16], p[16], dov[16], dq[16], dp[16];
       unpack16(tile + q * 3 * W + h * HP, qv);
       row_softmax(tile, h, qv, p);
+      asm volatile("" ::: "memory");
       unpack16(dot + q * W + h * HP, dov);
       float delta = 0.f;
 #pragma unroll
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(256) void seq16_bwd_kernel(const bf16_t* __restrict
         dp[key] = a;
         delta += p[key] * a;
       }
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int e = 0; e < 16; ++e) dq[e] = 0.f;
 #pragma unroll
@@ -143,8 +146,8 @@ __global__ __launch_bounds__(256) void seq16_bwd_kernel(const bf16_t* __restrict
         unpack16(tile + key * 3 * W + W + h * HP, kv);
 #pragma unroll
         for (int e = 0; e < 16; ++e) dq[e] += ds * kv[e];
-        pm[wave][(h * T + key) * T + q] = round_bf16(p[key]);
-        dsm[wave][(h * T + key) * T + q] = ds;
+        pm[wave][(h * T + key) * T + q] = f32_to_bf16(p[key]);
+        dsm[wave][(h * T + key) * T + q] = f32_to_bf16(ds);
       }
       store16(dqkv + ((size_t)seq * T + q) * 3 * W + h * HP, dq, dq_scale);
     }
@@ -152,13 +155,8 @@ __global__ __launch_bounds__(256) void seq16_bwd_kernel(const bf16_t* __restrict
     if (live) {  // pass 2: lane = (h, key)
       const int key = q;
       float pc[16], dc[16], dk[16], dv[16];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 a = reinterpret_cast<const float4*>(pm[wave] + (h * T + key) * T)[i];
-        const float4 b = reinterpret_cast<const float4*>(dsm[wave] + (h * T + key) * T)[i];
-        pc[4 * i] = a.x; pc[4 * i + 1] = a.y; pc[4 * i + 2] = a.z; pc[4 * i + 3] = a.w;
-        dc[4 * i] = b.x; dc[4 * i + 1] = b.y; dc[4 * i + 2] = b.z; dc[4 * i + 3] = b.w;
-      }
+      unpack16(pm[wave] + (h * T + key) * T, pc);
+      unpack16(dsm[wave] + (h * T + key) * T, dc);
 #pragma unroll
       for (int e = 0; e < 16; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
 #pragma unroll
