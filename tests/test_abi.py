@@ -58,3 +58,32 @@ def test_product_does_not_import_oracle():
                 s = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M), f"{f} imports the oracle"
                 assert "from oracle" not in s and "import oracle" not in s
+
+
+def test_shape_contracts_are_checked_on_the_host(built):
+    """Every entry point validates its arguments BEFORE touching the GPU (a wrong shape must never reach a hand-written kernel):
+    contract violations return SAVIT_EINVAL (1001) - checked here without a GPU, with fake non-null pointers."""
+    L = built.lib.load()
+    P, EINVAL = 0x1000, 1001  # 16-B aligned dummy address, never dereferenced on these paths
+    # one-wave-per-sequence attention accepts exactly 16 tokens x 4 heads x 16 padded columns
+    assert L.savit_seq16_attention_fwd(P, P, 8, 16, 6, 16, 192, None) == EINVAL
+    assert L.savit_seq16_attention_fwd(P, P, 8, 32, 4, 16, 192, None) == EINVAL
+    assert L.savit_seq16_attention_bwd(P, P, P, 8, 16, 4, 16, 200, 1.0, None) == EINVAL
+    # tiled attention: head_dim outside {16, 32, 48, 64}, too many tokens
+    assert L.savit_attention_fwd(P, P, None, 2, 197, 3, 40, 3 * 3 * 40, None) == EINVAL
+    assert L.savit_attention_fwd(P, P, None, 2, 700, 3, 64, 3 * 3 * 64, None) == EINVAL
+    # per-image transpose: pitches must be multiples of 8 and cover the matrix; residual in/out come together
+    assert L.savit_transpose_bf16(P, 196 * 128, 128, P, 128 * 190, 190, 2, 196, 128, None, None, 0, None, 0, None) == EINVAL  # ld_dst < R
+    assert L.savit_transpose_bf16(P, 196 * 124, 124, P, 128 * 200, 200, 2, 196, 128, None, None, 0, None, 0, None) == EINVAL  # ld_src < Cc
+    assert L.savit_transpose_bf16(P, 196 * 128, 128, None, 0, 128, 2, 128, 196, P, None, 0, None, 0, None) == EINVAL        # resid without out
+    # column-sum helpers are written for d <= 1024, LayerNorm for d % 4 == 0
+    assert L.savit_cast_colsum(P, P, P, 10, 2048, None) == EINVAL
+    assert L.savit_tnt_inner2outer_split(P, P, P, None, 2, 1, 64, None) == EINVAL  # needs a cls row plus at least one patch row
+    assert L.savit_layernorm_fwd(P, P, P, P, None, None, 4, 30, 32, 1e-6, 1, None) == EINVAL
+    assert L.savit_tnt_pixel_gather(P, P, 2, 224, 16, 5, 3, 80, None) == EINVAL  # patch % transformed patch != 0
+    # GEMM: K must be a multiple of the 32-deep K-step, pitches multiples of 8
+    a = built.lib.GemmArgs()
+    a.A, a.Bt, a.C, a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.epilogue, a.rows_per_sample = P, P, P, 64, 64, 40, 40, 40, 64, 0, 1
+    assert L.savit_gemm_bf16_tn(ctypes.byref(a), None) == EINVAL
+    a.K, a.ldb, a.lda = 64, 64, 20  # an operand pitch that is not a multiple of 8 elements
+    assert L.savit_gemm_bf16_tn(ctypes.byref(a), None) == EINVAL
