@@ -7,6 +7,12 @@
 // holds d/64 elements as float4 chunks (lane i takes chunks i, i+64, ...), so every wave-level load
 // is a coalesced 1 KiB and reductions are wave shuffles only.  d % 4 == 0, d <= 4096.
 // Algorithmic bytes: fwd (4+2)*rows*d + 8*rows; bwd (2+4+4+4+2)*rows*d.
+//
+// This file is compiled TWICE (csrc/Makefile): layernorm.o holds backward / LayerScale / finalize, layernorm_fwd.o (-DLN_FWD_TU
+// -fno-slp-vectorize) the forward kernels.  Reason: when two PROCESSES time-slice one GPU, a forward launch built with the SLP
+// vectoriser's packed fp32 math returned perturbed rows about once in 200 launches (the low half of a v_pk_*_f32 result, both the
+// wide and the narrow kernel; tools/kernel_det_probe.py), never when built without it and never in the backward kernels - which
+// lose 12 % without the packed math (register pressure), so they keep it.  One process per GPU was never affected.
 #include "common.h"
 #include "savit.h"
 
@@ -16,6 +22,7 @@ constexpr int LN_THREADS = 256;
 constexpr int LN_WAVES = LN_THREADS / 64;
 constexpr int LN_MAX_CHUNKS = 16;  // 16 float4 * 64 lanes = 4096 columns
 
+#ifdef LN_FWD_TU  // the forward kernels are compiled as their own translation unit (see the note at the end of this comment block)
 template <int CH>  // CH = ceil(d/4/64) chunks per lane
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, bf16_t* __restrict__ y,
@@ -83,6 +90,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
 //   out  = dx (+ dres_in)           -> fp32 dx_out (gradient of the residual stream) and optional bf16 copy
 //   dgamma += sum_rows dy*xhat ; dbeta += sum_rows dy ; dcolsum += sum_rows out   (per-lane registers ->
 //   LDS cross-wave -> per-block partial slab -> finalize kernel)
+#else  // !LN_FWD_TU
 template <int CH>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ gamma, const float* __restrict__ mean_in,
@@ -204,6 +212,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
   }
 }
 
+#endif  // LN_FWD_TU (row16_sum below is shared)
 // ------------------------------------------------------------------------------------------------------------
 // Narrow rows (d <= 64: TNT's pixel stream, 24 / 40 channels).  One 64-lane wave per row would keep 6 - 10 lanes busy; here a
 // row is owned by one DPP row of 16 lanes (a lane holds one float4), i.e. 4 rows per wave and 16 per workgroup, and the row
@@ -216,6 +225,7 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+#ifdef LN_FWD_TU
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_narrow_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, int d,
@@ -254,6 +264,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_narrow_kernel(const float* 
   }
 }
 
+#else  // !LN_FWD_TU
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_narrow_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                                     const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                                     const float* __restrict__ rstd_in, const float* __restrict__ dres_in,
@@ -409,6 +420,7 @@ __global__ __launch_bounds__(LN_THREADS) void layerscale_bwd_kernel(const float*
   }
 }
 
+#endif  // LN_FWD_TU
 inline int ln_grid(int rows, int cap) {
   int g = (rows + LN_WAVES - 1) / LN_WAVES;
   return g < cap ? (g < 1 ? 1 : g) : cap;
@@ -427,6 +439,7 @@ inline int ln_grid(int rows, int cap) {
     default: hipLaunchKernelGGL(KERNEL<16>, dim3(GRID), dim3(LN_THREADS), 0, s, __VA_ARGS__); break; \
   }
 
+#ifdef LN_FWD_TU
 extern "C" int savit_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                    int rows, int d, long x_stride, float eps, int round_params_bf16, void* stream) {
   SAVIT_CHECK_ARG(x && gamma && beta && y && x_stride >= d && (x_stride % 4) == 0 && rows >= 0 && d > 0 && (d % 4) == 0 && d <= 64 * 4 * LN_MAX_CHUNKS);
@@ -457,6 +470,7 @@ extern "C" int savit_layernorm_fwd_mapped(const float* x, const float* gamma, co
   SAVIT_LAUNCH_RET();
 }
 
+#else  // !LN_FWD_TU
 static int ln_bwd_grid(int rows) { return ln_grid(rows, 256 * 3); }
 extern "C" int savit_layernorm_bwd_mapped(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                           const float* dres_in, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* dcolsum, int rows,
@@ -526,3 +540,5 @@ extern "C" int savit_layerscale_bwd(const float* dres, const void* branch_bf16, 
   SAVIT_LAUNCH_RET();
 }
 
+
+#endif  // LN_FWD_TU

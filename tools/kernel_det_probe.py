@@ -1,12 +1,15 @@
-"""Bitwise repeatability of individual kernels (dev tool).  Alone on the GPU every kernel here repeats bit for bit (1 500 iterations);
-when TWO PROCESSES time-slice one GPU (the multi-rank rehearsal of tests/test_ddp_gpu.py) the LayerNorm forward kernels - wide and
-narrow - were observed to return a few wrong rows about once in 200 launches (one float4 component of every lane of a row group,
-1-25 % off), the GEMM and attention kernels never.  One process per GPU (the deployment model, bench.py) is not affected.
-Usage: python tools/kernel_det_probe.py [iterations]   (run two copies at once to reproduce)."""
+"""Bitwise repeatability of individual kernels (dev tool).  Alone on the GPU every kernel here repeats bit for bit (1 500 iterations).
+When TWO PROCESSES time-slice one GPU (the multi-rank rehearsal of tests/test_ddp_gpu.py) the LayerNorm FORWARD kernels built with
+SLP-packed fp32 math returned a few wrong rows about once in 200 launches; built without it (csrc/Makefile: layernorm_fwd.o) none in
+2 x 1 500 launches.  Backward, GEMM and attention kernels never differed.  One process per GPU (bench.py) was never affected.
+Usage: python tools/kernel_det_probe.py [iterations]   (run two copies at once to reproduce; SAVIT_EXP_LIB selects a variant build)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import savit_amd
+from savit_amd import lib as _l0
+if os.environ.get("SAVIT_EXP_LIB"):
+    _l0.LIB_PATH = os.path.join(os.path.dirname(_l0.LIB_PATH), "exp", "libsavit_%s.so" % os.environ["SAVIT_EXP_LIB"])
 from savit_amd import ops
 bf = torch.bfloat16
 torch.manual_seed(0)
@@ -27,13 +30,25 @@ def gemm(A, Bt, M, N, K, lda, epi, C, auxp=None):
     if auxp is not None: a.aux, a.ldaux = auxp.data_ptr(), N
     rc = L.savit_gemm_bf16_tn(ctypes.byref(a), torch.cuda.current_stream().cuda_stream); assert rc == 0, rc
     return C
+dy24 = torch.randn(rows, 24, device="cuda").to(bf); dres24 = torch.randn(rows, 24, device="cuda")
+dy384 = torch.randn(4 * 197, 384, device="cuda").to(bf); dres384 = torch.randn(4 * 197, 384, device="cuda")
+_, m24, r24 = ops.layernorm_fwd(x24, g24, b24)
+_, m384, r384 = ops.layernorm_fwd(x384, g384, b384)
+def ln_bwd(dy, x, g, m, r, dres):
+    d = x.shape[1]
+    dg, db = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+    out = ops.layernorm_bwd(dy, x, g, m, r, dg, db, dres_in=dres)
+    dx = out[0] if isinstance(out, (tuple, list)) else out
+    return dx.clone(), dg  # dg is reduced through a finalize with atomics: compared loosely below
 def tests():
     y24, m, r = ops.layernorm_fwd(x24, g24, b24)
     y384, m2, r2 = ops.layernorm_fwd(x384, g384, b384)
     c = gemm(A32, W, rows, 192, 32, 24, 0, torch.empty(rows, 192, device="cuda", dtype=bf))
     c2 = gemm(A64, W64, rows, 24, 64, 64, 2, torch.empty(rows, 24, device="cuda"), aux)
     o = ops.seq16_attention_fwd(qkv, 4 * 196)
-    return {"ln24": y24.clone(), "ln24_mean": m.clone(), "ln384": y384.clone(), "gemm_k32": c, "gemm_resid_k64": c2, "seq16": o}
+    bx24, _ = ln_bwd(dy24, x24, g24, m24, r24, dres24)
+    bx384, _ = ln_bwd(dy384, x384, g384, m384, r384, dres384)
+    return {"lnbwd24": bx24, "lnbwd384": bx384, "ln24": y24.clone(), "ln24_mean": m.clone(), "ln384": y384.clone(), "gemm_k32": c, "gemm_resid_k64": c2, "seq16": o}
 ref = tests(); torch.cuda.synchronize()
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 300):
     cur = tests(); torch.cuda.synchronize()
