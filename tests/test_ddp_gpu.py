@@ -73,7 +73,7 @@ def _rank_main(rank, world, port, cfg_name, B, steps, out_path):
 
 
 @pytest.mark.parametrize("cfg_name,side_streams", [("vit_ti_patch16", "1"), ("vit_ti_patch16", "3"), ("mixer_s_patch32", "1"),
-                                                   ("tnt_b_patch16", "1")])
+                                                   ("tnt_b_patch16", "1"), ("cait_xxs_24", "1")])
 def test_two_rank_step_matches_single_engine(tmp_path, cfg_name, side_streams, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -82,7 +82,7 @@ def test_two_rank_step_matches_single_engine(tmp_path, cfg_name, side_streams, m
     monkeypatch.setenv("SAVIT_SIDE_STREAMS", side_streams)
     B, steps = 8, 2
     out = str(tmp_path / "p.pt")
-    port = 29600 + int(side_streams) + 10 * ["vit_ti_patch16", "mixer_s_patch32", "tnt_b_patch16"].index(cfg_name)
+    port = 29600 + int(side_streams) + 10 * ["vit_ti_patch16", "mixer_s_patch32", "tnt_b_patch16", "cait_xxs_24"].index(cfg_name)
     mp.spawn(_rank_main, args=(2, port, cfg_name, B, steps, out), nprocs=2, join=True)
     dp = torch.load(out)
 
