@@ -158,7 +158,7 @@ int savit_seq16_attention_bwd(const void* qkv, const void* d_o, void* dqkv, long
 
 /* ---- Talking-heads attention (CaiT SA layers: attention.py:41-58 with talking_heads=True, talking_heads.py:9-14)
  *   S_h = q_h k_h^T ; S'_i = sum_h T1[h,i] S_h ; P_i = softmax_k(S'_i) ; P'_i = sum_h T2[h,i] P_h ; O_i = P'_i v_i
- * T1/T2 fp32 [H,H] ('h i, b h ... -> b i ...').  H in {2,4,6,8}, head_dim 48 or 64, N <= 256, Np = row pitch of the
+ * T1/T2 fp32 [H,H] ('h i, b h ... -> b i ...').  H in {2,4,6,8,16}, head_dim 48 or 64, N <= 256, Np = row pitch of the
  * score buffers (multiple of 8, >= N).  s_buf / p_buf: bf16 [B,H,N,Np] outputs of forward that backward consumes (S is kept,
  * p_buf is overwritten with dS); ds_buf: bf16 scratch of the same size; dT1/dT2 fp32 [H,H] are accumulated.
  * dqkv receives dQ*dq_scale | dK | dV like savit_attention_bwd. */

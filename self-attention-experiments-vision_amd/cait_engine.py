@@ -117,8 +117,8 @@ class CaiTEngine:
     def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True):
         if cfg.kind != "cait":
             raise ValueError("CaiTEngine needs a CaiT config")
-        if cfg.head_dim not in (48, 64) or cfg.num_heads not in (2, 4, 6, 8):
-            raise NotImplementedError("talking-heads kernels: head_dim 48/64 and 2/4/6/8 heads (cait_m_* has 16 heads)")
+        if cfg.head_dim not in (48, 64) or cfg.num_heads not in (2, 4, 6, 8, 16):
+            raise NotImplementedError("talking-heads kernels: head_dim 48/64 and 2/4/6/8/16 heads")
         if cfg.n_patches + 1 > 256:
             raise NotImplementedError("talking-heads / class-attention kernels: at most 255 patches")
         if cfg.embed_dim % 32 or cfg.patch % 8 or cfg.num_classes % 8:

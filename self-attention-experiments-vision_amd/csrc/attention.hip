@@ -1136,16 +1136,19 @@ template <int H>
 __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __restrict__ S, const bf16_t* __restrict__ dPp, bf16_t* __restrict__ dS,
                                                               const float* __restrict__ T1g, const float* __restrict__ T2g,
                                                               float* __restrict__ slab, int B, int N, int Np) {
-  static_assert(H <= 8, "dT partials are reduce-scattered as 8x8 tiles");
+  static_assert(H <= 8 || H == 16, "dT partials are reduce-scattered as 8x8 tiles: up to 8 heads, or 16 as four tiles per matrix");
+  constexpr int NB = (H + 7) / 8;  // 8x8 tiles per dimension of dT (H = 16: cait_m_*; that path spills registers - correct, not fast)
   __shared__ float T1[H * H], T2[H * H];
-  __shared__ float red[4][128];
+  __shared__ float red[4][2 * NB * NB * 64];
   for (int i = threadIdx.x; i < H * H; i += blockDim.x) {
     T1[i] = T1g[i];
     T2[i] = T2g[i];
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float acc1 = 0.f, acc2 = 0.f;  // lane l accumulates dT1 / dT2 entry (h = l>>3, i = l&7)
+  float acc1[NB * NB], acc2[NB * NB];  // lane l accumulates dT1 / dT2 entry (h = 8*hb + (l>>3), i = 8*ib + (l&7)) of tile hb*NB + ib
+#pragma unroll
+  for (int t = 0; t < NB * NB; ++t) acc1[t] = acc2[t] = 0.f;
   const long rows = (long)B * N;
   for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
     const int b = (int)(row / N), q = (int)(row - (long)b * N);
@@ -1194,7 +1197,7 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
     }
     // ---- dT2[h][i] += sum_k P_h dP'_i ; dP_h = sum_i T2[h][i] dP'_i ; delta_h = sum_k P_h dP_h
     float dp[H][TH_KPL], del[H];
-    {
+    if constexpr (H <= 8) {
       float g[64];
 #pragma unroll
       for (int j = 0; j < 64; ++j) g[j] = 0.f;
@@ -1217,12 +1220,74 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
           del[h] += pr[h][k] * a;
         }
       }
-      acc2 += reduce_scatter64(g, lane);
+      acc2[0] += reduce_scatter64(g, lane);
+    } else {
+#pragma unroll
+      for (int h = 0; h < H; ++h) del[h] = 0.f;
+#pragma unroll
+      for (int k = 0; k < TH_KPL; ++k) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          float a = 0.f;
+#pragma unroll
+          for (int i = 0; i < H; ++i) a += T2[h * H + i] * th_unpack(dq[i][k >> 1], k & 1);
+          dp[h][k] = a;
+          del[h] += pr[h][k] * a;
+        }
+      }
+#pragma unroll
+      for (int hb = 0; hb < NB; ++hb)
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) {
+          float g[64];
+#pragma unroll
+          for (int j = 0; j < 64; ++j) g[j] = 0.f;
+#pragma unroll
+          for (int k = 0; k < TH_KPL; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const float dvi = th_unpack(dq[ib * 8 + i][k >> 1], k & 1);
+#pragma unroll
+              for (int h = 0; h < 8; ++h) g[h * 8 + i] += pr[hb * 8 + h][k] * dvi;
+            }
+          acc2[hb * NB + ib] += reduce_scatter64(g, lane);
+        }
     }
 #pragma unroll
     for (int h = 0; h < H; ++h) del[h] = wave_sum(del[h]);
     // ---- dS'_i = P_i (dP_i - delta_i) ; dS_h = sum_i T1[h][i] dS'_i ; dT1[h][i] += sum_k S_h dS'_i
-    {
+    if constexpr (H > 8) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float o4[TH_KPL];
+#pragma unroll
+        for (int k = 0; k < TH_KPL; ++k) {
+          float a = 0.f;
+#pragma unroll
+          for (int i = 0; i < H; ++i) a += T1[h * H + i] * (pr[i][k] * (dp[i][k] - del[i]));
+          o4[k] = (4 * lane + k < N) ? a : 0.f;
+        }
+        if (in_row)
+          *reinterpret_cast<uint2*>(dS + (((size_t)b * H + h) * N + q) * Np + 4 * lane) = make_uint2(pack_bf16x2(o4[0], o4[1]), pack_bf16x2(o4[2], o4[3]));
+      }
+#pragma unroll
+      for (int hb = 0; hb < NB; ++hb)
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) {
+          float g[64];
+#pragma unroll
+          for (int j = 0; j < 64; ++j) g[j] = 0.f;
+#pragma unroll
+          for (int k = 0; k < TH_KPL; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const float dspi = pr[ib * 8 + i][k] * (dp[ib * 8 + i][k] - del[ib * 8 + i]);
+#pragma unroll
+              for (int h = 0; h < 8; ++h) g[h * 8 + i] += th_unpack(sp[hb * 8 + h][k >> 1], k & 1) * dspi;
+            }
+          acc1[hb * NB + ib] += reduce_scatter64(g, lane);
+        }
+    } else {
       float g[64];
 #pragma unroll
       for (int j = 0; j < 64; ++j) g[j] = 0.f;
@@ -1252,16 +1317,20 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
           *reinterpret_cast<uint2*>(dS + (((size_t)b * H + h) * N + q) * Np + 4 * lane) =
               make_uint2(pack_bf16x2(dsv[h][0], dsv[h][1]), pack_bf16x2(dsv[h][2], dsv[h][3]));
       }
-      acc1 += reduce_scatter64(g, lane);
+      acc1[0] += reduce_scatter64(g, lane);
     }
   }
-  red[wave][lane] = acc1;
-  red[wave][64 + lane] = acc2;
+#pragma unroll
+  for (int t = 0; t < NB * NB; ++t) {
+    red[wave][t * 64 + lane] = acc1[t];
+    red[wave][(NB * NB + t) * 64 + lane] = acc2[t];
+  }
   __syncthreads();
-  // slab row: [dT1 (H*H) | dT2 (H*H)], entry (h, i) sits in reduce-scatter lane h*8 + i
+  // slab row: [dT1 (H*H) | dT2 (H*H)], entry (h, i) sits in tile (h/8, i/8), reduce-scatter lane (h%8)*8 + i%8
   for (int t = threadIdx.x; t < 2 * H * H; t += blockDim.x) {
     const int which = t / (H * H), e = t - which * H * H;
-    const int src = which * 64 + (e / H) * 8 + (e % H);
+    const int h = e / H, i = e % H;
+    const int src = (which * NB * NB + (h >> 3) * NB + (i >> 3)) * 64 + (h & 7) * 8 + (i & 7);
     slab[(size_t)blockIdx.x * 2 * H * H + t] = red[0][src] + red[1][src] + red[2][src] + red[3][src];
   }
 }
@@ -1386,6 +1455,7 @@ static int th_fill(ThParams& p, const void* qkv, int B, int N, int H, int head_d
     case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(GRID), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
     case 6: hipLaunchKernelGGL(KERNEL<6>, dim3(GRID), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
     case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(GRID), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(GRID), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
     default: return SAVIT_EINVAL;                                                                          \
   }
 
@@ -1400,7 +1470,7 @@ extern "C" int savit_th_attention_fwd(const void* qkv, const float* T1, const fl
   ThParams p{};
   int rc = th_fill(p, qkv, B, N, H, head_dim, ld_qkv, Np);
   if (rc) return rc;
-  SAVIT_CHECK_ARG(T1 && T2 && s_buf && p_buf && o && (H == 2 || H == 4 || H == 6 || H == 8));
+  SAVIT_CHECK_ARG(T1 && T2 && s_buf && p_buf && o && (H == 2 || H == 4 || H == 6 || H == 8 || H == 16));
   if (B == 0) return SAVIT_OK;
   p.sbuf = (bf16_t*)s_buf; p.pbuf = (bf16_t*)p_buf; p.o = (bf16_t*)o;
   const size_t lds = (size_t)p.nt * 32 * ROWB;
@@ -1423,7 +1493,7 @@ extern "C" int savit_th_attention_bwd(const void* qkv, const float* T1, const fl
   ThParams p{};
   int rc = th_fill(p, qkv, B, N, H, head_dim, ld_qkv, Np);
   if (rc) return rc;
-  SAVIT_CHECK_ARG(T1 && T2 && s_buf && p_buf && d_o && ds_buf && dqkv && dT1 && dT2 && (H == 2 || H == 4 || H == 6 || H == 8));
+  SAVIT_CHECK_ARG(T1 && T2 && s_buf && p_buf && d_o && ds_buf && dqkv && dT1 && dT2 && (H == 2 || H == 4 || H == 6 || H == 8 || H == 16));
   SAVIT_CHECK_ARG(workspace && workspace_bytes >= savit_th_attention_bwd_workspace_bytes(B, N, H) && ((uintptr_t)workspace % 16) == 0);
   if (B == 0) return SAVIT_OK;
   const int threads = 64 * (p.nt < 8 ? p.nt : 8);

@@ -499,7 +499,8 @@ def test_cast_transpose_and_layout(ops):
 
 
 # ------------------------------------------------------------------------------------------ talking-heads attention (CaiT)
-@pytest.mark.parametrize("B,N,H,hd", [(2, 196, 8, 48), (1, 196, 4, 48), (2, 50, 6, 48), (1, 33, 2, 64), (1, 197, 8, 48)])
+@pytest.mark.parametrize("B,N,H,hd", [(2, 196, 8, 48), (1, 196, 4, 48), (2, 50, 6, 48), (1, 33, 2, 64), (1, 197, 8, 48),
+                                      (2, 196, 16, 48), (1, 37, 16, 48)])  # 16 heads: cait_m_* (dT reduced as four 8x8 tiles)
 def test_talking_heads_attention(ops, B, N, H, hd):
     """attention.py:41-58 with talking_heads=True: fp64 autograd reference incl. dT1/dT2 (talking_heads.py:13)."""
     rng = np.random.default_rng(B + N + H)

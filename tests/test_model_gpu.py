@@ -192,10 +192,13 @@ CAIT_CASES = {
                       stoch_depth_rate=0.1, layerscale_eps=1e-5),
     "xxs2": dict(kind="cait", num_layers=2, num_heads=4, embed_dim=192, patch=16, num_classes=1000, img_size=224, num_layers_token_only=2,
                  stoch_depth_rate=0.05, layerscale_eps=1e-5),
+    # the cait_m_* geometry: 16 heads of 48 (d = 768), 196 patches
+    "m1": dict(kind="cait", num_layers=1, num_heads=16, embed_dim=768, patch=16, num_classes=1000, img_size=224, num_layers_token_only=1,
+               stoch_depth_rate=0.2, layerscale_eps=1e-5),
 }
 
 
-@pytest.mark.parametrize("case,B,training", [("tiny_cait", 3, False), ("tiny_cait", 4, True), ("xxs2", 2, True)])
+@pytest.mark.parametrize("case,B,training", [("tiny_cait", 3, False), ("tiny_cait", 4, True), ("xxs2", 2, True), ("m1", 2, True)])
 def test_cait_forward_backward_parity(pkg, case, B, training):
     """Talking-heads SA + LayerScale + stochastic depth + class attention end to end vs the fp32 oracle / fp32 autograd.
     Training mode uses explicit per-sample keep masks (the JAX rng stream cannot be reproduced)."""
@@ -237,7 +240,7 @@ def test_cait_reference_shapes_and_known_answers(pkg):
     """models/cait_test.py:13-40 (logits (2, 1000) on ones for the CaiT sizes; here the smallest and cait_s_24) + SURVEY 8c vi."""
     from savit_amd.model import create_model
 
-    for name, count in (("cait_xxs_24", None), ("cait_s_24", 46_875_496)):
+    for name, count in (("cait_xxs_24", None), ("cait_s_24", 46_875_496), ("cait_m_24", None)):
         model = create_model(name)
         logits, params = model.init_with_output(0, torch.ones(2, 224, 224, 3, device="cuda"), is_training=False)
         assert tuple(logits.shape) == (2, 1000)
