@@ -769,6 +769,26 @@ __device__ __forceinline__ void store_tile_T(bf16_t* rowp, const f32x16& a, int 
       *reinterpret_cast<uint2*>(rowp + key) = make_uint2(pack_bf16x2(a[4 * g4], a[4 * g4 + 1]), pack_bf16x2(a[4 * g4 + 2], a[4 * g4 + 3]));
   }
 }
+// Two adjacent key tiles (64 keys = one 128-B row segment per query) through a 4 KB image private to the wave, so that the HBM
+// stores are whole row segments: 8 lanes x 16 B per row, 8 rows per instruction, instead of 16 B per row and 32 rows per
+// instruction (partial lines: the 167 MB S / dP' tensors were written at 2.3 TB/s).  `tile` uses the staged images' layout
+// (128-B rows, 16-B chunk index XORed with rot3(row)); the LDS pipe is in order per wave, so no barrier is needed.
+__device__ __forceinline__ void park_tile_T(char* tile, const f32x16& a, int sub, int ql, int half) {
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4)
+    *reinterpret_cast<uint2*>(tile + ql * ROWB + (((sub * 4 + g4) ^ rot3(ql)) << 4) + 8 * half) =
+        make_uint2(pack_bf16x2(a[4 * g4], a[4 * g4 + 1]), pack_bf16x2(a[4 * g4 + 2], a[4 * g4 + 3]));
+}
+__device__ __forceinline__ void drain_tile_pair(const char* tile, bf16_t* buf, int q0, int ktp, int lane, int N, int Np) {
+  const int r = lane >> 3, c = lane & 7;
+  const int key = ktp * 64 + 8 * c;  // Np % 8 == 0: a 16-B chunk is entirely inside or outside the row
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = r + 8 * i;
+    const uint4 v = *reinterpret_cast<const uint4*>(tile + row * ROWB + ((c ^ rot3(row)) << 4));
+    if (q0 + row < N && key < Np) *reinterpret_cast<uint4*>(buf + (size_t)(q0 + row) * Np + key) = v;
+  }
+}
 // B-operand fragment of k-step s2 read from buf[q][.]: elements j <-> key = kt*32 + 16*s2 + 8*(j>>2) + 4*half + (j&3)
 __device__ __forceinline__ bf16x8 load_tile_T_frag(const bf16_t* rowp, bool row_ok, int kt, int s2, int half, int Np) {
   union { uint2 u[2]; bf16x8 v; } r;
@@ -807,6 +827,7 @@ __global__ __launch_bounds__(512) void th_scores_kernel(const ThParams p) {
   __syncthreads();
   const int ql = lane & 31, half = lane >> 5;
   bf16_t* sb = p.sbuf + ((size_t)b * p.H + hh) * p.N * p.Np;
+  char* tile = smem + (size_t)NT * 32 * ROWB + (size_t)wave * (32 * ROWB);
   for (int qb = wave; qb < NT; qb += nwv) {
     const int q = qb * 32 + ql;
     bf16x8 qf[4];
@@ -820,7 +841,8 @@ __global__ __launch_bounds__(512) void th_scores_kernel(const ThParams p) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
         if (16 * ks < hd) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(smem, kt * 32 + ql, 2 * ks + half), qf[ks], sa, 0, 0, 0);
-      if (q < p.N) store_tile_T(sb + (size_t)q * p.Np, sa, kt, half, p.Np);
+      park_tile_T(tile, sa, kt & 1, ql, half);
+      if ((kt & 1) || kt + 1 == NT) drain_tile_pair(tile, sb, qb * 32, kt >> 1, lane, p.N, p.Np);
     }
   }
 }
@@ -918,6 +940,7 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  char* ptile = smem + (size_t)NT * 32 * ROWB + (size_t)wave * (32 * ROWB);  // the wave's private tile (pass B reuses it)
   if (qb < NT) {
     if (MODE == 0) {
       for (int kt = 0; kt < NT; ++kt) {
@@ -927,7 +950,8 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
           if (16 * ks < hd) da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(smem, kt * 32 + ql, 2 * ks + half), df[ks], da, 0, 0, 0);
-        if (q < p.N) store_tile_T(p.pbuf + bh + (size_t)q * p.Np, da, kt, half, p.Np);
+        park_tile_T(ptile, da, kt & 1, ql, half);
+        if ((kt & 1) || kt + 1 == NT) drain_tile_pair(ptile, p.pbuf + bh, qb * 32, kt >> 1, lane, p.N, p.Np);
       }
     } else {
       f32x16 dq[2];
@@ -1475,11 +1499,12 @@ extern "C" int savit_th_attention_fwd(const void* qkv, const float* T1, const fl
   p.sbuf = (bf16_t*)s_buf; p.pbuf = (bf16_t*)p_buf; p.o = (bf16_t*)o;
   const size_t lds = (size_t)p.nt * 32 * ROWB;
   const int threads = 64 * (p.nt < 8 ? p.nt : 8);
-  hipError_t e = hipFuncSetAttribute((const void*)th_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const size_t lds_scores = lds + (size_t)(threads / 64) * 32 * ROWB;  // + one 32-row tile per wave for the coalesced S stores
+  hipError_t e = hipFuncSetAttribute((const void*)th_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scores);
   if (e != hipSuccess) return (int)e;
   e = hipFuncSetAttribute((const void*)th_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(th_scores_kernel, dim3(B * H), dim3(threads), lds, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(th_scores_kernel, dim3(B * H), dim3(threads), lds_scores, (hipStream_t)stream, p);
   long rows = (long)B * N, blocks = (rows + 3) / 4;
   if (blocks > 16384) blocks = 16384;
   TH_H_DISPATCH(th_softmax_fwd_kernel, (unsigned)blocks, (const bf16_t*)s_buf, (bf16_t*)p_buf, T1, T2, B, N, Np)
