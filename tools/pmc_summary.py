@@ -7,7 +7,7 @@ def agg(path):
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
-        m = re.search(r"(gemm_\w+<[^>]*>|attn_\w+<\d+>|ln_\w+<\d+>|adamw_kernel|th_\w+(<\d+>)?|layerscale_bwd_kernel<\d+>|class_attn_\w+<\d+>)", name)
+        m = re.search(r"(gemm_\w+<[^>]*>|attn_\w+<\d+>|ln_\w+<\d+>|adamw_kernel|th_\w+(<\d+>)?|layerscale_bwd_kernel<\d+>|class_attn_\w+<\d+>|transpose_bf16_kernel|token_mean_\w+|seq16_\w+_kernel|cast_colsum_kernel|inner2outer_\w+_kernel|pixel_gather_kernel|colsum_finalize_kernel)", name)
         if m:
             d[m.group(1).replace(" ", "")].append(float(r["Counter_Value"]))
     return d
@@ -21,7 +21,8 @@ for k in sorted(set(f) | set(w)):
     wk = sum(w.get(k, [0])) / max(1, len(w.get(k, [0])))
     res[k] = {"launches": len(f.get(k, [])), "fetch_bytes_corrected": round(2 * fk * 1024), "write_bytes": round(wk * 1024),
               "traffic_bytes": round((2 * fk + wk) * 1024)}
-json.dump({"note": "per-launch averages over one bench.py run (DeiT-B/16, 128 img); FETCH_SIZE doubled per MI355X_MICROARCH.md", "kernels": res},
+note = sys.argv[4] if len(sys.argv) > 4 else "DeiT-B/16, 128 img"
+json.dump({"note": f"per-launch averages over one bench.py run ({note}); FETCH_SIZE doubled per MI355X_MICROARCH.md", "kernels": res},
           open(out, "w"), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["traffic_bytes"])[:14]:
     print(f"{k:50s} fetch {v['fetch_bytes_corrected']/1e6:8.1f} MB  write {v['write_bytes']/1e6:8.1f} MB")
