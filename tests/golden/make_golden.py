@@ -18,6 +18,11 @@ TINY_CAIT = vit_ref.Cfg(kind="cait", num_layers=2, num_heads=2, embed_dim=32, pa
                         num_layers_token_only=2, stoch_depth_rate=0.1, layerscale_eps=1e-5)
 
 
+TINY_MIXER = vit_ref.Cfg(kind="mixer", num_layers=2, num_heads=1, embed_dim=32, patch=8, num_classes=10, img_size=32)
+TINY_TNT = vit_ref.Cfg(kind="tnt", num_layers=2, num_heads=2, embed_dim=32, patch=16, num_classes=10, img_size=32, inner_num_heads=2,
+                       inner_embed_dim=8)
+
+
 def make(cfg, name, seed):
     rng = np.random.default_rng(seed)
     params = vit_ref.init_params(cfg, seed=seed, randomize=True)
@@ -46,3 +51,7 @@ def make(cfg, name, seed):
 if __name__ == "__main__":
     make(TINY_VIT, "tiny_vit.npz", 1234)
     make(TINY_CAIT, "tiny_cait.npz", 4321)
+    if not os.path.exists(os.path.join(HERE, "tiny_mixer.npz")):  # added later: the two fixtures above are never rewritten
+        make(TINY_MIXER, "tiny_mixer.npz", 2468)
+    if not os.path.exists(os.path.join(HERE, "tiny_tnt.npz")):
+        make(TINY_TNT, "tiny_tnt.npz", 1357)

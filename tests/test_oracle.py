@@ -209,7 +209,13 @@ def test_bf16_round():
 
 
 # ---- golden fixtures
-@pytest.mark.parametrize("cfg,name", [(TINY_VIT, "tiny_vit.npz"), (TINY_CAIT, "tiny_cait.npz")])
+TINY_MIXER = vit_ref.Cfg(kind="mixer", num_layers=2, num_heads=1, embed_dim=32, patch=8, num_classes=10, img_size=32)
+TINY_TNT = vit_ref.Cfg(kind="tnt", num_layers=2, num_heads=2, embed_dim=32, patch=16, num_classes=10, img_size=32, inner_num_heads=2,
+                       inner_embed_dim=8)
+
+
+@pytest.mark.parametrize("cfg,name", [(TINY_VIT, "tiny_vit.npz"), (TINY_CAIT, "tiny_cait.npz"), (TINY_MIXER, "tiny_mixer.npz"),
+                                      (TINY_TNT, "tiny_tnt.npz")])
 def test_golden(cfg, name):
     z = np.load(os.path.join(GOLD, name))
     params = vit_ref.unflatten({k[2:]: z[k] for k in z.files if k.startswith("P:")})
