@@ -42,10 +42,14 @@ class ViT:
         self._bound_id: Optional[Tuple[int, int]] = None  # (id(tree), version) last loaded into the engines
 
     # -- engine management: one engine per batch size, sharing parameter / gradient / bf16-weight buffers
+    def _new_engine(self, batch: int):
+        """The family's engine class (overridden by the subclasses below)."""
+        return ViTEngine(self.cfg, batch)
+
     def engine(self, batch: int) -> ViTEngine:
         e = self._engines.get(batch)
         if e is None:
-            e = ViTEngine(self.cfg, batch)
+            e = self._new_engine(batch)
             if self._engines:
                 first = next(iter(self._engines.values()))
                 e.params, e.grads, e.w = first.params, first.grads, first.w
@@ -112,19 +116,10 @@ class CaiT(ViT):
     (stochastic_depth.py:16-27) from the engine's generator; pass `rngs={'stochastic_depth': seed}` to seed it (the reference needs
     that rng stream too and forgets to pass it, defect B7)."""
 
-    def engine(self, batch: int):
+    def _new_engine(self, batch: int):
         from .cait_engine import CaiTEngine
 
-        e = self._engines.get(batch)
-        if e is None:
-            e = CaiTEngine(self.cfg, batch)
-            if self._engines:
-                first = next(iter(self._engines.values()))
-                e.params, e.grads, e.w = first.params, first.grads, first.w
-                e.adam_m, e.adam_v = first.adam_m, first.adam_v
-                e.weights_stale = first.weights_stale
-            self._engines[batch] = e
-        return e
+        return CaiTEngine(self.cfg, batch)
 
     def apply(self, params: dict, images: torch.Tensor, is_training: bool = False, rngs=None) -> torch.Tensor:
         self.bind(params)
@@ -142,37 +137,19 @@ class CaiT(ViT):
 class MLPMixer(ViT):
     """models/mlp_mixer.py:34-64 behind mixer_engine.MixerEngine.  No stochastic layer: is_training selects nothing."""
 
-    def engine(self, batch: int):
+    def _new_engine(self, batch: int):
         from .mixer_engine import MixerEngine
 
-        e = self._engines.get(batch)
-        if e is None:
-            e = MixerEngine(self.cfg, batch)
-            if self._engines:
-                first = next(iter(self._engines.values()))
-                e.params, e.grads, e.w = first.params, first.grads, first.w
-                e.adam_m, e.adam_v = first.adam_m, first.adam_v
-                e.weights_stale = first.weights_stale
-            self._engines[batch] = e
-        return e
+        return MixerEngine(self.cfg, batch)
 
 
 class TNT(ViT):
     """models/tnt.py:136-193 behind tnt_engine.TNTEngine.  Every dropout rate is 0: is_training selects nothing."""
 
-    def engine(self, batch: int):
+    def _new_engine(self, batch: int):
         from .tnt_engine import TNTEngine
 
-        e = self._engines.get(batch)
-        if e is None:
-            e = TNTEngine(self.cfg, batch)
-            if self._engines:
-                first = next(iter(self._engines.values()))
-                e.params, e.grads, e.w = first.params, first.grads, first.w
-                e.adam_m, e.adam_v = first.adam_m, first.adam_v
-                e.weights_stale = first.weights_stale
-            self._engines[batch] = e
-        return e
+        return TNTEngine(self.cfg, batch)
 
 
 def create_model(model_name: str, num_classes: int = 1000, dtype=torch.bfloat16, img_size: int = 224):
