@@ -237,13 +237,7 @@ class ViTEngine:
         self.Cp = _align(C, 64)
         z = lambda *s, dt=f32: torch.zeros(*s, dtype=dt, device=self.dev)  # noqa: E731
         e = lambda *s, dt=f32: torch.empty(*s, dtype=dt, device=self.dev)  # noqa: E731
-        # ---- parameters, gradients, optimizer state
-        self.params = z(self.layout.total)
-        self.grads = z(self.layout.total)
-        self.adam_m = None
-        self.adam_v = None
-        self.step_count = 0
-        self.gnorm_sq = z(1)
+        self._init_flat_buffers()
         # ---- bf16 operand copies
         self.w = {
             "Wqkv_n": e(NL, d, 3 * d, dt=bf16), "Wqkv_t": e(NL, 3 * d, d, dt=bf16),
@@ -267,7 +261,6 @@ class ViTEngine:
         self.lse = [e(self.B, cfg.num_heads, N) for _ in range(NL)]
         self.zcls = e(self.B, d, dt=bf16)
         self.fstats = e(2, self.B)
-        self.logits = e(self.B, C)
         # ---- backward scratch
         self.dres = e(M, d)
         # scratch that the side-stream weight-gradient GEMMs read is rotated, so the main chain rarely has to wait for them
@@ -281,18 +274,34 @@ class ViTEngine:
         self.dqkv_ring = [e(M, 3 * d, dt=bf16) for _ in range(depth)]
         self.dqkv = self.dqkv_ring[0]
         self.colsum_slab = e(max(1, self.L.savit_gemm_colsum_rows(M, F, d, 0)), F)
-        self.dlogits = z(self.B, self.Cp, dt=bf16)
         self.d_z = e(self.B, d, dt=bf16)
         ws = self.L.savit_layernorm_bwd_workspace_bytes(M, d)
         self.ln_ws = torch.empty(max(int(ws), 16), dtype=torch.uint8, device=self.dev)
-        # ---- loss I/O
-        self.labels = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
+        self._init_step_state()
+
+    # ---- state every engine of this package shares (the Mixer / TNT engines subclass this one and lay out their own activations)
+    def _init_flat_buffers(self):
+        """Parameters, gradients, optimizer state: flat fp32 buffers in the layout's order (Adam moments allocated on first use)."""
+        self.params = torch.zeros(self.layout.total, dtype=f32, device=self.dev)
+        self.grads = torch.zeros(self.layout.total, dtype=f32, device=self.dev)
+        self.adam_m = None
+        self.adam_v = None
+        self.step_count = 0
+        self.gnorm_sq = torch.zeros(1, dtype=f32, device=self.dev)
+
+    def _init_step_state(self):
+        """Loss I/O, the bf16 NHWC input buffer, launch plans, DDP hooks and the side-stream settings."""
+        cfg, B = self.cfg, self.B
+        z = lambda *s, dt=f32: torch.zeros(*s, dtype=dt, device=self.dev)  # noqa: E731
+        self.logits = torch.empty(B, cfg.num_classes, dtype=f32, device=self.dev)
+        self.dlogits = z(B, self.Cp, dt=bf16)
+        self.labels = torch.zeros(B, dtype=torch.int32, device=self.dev)
         self.loss = z(1)
-        self.loss_rows = z(self.B)
-        self.top1 = z(self.B)
-        self.top5 = z(self.B)
+        self.loss_rows = z(B)
+        self.top1 = z(B)
+        self.top5 = z(B)
         self.images: Optional[torch.Tensor] = None  # bf16 NHWC, set by forward()
-        self._img_buf = e(self.B, cfg.img_size, cfg.img_size, 3, dt=bf16)
+        self._img_buf = torch.empty(B, cfg.img_size, cfg.img_size, 3, dtype=bf16, device=self.dev)
         self._fwd_plan: Optional[_Plan] = None
         self._bwd_plan: Optional[_Plan] = None
         self._cast_plan: Optional[_Plan] = None

@@ -131,12 +131,7 @@ class MixerEngine(ViTEngine):
         self.Cp = _align(C, 64)
         z = lambda *s, dt=f32: torch.zeros(*s, dtype=dt, device=self.dev)  # noqa: E731
         e = lambda *s, dt=f32: torch.empty(*s, dtype=dt, device=self.dev)  # noqa: E731
-        self.params = z(self.layout.total)
-        self.grads = z(self.layout.total)
-        self.adam_m = None
-        self.adam_v = None
-        self.step_count = 0
-        self.gnorm_sq = z(1)
+        self._init_flat_buffers()
         self.w = {
             "tW1_n": e(NL, Lp, Fp, dt=bf16), "tW1_t": e(NL, Fp, Lp, dt=bf16),
             "tW2_n": e(NL, Fp, Lp, dt=bf16), "tW2_t": e(NL, Lp, Fp, dt=bf16),
@@ -160,7 +155,6 @@ class MixerEngine(ViTEngine):
         self.yT = e(Md, Lp, dt=bf16)      # token-mixing branch before the transpose back
         self.zcls = e(self.B, d, dt=bf16)  # pooled features (name shared with the ViT engine)
         self.fstats = e(2, M)
-        self.logits = e(self.B, C)
         # ---- backward scratch (rotated where a side-stream weight-gradient GEMM reads it, as in the ViT engine)
         self.dres = e(M, d)
         depth = max(2, int(os.environ.get("SAVIT_RING_DEPTH", "2")))
@@ -174,29 +168,10 @@ class MixerEngine(ViTEngine):
         self.colsum_slab = e(max(1, self.L.savit_gemm_colsum_rows(M, F, d, 0)), F)
         self.tcolsum_slab = e(max(1, self.L.savit_gemm_colsum_rows(Md, Fp, Lp, 0)), Fp)
         self.trowsum_slab = z(max(1, self.L.savit_transpose_rowsum_rows(self.B, d)), Lp)  # pad columns stay zero
-        self.dlogits = z(self.B, self.Cp, dt=bf16)
         self.d_z = e(self.B, d, dt=bf16)
         ws = self.L.savit_layernorm_bwd_workspace_bytes(M, d)
         self.ln_ws = torch.empty(max(int(ws), 16), dtype=torch.uint8, device=self.dev)
-        self.labels = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
-        self.loss = z(1)
-        self.loss_rows = z(self.B)
-        self.top1 = z(self.B)
-        self.top5 = z(self.B)
-        self.images: Optional[torch.Tensor] = None
-        self._img_buf = e(self.B, cfg.img_size, cfg.img_size, 3, dt=bf16)
-        self._fwd_plan: Optional[_Plan] = None
-        self._bwd_plan: Optional[_Plan] = None
-        self._cast_plan: Optional[_Plan] = None
-        self.bwd_hooks: Dict[str, Callable[[], None]] = {}
-        self.weights_stale = True
-        self.overlap_wgrad = os.environ.get("SAVIT_OVERLAP_WGRAD", "1") != "0"
-        self.n_side_streams = int(os.environ.get("SAVIT_SIDE_STREAMS", "1"))
-        self.wgrad_cu_share = float(os.environ.get("SAVIT_WGRAD_CU_SHARE", "0.56"))
-        self.n_cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
-        self._side_streams: List[torch.cuda.Stream] = []
-        self._building_serial = False
-        self._bwd_plan_serial: Optional[_Plan] = None
+        self._init_step_state()
 
     # ------------------------------------------------------------------------------------ parameters
     def init_params(self, seed: int = 0):

@@ -164,12 +164,7 @@ class TNTEngine(ViTEngine):
         self.Cp = _align(C, 64)
         z = lambda *s, dt=f32: torch.zeros(*s, dtype=dt, device=self.dev)  # noqa: E731
         e = lambda *s, dt=f32: torch.empty(*s, dtype=dt, device=self.dev)  # noqa: E731
-        self.params = z(lay.total)
-        self.grads = z(lay.total)
-        self.adam_m = None
-        self.adam_v = None
-        self.step_count = 0
-        self.gnorm_sq = z(1)
+        self._init_flat_buffers()
         # bf16 operand copies; the ones that multiply a width-di operand are zero-padded along K (allocated zeroed, the cast
         # writes the real columns only)
         self.w = {
@@ -212,7 +207,6 @@ class TNTEngine(ViTEngine):
         self.lse = [e(self.B, cfg.num_heads, N) for _ in range(NL)]
         self.yb = e(Ms, do, dt=bf16)                                    # Inner2Outer projection (scratch)
         self.zcls = e(self.B, do, dt=bf16)
-        self.logits = e(self.B, C)
         # ---- backward scratch
         depth = max(2, int(os.environ.get("SAVIT_RING_DEPTH", "2")))
         self.dres = e(Mo, do)                                           # patch-stream cotangent
@@ -232,29 +226,10 @@ class TNTEngine(ViTEngine):
         self.id_o = e(Mi, dap, dt=bf16)
         self.colsum_slab = e(max(1, self.L.savit_gemm_colsum_rows(Mo, Fo, do, 0)), Fo)
         self.icolsum_slab = e(max(1, self.L.savit_gemm_colsum_rows(Mi, Fi, Kpi, 0)), Fi)
-        self.dlogits = z(self.B, self.Cp, dt=bf16)
         self.d_z = e(self.B, do, dt=bf16)
         ws = max(self.L.savit_layernorm_bwd_workspace_bytes(Mo, do), self.L.savit_layernorm_bwd_workspace_bytes(Mi, di))
         self.ln_ws = torch.empty(max(int(ws), 16), dtype=torch.uint8, device=self.dev)
-        self.labels = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
-        self.loss = z(1)
-        self.loss_rows = z(self.B)
-        self.top1 = z(self.B)
-        self.top5 = z(self.B)
-        self.images: Optional[torch.Tensor] = None
-        self._img_buf = e(self.B, cfg.img_size, cfg.img_size, 3, dt=bf16)
-        self._fwd_plan: Optional[_Plan] = None
-        self._bwd_plan: Optional[_Plan] = None
-        self._cast_plan: Optional[_Plan] = None
-        self.bwd_hooks: Dict[str, Callable[[], None]] = {}
-        self.weights_stale = True
-        self.overlap_wgrad = os.environ.get("SAVIT_OVERLAP_WGRAD", "1") != "0"
-        self.n_side_streams = int(os.environ.get("SAVIT_SIDE_STREAMS", "1"))
-        self.wgrad_cu_share = float(os.environ.get("SAVIT_WGRAD_CU_SHARE", "0.56"))
-        self.n_cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
-        self._side_streams: List[torch.cuda.Stream] = []
-        self._building_serial = False
-        self._bwd_plan_serial: Optional[_Plan] = None
+        self._init_step_state()
 
     # ------------------------------------------------------------------------------------ parameters
     def init_params(self, seed: int = 0):
