@@ -1125,20 +1125,19 @@ __device__ __forceinline__ float th_unpack(uint32_t w, int odd) { return odd ? _
 // The two widest exchanges (lanes 32 and 16 apart: 48 of the 63) are gfx950's v_permlane32_swap / v_permlane16_swap: swapping
 // the upper half (odd rows) of g[j] with the lower half (even rows) of g[j + n2] leaves exactly "kept + received" in the two
 // registers, so one swap + one add replaces two selects, a ds_bpermute and an add (126 bpermutes per row kept the LDS pipe busy
-// for a third of this kernel).  Four swaps share one pair of hazard nops (common.h: SAVIT_PERMLANE_SWAP).
-#define TH_SWAP4(OP, a0, b0, a1, b1, a2, b2, a3, b3)                                                                        \
-  asm volatile("s_nop 3\n " OP " %0, %1\n " OP " %2, %3\n " OP " %4, %5\n " OP " %6, %7\n s_nop 3"                          \
-               : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3))
+// for a third of this kernel).  The swaps are the builtins of common.h (hazards placed by hipcc).
 __device__ __forceinline__ float reduce_scatter64(float (&g)[64], int lane) {
 #pragma unroll
   for (int j = 0; j < 32; j += 4) {
-    TH_SWAP4("v_permlane32_swap_b32", g[j], g[j + 32], g[j + 1], g[j + 33], g[j + 2], g[j + 34], g[j + 3], g[j + 35]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) permlane32_swap(g[j + k], g[j + k + 32]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) g[j + k] += g[j + k + 32];
   }
 #pragma unroll
   for (int j = 0; j < 16; j += 4) {
-    TH_SWAP4("v_permlane16_swap_b32", g[j], g[j + 16], g[j + 1], g[j + 17], g[j + 2], g[j + 18], g[j + 3], g[j + 19]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) permlane16_swap(g[j + k], g[j + k + 16]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) g[j + k] += g[j + k + 16];
   }

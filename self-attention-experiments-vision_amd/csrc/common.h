@@ -62,11 +62,24 @@ __device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to
 // Wave-wide all-reduce without the LDS crossbar: __shfl_xor lowers to ds_bpermute_b32 (six dependent ~100-cycle hops per
 // reduction).  Here lanes 1, 2 apart exchange by DPP quad_perm, 4 and 8 apart by row_half_mirror / row_mirror (after the quad steps
 // every quad is uniform, so mirroring reaches "the other quad / the other half row"), 16 and 32 apart by gfx950's
-// v_permlane16_swap / v_permlane32_swap on two copies of the value (a' + b' then holds both partners everywhere).  The swaps are
-// inline asm: ROCm 7.2's __builtin_amdgcn_permlane{16,32}_swap returns its first result twice.  hipcc does not see the hazards
-// of inline-asm instructions: without wait states between the VALU write of the operands and the swap (and before the results
-// are read) the swap exchanges stale rows (measured, tools/scratch/wave_reduce_test.hip), hence the s_nops.
-#define SAVIT_PERMLANE_SWAP(OP, a, b) asm volatile("s_nop 3\n " OP " %0, %1\n s_nop 3" : "+v"(a), "+v"(b))
+// v_permlane16_swap / v_permlane32_swap on two copies of the value (a' + b' then holds both partners everywhere).
+// The swaps are the compiler's builtins, so hipcc's hazard recogniser places the wait states (2 between a VALU write of an operand
+// and the swap, none after it) - round 1 used inline asm with hand-counted s_nops because the builtin seemed to "return its first
+// result twice".  That was a front-end bug in how the result was READ: __builtin_bit_cast(float, r[i]) on an element of the
+// returned vector loads element 0 for every i (clang 19 / ROCm 7.2, visible in the -O0 IR); copying the elements to scalars first
+// is compiled correctly (tools/scratch/permlane_builtin.hip holds the two forms).
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) {  // lanes 32-63 of a <-> lanes 0-31 of b
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = __uint_as_float(r0);
+  b = __uint_as_float(r1);
+}
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) {  // odd rows (16 lanes) of a <-> even rows of b
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = __uint_as_float(r0);
+  b = __uint_as_float(r1);
+}
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
@@ -74,12 +87,12 @@ __device__ __forceinline__ float dpp_mov(float v) {
 // v(l) (+ / max) v(l ^ 32): the two halves of a wave, e.g. the two key halves of a 32x32 MFMA accumulator column
 __device__ __forceinline__ float half_sum(float v) {
   float a = v, b = v;
-  SAVIT_PERMLANE_SWAP("v_permlane32_swap_b32", a, b);
+  permlane32_swap(a, b);
   return a + b;
 }
 __device__ __forceinline__ float half_max(float v) {
   float a = v, b = v;
-  SAVIT_PERMLANE_SWAP("v_permlane32_swap_b32", a, b);
+  permlane32_swap(a, b);
   return fmaxf(a, b);
 }
 __device__ __forceinline__ float wave_sum(float v) {
@@ -88,11 +101,11 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_mov<0x141>(v);  // row_half_mirror
   v += dpp_mov<0x140>(v);  // row_mirror
   float a = v, b = v;
-  SAVIT_PERMLANE_SWAP("v_permlane16_swap_b32", a, b);
+  permlane16_swap(a, b);
   v = a + b;
   a = v;
   b = v;
-  SAVIT_PERMLANE_SWAP("v_permlane32_swap_b32", a, b);
+  permlane32_swap(a, b);
   return a + b;
 }
 __device__ __forceinline__ float wave_max(float v) {
@@ -101,11 +114,11 @@ __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_mov<0x141>(v));
   v = fmaxf(v, dpp_mov<0x140>(v));
   float a = v, b = v;
-  SAVIT_PERMLANE_SWAP("v_permlane16_swap_b32", a, b);
+  permlane16_swap(a, b);
   v = fmaxf(a, b);
   a = v;
   b = v;
-  SAVIT_PERMLANE_SWAP("v_permlane32_swap_b32", a, b);
+  permlane32_swap(a, b);
   return fmaxf(a, b);
 }
 

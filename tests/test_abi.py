@@ -87,3 +87,38 @@ def test_shape_contracts_are_checked_on_the_host(built):
     assert L.savit_gemm_bf16_tn(ctypes.byref(a), None) == EINVAL
     a.K, a.ldb, a.lda = 64, 64, 20  # an operand pitch that is not a multiple of 8 elements
     assert L.savit_gemm_bf16_tn(ctypes.byref(a), None) == EINVAL
+
+
+def _device_isa(obj_name, tmp_path):
+    """Disassemble the gfx950 code object embedded in csrc/<obj_name> (llvm-objdump --offloading extracts next to its input)."""
+    import shutil
+    import subprocess
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    src = os.path.join(ROOT, "self-attention-experiments-vision_amd", "csrc", obj_name)
+    dst = os.path.join(str(tmp_path), obj_name)
+    shutil.copy(src, dst)
+    subprocess.run([objdump, "--offloading", dst], check=True, capture_output=True)
+    cos = [f for f in os.listdir(str(tmp_path)) if "gfx950" in f]
+    assert len(cos) == 1, cos
+    return subprocess.run([objdump, "-d", os.path.join(str(tmp_path), cos[0])], check=True, capture_output=True, text=True).stdout
+
+
+def test_layernorm_forward_has_no_packed_fp32_math(built, tmp_path):
+    """The LayerNorm forward kernels must not contain v_pk_*_f32 (csrc/layernorm_fwd.hip explains why: the in-place packed
+    subtraction of the mean was the one instruction that misbehaved under GPU time-slicing between processes)."""
+    isa = _device_isa("layernorm_fwd.o", tmp_path)
+    assert "ln_fwd_kernel" in isa and "ln_fwd_narrow_kernel" in isa
+    assert not re.search(r"\bv_pk_\w+_f32\b", isa), "packed fp32 math in the LayerNorm forward object"
+
+
+def test_no_hand_timed_permlane_swaps(built, tmp_path):
+    """Lane swaps go through the compiler builtins (common.h), so hipcc places their hazard wait states: the library sources hold
+    no inline-asm v_permlane*_swap any more."""
+    csrc = os.path.join(ROOT, "self-attention-experiments-vision_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            s = open(os.path.join(csrc, f)).read()
+            assert not re.search(r'"[^"\n]*v_permlane(16|32)_swap', s), f"inline-asm permlane swap in {f}"
