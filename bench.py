@@ -14,8 +14,15 @@ whole-job images/s.  Rank 0 prints ONE JSON line.  Extra objects on that line:
                 peak = dense bf16 MFMA peak of MI355X.  `traffic` is null here (PMC passes are separate rocprofv3 runs;
                 see profiles/ and DESIGN.md).
   step_roofline whole-step figure of SURVEY.md 8d: images/s/GPU x 105.152 GFLOP per image / peak.
-  cpu_baseline  the CPU restatement (oracle/torch_ref.py, JAX absent: SURVEY 8c) of the same model's train step on this
-                host's cores, bounded sample, rank 0 at N=1 only.
+  cpu_baseline  the CPU restatement (oracle/torch_ref.py, JAX absent: SURVEY 8c) of BASELINE config 1 (ViT-Ti/16, batch 8,
+                fp32: forward+loss+backward = `value`, forward+loss alone = `forward_loss_value`) on this host's cores, bounded
+                sample, rank 0 at N=1 only; `headline_model_value` is the same restatement of the headline model.
+  other_configs (N=1, headline workload only) a short timing (>= 5 steps after 2 warm-up steps) of BASELINE configs 2, 4 and 5 on
+                the same GPU, each with images_per_gpu, ms_per_step and step_roofline.frac.
+
+`python bench.py --gpus N` with N > 1 and no launcher around it starts the N ranks itself: the parent makes no GPU call (it does
+not even import torch), runs `python -m torch.distributed.run --nproc-per-node N ... bench.py <same flags>` as a child process and
+returns its exit code; rank 0 of the children prints the JSON line.
 """
 import argparse
 import json
@@ -23,7 +30,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between the ranks of one node needs it on this driver
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC between the ranks' RCCL peers: the only mode this host driver supports
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -75,6 +82,127 @@ def kernel_class(label: str) -> str:
     return "other"
 
 
+OTHER_CONFIGS = (("vit_s_patch16", 256, 224, "2. DeiT-S/16 224^2, 256 img"), ("cait_s_24", 256, 224, "4. CaiT-S24 224^2, 256 img"),
+                 ("vit_l_patch16", 256, 384, "5. ViT-L/16 384^2, 256 img/GPU"))
+
+
+def launch_ranks(n: int) -> int:
+    """Parent of a multi-rank run: start one child process per rank through torch.distributed.run and return its exit code.
+    Nothing here touches the GPU (no torch import): a process that has initialised HIP must never fork / exec rank processes."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"  # dmabuf IPC between the ranks' RCCL peers (the only mode this host driver supports)
+    env.setdefault("OMP_NUM_THREADS", "4")   # torch.distributed.run would set 1; the CPU side of a rank only drives launches
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rank_probe():
+    """SAVIT_BENCH_RANK_PROBE=1: the ranks only rendezvous (gloo, CPU) and rank 0 prints what it saw - tests/test_ddp_cpu.py uses
+    this to cover the launcher without a GPU."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    t = torch.tensor([float(dist.get_rank())])
+    dist.all_reduce(t)
+    if dist.get_rank() == 0:
+        print(json.dumps({"launcher_probe": True, "world": dist.get_world_size(), "rank_sum": t.item(),
+                          "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def build_engine(cfg, B):
+    from savit_amd.engine import ViTEngine
+
+    if cfg.kind == "cait":
+        from savit_amd.cait_engine import CaiTEngine
+
+        return CaiTEngine(cfg, B)
+    if cfg.kind == "mixer":
+        from savit_amd.mixer_engine import MixerEngine
+
+        return MixerEngine(cfg, B)
+    if cfg.kind == "tnt":
+        from savit_amd.tnt_engine import TNTEngine
+
+        return TNTEngine(cfg, B)
+    return ViTEngine(cfg, B)
+
+
+def make_step(eng, cfg, B, world, rank, sync):
+    """Engine + synthetic batches resident in HBM -> step(i): N(0,1) NHWC images cast to bf16 (train.py:81), uniform labels,
+    seed 42+rank; lr*bs/512 (train.py:171,214-220), wd 1e-4 (:172-176), label smoothing 0.1, clip 1.0."""
+    import torch
+
+    gd = torch.Generator(device="cuda").manual_seed(42 + rank)
+    S = cfg.img_size
+    batches = [(torch.randn(B, S, S, 3, device="cuda", generator=gd).to(torch.bfloat16),
+                torch.randint(0, cfg.num_classes, (B,), device="cuda", generator=gd, dtype=torch.int32)) for _ in range(2)]
+    lr, wd = 5e-4 * (B * world) / 512.0, 1e-4
+
+    def step(i):
+        img, lab = batches[i & 1]
+        if cfg.kind == "cait":
+            eng.forward(img, is_training=True)  # stochastic depth active (cait.py:38,49)
+        else:
+            eng.forward(img)
+        eng.loss_backward(lab, label_smoothing=0.1)
+        if sync is not None:
+            sync.wait()
+        eng.optimizer_step(lr=lr, weight_decay=wd, max_norm=1.0, grad_scale=(sync.grad_scale if sync else 1.0))
+
+    return step, batches
+
+
+def init_bench_params(eng, cfg):
+    import torch
+
+    eng.init_params(seed=42)  # train.py:187-189 default seed
+    # the reference zero-initialises the head kernel (vit.py:98); a zero operand would make the first backward
+    # passes run on zeros (higher clocks, SURVEY 8d), so the benchmark gives the head a lecun-normal kernel.
+    g = torch.Generator().manual_seed(7)
+    eng.layout.view(eng.params, "Wh").copy_(torch.randn(cfg.embed_dim, cfg.num_classes, generator=g) * cfg.embed_dim ** -0.5)
+
+
+def time_other_config(model, B, img_size, steps=5, warmup=2):
+    """Short single-GPU timing of another BASELINE config (same step definition as the headline)."""
+    import torch
+
+    from savit_amd.config import get_config, train_flops_per_image
+
+    cfg = get_config(model, img_size=img_size)
+    eng = build_engine(cfg, B)
+    init_bench_params(eng, cfg)
+    eng.refresh_weights()
+    step, _ = make_step(eng, cfg, B, 1, 0, None)
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ips, fpi = B * steps / el, train_flops_per_image(cfg)
+    res = {"model": model, "img_size": img_size, "images_per_gpu": B, "steps": steps, "warmup": warmup, "value": round(ips, 1),
+           "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 3),
+           "step_roofline": {"bound": "mfma", "achieved": round(ips * fpi / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(ips * fpi / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "flops_per_image": fpi},
+           "final_loss": round(float(eng.loss.item()), 4)}
+    del step, eng
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,7 +214,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--bucket-mb", type=float, default=48.0)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short timings of BASELINE configs 2, 4, 5")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))  # this process stays GPU-free; the ranks are its grandchildren
+    if os.environ.get("SAVIT_BENCH_RANK_PROBE"):
+        return rank_probe()
 
     import torch
 
@@ -94,8 +228,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (WORLD_SIZE is 1)")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU execution path for the product")
@@ -117,29 +249,11 @@ def main():
     import savit_amd  # noqa: F401
     from savit_amd import ddp
     from savit_amd.config import get_config, train_flops_per_image
-    from savit_amd.engine import ViTEngine
 
     cfg = get_config(args.model, img_size=args.img_size)
     B = args.batch
-    if cfg.kind == "cait":
-        from savit_amd.cait_engine import CaiTEngine
-
-        eng = CaiTEngine(cfg, B)
-    elif cfg.kind == "mixer":
-        from savit_amd.mixer_engine import MixerEngine
-
-        eng = MixerEngine(cfg, B)
-    elif cfg.kind == "tnt":
-        from savit_amd.tnt_engine import TNTEngine
-
-        eng = TNTEngine(cfg, B)
-    else:
-        eng = ViTEngine(cfg, B)
-    eng.init_params(seed=42)  # train.py:187-189 default seed
-    # the reference zero-initialises the head kernel (vit.py:98); a zero operand would make the first backward
-    # passes run on zeros (higher clocks), so the benchmark gives the head a lecun-normal kernel.
-    g = torch.Generator().manual_seed(7)
-    eng.layout.view(eng.params, "Wh").copy_(torch.randn(cfg.embed_dim, cfg.num_classes, generator=g) * cfg.embed_dim ** -0.5)
+    eng = build_engine(cfg, B)
+    init_bench_params(eng, cfg)
     sync = None
     if world > 1:
         ddp.broadcast_params(eng.params)
@@ -147,24 +261,8 @@ def main():
         sync = ddp.GradSync(eng.grads, buckets)
         eng.bwd_hooks = sync.hooks()
     eng.refresh_weights()
-
-    # synthetic data, resident in HBM: N(0,1) NHWC images cast to bf16 (train.py:81), uniform labels, seed 42+rank
-    gd = torch.Generator(device="cuda").manual_seed(42 + rank)
+    step, batches = make_step(eng, cfg, B, world, rank, sync)
     S = cfg.img_size
-    batches = [(torch.randn(B, S, S, 3, device="cuda", generator=gd).to(torch.bfloat16),
-                torch.randint(0, cfg.num_classes, (B,), device="cuda", generator=gd, dtype=torch.int32)) for _ in range(2)]
-    lr, wd = 5e-4 * (B * world) / 512.0, 1e-4  # train.py:171,214-220 (lr*bs/512), :172-176
-
-    def step(i):
-        img, lab = batches[i & 1]
-        if cfg.kind == "cait":
-            eng.forward(img, is_training=True)  # stochastic depth active (cait.py:38,49)
-        else:
-            eng.forward(img)
-        eng.loss_backward(lab, label_smoothing=0.1)
-        if sync is not None:
-            sync.wait()
-        eng.optimizer_step(lr=lr, weight_decay=wd, max_norm=1.0, grad_scale=(sync.grad_scale if sync else 1.0))
 
     for i in range(args.warmup):
         step(i)
@@ -261,15 +359,31 @@ def main():
         out["kernel_breakdown_ms"]["sum_fwd_bwd"] = round(total_ms, 3)
         out["gemm_class_tflops"] = {c: round(cls_fl[c] / (cls_ms[c] * 1e-3) / 1e12, 2) for c in ("gemm_tn", "gemm_wgrad") if cls_ms.get(c)}
 
-    # ---- CPU baseline leg (rank 0, N=1 only): the oracle's torch-CPU restatement, bounded sample
+    # ---- other BASELINE configs on this GPU (rank 0, N=1, headline workload only): short timings, after the headline engine is freed
+    headline = args.model == "vit_b_patch16" and B == 128 and args.img_size == 224
+    if rank == 0 and world == 1 and headline and not args.no_other_configs:
+        del step, batches, eng
+        torch.cuda.empty_cache()
+        out["other_configs"] = {}
+        for model, ob, osz, name in OTHER_CONFIGS:
+            out["other_configs"][name] = time_other_config(model, ob, osz)
+
+    # ---- CPU baseline leg (rank 0, N=1 only): the oracle's torch-CPU restatement of BASELINE config 1, bounded samples
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import torch_ref, vit_ref
 
-        ocfg = vit_ref.get_cfg(args.model, img_size=args.img_size)
-        cb = torch_ref.time_train_step(ocfg, batch=8, seconds=args.cpu_seconds)
-        out["cpu_baseline"] = {"value": round(cb["images_per_s"], 3), "unit": "images/s", "cores": cb["cores"], "kind": "port",
-                               "sample": f"{cb['steps']} fp32 train steps (fwd+loss+bwd, no optimizer) of {args.model} at batch 8, "
-                                         f"torch-CPU eager restatement of the reference (JAX absent), {cb['seconds']:.1f} s"}
+        c1 = vit_ref.get_cfg("vit_ti_patch16", img_size=224)
+        fb = torch_ref.time_train_step(c1, batch=8, seconds=args.cpu_seconds * 0.5)
+        fo = torch_ref.time_train_step(c1, batch=8, seconds=args.cpu_seconds * 0.25, backward=False)
+        out["cpu_baseline"] = {"value": round(fb["images_per_s"], 3), "unit": "images/s", "cores": fb["cores"], "kind": "port",
+                               "forward_loss_value": round(fo["images_per_s"], 3),
+                               "sample": f"BASELINE config 1 (ViT-Ti/16 224^2, batch 8, fp32), torch-CPU eager restatement of the reference "
+                                         f"(JAX absent): {fb['steps']} steps of fwd+loss+bwd in {fb['seconds']:.1f} s (= value), "
+                                         f"{fo['steps']} steps of fwd+loss in {fo['seconds']:.1f} s (= forward_loss_value)"}
+        if headline:
+            hb = torch_ref.time_train_step(vit_ref.get_cfg(args.model, img_size=args.img_size), batch=8, seconds=args.cpu_seconds * 0.5)
+            out["cpu_baseline"]["headline_model_value"] = round(hb["images_per_s"], 3)
+            out["cpu_baseline"]["headline_model_sample"] = f"{hb['steps']} fp32 fwd+loss+bwd steps of {args.model} at batch 8, {hb['seconds']:.1f} s"
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

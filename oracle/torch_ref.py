@@ -212,8 +212,9 @@ def host_cores(cap: int = 16) -> int:
     return max(1, min(n, cap))
 
 
-def time_train_step(cfg, batch: int, seconds: float = 12.0, threads: Optional[int] = None, seed: int = 0, max_steps: int = 50):
-    """CPU baseline leg of bench.py: fp32 forward+loss+backward of `cfg` at `batch` on this host's
+def time_train_step(cfg, batch: int, seconds: float = 12.0, threads: Optional[int] = None, seed: int = 0, max_steps: int = 50,
+                    backward: bool = True):
+    """CPU baseline leg of bench.py: fp32 forward+loss (+backward) of `cfg` at `batch` on this host's
     cores with torch eager; returns dict(images_per_s, cores, steps, seconds).  Bounded: stops after `seconds`
     (checked after every step, the first included) or max_steps."""
     import time
@@ -229,8 +230,12 @@ def time_train_step(cfg, batch: int, seconds: float = 12.0, threads: Optional[in
     tensors = [t for _, t in leaves(p)]
 
     def step():
-        loss = loss_from_logits(forward(p, images, cfg), labels)
-        torch.autograd.grad(loss, tensors, allow_unused=True)
+        if backward:
+            loss = loss_from_logits(forward(p, images, cfg), labels)
+            torch.autograd.grad(loss, tensors, allow_unused=True)
+        else:
+            with torch.no_grad():
+                loss_from_logits(forward(p, images, cfg), labels)
 
     t0 = time.perf_counter()
     step()  # first step doubles as warm-up; it is kept only if the budget is already gone

@@ -124,3 +124,30 @@ def test_gradsync_gloo_world2():
         assert abs(res[r][3] - 1.5) < 1e-6  # psum(loss)/n
         assert abs(res[r][4] - 2.0) < 1e-6  # second step: sum of ones over 2 ranks
         assert flags[r] == "raised"
+
+
+def test_bench_self_launches_its_ranks(repo_root):
+    """`python bench.py --gpus 2` with no launcher around it starts two rank processes itself (the parent stays GPU-free) and rank 0
+    prints one JSON line.  SAVIT_BENCH_RANK_PROBE makes the ranks stop after the rendezvous, so this runs without a GPU."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SAVIT_BENCH_RANK_PROBE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d == {"launcher_probe": True, "world": 2, "rank_sum": 1.0, "ipc_mode_legacy": "0"}
+
+
+def test_bench_rejects_mismatched_world(repo_root):
+    import subprocess
+    import sys
+
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "!= WORLD_SIZE" in r.stderr

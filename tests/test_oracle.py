@@ -238,3 +238,28 @@ def test_bf16_emulation_noise_floor():
     z = np.load(os.path.join(GOLD, "tiny_vit.npz"))
     r = rel(z["logits_bf16"], z["logits"])
     assert 1e-4 < r < 5e-2
+
+
+@pytest.mark.parametrize("name", ["block_d192_n197", "block_d384_n197", "block_cait_d384_n196", "block_d768_n197"])
+def test_block_fixtures_pin_the_oracle(name):
+    """Real-width single-block fixtures (tests/golden/block_*.npz): the inputs regenerated from the seed match the stored checksums
+    and the oracle reproduces the stored fp64 logits, bf16-emulated logits and loss (the gradients too for the smallest block; the
+    d 1024 / N 577 fixture is exercised by the GPU test only - its fp64 forward takes a minute on this container's cores)."""
+    from tests.golden import make_golden
+
+    fx = np.load(os.path.join(GOLD, name + ".npz"))
+    kw, seed = make_golden.BLOCKS[name]
+    cfg, params, images, labels = make_golden.block_inputs(kw, seed)
+    for k, v in make_golden.checksums(params, images).items():
+        np.testing.assert_allclose(v, fx[k], rtol=1e-12, atol=1e-12, err_msg=k)
+    assert np.array_equal(labels, fx["labels"])
+    logits = vit_ref.forward(params, images, cfg, mode="f64")
+    assert rel(logits, fx["logits"]) < 1e-9
+    assert abs(vit_ref.loss_fn(logits, labels, 0.1) - float(fx["loss"])) < 1e-9
+    assert rel(vit_ref.forward(params, images, cfg, mode="bf16"), fx["logits_bf16"]) < 1e-6
+    if name == "block_d192_n197":
+        _, _, grads = torch_ref.loss_and_grads(params, images, labels, cfg, 0.1, dtype=torch.float64)
+        for k, g in grads.items():
+            g = np.asarray(g, np.float64).ravel()
+            assert abs(np.linalg.norm(g) - float(fx["GN:" + k])) <= 1e-9 * max(1.0, float(fx["GN:" + k])), k
+            assert rel(g[fx["GI:" + k]], fx["GV:" + k]) < 1e-6, k
