@@ -63,6 +63,14 @@ BLOCKS = {
     # DeiT-S width: d 384, 6 heads (config 2) and ViT-Ti width: d 192, 3 heads (config 1)
     "block_d384_n197": (dict(kind="vit", num_layers=1, num_heads=6, embed_dim=384, patch=16, num_classes=1000, img_size=224), 9004),
     "block_d192_n197": (dict(kind="vit", num_layers=1, num_heads=3, embed_dim=192, patch=16, num_classes=1000, img_size=224), 9005),
+    # small end-to-end models of all four families at sizes the HIP engines accept (the d = 32 tiny_*.npz models above are below the
+    # engines' minimum width; they pin the oracle only)
+    "e2e_vit_d128": (dict(kind="vit", num_layers=2, num_heads=2, embed_dim=128, patch=8, num_classes=16, img_size=32), 9011),
+    "e2e_cait_d128": (dict(kind="cait", num_layers=2, num_heads=2, embed_dim=128, patch=8, num_classes=16, img_size=32,
+                           num_layers_token_only=2, stoch_depth_rate=0.1, layerscale_eps=1e-5), 9012),
+    "e2e_mixer_d128": (dict(kind="mixer", num_layers=2, num_heads=1, embed_dim=128, patch=8, num_classes=16, img_size=32), 9013),
+    "e2e_tnt_d128": (dict(kind="tnt", num_layers=2, num_heads=2, embed_dim=128, patch=16, num_classes=16, img_size=32, inner_num_heads=4,
+                          inner_embed_dim=24), 9014),
 }
 BLOCK_B = 2
 N_SAMPLES = 2048

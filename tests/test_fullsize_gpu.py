@@ -173,3 +173,65 @@ def test_cait_s24_full_size_properties():
     eng.loss_backward(lab)
     torch.cuda.synchronize()
     assert torch.isfinite(eng.grads).all() and float(eng.grads.abs().max()) > 0
+
+
+def _full_workload_properties(model, img_size, B, sub, seed):
+    """Size-independent properties at a BASELINE config's FULL per-GPU workload: zero-head known answers, bitwise repeatability,
+    permutation equivariance, a `sub`-image engine reproducing rows of the full batch, finite non-zero gradients, and the mean
+    gradient equal to the mean of the two half-batch gradients."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import savit_amd  # noqa: F401
+    from savit_amd.config import get_config
+    from savit_amd.engine import ViTEngine
+
+    cfg = get_config(model, img_size=img_size)
+    eng = ViTEngine(cfg, B)
+    eng.init_params(seed)
+    g = torch.Generator(device="cuda").manual_seed(seed + 1)
+    img = torch.randn(B, img_size, img_size, 3, device="cuda", generator=g).to(torch.bfloat16)
+    lab = torch.randint(0, 1000, (B,), device="cuda", generator=g, dtype=torch.int32)
+    assert float(eng.forward(img).abs().max()) == 0.0  # vit.py:96-98
+    assert abs(float(eng.loss_backward(lab, label_smoothing=0.1)) - math.log(1000.0)) < 1e-4
+    gt = eng.layout.flax_tree(eng.grads)["params"]
+    assert float(gt["Dense_0"]["bias"].abs().max()) > 0 and float(gt["PatchEmbedBlock_0"]["Dense_0"]["kernel"].abs().max()) == 0.0
+    _head(eng, cfg)
+    full = eng.forward(img).clone()
+    assert torch.isfinite(full).all() and float(full.abs().max()) > 0.1
+    assert torch.equal(eng.forward(img), full)
+    perm = torch.randperm(B, device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed + 2))
+    assert torch.equal(eng.forward(img[perm].contiguous()), full[perm])
+    eng.forward(img)
+    eng.loss_backward(lab, label_smoothing=0.1)
+    torch.cuda.synchronize()
+    g_full = eng.grads.clone()
+    assert torch.isfinite(g_full).all() and float(g_full.abs().max()) > 0
+    small = ViTEngine(cfg, sub)
+    small.params, small.w, small.weights_stale = eng.params, eng.w, False
+    lo = B // 4
+    got = small.forward(img[lo:lo + sub].contiguous())
+    err = float((got - full[lo:lo + sub]).norm() / full[lo:lo + sub].norm())
+    assert err < 2e-3, err
+    del small
+    half = ViTEngine(cfg, B // 2)
+    half.params, half.w, half.weights_stale = eng.params, eng.w, False
+    acc = torch.zeros_like(g_full)
+    for lo in (0, B // 2):
+        half.forward(img[lo:lo + B // 2].contiguous())
+        half.loss_backward(lab[lo:lo + B // 2].contiguous(), label_smoothing=0.1)
+        torch.cuda.synchronize()
+        acc += half.grads
+    acc *= 0.5
+    rel = float((acc - g_full).norm() / g_full.norm())
+    print(f"[{model} {img_size} B={B}] sub-batch rows {err:.2e}, half-batch gradient linearity {rel:.2e}")
+    assert rel < 2e-3, rel
+
+
+def test_deit_small_full_workload():
+    """BASELINE config 2: DeiT-S/16 224^2 at 256 images."""
+    _full_workload_properties("vit_s_patch16", 224, 256, 16, 11)
+
+
+def test_vit_large_384_full_workload():
+    """BASELINE config 5: ViT-L/16 at 384^2, 256 images per GPU (N = 577, 24 layers; ~130 GB of saved activations)."""
+    _full_workload_properties("vit_l_patch16", 384, 256, 8, 21)

@@ -1,14 +1,15 @@
 """GPU parity against the COMMITTED fixtures of tests/golden/ (SURVEY 8c "Golden vectors").
 
-Two sets: the tiny end-to-end models (tiny_*.npz: parameters, images, fp64 logits, bf16-emulated logits, loss, every gradient) and
-single encoder blocks at the real widths of the BASELINE configs (block_*.npz: d 192 / 384 / 768 / 1024, N 197 / 577, the CaiT
-talking-heads + class-attention block), whose parameters and images are regenerated from the fixture's seed and pinned by the
-stored checksums.  No oracle forward runs here: the stored numbers are the judge.
+Two sets: single encoder blocks at the real widths of the BASELINE configs (block_*.npz: d 192 / 384 / 768 / 1024, N 197 / 577, the
+CaiT talking-heads + class-attention block) and small two-layer models of all four families (e2e_*.npz).  Parameters and images
+are regenerated from the fixture's seed and pinned by the stored checksums; expected logits (fp64 and bf16-emulated), loss and
+gradients (norm + 2048 sampled entries per tensor) are stored.  No oracle forward runs here: the stored numbers are the judge.
+(The d = 32 tiny_*.npz fixtures are narrower than the engines' minimum width; tests/test_oracle.py uses them to pin the oracle.)
 
-Bars (measured on MI355X, printed by the tests, bar = ~1.5x the measured value):
-  logits vs fp64 oracle            single block  <= 6e-3   (bf16 storage of every activation: ~2^-9 per rounding, a dozen of them)
-  logits vs bf16-emulating oracle  single block  <= 7e-3   (two bf16 evaluations that round at the same places but sum in different
-                                                            orders differ by as much as either differs from exact math)
+Bars = ~1.5x the values measured on MI355X (printed by the tests):
+  logits vs fp64 oracle            7.4e-3 - 9.7e-3 measured on the single blocks (the bf16-emulating oracle itself: 8.8e-3 - 1.0e-2)
+  logits vs bf16-emulating oracle  7.6e-3 - 8.6e-3 measured: two bf16 evaluations that round at the same places but sum in different
+                                   orders differ by as much as either differs from exact math
   gradients vs fp64 autograd       norm within 1.5e-2, sampled entries rel-L2 <= 2.5e-2
 north_star's "<= 1e-3 rel bf16" holds per kernel (tests/test_kernels_gpu.py: each kernel vs exact math on the same bf16 inputs)
 and cannot hold for a chain of bf16 roundings: DESIGN.md section 2 has the per-layer growth curve."""
@@ -57,12 +58,17 @@ def _flat(tree):
     return {k: v.detach().float().cpu().numpy() for k, v in torch_ref.leaves(tree)}
 
 
-BLOCK_BARS = {  # name: (logits vs fp64, logits vs bf16-emulation, gradient norm, gradient samples)
-    "block_d192_n197": (6e-3, 7e-3, 1.5e-2, 2.5e-2),
-    "block_d384_n197": (6e-3, 7e-3, 1.5e-2, 2.5e-2),
-    "block_d768_n197": (6e-3, 7e-3, 1.5e-2, 2.5e-2),
-    "block_d1024_n577": (6e-3, 7e-3, 1.5e-2, 2.5e-2),
-    "block_cait_d384_n196": (6e-3, 7e-3, 1.5e-2, 2.5e-2),
+# name: (logits vs fp64, logits vs bf16-emulation, gradient norm, gradient samples) = ~1.5x the values measured on MI355X
+BLOCK_BARS = {
+    "block_d192_n197": (1.45e-2, 1.25e-2, 1.5e-2, 2.5e-2),
+    "block_d384_n197": (1.25e-2, 1.2e-2, 1.5e-2, 2.5e-2),
+    "block_d768_n197": (1.3e-2, 1.2e-2, 1.5e-2, 2.5e-2),
+    "block_d1024_n577": (1.25e-2, 1.15e-2, 1.5e-2, 2.5e-2),
+    "block_cait_d384_n196": (1.15e-2, 1.3e-2, 1.5e-2, 2.5e-2),
+    "e2e_vit_d128": (1.5e-2, 1.5e-2, 2.5e-2, 2.5e-2),
+    "e2e_cait_d128": (1.5e-2, 1.5e-2, 2.5e-2, 2.5e-2),
+    "e2e_mixer_d128": (1.5e-2, 1.5e-2, 2.5e-2, 2.5e-2),
+    "e2e_tnt_d128": (1.5e-2, 1.5e-2, 2.5e-2, 2.5e-2),
 }
 
 
@@ -86,9 +92,12 @@ def test_real_width_block_fixture(name):
     r64, rbf, r_emul = rel(logits, fx["logits"]), rel(logits, fx["logits_bf16"]), rel(fx["logits_bf16"], fx["logits"])
     print(f"[{name}] logits rel-L2: engine vs fp64 {r64:.2e}, engine vs bf16-emulation {rbf:.2e} (bf16-emulation vs fp64 {r_emul:.2e})")
     assert np.isfinite(logits).all()
-    assert r64 < b64 and rbf < bbf
+    bad = []  # every figure is printed before the first failure is raised
+    if not (r64 < b64 and rbf < bbf):
+        bad.append(("logits", r64, rbf))
     loss = float(eng.loss_backward(torch.as_tensor(labels).cuda(), 0.1))
-    assert abs(loss - float(fx["loss"])) < 5e-3 * max(1.0, abs(float(fx["loss"])))
+    if not abs(loss - float(fx["loss"])) < 5e-3 * max(1.0, abs(float(fx["loss"]))):
+        bad.append(("loss", loss, float(fx["loss"])))
     got = _flat(eng.grad_tree()["params"])
     keys = [k[3:] for k in fx.files if k.startswith("GN:")]
     assert set(keys) == set(got)
@@ -100,42 +109,7 @@ def test_real_width_block_fixture(name):
         rs = rel(g[fx["GI:" + k]], fx["GV:" + k]) if gn > 0 else 0.0
         worst_n = max(worst_n, (rn, k))
         worst_s = max(worst_s, (rs, k))
-        assert rn < bgn and rs < bgs, (k, rn, rs)
+        if not (rn < bgn and rs < bgs):
+            bad.append((k, rn, rs))
     print(f"[{name}] gradients vs fp64 autograd: worst norm deviation {worst_n[0]:.2e} ({worst_n[1]}), worst sampled rel-L2 {worst_s[0]:.2e} ({worst_s[1]})")
-
-
-TINY = {"tiny_vit": (make_golden.TINY_VIT, 3e-3, 6e-2), "tiny_cait": (make_golden.TINY_CAIT, 3e-3, 6e-2),
-        "tiny_mixer": (make_golden.TINY_MIXER, 3e-3, 6e-2), "tiny_tnt": (make_golden.TINY_TNT, 3e-3, 6e-2)}
-
-
-@pytest.mark.parametrize("name", sorted(TINY))
-def test_tiny_model_fixture(name):
-    """The d = 32 end-to-end fixtures through the HIP engines (every parameter, the images and every gradient are stored)."""
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
-    fx = np.load(os.path.join(GOLD, name + ".npz"))
-    ocfg, blog, bgrad = TINY[name]
-    kw = {f: getattr(ocfg, f) for f in ocfg.__dataclass_fields__}
-    from savit_amd.config import ModelConfig
-
-    kw = {k: v for k, v in kw.items() if k in ModelConfig.__dataclass_fields__}
-    params = vit_ref.unflatten({k[2:]: fx[k] for k in fx.files if k.startswith("P:")})
-    images = vit_ref.bf16_round(fx["images"])  # the engines take bf16 images; the fixture's logits used fp32 images
-    B = images.shape[0]
-    eng = _engine(kw, B)
-    eng.load_params(params)
-    x = torch.as_tensor(images).cuda()
-    logits = (eng.forward(x, is_training=False) if ocfg.kind == "cait" else eng.forward(x)).float().cpu().numpy()
-    r = rel(logits, fx["logits"])
-    print(f"[{name}] logits rel-L2 vs stored fp64 logits: {r:.2e}  (stored bf16-emulation: {rel(fx['logits_bf16'], fx['logits']):.2e})")
-    assert r < blog * 10  # the stored logits are of the UNROUNDED fp32 images: input rounding alone is ~4e-3 on d = 32 models
-    loss = float(eng.loss_backward(torch.as_tensor(fx["labels"]).cuda(), 0.1))
-    assert abs(loss - float(fx["loss"])) < 3e-2 * max(1.0, abs(float(fx["loss"])))
-    got = _flat(eng.grad_tree()["params"])
-    worst = (0.0, "")
-    for k in fx.files:
-        if k.startswith("G:params/"):
-            rr = rel(got[k[9:]], fx[k])
-            worst = max(worst, (rr, k[9:]))
-    print(f"[{name}] worst gradient rel-L2 vs stored fp64 gradients: {worst[0]:.2e} ({worst[1]})")
-    assert worst[0] < bgrad
+    assert not bad, bad

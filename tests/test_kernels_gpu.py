@@ -536,3 +536,96 @@ def test_talking_heads_attention(ops, B, N, H, hd):
         assert rel(out[:, sl], g[:, sl]) < 2e-2, (name, rel(out[:, sl], g[:, sl]))
     assert rel(host(dT1), t1.grad.numpy()) < 2e-2, rel(host(dT1), t1.grad.numpy())
     assert rel(host(dT2), t2.grad.numpy()) < 2e-2, rel(host(dT2), t2.grad.numpy())
+
+
+# ------------------------------------------------------------------------------------------ LayerScale backward (row a9)
+@pytest.mark.parametrize("rows,d,rps,with_bias", [(2 * 196, 384, 196, True), (5 * 197, 192, 197, False), (7, 768, 1, True), (64, 4096, 1, True)])
+def test_layerscale_bwd(ops, rows, d, rps, with_bias):
+    """out = res + rowscale[sample] * layerscale * branch (layerscale.py:18-23, stochastic_depth.py:16-27; cait.py:36-52):
+    dbranch = bf16(dres * rs * ls), d_layerscale += sum_rows dres * rs * branch, dbias += column sums of dbranch."""
+    import ctypes
+
+    from savit_amd import lib as _lib
+
+    L = _lib.load()
+    rng = np.random.default_rng(rows + d)
+    nsamp = rows // rps
+    dres = rng.standard_normal((rows, d)).astype(np.float32)
+    branch = rb(rng.standard_normal((rows, d)))
+    ls = (0.5 + rng.random(d)).astype(np.float32)
+    rs = np.where(rng.random(nsamp) < 0.7, 1.0 / 0.9, 0.0).astype(np.float32)  # stochastic-depth keep masks / keep (dropped samples: 0)
+    dls0 = rng.standard_normal(d).astype(np.float32)  # the outputs ACCUMULATE
+    db0 = rng.standard_normal(d).astype(np.float32)
+    t_dres, t_br, t_ls, t_rs = dev(dres), dev(branch, bf16), dev(ls), dev(rs)
+    t_dbr = torch.empty(rows, d, dtype=bf16, device="cuda")
+    t_dls, t_db = dev(dls0.copy()), dev(db0.copy())
+    ws = int(L.savit_layernorm_bwd_workspace_bytes(rows, d))
+    t_ws = torch.empty(max(ws, 16), dtype=torch.uint8, device="cuda")
+    rc = L.savit_layerscale_bwd(t_dres.data_ptr(), t_br.data_ptr(), t_ls.data_ptr(), t_rs.data_ptr(), rps, t_dbr.data_ptr(), t_dls.data_ptr(),
+                                t_db.data_ptr() if with_bias else None, rows, d, d, t_ws.data_ptr(), ws, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    rs_rows = np.repeat(rs, rps)[:, None].astype(np.float64)
+    want_dbr = dres.astype(np.float64) * rs_rows * ls
+    got_dbr = host(t_dbr)
+    assert np.array_equal(got_dbr, rb(want_dbr.astype(np.float32))) or rel(got_dbr, rb(want_dbr.astype(np.float32))) < 1e-3
+    want_dls = dls0 + (dres.astype(np.float64) * rs_rows * branch).sum(0)
+    assert rel(host(t_dls), want_dls) < 2e-5, rel(host(t_dls), want_dls)
+    if with_bias:
+        want_db = db0 + rb(want_dbr.astype(np.float32)).astype(np.float64).sum(0)
+        assert rel(host(t_db), want_db) < 2e-5, rel(host(t_db), want_db)
+    assert np.all(got_dbr[np.repeat(rs, rps) == 0] == 0)  # a dropped sample sends no cotangent into its branch
+    # vs autograd of the forward formula (fp64): same numbers by another route
+    tb = torch.tensor(branch, dtype=torch.float64, requires_grad=True)
+    tl = torch.tensor(ls, dtype=torch.float64, requires_grad=True)
+    (torch.tensor(rs_rows) * tl * tb * torch.tensor(dres, dtype=torch.float64)).sum().backward()
+    assert rel(host(t_dls) - dls0, tl.grad.numpy()) < 2e-4
+    assert rel(got_dbr, tb.grad.numpy()) < 3e-3  # bf16 output
+
+
+# ------------------------------------------------------------------------------------------ class attention (row a12)
+@pytest.mark.parametrize("B,Nk,H,hd", [(3, 197, 8, 48), (2, 197, 4, 64), (5, 65, 6, 64), (2, 256, 16, 48)])
+def test_class_attention_fwd_bwd(ops, B, Nk, H, hd):
+    """ClassSelfAttentionBlock (cait.py:10-15 over attention.py:39-58): one (pre-scaled) query per image against Nk keys, packed the way
+    the CaiT engine packs them - q at row b*Nk of a [B*Nk, 3d] buffer, k | v at columns d.. of every row.  Forward vs fp64 softmax
+    attention on the same bf16 inputs (scores rounded to bf16 like the reference's bf16 score tensor), backward vs fp64 autograd."""
+    import math
+
+    from savit_amd import lib as _lib
+
+    L = _lib.load()
+    d = H * hd
+    rng = np.random.default_rng(B * 1000 + Nk)
+    qkv = rb(rng.standard_normal((B * Nk, 3 * d)) * 0.7)
+    d_o = rb(rng.standard_normal((B, d)))
+    t_qkv, t_do = dev(qkv, bf16), dev(d_o, bf16)
+    t_o = torch.empty(B, d, dtype=bf16, device="cuda")
+    t_p = torch.empty(B, H, Nk, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    qk = t_qkv.data_ptr()
+    assert L.savit_class_attention_fwd(qk, Nk * 3 * d, qk + d * 2, 3 * d, t_o.data_ptr(), t_p.data_ptr(), B, Nk, H, hd, st) == 0
+    t_dqkv = torch.zeros(B * Nk, 3 * d, dtype=bf16, device="cuda")
+    dqk = t_dqkv.data_ptr()
+    dqs = 1.0 / math.sqrt(hd)
+    assert L.savit_class_attention_bwd(qk, Nk * 3 * d, qk + d * 2, 3 * d, t_p.data_ptr(), t_do.data_ptr(), dqk, Nk * 3 * d, dqk + d * 2, B, Nk,
+                                       H, hd, dqs, st) == 0
+    torch.cuda.synchronize()
+    # fp64 reference; q0 is the UNSCALED query whose scaled, bf16-rounded value sits in the buffer: dq_scale maps d(scaled q) to d(q0)
+    x = torch.tensor(qkv.reshape(B, Nk, 3, H, hd), dtype=torch.float64)
+    q = x[:, 0, 0].clone().requires_grad_(True)   # [B,H,hd] (already scaled)
+    k = x[:, :, 1].clone().requires_grad_(True)   # [B,Nk,H,hd]
+    v = x[:, :, 2].clone().requires_grad_(True)
+    s = torch.einsum("bhe,bkhe->bhk", q, k)
+    s_b = s + (torch.tensor(rb(s.detach().numpy().astype(np.float32)), dtype=torch.float64) - s).detach()  # bf16 score tensor, straight-through
+    p = torch.softmax(s_b, dim=-1)
+    o = torch.einsum("bhk,bkhe->bhe", p, v)
+    assert rel(host(t_p), p.detach().numpy()) < 1e-5
+    o_want = o.detach().numpy().reshape(B, d)
+    assert rel(host(t_o), o_want) < 3e-3, rel(host(t_o), o_want)
+    assert np.abs(host(t_o) - o_want).max() <= 2.0 ** -7 * max(1.0, np.abs(o_want).max())
+    o.backward(torch.tensor(d_o.reshape(B, H, hd), dtype=torch.float64))
+    got = host(t_dqkv).reshape(B, Nk, 3, H, hd)
+    assert rel(got[:, 0, 0], q.grad.numpy() * dqs) < 5e-3, rel(got[:, 0, 0], q.grad.numpy() * dqs)
+    assert np.all(got[:, 1:, 0] == 0)  # only the cls row has a query
+    assert rel(got[:, :, 1], k.grad.numpy()) < 5e-3, rel(got[:, :, 1], k.grad.numpy())
+    assert rel(got[:, :, 2], v.grad.numpy()) < 5e-3, rel(got[:, :, 2], v.grad.numpy())

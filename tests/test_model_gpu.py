@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from oracle import torch_ref, vit_ref
+from tests import parity_bars
 
 pytestmark = pytest.mark.gpu
 
@@ -67,21 +68,13 @@ def test_forward_backward_parity(pkg, case, B):
     logits = eng.forward(torch.as_tensor(images).cuda()).float().cpu().numpy()
     ref32 = vit_ref.forward(params, images, oc, mode="f32")
     refbf = vit_ref.forward(params, images, oc, mode="bf16")
-    r_us, r_emul = rel(logits, ref32), rel(refbf, ref32)
-    print(f"[{case}] logits rel-L2 vs fp32 oracle: engine {r_us:.2e}, bf16-emulating oracle {r_emul:.2e}")
-    assert np.isfinite(logits).all()
-    assert r_us < max(2.5 * r_emul, 5e-3)
+    parity_bars.check_logits(f"vit:{case}", logits, ref32, refbf)
     # loss + backward
     loss = float(eng.loss_backward(torch.as_tensor(labels).cuda(), 0.1))
     loss_ref, _, grads_ref = torch_ref.loss_and_grads(params, images, labels, oc, 0.1)
     assert abs(loss - loss_ref) < 2e-2 * max(1.0, abs(loss_ref))
     got = _flat(eng.grad_tree()["params"])
-    worst = 0.0
-    for k, g in grads_ref.items():
-        r = rel(got[k], g)
-        worst = max(worst, r)
-        assert r < 6e-2, (k, r)
-    print(f"[{case}] worst parameter-gradient rel-L2 vs fp32 autograd: {worst:.2e}")
+    parity_bars.check_grads(f"vit:{case}", got, grads_ref)
     # the engine's loss must equal the oracle loss evaluated on the engine's own logits
     assert abs(loss - vit_ref.loss_fn(logits, labels, 0.1)) < 1e-4 * max(1.0, abs(loss))
 
@@ -218,22 +211,13 @@ def test_cait_forward_backward_parity(pkg, case, B, training):
                          keep_masks=None if masks is None else torch.as_tensor(masks)).float().cpu().numpy()
     ref32 = vit_ref.forward(params, images, oc, mode="f32", is_training=training, keep_masks=masks)
     refbf = vit_ref.forward(params, images, oc, mode="bf16", is_training=training, keep_masks=masks)
-    r_us, r_emul = rel(logits, ref32), rel(refbf, ref32)
-    print(f"[{case} train={training}] logits rel-L2 vs fp32 oracle: engine {r_us:.2e}, bf16-emulating oracle {r_emul:.2e}")
-    assert np.isfinite(logits).all()
-    assert r_us < max(2.5 * r_emul, 8e-3)
+    parity_bars.check_logits(f"cait:{case}:{training}", logits, ref32, refbf)
     loss = float(eng.loss_backward(torch.as_tensor(labels).cuda(), 0.1))
     loss_ref, _, grads_ref = torch_ref.loss_and_grads(params, images, labels, oc, 0.1, is_training=training, keep_masks=masks)
     assert abs(loss - loss_ref) < 2e-2 * max(1.0, abs(loss_ref))
     got = _flat(eng.grad_tree()["params"])
     assert set(got) == set(grads_ref)
-    worst, worst_k = 0.0, ""
-    for k, g in grads_ref.items():
-        r = rel(got[k], g)
-        if r > worst:
-            worst, worst_k = r, k
-        assert r < 8e-2, (k, r)
-    print(f"[{case} train={training}] worst parameter-gradient rel-L2 vs fp32 autograd: {worst:.2e} ({worst_k})")
+    parity_bars.check_grads(f"cait:{case}:{training}", got, grads_ref)
 
 
 def test_cait_reference_shapes_and_known_answers(pkg):

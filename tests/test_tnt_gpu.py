@@ -5,8 +5,12 @@ import pytest
 import torch
 
 from oracle import torch_ref, vit_ref
+from tests import parity_bars
 
 pytestmark = pytest.mark.gpu
+
+LINEARITY_BAR = 2e-2       # tightened after measuring (see the test)
+FULL_DEPTH_GRAD_BAR = 5e-2
 
 
 @pytest.fixture(scope="module")
@@ -138,22 +142,13 @@ def test_forward_backward_parity(pkg, case, B):
     logits = eng.forward(torch.as_tensor(images).cuda()).float().cpu().numpy()
     ref32 = vit_ref.forward(params, images, oc, mode="f32")
     refbf = vit_ref.forward(params, images, oc, mode="bf16")
-    r_us, r_emul = rel(logits, ref32), rel(refbf, ref32)
-    print(f"[tnt {case}] logits rel-L2 vs fp32 oracle: engine {r_us:.2e}, bf16-emulating oracle {r_emul:.2e}")
-    assert np.isfinite(logits).all()
-    assert r_us < max(2.5 * r_emul, 5e-3)
+    parity_bars.check_logits(f"tnt:{case}", logits, ref32, refbf)
     loss = float(eng.loss_backward(torch.as_tensor(labels).cuda(), 0.1))
     loss_ref, _, grads_ref = torch_ref.loss_and_grads(params, images, labels, oc, 0.1)
     assert abs(loss - loss_ref) < 2e-2 * max(1.0, abs(loss_ref))
     got = _flat(eng.grad_tree()["params"])
     assert set(got) == set(grads_ref)
-    worst = 0.0
-    for k, g in grads_ref.items():
-        assert got[k].shape == g.shape, k
-        r = rel(got[k], g)
-        worst = max(worst, r)
-        assert r < 6e-2, (k, r)
-    print(f"[tnt {case}] worst parameter-gradient rel-L2 vs fp32 autograd: {worst:.2e}")
+    parity_bars.check_grads(f"tnt:{case}", got, grads_ref)
     # the head padding of the inner attention kernels holds zeros and receives exactly zero gradient
     lay = eng.layout
     for flat in (eng.params, eng.grads):
@@ -249,9 +244,49 @@ def test_full_size_properties(pkg):
         half.loss_backward(lab[32 * k:32 * (k + 1)].contiguous(), label_smoothing=0.1)
         acc += half.grads
     acc *= 0.5
-    assert float((acc - g_full).norm() / g_full.norm()) < 2e-2
-    for _ in range(8):
-        eng.optimizer_step(lr=1e-4, weight_decay=1e-4, max_norm=1.0)
+    lin = float((acc - g_full).norm() / g_full.norm())
+    print(f"[tnt_b full size] half-batch gradient linearity {lin:.2e}")
+    assert lin < LINEARITY_BAR, lin
+    # descent at the reference's learning-rate scale: lr = 5e-4 * batch / 512 reached by a linear warm-up (train.py:171,214-220)
+    peak, warm = 5e-4 * B / 512.0, 6
+    losses = [l0]
+    for k in range(12):
+        eng.optimizer_step(lr=peak * min(1.0, (k + 1) / warm), weight_decay=1e-4, max_norm=1.0)
         eng.forward(img)
-        l1 = float(eng.loss_backward(lab, label_smoothing=0.1))
-    assert np.isfinite(l1) and l1 < l0 - 0.02, (l0, l1)
+        losses.append(float(eng.loss_backward(lab, label_smoothing=0.1)))
+    print("[tnt_b full size] losses", [round(v, 3) for v in losses])
+    assert all(np.isfinite(v) for v in losses) and losses[-1] < l0 - 0.3, losses
+
+
+def test_full_depth_gradients_vs_oracle(pkg):
+    """tnt_b_patch16 (all 12 layers, both streams) at 2 images: every parameter gradient vs fp32 autograd of the torch restatement
+    (the 1-2 layer cases above do not exclude a defect that grows with depth)."""
+    from savit_amd.tnt_engine import TNTEngine
+
+    mc, oc = _cfgs(**{k: v for k, v in vit_ref.MODEL_ZOO["tnt_b_patch16"].items()}, num_classes=1000, img_size=224)
+    B = 2
+    rng = np.random.default_rng(41)
+    params = vit_ref.init_params(oc, seed=9, randomize=True)
+    params["params"]["Dense_0"]["kernel"] *= 0.05  # no LayerNorm in front of the head (tnt.py:187): keep the logits O(1)
+    images = vit_ref.bf16_round(rng.standard_normal((B, 224, 224, 3)).astype(np.float32))
+    labels = rng.integers(0, 1000, B)
+    eng = TNTEngine(mc, B)
+    eng.load_params(params)
+    logits = eng.forward(torch.as_tensor(images).cuda()).float().cpu().numpy()
+    ref32 = vit_ref.forward(params, images, oc, mode="f32")
+    print(f"[tnt_b 12 layers] logits rel-L2 vs fp32 oracle {rel(logits, ref32):.2e}")
+    assert rel(logits, ref32) < 3e-2
+    loss = float(eng.loss_backward(torch.as_tensor(labels).cuda(), 0.1))
+    loss_ref, _, grads_ref = torch_ref.loss_and_grads(params, images, labels, oc, 0.1)
+    assert abs(loss - loss_ref) < 2e-2 * max(1.0, abs(loss_ref))
+    got = _flat(eng.grad_tree()["params"])
+    worst, worst_k, per_layer = 0.0, "", {}
+    for k, g in grads_ref.items():
+        r = rel(got[k], g)
+        lay = k.split("/")[1] if k.startswith("Encoder_0/") else k.split("/")[0]
+        per_layer[lay] = max(per_layer.get(lay, 0.0), r)
+        if r > worst:
+            worst, worst_k = r, k
+    print("[tnt_b 12 layers] worst gradient rel-L2 per block:", {k: f"{v:.1e}" for k, v in per_layer.items()})
+    print(f"[tnt_b 12 layers] worst parameter-gradient rel-L2 vs fp32 autograd: {worst:.2e} ({worst_k})")
+    assert worst < FULL_DEPTH_GRAD_BAR, (worst_k, worst)
