@@ -39,7 +39,21 @@ def check_grads(tag, got, grads_ref, skip=()):
     assert worst < bar, (tag, worst_k, worst, bar)
 
 
-_MEASURING = (5e-2, 5e-2, GRAD_CAP)
-for _t in ("vit:tiny", "vit:ti2", "vit:s1_p32", "vit:n577", "vit:hd48", "cait:tiny_cait:False", "cait:tiny_cait:True", "cait:xxs2:True",
-           "cait:m1:True", "mixer:tiny", "mixer:p16", "mixer:p32", "tnt:tiny24", "tnt:tiny40", "tnt:b1"):
-    BARS[_t] = _MEASURING
+# measured on MI355X in round 2 (gpurun_out/r2d/parity.log):  logits vs fp32 | logits vs bf16-emulation | worst gradient
+BARS.update({
+    "vit:tiny": (1.5e-2, 1.05e-2, 2.5e-2),       # 9.85e-3 | 6.82e-3 | 1.89e-2
+    "vit:ti2": (1.4e-2, 1.25e-2, 2.4e-2),        # 9.20e-3 | 8.28e-3 | 1.57e-2
+    "vit:s1_p32": (1.3e-2, 1.2e-2, 1.75e-2),     # 8.47e-3 | 7.99e-3 | 1.16e-2
+    "vit:n577": (9.2e-3, 1.05e-2, 1.7e-2),       # 6.09e-3 | 6.89e-3 | 1.14e-2
+    "vit:hd48": (1.3e-2, 1.2e-2, 2.5e-2),        # 8.77e-3 | 7.77e-3 | 1.80e-2
+    "cait:tiny_cait:False": (1.4e-2, 1.4e-2, 2.5e-2),
+    "cait:tiny_cait:True": (1.4e-2, 1.4e-2, 2.5e-2),
+    "cait:xxs2:True": (1.15e-2, 1.25e-2, 2.5e-2),  # 7.53e-3 | 8.24e-3 | 1.77e-2
+    "cait:m1:True": (7e-3, 7.2e-3, 9.5e-3),        # 4.63e-3 | 4.75e-3 | 6.24e-3
+    "mixer:tiny": (7.2e-3, 9.1e-3, 2.5e-2),      # 4.76e-3 | 6.05e-3 | 2.04e-2
+    "mixer:p16": (5.6e-3, 6.1e-3, 1.5e-2),       # 3.73e-3 | 4.01e-3 | 9.75e-3
+    "mixer:p32": (6.8e-3, 7.8e-3, 1.6e-2),       # 4.47e-3 | 5.15e-3 | 1.06e-2
+    "tnt:tiny24": (1.2e-2, 1.65e-2, 2.5e-2),     # 7.77e-3 | 1.10e-2 | 2.15e-2
+    "tnt:tiny40": (1.5e-2, 1.4e-2, 2.5e-2),      # 9.93e-3 | 9.27e-3 | 2.07e-2
+    "tnt:b1": (1.15e-2, 1.25e-2, 2.5e-2),        # 7.52e-3 | 8.22e-3 | 1.84e-2
+})

@@ -211,7 +211,7 @@ def _full_workload_properties(model, img_size, B, sub, seed):
     lo = B // 4
     got = small.forward(img[lo:lo + sub].contiguous())
     err = float((got - full[lo:lo + sub]).norm() / full[lo:lo + sub].norm())
-    assert err < 2e-3, err
+    assert err < 1e-6, err  # measured 0: same K order whatever the grid
     del small
     half = ViTEngine(cfg, B // 2)
     half.params, half.w, half.weights_stale = eng.params, eng.w, False
@@ -224,7 +224,7 @@ def _full_workload_properties(model, img_size, B, sub, seed):
     acc *= 0.5
     rel = float((acc - g_full).norm() / g_full.norm())
     print(f"[{model} {img_size} B={B}] sub-batch rows {err:.2e}, half-batch gradient linearity {rel:.2e}")
-    assert rel < 2e-3, rel
+    assert rel < 2e-5, rel  # measured 3.8e-7 / 1.3e-6: fp32 summation order only
 
 
 def test_deit_small_full_workload():

@@ -59,16 +59,16 @@ def _flat(tree):
 
 
 # name: (logits vs fp64, logits vs bf16-emulation, gradient norm, gradient samples) = ~1.5x the values measured on MI355X
-BLOCK_BARS = {
-    "block_d192_n197": (1.45e-2, 1.25e-2, 1.5e-2, 2.5e-2),
-    "block_d384_n197": (1.25e-2, 1.2e-2, 1.5e-2, 2.5e-2),
-    "block_d768_n197": (1.3e-2, 1.2e-2, 1.5e-2, 2.5e-2),
-    "block_d1024_n577": (1.25e-2, 1.15e-2, 1.5e-2, 2.5e-2),
-    "block_cait_d384_n196": (1.15e-2, 1.3e-2, 1.5e-2, 2.5e-2),
-    "e2e_vit_d128": (1.5e-2, 1.5e-2, 2.5e-2, 2.5e-2),
-    "e2e_cait_d128": (1.5e-2, 1.5e-2, 2.5e-2, 2.5e-2),
-    "e2e_mixer_d128": (1.5e-2, 1.5e-2, 2.5e-2, 2.5e-2),
-    "e2e_tnt_d128": (1.5e-2, 1.5e-2, 2.5e-2, 2.5e-2),
+BLOCK_BARS = {  # measured (gpurun_out/r2d/parity.log):          logits f64 | bf16-emu | grad norm | grad samples
+    "block_d192_n197": (1.45e-2, 1.25e-2, 5e-3, 2.5e-2),         # 9.66e-3 | 8.07e-3 | 3.2e-3 | 2.08e-2
+    "block_d384_n197": (1.25e-2, 1.2e-2, 5e-3, 1.8e-2),          # 8.29e-3 | 7.90e-3 | 2.3e-3 | 1.15e-2
+    "block_d768_n197": (1.3e-2, 1.2e-2, 5e-3, 1.8e-2),           # 8.73e-3 | 7.68e-3 | 1.9e-3 | 1.20e-2
+    "block_d1024_n577": (1.25e-2, 1.15e-2, 5e-3, 1.7e-2),        # 8.22e-3 | 7.59e-3 | 1.1e-3 | 1.10e-2
+    "block_cait_d384_n196": (1.15e-2, 1.3e-2, 5e-3, 2.2e-2),     # 7.44e-3 | 8.64e-3 | 1.8e-3 | 1.42e-2
+    "e2e_vit_d128": (1.25e-2, 1.2e-2, 6e-3, 2.1e-2),             # 8.20e-3 | 7.69e-3 | 3.4e-3 | 1.38e-2
+    "e2e_cait_d128": (1e-2, 1.35e-2, 1.4e-2, 2.5e-2),            # 6.42e-3 | 8.74e-3 | 9.0e-3 | 1.79e-2
+    "e2e_mixer_d128": (1.15e-2, 1.25e-2, 1.5e-2, 2.5e-2),        # 7.55e-3 | 8.15e-3
+    "e2e_tnt_d128": (1.4e-2, 1.85e-2, 1.8e-2, 2.5e-2),           # 9.23e-3 | 1.23e-2 | 1.16e-2 | 2.34e-2
 }
 
 
@@ -102,9 +102,17 @@ def test_real_width_block_fixture(name):
     keys = [k[3:] for k in fx.files if k.startswith("GN:")]
     assert set(keys) == set(got)
     worst_n, worst_s = (0.0, ""), (0.0, "")
+    gn_max = max(float(fx["GN:" + k]) for k in keys)
     for k in keys:
         g = got[k].astype(np.float64).ravel()
         gn = float(fx["GN:" + k])
+        if gn < 1e-9 * gn_max:
+            # a gradient that is exactly zero in exact arithmetic (the Mixer's token-Dense output bias: every later LayerNorm removes the
+            # shift it causes; tests/test_mixer_oracle.py) - both sides hold rounding noise only: bounded against its sibling bias
+            scale = float(fx["GN:" + k.replace("Dense_1/bias", "Dense_0/bias")])
+            if not np.linalg.norm(g) < 2e-2 * scale:
+                bad.append((k, float(np.linalg.norm(g)), scale))
+            continue
         rn = abs(np.linalg.norm(g) - gn) / gn
         rs = rel(g[fx["GI:" + k]], fx["GV:" + k]) if gn > 0 else 0.0
         worst_n = max(worst_n, (rn, k))

@@ -191,10 +191,12 @@ CAIT_CASES = {
 }
 
 
-@pytest.mark.parametrize("case,B,training", [("tiny_cait", 3, False), ("tiny_cait", 4, True), ("xxs2", 2, True), ("m1", 2, True)])
+@pytest.mark.parametrize("case,B,training", [("tiny_cait", 32, False), ("tiny_cait", 32, True), ("xxs2", 2, True), ("m1", 2, True)])
 def test_cait_forward_backward_parity(pkg, case, B, training):
     """Talking-heads SA + LayerScale + stochastic depth + class attention end to end vs the fp32 oracle / fp32 autograd.
-    Training mode uses explicit per-sample keep masks (the JAX rng stream cannot be reproduced)."""
+    Training mode uses explicit per-sample keep masks (the JAX rng stream cannot be reproduced).  The tiny model runs 32 images: the
+    gradient of its 2 x 2 talking-heads matrices is a strongly cancelling sum over (image, query, key) of bf16-rounded scores times
+    cotangents, and with 3 images of 17 tokens its rounding noise alone was 4.7e-2 of the sum."""
     from savit_amd.cait_engine import CaiTEngine
     from savit_amd.config import ModelConfig
 
