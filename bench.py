@@ -149,6 +149,9 @@ def make_step(eng, cfg, B, world, rank, sync):
                 torch.randint(0, cfg.num_classes, (B,), device="cuda", generator=gd, dtype=torch.int32)) for _ in range(2)]
     lr, wd = 5e-4 * (B * world) / 512.0, 1e-4
 
+    if cfg.kind == "cait":
+        eng.gen.manual_seed(42 + rank)  # per-rank stochastic-depth masks
+
     def step(i):
         img, lab = batches[i & 1]
         if cfg.kind == "cait":

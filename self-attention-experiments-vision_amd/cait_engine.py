@@ -113,6 +113,16 @@ class CaiTLayout:
         return {"params": p}
 
 
+def stochastic_depth_seed(seed: int, rank: int, step: int) -> int:
+    """Seed of the stochastic-depth masks of one (run seed, data-parallel rank, global step): Flax draws them from a per-device,
+    per-step 'stochastic_depth' rng (stochastic_depth.py:17-21 under pmap; train.py never passes one - defect B7).  Every rank gets
+    its own masks, a resumed run continues with the masks it would have drawn, and --seed changes all of them."""
+    x = (int(seed) * 1000003 + int(rank)) * 0x9E3779B97F4A7C15 + int(step) * 0xBF58476D1CE4E5B9
+    x &= (1 << 64) - 1
+    x ^= x >> 31
+    return x & ((1 << 63) - 1)
+
+
 class CaiTEngine:
     def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True):
         if cfg.kind != "cait":
@@ -483,10 +493,12 @@ class CaiTEngine:
         u = torch.rand(self.sd.shape, device=self.dev, generator=self.gen)
         self.sd.copy_(torch.floor(keep + u) / keep)
 
-    def forward(self, images: Optional[torch.Tensor] = None, is_training: bool = False, keep_masks=None) -> torch.Tensor:
+    def forward(self, images: Optional[torch.Tensor] = None, is_training: bool = False, keep_masks=None,
+                sd_seed: Optional[int] = None) -> torch.Tensor:
+        """sd_seed: seed of THIS step's stochastic-depth masks (see stochastic_depth_seed); None continues the engine's stream."""
         if images is not None:
             self.set_images(images)
-        self.set_stochastic_depth(is_training, keep_masks)
+        self.set_stochastic_depth(is_training, keep_masks, seed=sd_seed)
         if self.weights_stale:
             self.refresh_weights()
         if self._fwd_plan is None:

@@ -96,3 +96,40 @@ def test_short_run_tnt(capsys):
     train = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{") and "train/loss" in l]
     assert len(train) == 3 and abs(train[0]["train/loss"] - 6.9078) < 1e-2
     assert all(np.isfinite(t["train/loss"]) for t in train)
+
+
+def test_stochastic_depth_seed_depends_on_seed_rank_and_step():
+    """every rank and every step gets its own masks, and a resumed run continues the sequence (the seed is a pure
+    function of (--seed, rank, global step))."""
+    import importlib
+
+    sd = importlib.import_module("savit_amd.cait_engine").stochastic_depth_seed
+    seen = {sd(s, r, k) for s in (0, 42) for r in range(8) for k in range(50)}
+    assert len(seen) == 2 * 8 * 50
+    assert sd(42, 3, 17) == sd(42, 3, 17) and 0 <= sd(42, 3, 17) < 2 ** 63
+
+
+@pytest.mark.gpu
+def test_cait_masks_differ_across_ranks_and_resume_consistently():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from savit_amd.cait_engine import CaiTEngine, stochastic_depth_seed
+    from savit_amd.config import ModelConfig
+
+    mc = ModelConfig(kind="cait", num_layers=2, num_heads=2, embed_dim=128, patch=8, num_classes=16, img_size=32, num_layers_token_only=2,
+                     stoch_depth_rate=0.3, layerscale_eps=1e-5)
+    eng = CaiTEngine(mc, 64)
+
+    def masks(rank, step):
+        eng.set_stochastic_depth(True, seed=stochastic_depth_seed(42, rank, step))
+        return eng.sd.clone()
+
+    a = masks(0, 5)
+    assert torch.equal(a, masks(0, 5))            # resume: step 5 draws what step 5 drew
+    assert not torch.equal(a, masks(1, 5))        # another rank
+    assert not torch.equal(a, masks(0, 6))        # the next step
+    keep = 1.0 - mc.stoch_depth_rate
+    assert set(torch.unique(a).tolist()) <= {0.0, 1.0 / keep} or torch.allclose(torch.unique(a), torch.tensor([0.0, 1.0 / keep], device=a.device))
+    assert abs(float((a > 0).float().mean()) - keep) < 0.08  # floor(keep + U) keeps with probability `keep` (stochastic_depth.py:21-23)

@@ -214,7 +214,9 @@ def main(argv=None):
                 if ml is not None:
                     batch = dict(batch, mix_labels=ml, ratio=ratio)
             if eng.cfg.kind == "cait":
-                eng.forward(images, is_training=True)
+                from savit_amd.cait_engine import stochastic_depth_seed
+
+                eng.forward(images, is_training=True, sd_seed=stochastic_depth_seed(args.seed, rank, step))
             else:
                 eng.forward(images)
             eng.loss_backward(batch["labels"], args.label_smoothing, batch.get("mix_labels"), batch.get("ratio"))
