@@ -133,6 +133,15 @@ int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue);
  * b*tokens + token_offset + p of the bf16 cotangent buffer [B*tokens, lddy]. */
 int savit_gemm_bf16_wgrad(const void* X, const void* dY, float* dW, int M, int Kin, int Nout, int ldx, int lddy, int lddw,
                           int splits, int patch, int img_size, int tokens, int token_offset, void* stream);
+/* The same product without atomics: every split of the reduction stores its partial [Kin, Nout] tile set to `workspace` with plain
+ * stores and a second launch adds the splits to dW in index order - bitwise reproducible, and the partial traffic moves at the
+ * plain-store rate instead of the chip-wide float-atomic rate.  workspace: 16-B aligned, at least
+ * savit_gemm_wgrad_workspace_bytes(M, Kin, Nout, splits, patch) bytes (the split count the launch will use x Kin x Nout x 4; 0 for the
+ * shapes served by the small 2-stage kernel, which keeps atomics); NULL or too small a workspace falls back to the atomic form. */
+int savit_gemm_bf16_wgrad_ws(const void* X, const void* dY, float* dW, int M, int Kin, int Nout, int ldx, int lddy, int lddw,
+                             int splits, int patch, int img_size, int tokens, int token_offset, void* workspace, long workspace_bytes,
+                             void* stream);
+long savit_gemm_wgrad_workspace_bytes(int M, int Kin, int Nout, int splits, int patch);
 /* Kernel the wgrad heuristic picks: 1 = 128x128 ring (4 waves), 3 = 256x256 ring (8 waves). */
 int savit_gemm_wgrad_auto_variant(int Kin, int Nout, int patch);
 

@@ -25,7 +25,7 @@ import torch
 
 from . import lib as _lib
 from .config import ModelConfig
-from .engine import _Plan, _align, _copy_tree
+from .engine import _Plan, _align, _copy_tree, add_wgrad, finalize_wgrad_ws
 
 bf16 = torch.bfloat16
 f32 = torch.float32
@@ -278,8 +278,7 @@ class CaiTEngine:
             if self.L.savit_gemm_wgrad_auto_variant(Kin, Nout, patch[0]) == 3:  # big weights only (see ViTEngine._wgrad_splits)
                 tiles = -(-Kin // 256) * -(-Nout // 256)
                 splits = max(1, min(24, round(self.wgrad_cu_share * self.n_cus / tiles)))
-        plan.add(self.L.savit_gemm_bf16_wgrad, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, splits, patch[0], patch[1], patch[2], patch[3]), label,
-                 side=side, reads=(dY,) if side else ())
+        add_wgrad(self, plan, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, splits, patch, side)
 
     def _build_cast_plan(self):
         P, L, lay, cfg = _Plan(), self.L, self.layout, self.cfg
@@ -450,6 +449,7 @@ class CaiTEngine:
         P.add(L.savit_pos_cls_grad, (self.dres.data_ptr(), gp("pos"), None, B, N, d, 0), "pos.grad")
         self._wgrad(P, "Wpe.wgrad", self._img_buf.data_ptr(), self.dres_b.data_ptr(), gp("Wpe"), M, cfg.patch_dim, d, 0, d, d,
                     patch=(cfg.patch, cfg.img_size, N, 0))
+        finalize_wgrad_ws(self, P)
         return P
 
     # ------------------------------------------------------------------------------------ execution

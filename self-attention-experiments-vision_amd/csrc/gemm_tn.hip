@@ -28,6 +28,8 @@ struct GemmParams {
   int tiles_m, tiles_n;
   int chunks_per_prow;  // PATCH: 16-B chunks per (patch row) = patch*3/8
   int grid_side;        // PATCH: patches per image side
+  int desync_phases;    // ping-pong kernel: workgroups start in this many phase groups ...
+  int desync_sleep;     // ... each delayed by (group index) x this many s_sleep(127) units (0 = all start together)
 };
 
 template <int EPI>
@@ -783,6 +785,226 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_pair_kernel(const G
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Ping-pong variant (256 x 256 x 64, 8 waves = 2 (M) x 4 (N), one workgroup per CU).  In the kernels above all waves of a workgroup
+// do the same thing at the same time: the two waves that share a SIMD both want the matrix pipe, then both wait at the barrier.
+// Here the waves of M-half 0 (waves 0-3, one per SIMD) and of M-half 1 (waves 4-7) run the SAME program one barrier apart: between
+// two consecutive barriers one group issues the 16 MFMAs of a 64 x 32 output quadrant (K = 64) while its SIMD partners read their
+// next fragments from LDS and issue the LDS-DMA of a later K-tile, then the roles swap - the matrix pipe of every SIMD always has a
+// wave in its MFMA segment (cdna_hip_programming.md "256^2 8-phase template"; MI355X_MICROARCH.md "Two waves per SIMD").
+//   LDS: 2 buffers x 64 KB (one K-tile: 256 A rows + 256 Bt rows of 128 B), same XOR swizzle as the pair kernel (conflict-free
+//   ds_read_b128, applied on the LDS-DMA source side).  A buffer is cut into 8 UNITS of 64 rows: A(h, qm) = unit 2h + qm (rows
+//   of M-half h, 64-row quadrant qm), B(wc) = unit 4 + wc (the 64 Bt rows = output columns of the waves in N-quarter wc).  One unit
+//   = one 1-KB LDS-DMA instruction from each of the 8 waves.
+//   K-tile t, phase p = 0..3 computes quadrant (qm, qn) = (0,0) (0,1) (1,1) (1,0) of the wave's 128 x 64 tile.  Load segment
+//   L(t,p) (what a wave does between its previous MFMA segment and the barrier that opens this one):
+//     p0: read A(wr,0) [8 x ds_read_b128] and the qn = 0 half of B(wc) [4]   | DMA units 6, 7 of K-tile t+1
+//     p1: read the qn = 1 half of B(wc) [4]                                    | DMA units 1, 3 of K-tile t+1
+//     p2: read A(wr,1) [8]                                                     | DMA units 0, 2 of K-tile t+2
+//     p3: -                                                                    | DMA units 4, 5 of K-tile t+2 ; s_waitcnt vmcnt(4)
+//   Hazards.  WAR: a unit is overwritten two phases after its last read or later (A(h,0): read p0, written from p2 on; B: read
+//   p0/p1, written p3 / next p0; A(h,1): read p2, written next p1) - with the groups one barrier apart that is at least one
+//   barrier after the last reader's lgkmcnt(0).  RAW: K-tile t+1 is complete in LDS once every wave has passed the vmcnt(4) of
+//   L(t,p3) (all but the four DMAs of K-tile t+2 have landed) and the barrier behind it; its first read is in L(t+1,p0), which
+//   for both groups lies behind a barrier that every wave reaches after that wait.
+template <int EPI, int ABL = 0>  // ABL: timing-only ablation builds (tools/gemm_pp_check.py): 1 no main-loop DMA, 2 no LDS reads, 4 no barriers, 8 no MFMA
+__global__ __launch_bounds__(512) void gemm_tn_pp_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 256, RB = 128;
+  constexpr int UNIT = 64 * RB, BUF = (BM + BN) * RB;
+  constexpr int WTM = 128, WTN = 64, MI = 8, NI = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const savit_gemm_args& a = p.a;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int tid = xcd_remap(blockIdx.x, nwg);
+  const int tm = tid / p.tiles_n, tn = tid - tm * p.tiles_n;
+  const int row0 = tm * BM, col0 = tn * BN;
+
+  const bf16_t* Abase = reinterpret_cast<const bf16_t*>(a.A) + (size_t)row0 * a.lda;
+  const bf16_t* Bbase = reinterpret_cast<const bf16_t*>(a.Bt) + (size_t)col0 * a.ldb;
+  uint32_t a_bytes, b_bytes;
+  {
+    const size_t ta = (size_t)(a.M - row0) * a.lda * 2, tb = (size_t)(a.N - col0) * a.ldb * 2;
+    a_bytes = (uint32_t)(ta > 0xfffffff0ull ? 0xfffffff0ull : ta);
+    b_bytes = (uint32_t)(tb > 0xfffffff0ull ? 0xfffffff0ull : tb);
+  }
+  const auto srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Abase), 0, a_bytes, 0x00020000);
+  const auto srdB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bbase), 0, b_bytes, 0x00020000);
+
+  // LDS-DMA geometry: one wave-instruction = 8 rows x 128 B; this wave owns rows wave*8 .. +7 of every unit
+  const int lrow = lane >> 3, pch = lane & 7;
+  const int ur = wave * 8 + lrow;                               // row inside a unit (0..63)
+  const int uc = (pch ^ ((ur >> 1) & 7)) * 16;                  // byte offset of the logical chunk stored at this lane's position
+  const uint32_t a_voff = (uint32_t)ur * (uint32_t)(a.lda * 2) + (uint32_t)uc;
+  const uint32_t b_voff = (uint32_t)ur * (uint32_t)(a.ldb * 2) + (uint32_t)uc;
+  const uint32_t a_unit = 64u * (uint32_t)(a.lda * 2), b_unit = 64u * (uint32_t)(a.ldb * 2);
+  const int KT = a.K / 64;
+  auto dma = [&](int kt, int u) {  // unit u (compile-time) of K-tile kt into buffer kt & 1
+    if (kt >= KT) return;
+    if ((ABL & 1) && kt >= 2) return;
+    char* dst = smem + (kt & 1) * BUF + u * UNIT + wave * 1024;
+    if (u < 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (__attribute__((address_space(3))) void*)dst, 16, a_voff + (uint32_t)u * a_unit, kt * RB, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (__attribute__((address_space(3))) void*)dst, 16, b_voff + (uint32_t)(u - 4) * b_unit, kt * RB, 0, 0);
+  };
+
+  // fragment read offsets (bytes inside a unit): row = 16 i + (lane & 15), logical chunk = 4 ks + (lane >> 4)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = (fr >> 1) & 7;
+  const int foff0 = fr * RB + ((fq ^ sw) << 4);
+  const int foff1 = fr * RB + (((fq + 4) ^ sw) << 4);
+  const int a_base = (2 * wr) * UNIT, b_base = (4 + wc) * UNIT;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2], bf[4][2];
+
+  if (p.desync_sleep > 0 && blockIdx.x < 256u) {  // the first round only: later workgroups inherit the phase of the CU they land on
+    // spread the workgroups of a round over phase groups: with every CU in its epilogue at the same moment the output stores of
+    // a round queue behind one another at the memory side while the matrix pipes idle (and the reverse during the main loops)
+    const int n = (int)(blockIdx.x % (unsigned)p.desync_phases) * p.desync_sleep;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);  // ~1 us per unit
+  }
+  // prologue: all of K-tile 0 and the four units of K-tile 1 that L(-1,p2), L(-1,p3) would have issued
+#pragma unroll
+  for (int u = 0; u < 8; ++u) dma(0, u);
+  dma(1, 0); dma(1, 2); dma(1, 4); dma(1, 5);
+  if (KT > 1) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // M-half 1 runs one barrier behind M-half 0
+
+#define PP_READ_A(QM)                                                                                          \
+  if (!(ABL & 2) || kt == 0) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+    af[i][0] = *reinterpret_cast<const bf16x8*>(cur + a_base + (QM) * UNIT + i * 16 * RB + foff0);             \
+    af[i][1] = *reinterpret_cast<const bf16x8*>(cur + a_base + (QM) * UNIT + i * 16 * RB + foff1);             \
+  }
+#define PP_READ_B(QN)                                                                                          \
+  if (!(ABL & 2) || kt == 0) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
+    bf[2 * (QN) + j][0] = *reinterpret_cast<const bf16x8*>(cur + b_base + (2 * (QN) + j) * 16 * RB + foff0);  \
+    bf[2 * (QN) + j][1] = *reinterpret_cast<const bf16x8*>(cur + b_base + (2 * (QN) + j) * 16 * RB + foff1);  \
+  }
+#define PP_COMPUTE(QM, QN)                                                                                     \
+  if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                                                                \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                                                           \
+  __builtin_amdgcn_s_setprio(1);                                                                               \
+  if (!(ABL & 8)) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+        acc[4 * (QM) + i][2 * (QN) + j] =                                                                      \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[2 * (QN) + j][ks], af[i][ks], acc[4 * (QM) + i][2 * (QN) + j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                               \
+  __builtin_amdgcn_sched_barrier(0);                                                                           \
+  if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const char* cur = smem + (kt & 1) * BUF;
+    // ---- phase 0: quadrant (0,0)
+    PP_READ_B(0)
+    __builtin_amdgcn_sched_barrier(0);
+    PP_READ_A(0)
+    dma(kt + 1, 6); dma(kt + 1, 7);
+    PP_COMPUTE(0, 0)
+    // ---- phase 1: quadrant (0,1)
+    PP_READ_B(1)
+    dma(kt + 1, 1); dma(kt + 1, 3);
+    PP_COMPUTE(0, 1)
+    // ---- phase 2: quadrant (1,1)
+    PP_READ_A(1)
+    dma(kt + 2, 0); dma(kt + 2, 2);
+    PP_COMPUTE(1, 1)
+    // ---- phase 3: quadrant (1,0); K-tile kt+1 must be complete behind this phase's first barrier
+    dma(kt + 2, 4); dma(kt + 2, 5);
+    if (kt + 2 < KT) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PP_COMPUTE(1, 0)
+  }
+#undef PP_READ_A
+#undef PP_READ_B
+#undef PP_COMPUTE
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count: every wave is past its last LDS read after this one
+  if (ABL & 8) {  // keep the fragments alive
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        asm volatile("" ::"v"(af[i][ks]));
+        asm volatile("" ::"v"(bf[i][ks]));
+      }
+  }
+
+  if constexpr (epi_uses_lds<EPI>()) {
+    epilogue_lds<EPI, WTM, WTN, MI, NI>(p, acc, smem + wave * (WTM * WTN * 2), row0 + wr * WTM, col0 + wc * WTN, lane, tm * 2 + wr);
+  } else {
+    const int mrow = row0 + wr * WTM + fr;
+    const int ncol = col0 + wc * WTN + fq * 4;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < MI; ++i) epilogue_store<EPI>(p, mrow + i * 16, ncol + j * 16, acc[i][j], csum);
+    }
+  }
+}
+
+template <int ABL>
+int launch_pp_ablation(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  p.tiles_m = (p.a.M + 255) / 256;
+  p.tiles_n = (p.a.N + 255) / 256;
+  auto kfn = gemm_tn_pp_kernel<SAVIT_EPI_BF16, ABL>;
+  hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kfn, dim3(p.tiles_m * p.tiles_n), dim3(512), 2 * 512 * 128, s, p);
+  SAVIT_LAUNCH_RET();
+}
+
+int launch_pp(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  p.tiles_m = (p.a.M + 255) / 256;
+  p.tiles_n = (p.a.N + 255) / 256;
+  {
+    const char* e1 = getenv("SAVIT_PP_PHASES");
+    const char* e2 = getenv("SAVIT_PP_SLEEP");
+    p.desync_phases = e1 ? atoi(e1) : 1;
+    p.desync_sleep = e2 ? atoi(e2) : 0;
+    if (p.desync_phases < 1) p.desync_phases = 1;
+  }
+  const dim3 grid(p.tiles_m * p.tiles_n);
+  const size_t lds = 2 * 512 * 128;
+#define SAVIT_LAUNCH_EPI(E)                                                                            \
+  case E: {                                                                                            \
+    auto kfn = gemm_tn_pp_kernel<E>;                                                                   \
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return (int)e;                                                                \
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, p);                                               \
+  } break;
+  switch (p.a.epilogue) {
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_BF16)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_BIAS_GELU)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_RESID)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_DGELU)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_F32)
+    default: return SAVIT_EINVAL;
+  }
+#undef SAVIT_LAUNCH_EPI
+  SAVIT_LAUNCH_RET();
+}
+
 template <int BM, int BN, int WGM, int WGN, int ND>
 int launch_pair(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
@@ -946,6 +1168,7 @@ inline bool tile_geometry(int tile, int* bm, int* wgm) {
     case 2: case 5: case 7: case 10: case 13: case 15: *bm = 256; *wgm = 2; return true;
     case 3: *bm = 256; *wgm = 4; return true;
     case 17: *bm = 192; *wgm = 2; return true;
+    case 20: *bm = 256; *wgm = 2; return true;
     default: return false;
   }
 }
@@ -1010,6 +1233,16 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
     case 14: return a.K % 64 ? SAVIT_EINVAL : launch_pair<128, 256, 2, 2, 2>(p, s);
     case 15: return a.K % 64 ? SAVIT_EINVAL : launch_pair<256, 128, 2, 2, 2>(p, s);
     case 17: return a.K % 64 ? SAVIT_EINVAL : launch_pair<192, 128, 2, 2, 2>(p, s);
+    case 20: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp(p, s);
+    // timing-only ablations of tile 20 (wrong results by construction; SAVIT_EPI_BF16 only)
+    case 101: return launch_pp_ablation<1>(p, s);
+    case 102: return launch_pp_ablation<2>(p, s);
+    case 103: return launch_pp_ablation<3>(p, s);
+    case 104: return launch_pp_ablation<4>(p, s);
+    case 107: return launch_pp_ablation<7>(p, s);
+    case 108: return launch_pp_ablation<8>(p, s);
+    case 109: return launch_pp_ablation<9>(p, s);
+    case 110: return launch_pp_ablation<10>(p, s);
     default: return SAVIT_EINVAL;
   }
 }

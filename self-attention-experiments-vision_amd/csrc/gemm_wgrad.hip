@@ -30,6 +30,9 @@ struct WgradParams {
   int M, Kin, Nout, ldx, lddy, lddw;
   int tiles_i, tiles_j, splits, tiles_per_split;
   int patch, img_size, tokens, token_offset, grid_side, chunks_per_prow;
+  int abl;  // timing-only ablation (SAVIT_WGRAD_ABL): 1 = skip the epilogue
+  float* slab;       // non-null: every split stores its partial tile to slab + split * slab_stride (dense [Kin, Nout]) with plain
+  long slab_stride;  // stores and wgrad_reduce_kernel sums the splits into dW: no atomics, bitwise reproducible
 };
 
 __device__ __forceinline__ bf16x4 ds_read_tr16_b64(const char* p) {
@@ -399,8 +402,25 @@ __global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_ring_kernel(cons
   frag_wait(f0);  // nothing may stay in flight into the epilogue
 #undef SAVIT_ISSUE_FRAGS
 #undef SAVIT_TR_READ
+  if ((p.abl & 1) && p.M > 0) return;  // timing-only: the accumulators stay live (the condition is a run-time value)
 
   const int jl = lane & 31, hi5 = lane >> 5;
+  if (p.slab != nullptr) {
+    // one accumulator register = 2 rows x 128 B: whole lines per wave-instruction, the shape plain dword stores run at the HBM rate with
+    float* out = p.slab + (size_t)split * p.slab_stride;
+#pragma unroll
+    for (int a = 0; a < II; ++a)
+#pragma unroll
+      for (int b = 0; b < JJ; ++b) {
+        const int j = j0 + wj * WTJ + 32 * b + jl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = i0 + wi * WTI + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi5;
+          if (i < p.Kin && j < p.Nout) out[(size_t)i * p.Nout + j] = acc[a][b][r];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < II; ++a)
 #pragma unroll
@@ -414,15 +434,33 @@ __global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_ring_kernel(cons
     }
 }
 
-template <int BI, int BJ, int WGI, int WGJ, int S>
-int launch_wgrad_ring(WgradParams p, hipStream_t s, int slots) {
-  constexpr int TS = 32;
-  p.tiles_i = (p.Kin + BI - 1) / BI;
-  p.tiles_j = (p.Nout + BJ - 1) / BJ;
-  const int st_total = (p.M + TS - 1) / TS;
-  int splits = p.splits;
+// dW[i, j] += sum over splits of slab[s][i][j], splits added in index order (fixed order: the result is bitwise reproducible).
+// HBM / memory-side-cache bound: (splits + 2) * 4 B per element; a lane owns 4 consecutive columns (16-B accesses).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, long stride, float* __restrict__ dW,
+                                                            int Kin, int Nout, int lddw) {
+  const int n4 = Nout >> 2;
+  const long total = (long)Kin * n4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int i = (int)(e / n4), j4 = (int)(e - (long)i * n4);
+    const float* src = slab + (size_t)i * Nout + 4 * j4;
+    float4 acc = nt_load_f4(src);
+    for (int sp = 1; sp < splits; ++sp) {
+      const float4 v = nt_load_f4(src + (size_t)sp * stride);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float4* dst = reinterpret_cast<float4*>(dW + (size_t)i * lddw + 4 * j4);
+    const float4 old = *dst;
+    *dst = make_float4(old.x + acc.x, old.y + acc.y, old.z + acc.z, old.w + acc.w);
+  }
+}
+
+// Split count of the ring kernels (32-token stages): the caller's hint, or the smallest count whose grid fills whole rounds of
+// `slots` resident workgroups (>= 92 %); every split owns at least one stage.
+inline int ring_split_count(int M, int Kin, int Nout, int BI, int BJ, int slots, int hint, int* tiles_per_split) {
+  const int st_total = (M + 31) / 32;
+  int splits = hint;
   if (splits <= 0) {
-    const int tiles = p.tiles_i * p.tiles_j;
+    const int tiles = ((Kin + BI - 1) / BI) * ((Nout + BJ - 1) / BJ);
     splits = 1;
     float best = 0.f;
     for (int sp = 1; sp <= 24; ++sp) {
@@ -433,8 +471,24 @@ int launch_wgrad_ring(WgradParams p, hipStream_t s, int slots) {
     }
   }
   if (splits > st_total) splits = st_total;
-  p.tiles_per_split = (st_total + splits - 1) / splits;
-  p.splits = (st_total + p.tiles_per_split - 1) / p.tiles_per_split;
+  if (splits < 1) splits = 1;
+  const int tps = (st_total + splits - 1) / splits;
+  if (tiles_per_split) *tiles_per_split = tps;
+  return tps > 0 ? (st_total + tps - 1) / tps : 1;
+}
+
+template <int BI, int BJ, int WGI, int WGJ, int S>
+int launch_wgrad_ring(WgradParams p, hipStream_t s, int slots, long ws_bytes) {
+  constexpr int TS = 32;
+  p.tiles_i = (p.Kin + BI - 1) / BI;
+  p.tiles_j = (p.Nout + BJ - 1) / BJ;
+  p.splits = ring_split_count(p.M, p.Kin, p.Nout, BI, BJ, slots, p.splits, &p.tiles_per_split);
+  // partial slabs instead of atomics when the caller's workspace holds them (a single split needs neither: its tile IS the sum, but
+  // dW accumulates, so it goes through the same reduce)
+  p.slab_stride = (long)p.Kin * p.Nout;
+  const bool use_slab = p.slab != nullptr && ws_bytes >= (long)p.splits * p.slab_stride * 4 && p.lddw % 4 == 0 && p.Nout % 4 == 0 &&
+                        ((uintptr_t)p.dW % 16) == 0;
+  if (!use_slab) p.slab = nullptr;
   const dim3 grid(p.tiles_i * p.tiles_j * p.splits), block(64 * WGI * WGJ);
   const size_t lds = (size_t)S * TS * (BI + BJ) * 2;
   if (p.patch) {
@@ -451,6 +505,12 @@ int launch_wgrad_ring(WgradParams p, hipStream_t s, int slots) {
       if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(kfn, grid, block, lds, s, p);
+  }
+  if (use_slab) {
+    const long total4 = (long)p.Kin * (p.Nout / 4);
+    long blocks = (total4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.slab, p.splits, p.slab_stride, p.dW, p.Kin, p.Nout, p.lddw);
   }
   SAVIT_LAUNCH_RET();
 }
@@ -507,8 +567,47 @@ extern "C" int savit_gemm_wgrad_auto_variant(int Kin, int Nout, int patch) {
   return (Kin % 256 == 0 && Nout % 256 == 0 && (long)Kin * Nout >= (1 << 20) && !patch) ? 3 : 1;
 }
 
+static int wgrad_variant(int Kin, int Nout, int patch) {
+  // SAVIT_WGRAD_VARIANT (development aid): 0 = auto, 1..4 = ring kernels, 9 = the 2-stage kernel
+  static const int variant = [] { const char* e = getenv("SAVIT_WGRAD_VARIANT"); return e ? atoi(e) : 0; }();
+  return variant ? variant : savit_gemm_wgrad_auto_variant(Kin, Nout, patch);
+}
+
+static bool ring_geometry(int v, int* bi, int* bj, int* slots) {
+  switch (v) {
+    case 1: *bi = 128; *bj = 128; *slots = 256; return true;
+    case 2: *bi = 256; *bj = 128; *slots = 512; return true;
+    case 3: *bi = 256; *bj = 256; *slots = 256; return true;
+    case 4: *bi = 128; *bj = 128; *slots = 768; return true;
+    default: return false;
+  }
+}
+
+extern "C" long savit_gemm_wgrad_workspace_bytes(int M, int Kin, int Nout, int splits, int patch) {
+  if (M <= 0 || Kin <= 0 || Nout <= 0) return 0;
+  int bi, bj, slots;
+  if (!ring_geometry(wgrad_variant(Kin, Nout, patch), &bi, &bj, &slots)) return 0;  // the 2-stage kernel adds with atomics
+  return (long)ring_split_count(M, Kin, Nout, bi, bj, slots, splits, nullptr) * Kin * Nout * 4;
+}
+
+static int wgrad_dispatch(const void* X, const void* dY, float* dW, int M, int Kin, int Nout, int ldx, int lddy, int lddw, int splits, int patch,
+                          int img_size, int tokens, int token_offset, void* workspace, long workspace_bytes, void* stream);
+
 extern "C" int savit_gemm_bf16_wgrad(const void* X, const void* dY, float* dW, int M, int Kin, int Nout, int ldx, int lddy,
                                      int lddw, int splits, int patch, int img_size, int tokens, int token_offset, void* stream) {
+  return wgrad_dispatch(X, dY, dW, M, Kin, Nout, ldx, lddy, lddw, splits, patch, img_size, tokens, token_offset, nullptr, 0, stream);
+}
+
+extern "C" int savit_gemm_bf16_wgrad_ws(const void* X, const void* dY, float* dW, int M, int Kin, int Nout, int ldx, int lddy, int lddw,
+                                        int splits, int patch, int img_size, int tokens, int token_offset, void* workspace,
+                                        long workspace_bytes, void* stream) {
+  SAVIT_CHECK_ARG(workspace == nullptr || (((uintptr_t)workspace % 16) == 0 && workspace_bytes >= 0));
+  return wgrad_dispatch(X, dY, dW, M, Kin, Nout, ldx, lddy, lddw, splits, patch, img_size, tokens, token_offset, workspace, workspace_bytes,
+                        stream);
+}
+
+static int wgrad_dispatch(const void* X, const void* dY, float* dW, int M, int Kin, int Nout, int ldx, int lddy, int lddw, int splits, int patch,
+                          int img_size, int tokens, int token_offset, void* workspace, long workspace_bytes, void* stream) {
   SAVIT_CHECK_ARG(X && dY && dW && M >= 0 && Kin > 0 && Nout > 0 && lddw >= Nout);
   SAVIT_CHECK_ARG(Kin % 8 == 0 && Nout % 8 == 0 && lddy % 8 == 0 && lddy >= Nout);
   SAVIT_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)dY % 16) == 0);
@@ -516,6 +615,8 @@ extern "C" int savit_gemm_bf16_wgrad(const void* X, const void* dY, float* dW, i
   p.X = (const bf16_t*)X; p.dY = (const bf16_t*)dY; p.dW = dW;
   p.M = M; p.Kin = Kin; p.Nout = Nout; p.ldx = ldx; p.lddy = lddy; p.lddw = lddw; p.splits = splits;
   p.patch = patch; p.img_size = img_size; p.tokens = tokens; p.token_offset = token_offset;
+  { const char* e = getenv("SAVIT_WGRAD_ABL"); p.abl = e ? atoi(e) : 0; }
+  p.slab = (float*)workspace;
   if (patch) {
     SAVIT_CHECK_ARG(patch % 8 == 0 && img_size % patch == 0 && Kin == patch * patch * 3 && tokens > 0 && token_offset >= 0);
     p.grid_side = img_size / patch;
@@ -525,15 +626,12 @@ extern "C" int savit_gemm_bf16_wgrad(const void* X, const void* dY, float* dW, i
     SAVIT_CHECK_ARG(ldx % 8 == 0 && ldx >= Kin);
   }
   if (M == 0) return SAVIT_OK;
-  // SAVIT_WGRAD_VARIANT (development aid): 0 = auto, 1..4 = ring kernels below, 9 = the 2-stage kernel
-  static const int variant = [] { const char* e = getenv("SAVIT_WGRAD_VARIANT"); return e ? atoi(e) : 0; }();
-  int v = variant;
-  if (v == 0) v = savit_gemm_wgrad_auto_variant(Kin, Nout, patch);
+  const int v = wgrad_variant(Kin, Nout, patch);
   switch (v) {
-    case 1: return launch_wgrad_ring<128, 128, 2, 2, 4>(p, (hipStream_t)stream, 256);
-    case 2: return launch_wgrad_ring<256, 128, 2, 2, 3>(p, (hipStream_t)stream, 512);
-    case 3: return launch_wgrad_ring<256, 256, 2, 4, 4>(p, (hipStream_t)stream, 256);
-    case 4: return launch_wgrad_ring<128, 128, 2, 2, 3>(p, (hipStream_t)stream, 768);
-    default: return launch_wgrad<128, 128, 2, 2>(p, (hipStream_t)stream);
+    case 1: return launch_wgrad_ring<128, 128, 2, 2, 4>(p, (hipStream_t)stream, 256, workspace_bytes);
+    case 2: return launch_wgrad_ring<256, 128, 2, 2, 3>(p, (hipStream_t)stream, 512, workspace_bytes);
+    case 3: return launch_wgrad_ring<256, 256, 2, 4, 4>(p, (hipStream_t)stream, 256, workspace_bytes);
+    case 4: return launch_wgrad_ring<128, 128, 2, 2, 3>(p, (hipStream_t)stream, 768, workspace_bytes);
+    default: p.slab = nullptr; return launch_wgrad<128, 128, 2, 2>(p, (hipStream_t)stream);
   }
 }

@@ -151,6 +151,7 @@ class _Plan:
     def __init__(self):
         self.calls: List[Tuple[Callable, tuple, str]] = []
         self.keep: List[object] = []  # ctypes structs that must outlive the plan
+        self.ws_requests: List[Tuple[int, int, int]] = []  # (call index, workspace key, bytes): see add_wgrad / finalize_wgrad_ws
         self.side: Dict[int, int] = {}           # call index -> side-launch ordinal (stream = ordinal % number of side streams)
         self.guard: Dict[int, List[int]] = {}    # main call index -> side call indices that must have finished first
         self._readers: Dict[int, List[int]] = {}  # buffer address -> side calls reading it (build-time bookkeeping)
@@ -212,6 +213,41 @@ class _Plan:
         for j in last:
             if j is not None:
                 main.wait_event(self._ev_done[j])
+
+
+def add_wgrad(eng, plan: _Plan, label: str, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, splits: int, patch=(0, 0, 0, 0), side: bool = True):
+    """Record a weight-gradient launch of any engine of this package (savit_gemm_bf16_wgrad_ws: the splits of the reduction over the
+    tokens go through partial slabs + an ordered sum - no atomics, bitwise reproducible).  side launches have no consumer inside
+    backward, `_Plan.run_overlapped` puts them on a side stream.  The slab workspace is attached by `finalize_wgrad_ws` once the
+    whole plan is known: launches that can run at the same time must not share one, so side launches use the workspace of THEIR
+    side stream (ordinal % number of side streams, the stream run_overlapped will pick) and main-chain launches a separate one."""
+    need = int(eng.L.savit_gemm_wgrad_workspace_bytes(Mr, Kin, Nout, splits, patch[0]))
+    if os.environ.get("SAVIT_WGRAD_ATOMICS", "0") == "1":
+        need = 0
+    on_side = side and eng.overlap_wgrad and not eng._building_serial
+    key = (len(plan.side) % max(1, eng.n_side_streams)) if on_side else -1
+    plan.add(eng.L.savit_gemm_bf16_wgrad_ws, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, splits, patch[0], patch[1], patch[2], patch[3],
+                                              None, 0), label, side=side, reads=(dY,) if side else ())
+    if need > 0:
+        plan.ws_requests.append((len(plan.calls) - 1, key, need))
+
+
+def finalize_wgrad_ws(eng, plan: _Plan):
+    """Allocate (or grow) the engine's slab workspaces to the largest request of `plan` per key and patch its launches."""
+    if not hasattr(eng, "_wgrad_wsbuf"):
+        eng._wgrad_wsbuf, eng._wgrad_ws_old = {}, []
+    for key in sorted({k for _, k, _ in plan.ws_requests}):
+        need = max(n for _, k, n in plan.ws_requests if k == key)
+        buf = eng._wgrad_wsbuf.get(key)
+        if buf is None or buf.numel() < need:
+            if buf is not None:
+                eng._wgrad_ws_old.append(buf)  # an earlier plan still points at it
+            eng._wgrad_wsbuf[key] = torch.empty(need, dtype=torch.uint8, device=eng.dev)
+    for idx, key, _ in plan.ws_requests:
+        fn, args, label = plan.calls[idx]
+        buf = eng._wgrad_wsbuf[key]
+        plan.calls[idx] = (fn, args[:-2] + (buf.data_ptr(), buf.numel()), label)
+    plan.ws_requests = []
 
 
 class ViTEngine:
@@ -427,8 +463,7 @@ class ViTEngine:
 
         def wgrad(label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0)):
             # no later launch consumes dW: side stream.  X is a saved activation (stable until the next forward), dY is scratch
-            P.add(L.savit_gemm_bf16_wgrad, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, self._wgrad_splits(Kin, Nout, patch[0]),
-                                            patch[0], patch[1], patch[2], patch[3]), label, side=True, reads=(dY,))
+            self._add_wgrad(P, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, self._wgrad_splits(Kin, Nout, patch[0]), patch)
 
         ring, ri = [t.data_ptr() for t in self.dres_b_ring], 0
         # ---- head: dWh, d z_cls, final LayerNorm backward into the (zeroed) residual gradient
@@ -476,7 +511,12 @@ class ViTEngine:
         P.add(L.savit_pos_cls_grad, (self.dres.data_ptr(), gp("pos"), gp("cls"), B, N, d, 1), "pos_cls.grad")
         wgrad("Wpe.wgrad", self._img_buf.data_ptr(), ring[ri], gp("Wpe"), B * cfg.n_patches, cfg.patch_dim, d, 0, d, d,
               patch=(cfg.patch, cfg.img_size, N, 1))
+        finalize_wgrad_ws(self, P)
         return P
+
+    def _add_wgrad(self, plan: "_Plan", label: str, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, splits: int, patch=(0, 0, 0, 0),
+                   side: bool = True):
+        add_wgrad(self, plan, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, splits, patch, side)
 
     def _wgrad_splits(self, Kin: int, Nout: int, patch: int) -> int:
         """K-splits of a weight-gradient GEMM.  On its own a launch wants every CU (0 = the library's choice); beside the

@@ -24,7 +24,7 @@ import torch
 
 from . import lib as _lib
 from .config import ModelConfig
-from .engine import ViTEngine, _Plan, _align, _copy_tree, bf16, f32  # noqa: F401
+from .engine import ViTEngine, _Plan, _align, _copy_tree, bf16, f32, finalize_wgrad_ws  # noqa: F401
 
 
 class MixerLayout:
@@ -267,8 +267,7 @@ class MixerEngine(ViTEngine):
         ws, wsb = self.ln_ws.data_ptr(), self.ln_ws.numel()
 
         def wgrad(label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0)):
-            P.add(L.savit_gemm_bf16_wgrad, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, self._wgrad_splits(Kin, Nout, patch[0]),
-                                            patch[0], patch[1], patch[2], patch[3]), label, side=True, reads=(dY,))
+            self._add_wgrad(P, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, self._wgrad_splits(Kin, Nout, patch[0]), patch)
 
         ring, ri = [t.data_ptr() for t in self.dres_b_ring], 0
         # ---- head, mean over tokens, final LayerNorm (every row receives dz / l)
@@ -320,6 +319,7 @@ class MixerEngine(ViTEngine):
                                           gp(f"l{l - 1}.b2") if l > 0 else gp("bpe"), M, d, d, d, self.rp, ws, wsb), f"l{l}.ln1.bwd",
                   writes=(ring[ri],))
         wgrad("Wpe.wgrad", self._img_buf.data_ptr(), ring[ri], gp("Wpe"), M, cfg.patch_dim, d, 0, d, d, patch=(cfg.patch, cfg.img_size, n, 0))
+        finalize_wgrad_ws(self, P)
         return P
 
     def activation_bytes(self) -> int:

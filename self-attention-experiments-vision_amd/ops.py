@@ -207,8 +207,10 @@ def colsum_finalize(slab: torch.Tensor, out: torch.Tensor, accumulate: bool = Tr
 
 
 def gemm_wgrad(X: torch.Tensor, dY: torch.Tensor, dW: torch.Tensor, splits: int = 0, M: Optional[int] = None,
-               patch_geom: Optional[Tuple[int, int, int, int]] = None):
-    """dW[Kin,Nout] += X[M,Kin]^T @ dY[M,Nout] (fp32 atomics).  patch_geom as in gemm_tn (X = images)."""
+               patch_geom: Optional[Tuple[int, int, int, int]] = None, workspace: Optional[torch.Tensor] = None):
+    """dW[Kin,Nout] += X[M,Kin]^T @ dY[M,Nout].  patch_geom as in gemm_tn (X = images).  workspace (uint8, from
+    wgrad_workspace): the splits of the reduction go through partial slabs + an ordered sum (bitwise reproducible); without it they
+    are added with fp32 atomics."""
     _chk(dY, bf16, "dY", 2)
     _chk(dW, f32, "dW", 2)
     Kin, Nout, lddw = _rows2d(dW, "dW")
@@ -237,9 +239,21 @@ def gemm_wgrad(X: torch.Tensor, dY: torch.Tensor, dW: torch.Tensor, splits: int 
             raise ValueError("dY has fewer rows than X")
         pg = (0, 0, 0, 0)
     L = _lib.load()
+    if workspace is not None:
+        if workspace.dtype != torch.uint8 or not workspace.is_cuda or not workspace.is_contiguous():
+            raise ValueError("workspace must be a contiguous uint8 GPU tensor")
+        _lib.check(L.savit_gemm_bf16_wgrad_ws(_p(X), _p(dY), _p(dW), Mv, Kin, Nout, ldx, lddy, lddw, int(splits), pg[0], pg[1], pg[2],
+                                              pg[3], _p(workspace), workspace.numel(), _stream()), "savit_gemm_bf16_wgrad_ws")
+        return dW
     _lib.check(L.savit_gemm_bf16_wgrad(_p(X), _p(dY), _p(dW), Mv, Kin, Nout, ldx, lddy, lddw, int(splits), pg[0], pg[1], pg[2],
                                        pg[3], _stream()), "savit_gemm_bf16_wgrad")
     return dW
+
+
+def wgrad_workspace(M: int, Kin: int, Nout: int, splits: int = 0, patch: int = 0, device="cuda") -> torch.Tensor:
+    """Scratch for gemm_wgrad(..., workspace=...): one partial [Kin, Nout] fp32 slab per split of the reduction over M."""
+    n = int(_lib.load().savit_gemm_wgrad_workspace_bytes(int(M), int(Kin), int(Nout), int(splits), int(patch)))
+    return torch.empty(max(n, 16), dtype=torch.uint8, device=device)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -24,7 +24,7 @@ import torch
 
 from . import lib as _lib
 from .config import ModelConfig
-from .engine import ViTEngine, _Plan, _align, _copy_tree, bf16, f32  # noqa: F401
+from .engine import ViTEngine, _Plan, _align, _copy_tree, bf16, f32, finalize_wgrad_ws  # noqa: F401
 
 HDP = 16  # padded inner head width
 
@@ -384,8 +384,7 @@ class TNTEngine(ViTEngine):
             if Mr == Mi and not patch[0]:
                 tiles = -(-Kin // 128) * -(-Nout // 128)
                 sp = max(1, inner_splits // tiles)
-            P.add(L.savit_gemm_bf16_wgrad, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, sp,
-                                            patch[0], patch[1], patch[2], patch[3]), label, side=True, reads=(dY,))
+            self._add_wgrad(P, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, sp, patch)
 
         ring, ri = [t.data_ptr() for t in self.dres_b_ring], 0
         iring, iri = [t.data_ptr() for t in self.dresi_b_ring], 0
@@ -473,6 +472,7 @@ class TNTEngine(ViTEngine):
         P.add(L.savit_colsum_finalize, (gp("pos") + do * 4, n, do, gp("bpa"), 1), "bpa.grad")
         wgrad("Wpe.wgrad", self._img_buf.data_ptr(), ring[ri], gp("Wpe"), B * n, cfg.patch_dim, do, 0, do, do,
               patch=(cfg.patch, cfg.img_size, N, 1))
+        finalize_wgrad_ws(self, P)
         return P
 
     def backward_from_dlogits(self):

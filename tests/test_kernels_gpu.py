@@ -281,6 +281,31 @@ def test_wgrad(ops, M, Kin, Nout, splits):
     assert rel(host(dW), 2 * ref) < 2e-5
 
 
+@pytest.mark.parametrize("M,Kin,Nout,splits", [(25216, 768, 768, 0), (3000, 768, 3072, 5), (197 * 4, 192, 576, 0), (1000, 256, 1000, 3),
+                                               (4096, 64, 192, 9), (70, 768, 768, 0)])
+def test_wgrad_slab_reduction(ops, M, Kin, Nout, splits):
+    """savit_gemm_bf16_wgrad_ws: partial slabs + ordered sum instead of fp32 atomics - same values, accumulating, and bitwise
+    reproducible (the atomic form depends on arrival order)."""
+    rng = np.random.default_rng(M + Nout)
+    X, dY = dev(_mk(rng, M, Kin), bf16), dev(_mk(rng, M, Nout), bf16)
+    ws = ops.wgrad_workspace(M, Kin, Nout, splits)
+    base = torch.randn((Kin, Nout), dtype=torch.float32, device="cuda")
+    dW = base.clone()
+    ops.gemm_wgrad(X, dY, dW, splits=splits, workspace=ws)
+    ref = host(X).astype(np.float64).T @ host(dY).astype(np.float64)
+    assert rel(host(dW) - host(base), ref) < 2e-5
+    again = base.clone()
+    ops.gemm_wgrad(X, dY, again, splits=splits, workspace=ws)
+    assert torch.equal(dW, again)
+    ops.gemm_wgrad(X, dY, dW, splits=splits, workspace=ws)  # accumulates
+    assert rel(host(dW) - host(base), 2 * ref) < 2e-5
+    # a workspace that is too small falls back to the atomic form (same values)
+    small = torch.empty(16, dtype=torch.uint8, device="cuda")
+    dW2 = base.clone()
+    ops.gemm_wgrad(X, dY, dW2, splits=splits, workspace=small)
+    assert rel(host(dW2) - host(base), ref) < 2e-5
+
+
 def test_wgrad_padded_dy_columns(ops):
     """Head: dlogits lives in a [B, 1024] buffer, dW is [d, 1000]."""
     rng = np.random.default_rng(11)
