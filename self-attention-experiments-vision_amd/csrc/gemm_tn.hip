@@ -1109,6 +1109,11 @@ extern "C" int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue) {
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
   const bool big = (t256 >= 512 && N % 128 == 0);
   if (K % 64 != 0) return big ? 7 : 6;
+  //  * 256x256 ping-pong (tile 20: the two M-halves of the 8-wave workgroup run one barrier apart, one in its MFMA segment while
+  //    the other reads fragments and issues LDS-DMA): wide outputs on large grids with K >= 768 - measured against the next best
+  //    tile with cold operands (tools/gemm_epi_bench.py): fc1+GELU 172 -> 155 us, fc2 input-gradient+GELU' 179 -> 171 us, qkv 117 -> 111 us,
+  //    ViT-L shapes 4-6 % over the pair kernel.  Narrow outputs (N = 768) keep 192x128: 297 tiles of 256x256 are 1.16 rounds.
+  if (big && N >= 1024 && K >= 768 && epilogue != SAVIT_EPI_PATCH) return 20;
   if (big && (epilogue == SAVIT_EPI_BIAS_GELU || K >= 1024)) return 13;
   if (N % 128 == 0 && M >= 1536 && epilogue != SAVIT_EPI_PATCH) return 17;
   return big ? 13 : 12;
@@ -1214,7 +1219,10 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
   if (a.M == 0) return SAVIT_OK;
   hipStream_t s = (hipStream_t)stream;
   int tile = a.tile;
-  if (tile == 0) tile = savit_gemm_tn_auto_tile_epi(a.M, a.N, a.K, a.epilogue);
+  if (tile == 0) {
+    tile = savit_gemm_tn_auto_tile_epi(a.M, a.N, a.K, a.epilogue);
+    if (tile == 20 && a.lda < a.K) tile = 13;  // the ping-pong kernel does not take the aliased-row operand form
+  }
   if (a.colsum != nullptr && a.colsum_rows != 0) SAVIT_CHECK_ARG(a.colsum_rows == savit_gemm_colsum_rows(a.M, a.N, a.K, tile));
   switch (tile) {
     case 1: return launch_tile<128, 128, 2, 2>(p, s);
