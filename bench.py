@@ -206,6 +206,34 @@ def time_other_config(model, B, img_size, steps=5, warmup=2):
     return res
 
 
+def time_config1_fp32(steps=20, warmup=3):
+    """BASELINE config 1 on the GPU: ViT-Ti/16, batch 8, fp32 arithmetic, forward + loss (what simple_train.py's plumbing run computes
+    before its backward; the CPU restatement of the same thing is cpu_baseline.forward_loss_value)."""
+    import torch
+
+    from savit_amd.config import get_config
+    from savit_amd.engine_f32 import ViTEngineF32
+
+    cfg = get_config("vit_ti_patch16")
+    eng = ViTEngineF32(cfg, 8)
+    init_bench_params(eng, cfg)
+    g = torch.Generator(device="cuda").manual_seed(42)
+    img = torch.randn(8, 224, 224, 3, device="cuda", generator=g)
+    lab = torch.randint(0, 1000, (8,), device="cuda", generator=g, dtype=torch.int32)
+    for _ in range(warmup):
+        eng.forward(img)
+        eng.loss_fn(lab)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.forward(img)
+        eng.loss_fn(lab)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"model": "vit_ti_patch16", "dtype": "f32", "images_per_gpu": 8, "steps": steps, "warmup": warmup, "value": round(8 * steps / el, 1),
+            "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 3), "final_loss": round(float(eng.loss.item()), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -370,6 +398,7 @@ def main():
         out["other_configs"] = {}
         for model, ob, osz, name in OTHER_CONFIGS:
             out["other_configs"][name] = time_other_config(model, ob, osz)
+        out["other_configs"]["1. ViT-Ti/16 224^2 fp32, batch 8, forward + loss (fp32-input MFMA path)"] = time_config1_fp32()
 
     # ---- CPU baseline leg (rank 0, N=1 only): the oracle's torch-CPU restatement of BASELINE config 1, bounded samples
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -254,6 +254,24 @@ int savit_normalize_to_nhwc_bf16(const void* src, int src_format, void* dst, int
 int savit_batch_mixup_bf16(const void* x, void* out, const float* weight, const int* index, int B, long elems_per_image, void* stream);
 int savit_batch_cutmix_bf16(const void* x, void* out, const int* box, const int* index, int B, int H, int W, int C, void* stream);
 
+/* ---- fp32 arithmetic mode, forward + loss (create_model's default dtype=float32: models/create_model.py:6-8; BASELINE config 1,
+ * ViT-Tiny/16 fp32).  Exact fp32 products on v_mfma_f32_32x32x2_f32; weights are the fp32 Flax [in, out] kernels in place.
+ * savit_gemm_f32: C[M,N] = aux (nullable) + act( alpha_on_first_alpha_cols * (A[M,K] . W[K,N]) + bias ), act = tanh-GELU if gelu
+ *   (nn.Dense / DenseGeneral: attention.py:29-37,60-63 with q / sqrt(hd) :39, ff.py:26-31, patch_embed.py:23-25, vit.py:96-98;
+ *   residual adds vit.py:24,31).  K % 4 == 0, N % 4 == 0.
+ * savit_layernorm_fwd_f32: nn.LayerNorm(dtype=float32), eps as given (vit.py:19,26,57).
+ * savit_attention_fwd_f32: attention.py:41-57 per (batch, head) on a packed fp32 [B*N, ld] q|k|v buffer (q pre-scaled); N <= 256,
+ *   head_dim <= 64.
+ * savit_patchify_f32: patch_embed.py:19-22 rearrange on NHWC fp32 images -> [B*n, patch*patch*3].
+ * savit_assemble_tokens_f32: x0 = concat([cls, tok]) + pos (vit.py:81-85, position_embed.py:56). */
+int savit_gemm_f32(const float* A, const float* W, float* C, const float* bias, const float* aux, int M, int N, int K, int lda, int ldw,
+                   int ldc, int ldaux, float alpha, int alpha_cols, int gelu, void* stream);
+int savit_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, int rows, int d, long x_stride, long y_stride,
+                            float eps, void* stream);
+int savit_attention_fwd_f32(const float* qkv, float* o, int B, int N, int H, int head_dim, int ld_qkv, void* stream);
+int savit_patchify_f32(const float* images, float* patches, int B, int img_size, int patch, void* stream);
+int savit_assemble_tokens_f32(const float* tok, const float* cls, const float* pos, float* x0, int B, int N, int d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

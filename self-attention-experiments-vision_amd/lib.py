@@ -88,6 +88,12 @@ _SIGNATURES = {
                                              ctypes.POINTER(c_float), c_void_p]),
     "savit_batch_mixup_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "savit_batch_cutmix_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "savit_gemm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                               c_int, c_int, c_void_p]),
+    "savit_layernorm_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_long, c_float, c_void_p]),
+    "savit_attention_fwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "savit_patchify_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "savit_assemble_tokens_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None

@@ -4,13 +4,18 @@ Mirrors /root/reference/models/create_model.py:6-8 (`create_model(model_name, nu
 RuntimeError('Model not found.') on unknown names) and the Flax calling convention its callers use
 (train.py:29-37,82,115; models/vit_test.py:23-26):
 
-    model  = create_model('vit_b_patch16', num_classes=1000, dtype=torch.bfloat16)
+    model  = create_model('vit_b_patch16', num_classes=1000, dtype=torch.bfloat16)   # dtype defaults to float32, as in the reference
     params = model.init(seed, torch.ones(1, 224, 224, 3), is_training=False)        # {'params': Flax-shaped tree}
     logits = model.apply(params, images_NHWC, is_training=True)                      # [B, num_classes]
     logits, params = model.init_with_output(seed, x, is_training=True)               # as in the reference tests
     logits = model(images_NHWC, is_training)                                         # module(inputs, is_training)
 
 Every tensor lives on the GPU; the arithmetic is the HIP engine (engine.py).  There is no CPU execution path.
+
+dtype (create_model.py:6-8: `dtype=jnp.float32` by default; train.py passes bfloat16):
+  torch.bfloat16  the training path: bf16 MFMA kernels with fp32 residual stream / statistics / parameters (all four families);
+  torch.float32   the reference default: every op in fp32 (engine_f32.py, exact fp32-input MFMA) - forward and loss, ViT family.
+                  Training entry points raise on it, and the other families raise at construction: they compute in bf16 only.
 """
 from __future__ import annotations
 
@@ -32,9 +37,14 @@ class ViT:
     """models/vit.py:61-99 behind the HIP engine.  Stateless w.r.t. parameters in `apply` (the caller owns the
     tree, as with Flax); `init` / `bind` attach a tree for the `model(images, is_training)` form."""
 
-    def __init__(self, cfg: ModelConfig, dtype=torch.bfloat16):
-        if dtype not in (torch.bfloat16,):
-            raise NotImplementedError("the MI355X path computes in bf16 (MFMA) with fp32 residual/statistics; dtype must be bfloat16")
+    FP32_OK = True  # the ViT family has the fp32 forward engine
+
+    def __init__(self, cfg: ModelConfig, dtype=torch.float32):
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise NotImplementedError("dtype must be torch.bfloat16 (training path) or torch.float32 (forward + loss)")
+        if dtype == torch.float32 and not self.FP32_OK:
+            raise NotImplementedError(f"{type(self).__name__}: fp32 arithmetic is implemented for the ViT family only; this family "
+                                      "computes in bf16 - pass dtype=torch.bfloat16 (the reference's create_model default is float32)")
         assert cfg.embed_dim % cfg.num_heads == 0  # vit.py:75
         self.cfg = cfg
         self.dtype = dtype
@@ -44,6 +54,10 @@ class ViT:
     # -- engine management: one engine per batch size, sharing parameter / gradient / bf16-weight buffers
     def _new_engine(self, batch: int):
         """The family's engine class (overridden by the subclasses below)."""
+        if self.dtype == torch.float32:
+            from .engine_f32 import ViTEngineF32
+
+            return ViTEngineF32(self.cfg, batch)
         return ViTEngine(self.cfg, batch)
 
     def engine(self, batch: int) -> ViTEngine:
@@ -116,6 +130,8 @@ class CaiT(ViT):
     (stochastic_depth.py:16-27) from the engine's generator; pass `rngs={'stochastic_depth': seed}` to seed it (the reference needs
     that rng stream too and forgets to pass it, defect B7)."""
 
+    FP32_OK = False
+
     def _new_engine(self, batch: int):
         from .cait_engine import CaiTEngine
 
@@ -137,6 +153,8 @@ class CaiT(ViT):
 class MLPMixer(ViT):
     """models/mlp_mixer.py:34-64 behind mixer_engine.MixerEngine.  No stochastic layer: is_training selects nothing."""
 
+    FP32_OK = False
+
     def _new_engine(self, batch: int):
         from .mixer_engine import MixerEngine
 
@@ -146,15 +164,18 @@ class MLPMixer(ViT):
 class TNT(ViT):
     """models/tnt.py:136-193 behind tnt_engine.TNTEngine.  Every dropout rate is 0: is_training selects nothing."""
 
+    FP32_OK = False
+
     def _new_engine(self, batch: int):
         from .tnt_engine import TNTEngine
 
         return TNTEngine(self.cfg, batch)
 
 
-def create_model(model_name: str, num_classes: int = 1000, dtype=torch.bfloat16, img_size: int = 224):
-    """models/create_model.py:6-8.  Same names; `vit_ti_patch16` / `vit_s_patch16` added for BASELINE configs 1-2.
-    img_size is an extension (the reference fixes it through the init example; train.py --img_size)."""
+def create_model(model_name: str, num_classes: int = 1000, dtype=torch.float32, img_size: int = 224):
+    """models/create_model.py:6-8: same names, same default dtype (float32; train.py passes bfloat16).  `vit_ti_patch16` /
+    `vit_s_patch16` added for BASELINE configs 1-2.  img_size is an extension (the reference fixes it through the init example;
+    train.py --img_size)."""
     cfg = get_config(model_name, num_classes=num_classes, img_size=img_size)
     if cfg.kind == "vit":
         return ViT(cfg, dtype=dtype)

@@ -24,7 +24,7 @@ def _make(cfg_name, B):
     cfg = get_config(cfg_name, num_classes=64)
     if cfg.kind != "vit":
         cfg = dataclasses.replace(cfg, num_layers=3)  # the other families: three layers are enough for several buckets
-    model = create_model(cfg_name, num_classes=64)
+    model = create_model(cfg_name, num_classes=64, dtype=torch.bfloat16)
     model.cfg = cfg
     eng = model.engine(B)
     eng.init_params(5)

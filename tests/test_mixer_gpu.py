@@ -183,7 +183,7 @@ def test_create_model_protocol_and_tree(pkg):
     """create_model names (create_model.py:184-213), Flax-shaped tree, logits shape, init loss."""
     from savit_amd.model import create_model
 
-    model = create_model("mixer_s_patch32")
+    model = create_model("mixer_s_patch32", dtype=torch.bfloat16)
     x = torch.randn(2, 224, 224, 3, device="cuda")
     logits, params = model.init_with_output(0, x, is_training=True)
     assert tuple(logits.shape) == (2, 1000) and logits.dtype == torch.bfloat16
@@ -201,7 +201,7 @@ def test_create_model_protocol_and_tree(pkg):
     again = model.apply(params, x, is_training=False)
     assert torch.equal(again, logits)
     for name in ("mixer_s_patch16", "mixer_b_patch32", "mixer_b_patch16", "mixer_l_patch32", "mixer_l_patch16"):
-        assert create_model(name).cfg.kind == "mixer"
+        assert create_model(name, dtype=torch.bfloat16).cfg.kind == "mixer"
 
 
 def test_overlapped_backward_equals_serial(pkg):

@@ -83,7 +83,7 @@ def test_known_answers_zero_head(pkg):
     """reference initialisers => logits == 0, loss == ln(1000), only the head receives gradient."""
     from savit_amd.model import create_model
 
-    model = create_model("vit_ti_patch16")
+    model = create_model("vit_ti_patch16", dtype=torch.bfloat16)
     x = torch.randn(2, 224, 224, 3, device="cuda")
     logits, params = model.init_with_output(0, x, is_training=True)
     assert tuple(logits.shape) == (2, 1000) and logits.dtype == torch.bfloat16
@@ -113,7 +113,7 @@ def test_reference_shape_tests(pkg, name, N):
     """models/vit_test.py:13-26: logits (2, 1000) on ones(2,224,224,3)."""
     from savit_amd.model import create_model
 
-    model = create_model(name)
+    model = create_model(name, dtype=torch.bfloat16)
     assert model.cfg.seq_len == N
     logits, _ = model.init_with_output(0, torch.ones(2, 224, 224, 3, device="cuda"), is_training=True)
     assert tuple(logits.shape) == (2, 1000)
@@ -227,7 +227,7 @@ def test_cait_reference_shapes_and_known_answers(pkg):
     from savit_amd.model import create_model
 
     for name, count in (("cait_xxs_24", None), ("cait_s_24", 46_875_496), ("cait_m_24", None)):
-        model = create_model(name)
+        model = create_model(name, dtype=torch.bfloat16)
         logits, params = model.init_with_output(0, torch.ones(2, 224, 224, 3, device="cuda"), is_training=False)
         assert tuple(logits.shape) == (2, 1000)
         assert float(logits.float().abs().max()) == 0.0  # zero-init head (cait.py:179-182)
@@ -286,7 +286,7 @@ def test_flax_checkpoint_roundtrip(tmp_path, name):
     from savit_amd.model import create_model
 
     torch.manual_seed(0)
-    model = create_model(name, num_classes=16)
+    model = create_model(name, num_classes=16, dtype=torch.bfloat16)
     B = 2
     eng = model.engine(B)
     eng.init_params(11)
@@ -304,7 +304,7 @@ def test_flax_checkpoint_roundtrip(tmp_path, name):
     assert set(state) == {"step", "params", "opt_state"} and set(state["opt_state"]) == {"0", "1", "2", "3"}
     assert "Encoder_0" in state["params"]["params"] and "mu" in state["opt_state"]["1"]
 
-    model2 = create_model(name, num_classes=16)
+    model2 = create_model(name, num_classes=16, dtype=torch.bfloat16)
     eng2 = model2.engine(B)
     eng2.init_params(99)
     step = flax_ckpt.load_into_engine(eng2, state)

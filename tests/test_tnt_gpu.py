@@ -164,7 +164,7 @@ def test_create_model_known_answers(pkg):
 
     from savit_amd.model import create_model
 
-    model = create_model("tnt_b_patch16")
+    model = create_model("tnt_b_patch16", dtype=torch.bfloat16)
     x = torch.randn(2, 224, 224, 3, device="cuda")
     logits, params = model.init_with_output(0, x, is_training=True)
     assert tuple(logits.shape) == (2, 1000) and float(logits.float().abs().max()) == 0.0
@@ -174,7 +174,7 @@ def test_create_model_known_answers(pkg):
     eng = model.engine(2)
     loss = float(eng.loss_backward(torch.tensor([3, 7], device="cuda"), 0.1))
     assert abs(loss - math.log(1000.0)) < 1e-5
-    assert create_model("tnt_s_patch16").cfg.embed_dim == 640
+    assert create_model("tnt_s_patch16", dtype=torch.bfloat16).cfg.embed_dim == 640
 
 
 def test_overlapped_backward_equals_serial_and_flax_round_trip(pkg, tmp_path):

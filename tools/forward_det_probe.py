@@ -7,7 +7,7 @@ import savit_amd  # noqa: F401
 from savit_amd.model import create_model
 n_it = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 for name, B in (("vit_s_patch16", 16), ("cait_xxs_24", 16), ("mixer_s_patch16", 16), ("tnt_b_patch16", 8)):
-    m = create_model(name)
+    m = create_model(name, dtype=torch.bfloat16)
     e = m.engine(B)
     e.init_params(3)
     e.layout.view(e.params, "Wh").normal_(0, 0.02)
