@@ -30,6 +30,7 @@ struct GemmParams {
   int grid_side;        // PATCH: patches per image side
   int desync_phases;    // ping-pong kernel: workgroups start in this many phase groups ...
   int desync_sleep;     // ... each delayed by (group index) x this many s_sleep(127) units (0 = all start together)
+  int row_group;        // ping-pong kernel: tiles are visited in groups of this many row panels, column by column inside a group
 };
 
 template <int EPI>
@@ -820,7 +821,18 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(const GemmParams p) {
   const int wr = wave >> 2, wc = wave & 3;
   const int nwg = p.tiles_m * p.tiles_n;
   const int tid = xcd_remap(blockIdx.x, nwg);
-  const int tm = tid / p.tiles_n, tn = tid - tm * p.tiles_n;
+  // Tile order inside the XCD's contiguous chunk: row panels in groups of G, and inside a group column by column (all G rows of a
+  // column, then the next column).  The 32 tiles an XCD runs at a time then touch about G A-panels and 32/G W-panels instead of
+  // 2-3 A-panels and EVERY W-panel (N = 3072: 12 panels = 4.7 MB, more than the 4 MB L2, so each wave of tiles re-fetched all of W:
+  // 242 MB of L2 misses per fc1 launch for 43 MB of operands), and the group's A-panels stay in L2 across its columns.
+  int tm, tn;
+  {
+    const int G = p.row_group, per = G * p.tiles_n;
+    const int g = tid / per, rem = tid - g * per;
+    const int rows_g = (p.tiles_m - g * G) < G ? (p.tiles_m - g * G) : G;
+    tn = rem / rows_g;
+    tm = g * G + (rem - tn * rows_g);
+  }
   const int row0 = tm * BM, col0 = tn * BN;
 
   const bf16_t* Abase = reinterpret_cast<const bf16_t*>(a.A) + (size_t)row0 * a.lda;
@@ -961,11 +973,26 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(const GemmParams p) {
   }
 }
 
+// row panels per group of the ping-pong kernel's tile order: as many 256-row A-panels (256 x K x 2 B) as fit in about 3 MB of the
+// XCD's 4 MB L2, at most 8 (K = 768: 8, K = 1024: 6, K >= 3072: 1 = plain row-major order).  Measured on DeiT-B with cold operands
+// (tools/gemm_epi_bench.py, G = 1 -> 8): qkv 104 -> 97 us, fc1+GELU 156 -> 145 us; the GELU' epilogue, which also READS a [M, N]
+// tensor, is best at 4 (177 -> 172 us; 186 us at 8: fewer concurrent tiles per row of that tensor).  SAVIT_PP_ROW_GROUP overrides.
+inline int pp_row_group(int K, int tiles_m, int epilogue) {
+  static const int force = [] { const char* e = getenv("SAVIT_PP_ROW_GROUP"); return e ? atoi(e) : 0; }();
+  int g = force > 0 ? force : (int)((3l << 20) / ((long)256 * K * 2));
+  if (g < 1) g = 1;
+  if (g > 8) g = 8;
+  if (force <= 0 && epilogue == SAVIT_EPI_DGELU && g > 4) g = 4;
+  if (g > tiles_m) g = tiles_m;
+  return g;
+}
+
 template <int ABL>
 int launch_pp_ablation(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
   p.tiles_m = (p.a.M + 255) / 256;
   p.tiles_n = (p.a.N + 255) / 256;
+  p.row_group = pp_row_group(p.a.K, p.tiles_m, p.a.epilogue);
   auto kfn = gemm_tn_pp_kernel<SAVIT_EPI_BF16, ABL>;
   hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128);
   if (e != hipSuccess) return (int)e;
@@ -984,6 +1011,7 @@ int launch_pp(const GemmParams& p0, hipStream_t s) {
     p.desync_sleep = e2 ? atoi(e2) : 0;
     if (p.desync_phases < 1) p.desync_phases = 1;
   }
+  p.row_group = pp_row_group(p.a.K, p.tiles_m, p.a.epilogue);
   const dim3 grid(p.tiles_m * p.tiles_n);
   const size_t lds = 2 * 512 * 128;
 #define SAVIT_LAUNCH_EPI(E)                                                                            \

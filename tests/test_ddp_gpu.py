@@ -108,3 +108,54 @@ def test_two_rank_step_matches_single_engine(tmp_path, cfg_name, side_streams, m
     # after Adam: a weight whose gradient is ~0 can move by +-lr in either direction (sign of noise), so compare in the mean
     assert (dp["params"] - ref).abs().mean().item() < 2e-5
     assert (dp["params"] - ref).abs().max().item() < 2.5e-3  # <= 2*lr + rounding over two steps
+
+
+def _rccl_rank_main(rank, port, out_path):
+    """One rank on RCCL (backend 'nccl'): the exchange itself is the identity, what runs is RCCL's initialisation on this device,
+    the broadcast, the async all-reduce of every bucket from the backward hooks on RCCL's stream, and the stream hand-offs of wait()."""
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from savit_amd import ddp
+
+    cfg, eng = _make("vit_ti_patch16", 8)
+    img, lab = _data(cfg, 8)
+    ddp.broadcast_params(eng.params)
+    sync = ddp.GradSync(eng.grads, ddp.plan_buckets_for(eng.layout, 1 << 18))
+    eng.bwd_hooks = sync.hooks()
+    eng.forward(img)
+    eng.loss_backward(lab, label_smoothing=0.1)
+    sync.wait()
+    torch.cuda.synchronize()
+    g = eng.grads.cpu()
+    eng.optimizer_step(lr=1e-3, weight_decay=1e-4, max_norm=1.0, grad_scale=sync.grad_scale)
+    torch.cuda.synchronize()
+    torch.save({"grads": g, "params": eng.params.cpu(), "nbuckets": len(sync.buckets), "backend": dist.get_backend()}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank(tmp_path):
+    """The RCCL path of bench.py / train.py (backend 'nccl', device_id, bucket hooks) on the one GPU this box has: a 1-rank group."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "r.pt")
+    mp.spawn(_rccl_rank_main, args=(29711, out), nprocs=1, join=True)
+    got = torch.load(out)
+    assert got["backend"] == "nccl" and got["nbuckets"] > 2
+    cfg, eng = _make("vit_ti_patch16", 8)
+    img, lab = _data(cfg, 8)
+    eng.forward(img)
+    eng.loss_backward(lab, label_smoothing=0.1)
+    torch.cuda.synchronize()
+    g0, g1 = eng.grads.cpu().double(), got["grads"].double()
+    rel = float((g0 - g1).norm() / g0.norm())
+    print(f"[rccl world 1] gradient vs the plain engine: rel {rel:.2e}")
+    assert rel < 5e-6  # a 1-rank all-reduce is the identity; what differs is fp32 summation order in the few atomic reductions left
+    eng.optimizer_step(lr=1e-3, weight_decay=1e-4, max_norm=1.0)
+    torch.cuda.synchronize()
+    assert float((eng.params.cpu() - got["params"]).abs().max()) < 2.5e-3  # <= 2 lr where a ~0 gradient flips sign

@@ -7,7 +7,7 @@ def agg(path):
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
-        m = re.search(r"(gemm_\w+<[^>]*>|attn_\w+<\d+>|ln_\w+<\d+>|adamw_kernel|th_\w+(<\d+>)?|layerscale_bwd_kernel<\d+>|class_attn_\w+<\d+>|transpose_bf16_kernel|token_mean_\w+|seq16_\w+_kernel|cast_colsum_kernel|inner2outer_\w+_kernel|pixel_gather_kernel|colsum_finalize_kernel)", name)
+        m = re.search(r"(gemm_\w+<[^>]*>|attn_\w+<\d+>|ln_\w+<\d+>|adamw_kernel|th_\w+(<\d+>)?|layerscale_bwd_kernel<\d+>|class_attn_\w+<\d+>|transpose_bf16_kernel|token_mean_\w+|seq16_\w+_kernel|cast_colsum_kernel|inner2outer_\w+_kernel|pixel_gather_kernel|colsum_finalize_kernel|wgrad_reduce_kernel)", name)
         if m:
             d[m.group(1).replace(" ", "")].append(float(r["Counter_Value"]))
     return d
