@@ -561,10 +561,15 @@ int launch_wgrad(WgradParams p, hipStream_t s) {
 }  // namespace
 
 extern "C" int savit_gemm_wgrad_auto_variant(int Kin, int Nout, int patch) {
-  // measured on MI355X (tools/bench_wgrad.py, cold caches): big weights run best on 256x256 tiles with one 8-wave
-  // workgroup per CU (fewest L2->LDS bytes per flop and fewest atomic bytes: 4*Kin*Nout*splits); small or ragged ones on
-  // 128x128 tiles, also sized for ONE workgroup per CU so the split count - and with it the atomic traffic - stays low
-  return (Kin % 256 == 0 && Nout % 256 == 0 && (long)Kin * Nout >= (1 << 20) && !patch) ? 3 : 1;
+  // measured on MI355X (tools/bench_wgrad.py, tools/bench_wgrad_small.py, cold caches): big weights run best on 256x256 tiles with
+  // one 8-wave workgroup per CU (fewest L2->LDS bytes per flop and fewest partial-slab bytes: 4*Kin*Nout*splits); so do the MLP
+  // weights of the d = 384 models (384 x 1536: 113 -> 98 us although the second 256-row tile is half empty); small or ragged ones
+  // on 128x128 tiles, also sized for ONE workgroup per CU so the split count stays low
+  if (patch) return 1;
+  const long sz = (long)Kin * Nout;
+  if (Kin % 256 == 0 && Nout % 256 == 0 && sz >= (1 << 20)) return 3;
+  if (Kin % 128 == 0 && Nout % 128 == 0 && sz >= (1 << 19) && (Kin >= 1024 || Nout >= 1024)) return 3;
+  return 1;
 }
 
 static int wgrad_variant(int Kin, int Nout, int patch) {
@@ -579,6 +584,7 @@ static bool ring_geometry(int v, int* bi, int* bj, int* slots) {
     case 2: *bi = 256; *bj = 128; *slots = 512; return true;
     case 3: *bi = 256; *bj = 256; *slots = 256; return true;
     case 4: *bi = 128; *bj = 128; *slots = 768; return true;
+    case 5: *bi = 128; *bj = 256; *slots = 512; return true;
     default: return false;
   }
 }
@@ -632,6 +638,7 @@ static int wgrad_dispatch(const void* X, const void* dY, float* dW, int M, int K
     case 2: return launch_wgrad_ring<256, 128, 2, 2, 3>(p, (hipStream_t)stream, 512, workspace_bytes);
     case 3: return launch_wgrad_ring<256, 256, 2, 4, 4>(p, (hipStream_t)stream, 256, workspace_bytes);
     case 4: return launch_wgrad_ring<128, 128, 2, 2, 3>(p, (hipStream_t)stream, 768, workspace_bytes);
+    case 5: return launch_wgrad_ring<128, 256, 2, 2, 3>(p, (hipStream_t)stream, 512, workspace_bytes);
     default: p.slab = nullptr; return launch_wgrad<128, 128, 2, 2>(p, (hipStream_t)stream);
   }
 }
