@@ -41,7 +41,8 @@ MFMA_BF16_PEAK_TFLOPS = 2516.6  # 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (MI3
 
 TN_TILES = {6: "gemm_tn_ring_kernel<128,128,2,2,4,%d>", 7: "gemm_tn_ring_kernel<256,256,2,4,4,%d>",
             12: "gemm_tn_pair_kernel<128,128,2,2,2,%d>", 13: "gemm_tn_pair_kernel<256,256,2,4,2,%d>",
-            17: "gemm_tn_pair_kernel<192,128,2,2,2,%d>", 20: "gemm_tn_pp_kernel<%d,0>"}
+            17: "gemm_tn_pair_kernel<192,128,2,2,2,%d>", 18: "gemm_tn_pair_tail_kernel<192,128,128,2,2,2,%d>",
+            20: "gemm_tn_pp_kernel<%d,0>"}
 WG_VARIANTS = {1: "gemm_wgrad_ring_kernel<128,128,2,2,4,false>", 3: "gemm_wgrad_ring_kernel<256,256,2,4,4,false>"}
 EPI_OF = {"qkv": 0, "proj": 2, "fc1": 1, "fc2": 2, "fc2.dgrad": 3, "fc1.dgrad": 0, "proj.dgrad": 0, "qkv.dgrad": 0}
 
@@ -54,7 +55,8 @@ def kernel_symbol(label: str, lib, M: int, d: int, F: int) -> str:
               "proj.dgrad": (d, d), "qkv.dgrad": (d, 3 * d)}
     if op in shapes:
         N, K = shapes[op]
-        return TN_TILES[lib.savit_gemm_tn_auto_tile_epi(M, N, K, EPI_OF[op])] % EPI_OF[op]
+        tile = lib.savit_gemm_tn_auto_tile_epi(M, N, K, EPI_OF[op])
+        return TN_TILES.get(tile, "gemm_tn tile %d <%%d>" % tile) % EPI_OF[op]
     wshapes = {"Wqkv.wgrad": (d, 3 * d), "Wo.wgrad": (d, d), "W1.wgrad": (d, F), "W2.wgrad": (F, d)}
     if op in wshapes:
         return WG_VARIANTS[lib.savit_gemm_wgrad_auto_variant(wshapes[op][0], wshapes[op][1], 0)]
@@ -378,13 +380,16 @@ def main():
         # covers this kernel and this is the headline workload; null otherwise.
         try:
             if args.model == "vit_b_patch16" and B == 128:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(dom)
+                src = next(f for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                pm = json.load(open(os.path.join(ROOT, "profiles", src)))["kernels"].get(dom)
                 if pm:
                     out["roofline"]["traffic"] = pm["traffic_bytes"]
-                    out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled)"
-                    out["roofline"]["algorithmic_bytes_per_launch"] = int(sum(2 * M * (a + b_) + 4 * a * b_ for a, b_ in ((d, 3 * d), (d, F), (F, d))) / 3) \
-                        if dom.startswith("gemm_wgrad_ring_kernel<256") else None
-        except (OSError, ValueError, KeyError):
+                    out["roofline"]["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, FETCH doubled)"
+                    if dom.startswith("gemm_wgrad_ring_kernel<256"):
+                        # operands read once + the split partials written once (slab form; the reduce kernel is its own row of the profile)
+                        sp = max(1, eng.L.savit_gemm_wgrad_workspace_bytes(M, d, F, 0, 0) // (d * F * 4))
+                        out["roofline"]["algorithmic_bytes_per_launch"] = int(sum(2 * M * (a + b_) + 4 * a * b_ * sp for a, b_ in ((d, 3 * d), (d, F), (F, d))) / 3)
+        except (OSError, ValueError, KeyError, StopIteration):
             pass
         out["kernel_breakdown_ms"] = {c: round(v, 3) for c, v in sorted(cls_ms.items(), key=lambda kv: -kv[1])}
         out["kernel_breakdown_ms"]["sum_fwd_bwd"] = round(total_ms, 3)

@@ -31,6 +31,7 @@ struct GemmParams {
   int desync_phases;    // ping-pong kernel: workgroups start in this many phase groups ...
   int desync_sleep;     // ... each delayed by (group index) x this many s_sleep(127) units (0 = all start together)
   int row_group;        // ping-pong kernel: tiles are visited in groups of this many row panels, column by column inside a group
+  int big_tiles, small_tiles, big_rows;  // tail-split pair kernel: tile counts of the two heights, rows covered by the tall tiles
 };
 
 template <int EPI>
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_ring_kernel(const G
 //   odd step  : MFMAs of K-step 2p+1 | read fragments of 2p+2 (slot p+1) | issue the DMA of pair p+ND into slot p (free now)
 // i.e. ONE barrier per two K-steps, and the DMA issue is spread between the MFMAs of the odd step.
 template <int BM, int BN, int WGM, int WGN, int ND, int EPI>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_pair_kernel(const GemmParams p) {
+__device__ __forceinline__ void pair_tile(const GemmParams& p, char* smem, const int tm, const int tn, const int row_base) {
   constexpr int NW = WGM * WGN;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int MI = WTM / 16, NI = WTN / 16;
@@ -623,16 +624,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_pair_kernel(const G
   constexpr bool PATCH = (EPI == SAVIT_EPI_PATCH);
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
   static_assert(ND >= 2 && G * (ND - 2) <= 63, "ring depth / vmcnt immediate");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
   const savit_gemm_args& a = p.a;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int tid = xcd_remap(blockIdx.x, nwg);
-  const int tm = tid / p.tiles_n, tn = tid - tm * p.tiles_n;
-  const int row0 = tm * BM, col0 = tn * BN;
+  const int row0 = row_base + tm * BM, col0 = tn * BN;
 
   const bf16_t* Abase = reinterpret_cast<const bf16_t*>(a.A);
   const bf16_t* Bbase = reinterpret_cast<const bf16_t*>(a.Bt) + (size_t)col0 * a.ldb;
@@ -783,6 +779,34 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_pair_kernel(const G
 #pragma unroll
       for (int i = 0; i < MI; ++i) epilogue_store<EPI>(p, mrow + i * 16, ncol + j * 16, acc[i][j], csum);
     }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, int ND, int EPI>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_pair_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  const int tm = tid / p.tiles_n;
+  pair_tile<BM, BN, WGM, WGN, ND, EPI>(p, smem, tm, tid - tm * p.tiles_n, 0);
+}
+
+// Mixed tile heights in ONE launch ("tail split").  792 tiles of 192 x 128 on 512 workgroup slots are 1.55 rounds: the second
+// round runs at 55 % occupancy and the launch takes 2 tile times.  Here the first `big_tiles` workgroups (whole rounds of slots)
+// take BM-row tiles over the first big_rows rows and the remaining rows are cut into shorter BM2-row tiles, which start as the
+// big ones drain: about 1 + BM2/BM tile times.  Same arithmetic per output element (same K order), so results are bitwise those of
+// the plain kernel.  Epilogues without column sums only (the slab index is per row tile).
+template <int BM, int BM2, int BN, int WGM, int WGN, int ND, int EPI>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_pair_tail_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x;
+  if (b < p.big_tiles) {
+    const int tid = xcd_remap(b, p.big_tiles);
+    const int tm = tid / p.tiles_n;
+    pair_tile<BM, BN, WGM, WGN, ND, EPI>(p, smem, tm, tid - tm * p.tiles_n, 0);
+  } else {
+    const int tid = xcd_remap(b - p.big_tiles, p.small_tiles);
+    const int tm = tid / p.tiles_n;
+    pair_tile<BM2, BN, WGM, WGN, ND, EPI>(p, smem, tm, tid - tm * p.tiles_n, p.big_rows);
   }
 }
 
@@ -1062,6 +1086,57 @@ int launch_pair(const GemmParams& p0, hipStream_t s) {
   SAVIT_LAUNCH_RET();
 }
 
+// rounds of `slots` resident workgroups a tail-split launch saves: plan = (tall row panels, short row panels), or 0 panels if the
+// plain kernel is at least as good (less than one full round of tall tiles, or the remainder fills its round anyway)
+inline bool tail_split_plan(int M, int N, int BM, int BM2, int BN, int slots, int* big_panels, int* small_panels) {
+  const int tiles_n = (N + BN - 1) / BN;
+  const int panels = (M + BM - 1) / BM;
+  const long all = (long)panels * tiles_n;
+  const long rounds_plain = (all + slots - 1) / slots;
+  const int bp = (int)(((all / slots) * slots) / tiles_n);  // whole rounds of slots, rounded down to whole row panels
+  if (bp <= 0 || bp >= panels) return false;
+  const int rem_rows = M - bp * BM;
+  const int sp = (rem_rows + BM2 - 1) / BM2;
+  const long small_rounds = ((long)sp * tiles_n + slots - 1) / slots;
+  const double t_tail = (double)(((long)bp * tiles_n + slots - 1) / slots) + (double)small_rounds * BM2 / BM;  // in tall-tile times
+  if (t_tail > 0.93 * (double)rounds_plain) return false;
+  *big_panels = bp;
+  *small_panels = sp;
+  return true;
+}
+
+template <int BM, int BM2, int BN, int WGM, int WGN, int ND>
+int launch_pair_tail(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  int bp = 0, sp = 0;
+  if (!tail_split_plan(p.a.M, p.a.N, BM, BM2, BN, 512, &bp, &sp)) return launch_pair<BM, BN, WGM, WGN, ND>(p0, s);
+  p.tiles_n = (p.a.N + BN - 1) / BN;
+  p.tiles_m = bp;
+  p.big_tiles = bp * p.tiles_n;
+  p.small_tiles = sp * p.tiles_n;
+  p.big_rows = bp * BM;
+  const dim3 grid(p.big_tiles + p.small_tiles);
+  const size_t lds = (size_t)ND * (BM + BN) * 128;
+#define SAVIT_LAUNCH_EPI(E)                                                                            \
+  case E: {                                                                                            \
+    auto kfn = gemm_tn_pair_tail_kernel<BM, BM2, BN, WGM, WGN, ND, E>;                                 \
+    if (lds > 48 * 1024) {                                                                             \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return (int)e;                                                              \
+    }                                                                                                  \
+    hipLaunchKernelGGL(kfn, grid, dim3(64 * WGM * WGN), lds, s, p);                                   \
+  } break;
+  switch (p.a.epilogue) {
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_BF16)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_BIAS_GELU)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_RESID)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_F32)
+    default: return launch_pair<BM, BN, WGM, WGN, ND>(p0, s);  // column-sum slabs are indexed per row tile: plain kernel
+  }
+#undef SAVIT_LAUNCH_EPI
+  SAVIT_LAUNCH_RET();
+}
+
 template <int BM, int BN, int WGM, int WGN, int S, bool LATE = false>
 int launch_ring(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
@@ -1143,7 +1218,14 @@ extern "C" int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue) {
   //    ViT-L shapes 4-6 % over the pair kernel.  Narrow outputs (N = 768) keep 192x128: 297 tiles of 256x256 are 1.16 rounds.
   if (big && N >= 1024 && K >= 768 && epilogue != SAVIT_EPI_PATCH) return 20;
   if (big && (epilogue == SAVIT_EPI_BIAS_GELU || K >= 1024)) return 13;
-  if (N % 128 == 0 && M >= 1536 && epilogue != SAVIT_EPI_PATCH) return 17;
+  if (N % 128 == 0 && M >= 1536 && epilogue != SAVIT_EPI_PATCH) {
+    //  * 192x128 with the LAST partial round cut into 128-row tiles (tile 18) when that saves at least 7 % of a round count:
+    //    DeiT-B's N = 768 products are 792 tiles on 512 slots (2 rounds, the second at 55 %) -> 510 tall + 420 short tiles.
+    int bp, sp;
+    static const bool no_tail = getenv("SAVIT_NO_TAIL_SPLIT") != nullptr;  // development aid (A/B runs)
+    if (!no_tail && epilogue != SAVIT_EPI_DGELU && tail_split_plan(M, N, 192, 128, 128, 512, &bp, &sp)) return 18;
+    return 17;
+  }
   return big ? 13 : 12;
 }
 
@@ -1200,7 +1282,7 @@ inline bool tile_geometry(int tile, int* bm, int* wgm) {
     case 1: case 4: case 6: case 8: case 9: case 11: case 12: case 14: *bm = 128; *wgm = 2; return true;
     case 2: case 5: case 7: case 10: case 13: case 15: *bm = 256; *wgm = 2; return true;
     case 3: *bm = 256; *wgm = 4; return true;
-    case 17: *bm = 192; *wgm = 2; return true;
+    case 17: case 18: *bm = 192; *wgm = 2; return true;
     case 20: *bm = 256; *wgm = 2; return true;
     default: return false;
   }
@@ -1269,6 +1351,7 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
     case 14: return a.K % 64 ? SAVIT_EINVAL : launch_pair<128, 256, 2, 2, 2>(p, s);
     case 15: return a.K % 64 ? SAVIT_EINVAL : launch_pair<256, 128, 2, 2, 2>(p, s);
     case 17: return a.K % 64 ? SAVIT_EINVAL : launch_pair<192, 128, 2, 2, 2>(p, s);
+    case 18: return a.K % 64 ? SAVIT_EINVAL : launch_pair_tail<192, 128, 128, 2, 2, 2>(p, s);  // 17 with 128-row tiles for the last partial round
     case 20: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp(p, s);
     // timing-only ablations of tile 20 (wrong results by construction; SAVIT_EPI_BF16 only)
     case 101: return launch_pp_ablation<1>(p, s);

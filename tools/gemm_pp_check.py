@@ -38,6 +38,17 @@ for (M, N, K) in [(256, 256, 64), (256, 256, 128), (512, 512, 192), (1000, 768, 
                 d = (x.float() - y.float()).abs()
                 print(f"MISMATCH M{M} N{N} K{K} epi{epi} out{i}: max {float(d.max()):.3e} count {int((d > 0).sum())}")
 print("bitwise check:", "OK" if ok else "FAILED", flush=True)
+# tail-split pair kernel (tile 18) vs the plain 192x128 kernel (tile 17): bitwise, epilogues without column sums
+ok18 = True
+for (M, N, K) in [(25216, 768, 768), (25216, 768, 3072), (50432, 384, 1536), (3001, 1000, 256), (100000, 128, 64), (25216, 2304, 768)]:
+    for epi in (0, 1, 2, 4):
+        a = run(M, N, K, epi, 17); b = run(M, N, K, epi, 18)
+        for i, (x, y) in enumerate(zip(a, b)):
+            if not torch.equal(x, y):
+                ok18 = False
+                d = (x.float() - y.float()).abs()
+                print(f"MISMATCH18 M{M} N{N} K{K} epi{epi} out{i}: max {float(d.max()):.3e} count {int((d > 0).sum())}")
+print("tail-split bitwise check:", "OK" if ok18 else "FAILED", flush=True)
 def bench(M, N, K, tile, epi=0, n=20):
     A = torch.randn(M, K, device="cuda").to(bf16); Bt = (torch.randn(N, K, device="cuda") / K ** 0.5).to(bf16)
     C = torch.empty(M, N, device="cuda", dtype=bf16)
@@ -50,6 +61,6 @@ def bench(M, N, K, tile, epi=0, n=20):
     ms = a.elapsed_time(b) / n
     return ms * 1e3, 2.0 * M * N * K / ms / 1e9
 for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 8192), (25216, 2304, 768), (25216, 3072, 768), (25216, 768, 3072), (25216, 768, 768), (25216, 768, 2304), (147712, 1024, 1024), (147712, 4096, 1024)]:
-    for tile in (13, 17, NEW):
+    for tile in (13, 17, 18, NEW):
         us, tf = bench(M, N, K, tile)
         print(f"M{M} N{N} K{K} tile{tile}: {us:8.1f} us {tf:7.1f} TF/s", flush=True)
