@@ -60,6 +60,8 @@ def kernel_symbol(label: str, lib, M: int, d: int, F: int) -> str:
     wshapes = {"Wqkv.wgrad": (d, 3 * d), "Wo.wgrad": (d, d), "W1.wgrad": (d, F), "W2.wgrad": (F, d)}
     if op in wshapes:
         return WG_VARIANTS[lib.savit_gemm_wgrad_auto_variant(wshapes[op][0], wshapes[op][1], 0)]
+    if op.endswith(".wgrad.reduce"):
+        return "wgrad_reduce_kernel"
     if "attn" in op:
         return "attn_bwd_kernel" if op.endswith(".bwd") else "attn_fwd_kernel"
     if op.startswith("ln"):
@@ -68,6 +70,8 @@ def kernel_symbol(label: str, lib, M: int, d: int, F: int) -> str:
 
 
 def kernel_class(label: str) -> str:
+    if label.endswith(".wgrad.reduce"):
+        return "wgrad_reduce"
     if label.endswith(".wgrad") or label == "Wpe.wgrad":
         return "gemm_wgrad"
     if label.endswith(".dgrad") or label.split(".")[-1] in ("qkv", "proj", "fc1", "fc2", "q", "kv", "iqkv", "iproj", "ifc1", "ifc2", "fc") \

@@ -142,6 +142,14 @@ int savit_gemm_bf16_wgrad_ws(const void* X, const void* dY, float* dW, int M, in
                              int splits, int patch, int img_size, int tokens, int token_offset, void* workspace, long workspace_bytes,
                              void* stream);
 long savit_gemm_wgrad_workspace_bytes(int M, int Kin, int Nout, int splits, int patch);
+/* The two launches of savit_gemm_bf16_wgrad_ws as separate calls (so a profiler or a launch plan sees one kernel per entry):
+ * _partial stores the split partials to the workspace (SAVIT_EINVAL when the workspace is missing / too small or the shape is served by
+ * the atomic 2-stage kernel), _reduce adds the first `splits` slabs to dW in index order; savit_gemm_wgrad_split_count = the split
+ * count the launch uses for (M, Kin, Nout, splits hint, patch) - 0 for shapes without a slab form. */
+int savit_gemm_bf16_wgrad_partial(const void* X, const void* dY, int M, int Kin, int Nout, int ldx, int lddy, int splits, int patch,
+                                  int img_size, int tokens, int token_offset, void* workspace, long workspace_bytes, void* stream);
+int savit_gemm_wgrad_reduce(const void* workspace, int splits, int Kin, int Nout, float* dW, int lddw, void* stream);
+int savit_gemm_wgrad_split_count(int M, int Kin, int Nout, int splits, int patch);
 /* Kernel the wgrad heuristic picks: 1 = 128x128 ring (4 waves), 3 = 256x256 ring (8 waves). */
 int savit_gemm_wgrad_auto_variant(int Kin, int Nout, int patch);
 

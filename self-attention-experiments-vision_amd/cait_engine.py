@@ -530,11 +530,12 @@ class CaiTEngine:
                 self._side_streams.append(torch.cuda.Stream(device=self.dev))
             self._bwd_plan.run_overlapped(torch.cuda.current_stream(), self._side_streams[:n], self.bwd_hooks)
             return self.loss
-        for fn, args, label in self._serial_bwd_plan().calls:
+        plan = self._serial_bwd_plan()
+        for fn, args, label in plan.calls:
             rc = fn(*args, s)
             if rc != 0:
                 _lib.check(rc, label)
-            cb = self.bwd_hooks.get(label)
+            cb = plan.hook_for(self.bwd_hooks, label)
             if cb is not None:
                 cb()
         return self.loss

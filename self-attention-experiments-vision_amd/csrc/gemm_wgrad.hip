@@ -33,6 +33,7 @@ struct WgradParams {
   int abl;  // timing-only ablation (SAVIT_WGRAD_ABL): 1 = skip the epilogue
   float* slab;       // non-null: every split stores its partial tile to slab + split * slab_stride (dense [Kin, Nout]) with plain
   long slab_stride;  // stores and wgrad_reduce_kernel sums the splits into dW: no atomics, bitwise reproducible
+  int no_reduce;     // slab form only: leave the ordered sum to a later savit_gemm_wgrad_reduce call
 };
 
 __device__ __forceinline__ bf16x4 ds_read_tr16_b64(const char* p) {
@@ -506,7 +507,8 @@ int launch_wgrad_ring(WgradParams p, hipStream_t s, int slots, long ws_bytes) {
     }
     hipLaunchKernelGGL(kfn, grid, block, lds, s, p);
   }
-  if (use_slab) {
+  if (p.no_reduce && !use_slab) return SAVIT_EINVAL;  // the caller asked for partials only and gave no (or too small a) workspace
+  if (use_slab && !p.no_reduce) {
     const long total4 = (long)p.Kin * (p.Nout / 4);
     long blocks = (total4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -597,11 +599,11 @@ extern "C" long savit_gemm_wgrad_workspace_bytes(int M, int Kin, int Nout, int s
 }
 
 static int wgrad_dispatch(const void* X, const void* dY, float* dW, int M, int Kin, int Nout, int ldx, int lddy, int lddw, int splits, int patch,
-                          int img_size, int tokens, int token_offset, void* workspace, long workspace_bytes, void* stream);
+                          int img_size, int tokens, int token_offset, void* workspace, long workspace_bytes, int no_reduce, void* stream);
 
 extern "C" int savit_gemm_bf16_wgrad(const void* X, const void* dY, float* dW, int M, int Kin, int Nout, int ldx, int lddy,
                                      int lddw, int splits, int patch, int img_size, int tokens, int token_offset, void* stream) {
-  return wgrad_dispatch(X, dY, dW, M, Kin, Nout, ldx, lddy, lddw, splits, patch, img_size, tokens, token_offset, nullptr, 0, stream);
+  return wgrad_dispatch(X, dY, dW, M, Kin, Nout, ldx, lddy, lddw, splits, patch, img_size, tokens, token_offset, nullptr, 0, 0, stream);
 }
 
 extern "C" int savit_gemm_bf16_wgrad_ws(const void* X, const void* dY, float* dW, int M, int Kin, int Nout, int ldx, int lddy, int lddw,
@@ -609,11 +611,37 @@ extern "C" int savit_gemm_bf16_wgrad_ws(const void* X, const void* dY, float* dW
                                         long workspace_bytes, void* stream) {
   SAVIT_CHECK_ARG(workspace == nullptr || (((uintptr_t)workspace % 16) == 0 && workspace_bytes >= 0));
   return wgrad_dispatch(X, dY, dW, M, Kin, Nout, ldx, lddy, lddw, splits, patch, img_size, tokens, token_offset, workspace, workspace_bytes,
-                        stream);
+                        0, stream);
+}
+
+extern "C" int savit_gemm_bf16_wgrad_partial(const void* X, const void* dY, int M, int Kin, int Nout, int ldx, int lddy, int splits, int patch,
+                                             int img_size, int tokens, int token_offset, void* workspace, long workspace_bytes, void* stream) {
+  SAVIT_CHECK_ARG(workspace != nullptr && ((uintptr_t)workspace % 16) == 0 && Nout % 4 == 0);
+  // dW is not touched by the partial launch; the dispatcher only checks its alignment and pitch
+  return wgrad_dispatch(X, dY, (float*)workspace, M, Kin, Nout, ldx, lddy, Nout, splits, patch, img_size, tokens, token_offset, workspace,
+                        workspace_bytes, 1, stream);
+}
+
+extern "C" int savit_gemm_wgrad_reduce(const void* workspace, int splits, int Kin, int Nout, float* dW, int lddw, void* stream) {
+  SAVIT_CHECK_ARG(workspace && dW && splits >= 1 && Kin > 0 && Nout > 0 && Nout % 4 == 0 && lddw >= Nout && lddw % 4 == 0);
+  SAVIT_CHECK_ARG(((uintptr_t)workspace % 16) == 0 && ((uintptr_t)dW % 16) == 0);
+  const long total4 = (long)Kin * (Nout / 4);
+  long blocks = (total4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, splits, (long)Kin * Nout, dW,
+                     Kin, Nout, lddw);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_gemm_wgrad_split_count(int M, int Kin, int Nout, int splits, int patch) {
+  if (M <= 0 || Kin <= 0 || Nout <= 0) return 0;
+  int bi, bj, slots;
+  if (!ring_geometry(wgrad_variant(Kin, Nout, patch), &bi, &bj, &slots)) return 0;
+  return ring_split_count(M, Kin, Nout, bi, bj, slots, splits, nullptr);
 }
 
 static int wgrad_dispatch(const void* X, const void* dY, float* dW, int M, int Kin, int Nout, int ldx, int lddy, int lddw, int splits, int patch,
-                          int img_size, int tokens, int token_offset, void* workspace, long workspace_bytes, void* stream) {
+                          int img_size, int tokens, int token_offset, void* workspace, long workspace_bytes, int no_reduce, void* stream) {
   SAVIT_CHECK_ARG(X && dY && dW && M >= 0 && Kin > 0 && Nout > 0 && lddw >= Nout);
   SAVIT_CHECK_ARG(Kin % 8 == 0 && Nout % 8 == 0 && lddy % 8 == 0 && lddy >= Nout);
   SAVIT_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)dY % 16) == 0);
@@ -623,6 +651,7 @@ static int wgrad_dispatch(const void* X, const void* dY, float* dW, int M, int K
   p.patch = patch; p.img_size = img_size; p.tokens = tokens; p.token_offset = token_offset;
   { const char* e = getenv("SAVIT_WGRAD_ABL"); p.abl = e ? atoi(e) : 0; }
   p.slab = (float*)workspace;
+  p.no_reduce = no_reduce;
   if (patch) {
     SAVIT_CHECK_ARG(patch % 8 == 0 && img_size % patch == 0 && Kin == patch * patch * 3 && tokens > 0 && token_offset >= 0);
     p.grid_side = img_size / patch;
@@ -639,6 +668,9 @@ static int wgrad_dispatch(const void* X, const void* dY, float* dW, int M, int K
     case 3: return launch_wgrad_ring<256, 256, 2, 4, 4>(p, (hipStream_t)stream, 256, workspace_bytes);
     case 4: return launch_wgrad_ring<128, 128, 2, 2, 3>(p, (hipStream_t)stream, 768, workspace_bytes);
     case 5: return launch_wgrad_ring<128, 256, 2, 2, 3>(p, (hipStream_t)stream, 512, workspace_bytes);
-    default: p.slab = nullptr; return launch_wgrad<128, 128, 2, 2>(p, (hipStream_t)stream);
+    default:
+      if (no_reduce) return SAVIT_EINVAL;
+      p.slab = nullptr;
+      return launch_wgrad<128, 128, 2, 2>(p, (hipStream_t)stream);
   }
 }

@@ -151,25 +151,37 @@ class _Plan:
     def __init__(self):
         self.calls: List[Tuple[Callable, tuple, str]] = []
         self.keep: List[object] = []  # ctypes structs that must outlive the plan
-        self.ws_requests: List[Tuple[int, int, int]] = []  # (call index, workspace key, bytes): see add_wgrad / finalize_wgrad_ws
+        self.ws_requests: List[Tuple[int, int, int, int]] = []  # (call index, workspace key, bytes, argument position): add_wgrad
+        self.hook_alias: Dict[str, str] = {}     # launch label -> label whose hook fires behind THIS launch instead (add_wgrad)
         self.side: Dict[int, int] = {}           # call index -> side-launch ordinal (stream = ordinal % number of side streams)
         self.guard: Dict[int, List[int]] = {}    # main call index -> side call indices that must have finished first
         self._readers: Dict[int, List[int]] = {}  # buffer address -> side calls reading it (build-time bookkeeping)
         self._ev_ready: Dict[int, "torch.cuda.Event"] = {}
         self._ev_done: Dict[int, "torch.cuda.Event"] = {}
 
-    def add(self, fn, args: tuple, label: str, side: bool = False, reads: tuple = (), writes: tuple = ()):
+    def add(self, fn, args: tuple, label: str, side: bool = False, reads: tuple = (), writes: tuple = (), same_side_stream: bool = False):
         i = len(self.calls)
         self.calls.append((fn, args, label))
         if side:
             assert not writes
-            self.side[i] = len(self.side)
+            # same_side_stream: this launch continues the previous side launch (same ordinal -> same stream, issued right behind it)
+            self.side[i] = self.side[max(self.side)] if (same_side_stream and self.side) else (max(self.side.values()) + 1 if self.side else 0)
             for r in reads:
                 self._readers.setdefault(r, []).append(i)
         else:
             g = sorted({j for w in writes for j in self._readers.pop(w, [])})
             if g:
                 self.guard[i] = g
+
+    def hook_for(self, hooks, label: str):
+        """The hook to run right behind the launch `label`: a label that has an alias target fires there, not here."""
+        if not hooks:
+            return None
+        if label in self.hook_alias:
+            return hooks.get(self.hook_alias[label])
+        if label in self.hook_alias.values():
+            return None
+        return hooks.get(label)
 
     def run(self, stream: int):
         for fn, args, label in self.calls:
@@ -203,13 +215,12 @@ class _Plan:
                 rc = fn(*args, mh)
             if rc != 0:
                 _lib.check(rc, label)
-            if hooks:
-                cb = hooks.get(label)
-                if cb is not None:
-                    for j in last:
-                        if j is not None:
-                            main.wait_event(self._ev_done[j])
-                    cb()
+            cb = self.hook_for(hooks, label)
+            if cb is not None:
+                for j in last:
+                    if j is not None:
+                        main.wait_event(self._ev_done[j])
+                cb()
         for j in last:
             if j is not None:
                 main.wait_event(self._ev_done[j])
@@ -225,28 +236,41 @@ def add_wgrad(eng, plan: _Plan, label: str, X, dY, dW, Mr, Kin, Nout, ldx, lddy,
     if os.environ.get("SAVIT_WGRAD_ATOMICS", "0") == "1":
         need = 0
     on_side = side and eng.overlap_wgrad and not eng._building_serial
-    key = (len(plan.side) % max(1, eng.n_side_streams)) if on_side else -1
-    plan.add(eng.L.savit_gemm_bf16_wgrad_ws, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, splits, patch[0], patch[1], patch[2], patch[3],
-                                              None, 0), label, side=side, reads=(dY,) if side else ())
-    if need > 0:
-        plan.ws_requests.append((len(plan.calls) - 1, key, need))
+    key = ((max(plan.side.values()) + 1 if plan.side else 0) % max(1, eng.n_side_streams)) if on_side else -1
+    if need <= 0:  # small / ragged shapes served by the 2-stage kernel: fp32 atomics, one launch
+        plan.add(eng.L.savit_gemm_bf16_wgrad, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, splits, patch[0], patch[1], patch[2], patch[3]),
+                 label, side=side, reads=(dY,) if side else ())
+        return
+    nsplit = int(eng.L.savit_gemm_wgrad_split_count(Mr, Kin, Nout, splits, patch[0]))
+    # two plan entries = two kernels (the GEMM that stores the split partials, the ordered sum into dW), the second on the SAME
+    # stream as the first
+    plan.add(eng.L.savit_gemm_bf16_wgrad_partial, (X, dY, Mr, Kin, Nout, ldx, lddy, splits, patch[0], patch[1], patch[2], patch[3], None, 0),
+             label, side=side, reads=(dY,) if side else ())
+    plan.ws_requests.append((len(plan.calls) - 1, key, need, -2))
+    plan.add(eng.L.savit_gemm_wgrad_reduce, (None, nsplit, Kin, Nout, dW, lddw), label + ".reduce", side=side, same_side_stream=True)
+    plan.ws_requests.append((len(plan.calls) - 1, key, need, 0))
+    plan.hook_alias[label + ".reduce"] = label  # a hook registered for `label` (DDP bucket trigger) fires behind the reduce
 
 
 def finalize_wgrad_ws(eng, plan: _Plan):
     """Allocate (or grow) the engine's slab workspaces to the largest request of `plan` per key and patch its launches."""
     if not hasattr(eng, "_wgrad_wsbuf"):
         eng._wgrad_wsbuf, eng._wgrad_ws_old = {}, []
-    for key in sorted({k for _, k, _ in plan.ws_requests}):
-        need = max(n for _, k, n in plan.ws_requests if k == key)
+    for key in sorted({k for _, k, _, _ in plan.ws_requests}):
+        need = max(n for _, k, n, _ in plan.ws_requests if k == key)
         buf = eng._wgrad_wsbuf.get(key)
         if buf is None or buf.numel() < need:
             if buf is not None:
                 eng._wgrad_ws_old.append(buf)  # an earlier plan still points at it
             eng._wgrad_wsbuf[key] = torch.empty(need, dtype=torch.uint8, device=eng.dev)
-    for idx, key, _ in plan.ws_requests:
+    for idx, key, _, pos in plan.ws_requests:  # pos: index of the workspace pointer in the argument tuple (-2: pointer, then its size)
         fn, args, label = plan.calls[idx]
         buf = eng._wgrad_wsbuf[key]
-        plan.calls[idx] = (fn, args[:-2] + (buf.data_ptr(), buf.numel()), label)
+        args = list(args)
+        args[pos] = buf.data_ptr()
+        if pos == -2:
+            args[-1] = buf.numel()
+        plan.calls[idx] = (fn, tuple(args), label)
     plan.ws_requests = []
 
 
@@ -623,7 +647,7 @@ class ViTEngine:
             rc = fn(*args, s)
             if rc != 0:
                 _lib.check(rc, label)
-            cb = self.bwd_hooks.get(label)
+            cb = plan.hook_for(self.bwd_hooks, label)
             if cb is not None:
                 cb()
 

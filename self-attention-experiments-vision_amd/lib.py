@@ -53,6 +53,10 @@ _SIGNATURES = {
     "savit_gemm_bf16_wgrad_ws": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_int, c_void_p, c_long, c_void_p]),
     "savit_gemm_wgrad_workspace_bytes": (c_long, [c_int, c_int, c_int, c_int, c_int]),
+    "savit_gemm_bf16_wgrad_partial": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                              c_void_p, c_long, c_void_p]),
+    "savit_gemm_wgrad_reduce": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "savit_gemm_wgrad_split_count": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "savit_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "savit_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                     c_void_p]),

@@ -115,7 +115,7 @@ class ViT:
             raise ValueError("images must be NHWC [B,S,S,3]")
         e = self.engine(images.shape[0])
         logits = e.forward(images)
-        return logits.to(self.dtype)
+        return logits.to(self.dtype, copy=True)  # the engine owns (and reuses) its logits buffer
 
     # -- training conveniences used by train.py-shaped loops
     def parameters_tree(self) -> dict:
@@ -142,12 +142,12 @@ class CaiT(ViT):
         e = self.engine(images.shape[0])
         if rngs and "stochastic_depth" in rngs:
             e.gen.manual_seed(int(rngs["stochastic_depth"]))
-        return e.forward(images, is_training=is_training).to(self.dtype)
+        return e.forward(images, is_training=is_training).to(self.dtype, copy=True)
 
     def __call__(self, images: torch.Tensor, is_training: bool = False) -> torch.Tensor:
         if images.dim() != 4:
             raise ValueError("images must be NHWC [B,S,S,3]")
-        return self.engine(images.shape[0]).forward(images, is_training=is_training).to(self.dtype)
+        return self.engine(images.shape[0]).forward(images, is_training=is_training).to(self.dtype, copy=True)
 
 
 class MLPMixer(ViT):

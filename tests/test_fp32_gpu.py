@@ -110,6 +110,10 @@ def test_vit_tiny_fp32_forward_and_loss_vs_oracle(L):
     labels = rng.integers(0, 1000, 8)
     logits = model.apply(params, torch.as_tensor(images).cuda(), is_training=False)
     assert logits.dtype == torch.float32 and tuple(logits.shape) == (8, 1000)
+    other = model.apply(vit_ref.init_params(oc, seed=4, randomize=True), torch.as_tensor(images).cuda(), is_training=False)
+    assert not torch.equal(other, logits)  # apply() returns its own tensor, not a view of the engine's reused logits buffer
+    logits2 = model.apply(params, torch.as_tensor(images).cuda(), is_training=True)
+    assert torch.equal(logits2, logits)  # functional in the parameters; is_training selects nothing (all dropout rates are 0)
     ref32 = vit_ref.forward(params, images, oc, mode="f32")
     ref64 = vit_ref.forward(params, images, oc, mode="f64")
     r32, r64, r_o = rel(logits.cpu().numpy(), ref32), rel(logits.cpu().numpy(), ref64), rel(ref32, ref64)
