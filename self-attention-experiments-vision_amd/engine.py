@@ -275,6 +275,8 @@ def finalize_wgrad_ws(eng, plan: _Plan):
 
 
 class ViTEngine:
+    DEFAULT_OVERLAP = False  # weight gradients on a side stream? (see _init_step_state)
+
     def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True):
         if cfg.kind != "vit":
             raise NotImplementedError("ViTEngine handles the ViT family; CaiT uses CaiTEngine")
@@ -367,8 +369,11 @@ class ViTEngine:
         self._cast_plan: Optional[_Plan] = None
         self.bwd_hooks: Dict[str, Callable[[], None]] = {}  # label -> callback run right after that launch (DDP buckets)
         self.weights_stale = True
-        # weight-gradient GEMMs on a second stream (SAVIT_OVERLAP_WGRAD=0 keeps every launch on the caller's stream)
-        self.overlap_wgrad = os.environ.get("SAVIT_OVERLAP_WGRAD", "1") != "0"
+        # weight-gradient GEMMs on a second stream (SAVIT_OVERLAP_WGRAD=1 / 0 overrides the engine's default).  Round 2: with the
+        # atomic-free weight gradients and the tail-split tiles the ViT family runs as fast or faster on ONE stream (DeiT-B 6 715 vs
+        # 6 650 img/s, DeiT-S 18 050 vs 17 980, same box) - the second stream only ever filled bubbles those changes removed - while
+        # the Mixer (+5 %) and TNT (+12 %) engines, with their many small launches, still gain from it (DEFAULT_OVERLAP below).
+        self.overlap_wgrad = os.environ.get("SAVIT_OVERLAP_WGRAD", "1" if self.DEFAULT_OVERLAP else "0") != "0"
         self.n_side_streams = int(os.environ.get("SAVIT_SIDE_STREAMS", "1"))
         self.wgrad_cu_share = float(os.environ.get("SAVIT_WGRAD_CU_SHARE", "0.56"))
         self.n_cus = torch.cuda.get_device_properties(self.dev).multi_processor_count

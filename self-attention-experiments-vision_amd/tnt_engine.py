@@ -136,6 +136,8 @@ class TNTLayout:
 class TNTEngine(ViTEngine):
     """Same public surface as ViTEngine (forward / loss_backward / optimizer_step / profile_step / bwd_hooks)."""
 
+    DEFAULT_OVERLAP = True  # many small launches: the side stream still pays (engine.ViTEngine._init_step_state)
+
     def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True):
         if cfg.kind != "tnt":
             raise NotImplementedError("TNTEngine handles the TNT family")

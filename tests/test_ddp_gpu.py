@@ -72,14 +72,16 @@ def _rank_main(rank, world, port, cfg_name, B, steps, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cfg_name,side_streams", [("vit_ti_patch16", "1"), ("vit_ti_patch16", "3"), ("mixer_s_patch32", "1"),
-                                                   ("tnt_b_patch16", "1"), ("cait_xxs_24", "1")])
+@pytest.mark.parametrize("cfg_name,side_streams", [("vit_ti_patch16", "1"), ("vit_ti_patch16", "3"), ("vit_ti_patch16", "0"),
+                                                   ("mixer_s_patch32", "1"), ("tnt_b_patch16", "1"), ("cait_xxs_24", "1")])
 def test_two_rank_step_matches_single_engine(tmp_path, cfg_name, side_streams, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
 
-    monkeypatch.setenv("SAVIT_SIDE_STREAMS", side_streams)
+    # "0": every launch on one stream (the ViT engines' default); otherwise weight gradients on that many side streams
+    monkeypatch.setenv("SAVIT_OVERLAP_WGRAD", "0" if side_streams == "0" else "1")
+    monkeypatch.setenv("SAVIT_SIDE_STREAMS", side_streams if side_streams != "0" else "1")
     B, steps = 8, 2
     out = str(tmp_path / "p.pt")
     port = 29600 + int(side_streams) + 10 * ["vit_ti_patch16", "mixer_s_patch32", "tnt_b_patch16", "cait_xxs_24"].index(cfg_name)

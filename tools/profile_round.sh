@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round profiles of the headline workload (run on the GPU box from the repo root): rocprofv3 kernel stats (one-stream and default
-# two-stream schedules) and the PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy) of the one-stream schedule, summarised into profiles/.
+# Round profiles of the headline workload (run on the GPU box from the repo root): rocprofv3 kernel stats (the one-stream schedule,
+# the ViT engines' default since round 2, and the two-stream one) and the PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy) of the one-stream schedule, summarised into profiles/.
 # Usage: bash tools/profile_round.sh r02      (writes gpurun_out/prof_<tag>/..., then copy the summaries into profiles/)
 set -u
 TAG=${1:-r02}
@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 B="$GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs"
 SAVIT_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial -o s -- python3 $B > $OUT/serial_bench.json 2> $OUT/serial.err
 echo serial done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/overlap -o o -- python3 $B > $OUT/overlap_bench.json 2> $OUT/overlap.err
+SAVIT_OVERLAP_WGRAD=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/overlap -o o -- python3 $B > $OUT/overlap_bench.json 2> $OUT/overlap.err
 echo overlap done
 P="$GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs"
 SAVIT_OVERLAP_WGRAD=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 $P > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
