@@ -186,6 +186,25 @@ int savit_th_attention_bwd(const void* qkv, const float* T1, const float* T2, co
                            void* workspace, long workspace_bytes, void* stream);
 long savit_th_attention_bwd_workspace_bytes(int B, int N, int H);
 
+/* ---- Fused talking-heads attention (csrc/th_fused.hip): the same function with S and P' kept in LDS.  Forward saves nothing for
+ * backward; backward recomputes S / P from QKV, materialises only dS and P' (bf16 [B,H,N,Np] scratch shared by all layers) and
+ * finishes with savit_th_attention_bwd_products (dV = P'^T dO, dQ = dS K * dq_scale, dK = dS^T Q).  Covered: H in {2,4,6,8},
+ * head_dim 48 / 64, N <= 208 (savit_th_fused_supported); other geometries use the entries above.  savit_th_fused_preferred says
+ * which path a caller that has both should take (measured: the materialising kernels are faster on MI355X; SAVIT_TH_FUSED=1
+ * selects the fused ones, which keep no per-layer S / P').
+ * Workspaces: forward = V^T scratch, backward = dT1/dT2 partial slab (sizes from the *_workspace_bytes functions). */
+int savit_th_fused_supported(int N, int H, int head_dim);
+int savit_th_fused_preferred(int N, int H, int head_dim);
+long savit_th_fused_fwd_workspace_bytes(int B, int N, int H, int head_dim);
+long savit_th_fused_bwd_workspace_bytes(int B, int N, int H, int head_dim);
+int savit_th_fused_attention_fwd(const void* qkv, const float* T1, const float* T2, void* o, int B, int N, int H, int head_dim, int ld_qkv,
+                                 void* workspace, long workspace_bytes, void* stream);
+int savit_th_fused_attention_bwd(const void* qkv, const float* T1, const float* T2, const void* d_o, void* p_buf, void* ds_buf, void* dqkv,
+                                 float* dT1, float* dT2, int B, int N, int H, int head_dim, int ld_qkv, int Np, float dq_scale,
+                                 void* workspace, long workspace_bytes, void* stream);
+int savit_th_attention_bwd_products(const void* qkv, const void* p_buf, const void* ds_buf, const void* d_o, void* dqkv, int B, int N, int H,
+                                    int head_dim, int ld_qkv, int Np, float dq_scale, void* stream);
+
 /* ---- token assembly (vit.py:81-85, position_embed.py:52-57): x0[b,0,:] = cls + pos[0,:] (patch rows are written by
  * SAVIT_EPI_PATCH); and the backward of both adds: dpos[t,:] += sum_b dx0[b,t,:], dcls += sum_b dx0[b,0,:]. */
 int savit_cls_pos_rows(const float* cls, const float* pos, float* x0, int B, long row_stride, int d, void* stream);

@@ -4,7 +4,8 @@ cls token -> LN -> head.  Same design as engine.ViTEngine: flat fp32 parameter /
 copies in both layouts, prebuilt launch plans, every tensor operation a C-ABI kernel.
 
 Pieces specific to CaiT
-  * talking-heads attention (attention.py:44-52): savit_th_attention_fwd/bwd; S and P' are bf16 [B,H,N,Np] HBM tensors;
+  * talking-heads attention (attention.py:44-52): savit_th_attention_fwd/bwd with S and P' as bf16 [B,H,N,Np] HBM tensors, or (opt-in,
+    SAVIT_TH_FUSED=1) savit_th_fused_attention_fwd/bwd with S and P' in LDS;
   * LayerScale + stochastic depth (cait.py:36-40,47-52): fused into the residual GEMM epilogue (colscale / rowscale), which also
     stores the bf16 branch so that savit_layerscale_bwd can form d(layerscale) and the branch cotangent;
   * class attention (cait.py:96-122): LayerNorm over [cls; x] is two row-mapped LN calls into one [B*(N+1), d] operand (no fp32
@@ -161,8 +162,16 @@ class CaiTEngine:
         self.h1, self.h2, self.o = ([e(M, d, dt=bf16) for _ in range(NL)] for _ in range(3))
         self.br1, self.br2 = ([e(M, d, dt=bf16) for _ in range(NL)] for _ in range(2))
         self.qkv = [e(M, 3 * d, dt=bf16) for _ in range(NL)]
-        self.sbuf = [e(B, H, N, self.Np, dt=bf16) for _ in range(NL)]
-        self.pbuf = [e(B, H, N, self.Np, dt=bf16) for _ in range(NL)]
+        # talking-heads attention: the materialising kernels (S and P' [B,H,N,Np] saved per layer for backward), or with
+        # SAVIT_TH_FUSED=1 the fused ones (S / P' in LDS, nothing kept per layer; slower on MI355X: see csrc/th_fused.hip)
+        self.th_fused = bool(self.L.savit_th_fused_preferred(N, H, cfg.head_dim))
+        if self.th_fused:
+            self.sbuf, self.pbuf = [], []
+            self.th_pbuf = e(B, H, N, self.Np, dt=bf16)  # backward scratch: P' (dsbuf below takes dS)
+            self.th_vt = torch.empty(max(int(self.L.savit_th_fused_fwd_workspace_bytes(B, N, H, cfg.head_dim)), 16), dtype=torch.uint8, device=self.dev)
+        else:
+            self.sbuf = [e(B, H, N, self.Np, dt=bf16) for _ in range(NL)]
+            self.pbuf = [e(B, H, N, self.Np, dt=bf16) for _ in range(NL)]
         self.u, self.a = ([e(M, F, dt=bf16) for _ in range(NL)] for _ in range(2))
         self.stats = [e(4, M) for _ in range(NL)]
         # ---- CA activations
@@ -195,7 +204,8 @@ class CaiTEngine:
         self.dqkvc = z(Mc, 3 * d, dt=bf16)
         self.d_hc = e(Mc, d, dt=bf16)
         self.dlogits, self.d_z = z(B, self.Cp, dt=bf16), e(B, d, dt=bf16)
-        ws = max(self.L.savit_layernorm_bwd_workspace_bytes(M, d), self.L.savit_th_attention_bwd_workspace_bytes(B, N, H), 16)
+        ws = max(self.L.savit_layernorm_bwd_workspace_bytes(M, d), self.L.savit_th_attention_bwd_workspace_bytes(B, N, H),
+                 self.L.savit_th_fused_bwd_workspace_bytes(B, N, H, cfg.head_dim), 16)
         self.ws = torch.empty(int(ws), dtype=torch.uint8, device=self.dev)
         self.labels = torch.zeros(B, dtype=torch.int32, device=self.dev)
         self.loss, self.loss_rows, self.top1, self.top5 = z(1), z(B), z(B), z(B)
@@ -314,8 +324,12 @@ class CaiTEngine:
                                           st[1].data_ptr(), M, d, d, 1e-6, self.rp), f"l{l}.ln1")
             self._gemm(P, f"l{l}.qkv", A=self.h1[l].data_ptr(), Bt=w("Wqkv_t"), C=self.qkv[l].data_ptr(), M=M, N=3 * d, K=d, lda=d, ldb=d,
                        ldc=3 * d, epilogue=_lib.EPI_BF16, alpha=alpha, alpha_cols=d)
-            P.add(L.savit_th_attention_fwd, (self.qkv[l].data_ptr(), pp(f"l{l}.T1"), pp(f"l{l}.T2"), self.sbuf[l].data_ptr(), self.pbuf[l].data_ptr(),
-                                             self.o[l].data_ptr(), B, N, H, hd, 3 * d, Np), f"l{l}.th_attn")
+            if self.th_fused:
+                P.add(L.savit_th_fused_attention_fwd, (self.qkv[l].data_ptr(), pp(f"l{l}.T1"), pp(f"l{l}.T2"), self.o[l].data_ptr(), B, N, H, hd, 3 * d,
+                                                       self.th_vt.data_ptr(), self.th_vt.numel()), f"l{l}.th_attn")
+            else:
+                P.add(L.savit_th_attention_fwd, (self.qkv[l].data_ptr(), pp(f"l{l}.T1"), pp(f"l{l}.T2"), self.sbuf[l].data_ptr(),
+                                                 self.pbuf[l].data_ptr(), self.o[l].data_ptr(), B, N, H, hd, 3 * d, Np), f"l{l}.th_attn")
             self._gemm(P, f"l{l}.proj", A=self.o[l].data_ptr(), Bt=w("Wo_t"), C=self.xmid[l].data_ptr(), C2=self.br1[l].data_ptr(),
                        aux=x[l].data_ptr(), colscale=pp(f"l{l}.ls1"), rowscale=sd0, rows_per_sample=N, M=M, N=d, K=d, lda=d, ldb=d, ldc=d,
                        ldaux=d, epilogue=_lib.EPI_RESID)
@@ -437,9 +451,14 @@ class CaiTEngine:
             self._wgrad(P, f"l{l}.Wo.wgrad", self.o[l].data_ptr(), ring[ri], gp(f"l{l}.Wo"), M, d, d, d, d, d, side=True)
             self._gemm(P, f"l{l}.proj.dgrad", A=ring[ri], Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=M, N=d, K=d, lda=d, ldb=d, ldc=d,
                        epilogue=_lib.EPI_BF16)
-            P.add(L.savit_th_attention_bwd, (self.qkv[l].data_ptr(), pp(f"l{l}.T1"), pp(f"l{l}.T2"), self.sbuf[l].data_ptr(), self.pbuf[l].data_ptr(),
-                                             self.d_o.data_ptr(), self.dsbuf.data_ptr(), dqkv, gp(f"l{l}.T1"), gp(f"l{l}.T2"), B, N, H,
-                                             hd, 3 * d, Np, dqs, ws, wsb), f"l{l}.th_attn.bwd", writes=(dqkv,))
+            if self.th_fused:
+                P.add(L.savit_th_fused_attention_bwd, (self.qkv[l].data_ptr(), pp(f"l{l}.T1"), pp(f"l{l}.T2"), self.d_o.data_ptr(),
+                                                       self.th_pbuf.data_ptr(), self.dsbuf.data_ptr(), dqkv, gp(f"l{l}.T1"), gp(f"l{l}.T2"), B, N, H,
+                                                       hd, 3 * d, Np, dqs, ws, wsb), f"l{l}.th_attn.bwd", writes=(dqkv,))
+            else:
+                P.add(L.savit_th_attention_bwd, (self.qkv[l].data_ptr(), pp(f"l{l}.T1"), pp(f"l{l}.T2"), self.sbuf[l].data_ptr(),
+                                                 self.pbuf[l].data_ptr(), self.d_o.data_ptr(), self.dsbuf.data_ptr(), dqkv, gp(f"l{l}.T1"),
+                                                 gp(f"l{l}.T2"), B, N, H, hd, 3 * d, Np, dqs, ws, wsb), f"l{l}.th_attn.bwd", writes=(dqkv,))
             self._wgrad(P, f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), dqkv, gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d, side=True)
             self._gemm(P, f"l{l}.qkv.dgrad", A=dqkv, Bt=w("Wqkv_n"), C=self.d_h.data_ptr(), M=M, N=d, K=3 * d, lda=3 * d, ldb=3 * d,
                        ldc=d, epilogue=_lib.EPI_BF16)

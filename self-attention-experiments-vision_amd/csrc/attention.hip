@@ -21,13 +21,13 @@
 //     cross-workgroup reduction, bitwise reproducible.
 #include "common.h"
 #include "savit.h"
+#include "th_rows.h"
 #include <stdlib.h>
 
 namespace {
 
 constexpr int HD = 64;              // head dim
 constexpr int ROWB = HD * 2;        // LDS row bytes
-constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ int rot3(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
 
@@ -904,7 +904,10 @@ __global__ __launch_bounds__(512) void th_pv_kernel(const ThParams p) {
 // pass A writes out_t[q][key] = sum_e X[q][e] * IMG_A[key][e]; pass B accumulates G[key][e] = sum_q in_c[q][key] * IMG_B[q][e].
 template <int MODE>  // 0: pv backward (A image = V, X = dO, out = dP';  B image = dO, in = P', G = dV)
                      // 1: scores backward (pass A: dQ^T[e][q] = sum_key K^T[e][key] dS^T[key][q]; pass B: G = dK, B image = Q, in = dS)
+                     // 2: pass B of mode 0 alone (dV from P' and dO): dP' comes from the fused row kernel (th_fused.hip)
 __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
+  constexpr bool PV = MODE != 1;      // the dO / P' / dV flavour
+  constexpr bool PASS_A = MODE != 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NT = p.nt, hd = p.hd;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = blockDim.x >> 6;
@@ -924,6 +927,7 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
   // once per staging plus once per key tile.
   const int qb = wave, q = qb * 32 + ql;
   // ---- pass A
+  if constexpr (PASS_A) {
   if (MODE == 0) stage_image_rt<0>(smem, srd, row_base, p.N, p.ld, 2 * p.d + hh * hd, wave, nwv, lane, NT, hd);  // V
   else           stage_image_rt<0>(smem, srd, row_base, p.N, p.ld, p.d + hh * hd, wave, nwv, lane, NT, hd);      // K
   bf16x8 df[4];                    // MODE 0: dO row fragments
@@ -982,13 +986,14 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
       }
     }
   }
+  }  // PASS_A
   // ---- pass B: G^T[e][key] = sum_q IMG^T[e][q] * in[q][key]
   // The contraction index q is the ROW index of in[q][key].  Gathering the column strips from HBM with two-byte loads (8 per
   // fragment) made this pass 125 of the kernel's 230 us; instead every 32 x 32 tile is read row-contiguous (two 16-B loads per
   // lane, all tiles of the strip requested up front), parked in a 4 KB image private to the wave (same 128-B rows and chunk
   // swizzle as the staged images: 32 keys fill half of each row) and read back transposed by ds_read_b64_tr_b16.  The LDS pipe
   // serves a wave's operations in order, so the next tile's stores cannot overtake this tile's reads: no barrier.
-  const bf16_t* inb = p.sbuf + bh;  // MODE 0: P' ; MODE 1: dS
+  const bf16_t* inb = p.sbuf + bh;  // MODE 0, 2: P' ; MODE 1: dS
   char* tile = smem + (size_t)NT * 32 * ROWB + (size_t)wave * (32 * ROWB);
   const int lr = lane >> 2, lc = lane & 3;
   const int kb = wave, key = kb * 32 + ql;
@@ -1003,8 +1008,8 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
       if (qt < NT && qq < p.N && kcol < p.Np) raw[qt][i] = *reinterpret_cast<const uint4*>(inb + (size_t)qq * p.Np + kcol);
     }
   __syncthreads();  // every wave is done with the pass-A image
-  if (MODE == 0) stage_image_rt<0>(smem, srdO, row_base, p.N, p.d, hh * hd, wave, nwv, lane, NT, hd);   // dO
-  else           stage_image_rt<0>(smem, srd, row_base, p.N, p.ld, hh * hd, wave, nwv, lane, NT, hd);    // Q
+  if (PV) stage_image_rt<0>(smem, srdO, row_base, p.N, p.d, hh * hd, wave, nwv, lane, NT, hd);   // dO
+  else    stage_image_rt<0>(smem, srd, row_base, p.N, p.ld, hh * hd, wave, nwv, lane, NT, hd);    // Q
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (kb < NT) {
@@ -1030,7 +1035,7 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
       }
     }
     if (key < p.N) {
-      bf16_t* grow = p.dqkv + (size_t)(row_base + key) * p.ld + (MODE == 0 ? 2 : 1) * p.d + hh * hd;
+      bf16_t* grow = p.dqkv + (size_t)(row_base + key) * p.ld + (PV ? 2 : 1) * p.d + hh * hd;
 #pragma unroll
       for (int eb = 0; eb < 2; ++eb)
 #pragma unroll
@@ -1044,45 +1049,11 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
   }
 }
 
-// ---- head mixing + softmax rows: one wave per (b, q) row, all H heads, keys strided over the lanes (<= 4 per lane)
-constexpr int TH_KPL = 4;  // keys per lane: Np <= 256
-template <int H>
-__device__ __forceinline__ void th_row_forward(const float (&s)[H][TH_KPL], const float* T1, int N, int lane, float (&pr)[H][TH_KPL]) {
-#pragma unroll
-  for (int i = 0; i < H; ++i) {
-    float sp[TH_KPL];
-    float m = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < TH_KPL; ++k) {
-      float a = 0.f;
-#pragma unroll
-      for (int h = 0; h < H; ++h) a += T1[h * H + i] * s[h][k];
-      sp[k] = (4 * lane + k < N) ? a : -INFINITY;
-      m = fmaxf(m, sp[k]);
-    }
-    m = wave_max(m);
-    float l = 0.f;
-#pragma unroll
-    for (int k = 0; k < TH_KPL; ++k) {
-      sp[k] = __builtin_amdgcn_exp2f((sp[k] - m) * LOG2E);
-      l += sp[k];
-    }
-    l = wave_sum(l);
-    const float inv = 1.0f / l;
-#pragma unroll
-    for (int k = 0; k < TH_KPL; ++k) pr[i][k] = sp[k] * inv;
-  }
-}
-
 template <int H>
 __global__ __launch_bounds__(256) void th_softmax_fwd_kernel(const bf16_t* __restrict__ S, bf16_t* __restrict__ Pp, const float* __restrict__ T1g,
                                                               const float* __restrict__ T2g, int B, int N, int Np) {
-  __shared__ float T1[H * H], T2[H * H];
-  for (int i = threadIdx.x; i < H * H; i += blockDim.x) {
-    T1[i] = T1g[i];
-    T2[i] = T2g[i];
-  }
-  __syncthreads();
+  const float* __restrict__ T1 = T1g;
+  const float* __restrict__ T2 = T2g;
   const int lane = threadIdx.x & 63;
   const long rows = (long)B * N;
   for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
@@ -1118,56 +1089,15 @@ __global__ __launch_bounds__(256) void th_softmax_fwd_kernel(const bf16_t* __res
 // Register plan (H = 8): S and dP' stay PACKED as bf16 pairs (16 + 16 VGPRs), P / dP are fp32 [H][4] (32 + 32), the 2 x H x H
 // per-lane dT partials persist across the rows a wave processes (128); every mixing loop runs key-outer so only 8 + 8 unpacked
 // temporaries are live.  The first version kept everything in fp32 and spilled 580 B/lane to scratch (1.55 ms per layer).
-__device__ __forceinline__ float th_unpack(uint32_t w, int odd) { return odd ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16); }
-
-// Reduce-scatter of 64 per-lane partials over the 64 lanes: after 6 halving exchanges lane l holds sum_lanes g[l].
-// 63 shuffles instead of 64 full wave reductions, and the H x H dT partials need not persist in registers across rows.
-// The two widest exchanges (lanes 32 and 16 apart: 48 of the 63) are gfx950's v_permlane32_swap / v_permlane16_swap: swapping
-// the upper half (odd rows) of g[j] with the lower half (even rows) of g[j + n2] leaves exactly "kept + received" in the two
-// registers, so one swap + one add replaces two selects, a ds_bpermute and an add (126 bpermutes per row kept the LDS pipe busy
-// for a third of this kernel).  The swaps are the builtins of common.h (hazards placed by hipcc).
-__device__ __forceinline__ float reduce_scatter64(float (&g)[64], int lane) {
-#pragma unroll
-  for (int j = 0; j < 32; j += 4) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) permlane32_swap(g[j + k], g[j + k + 32]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) g[j + k] += g[j + k + 32];
-  }
-#pragma unroll
-  for (int j = 0; j < 16; j += 4) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) permlane16_swap(g[j + k], g[j + k + 16]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) g[j + k] += g[j + k + 16];
-  }
-#pragma unroll
-  for (int st = 2; st < 6; ++st) {
-    const int mask = 32 >> st, n2 = 32 >> st;
-    const bool upper = (lane & mask) != 0;
-#pragma unroll
-    for (int j = 0; j < n2; ++j) {
-      const float lo = g[j], hi = g[j + n2];
-      const float send = upper ? lo : hi, keep = upper ? hi : lo;
-      g[j] = keep + __shfl_xor(send, mask, 64);
-    }
-  }
-  return g[0];
-}
-
 template <int H>
 __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __restrict__ S, const bf16_t* __restrict__ dPp, bf16_t* __restrict__ dS,
                                                               const float* __restrict__ T1g, const float* __restrict__ T2g,
                                                               float* __restrict__ slab, int B, int N, int Np) {
   static_assert(H <= 8 || H == 16, "dT partials are reduce-scattered as 8x8 tiles: up to 8 heads, or 16 as four tiles per matrix");
   constexpr int NB = (H + 7) / 8;  // 8x8 tiles per dimension of dT (H = 16: cait_m_*; that path spills registers - correct, not fast)
-  __shared__ float T1[H * H], T2[H * H];
   __shared__ float red[4][2 * NB * NB * 64];
-  for (int i = threadIdx.x; i < H * H; i += blockDim.x) {
-    T1[i] = T1g[i];
-    T2[i] = T2g[i];
-  }
-  __syncthreads();
+  const float* __restrict__ T1 = T1g;
+  const float* __restrict__ T2 = T2g;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc1[NB * NB], acc2[NB * NB];  // lane l accumulates dT1 / dT2 entry (h = 8*hb + (l>>3), i = 8*ib + (l&7)) of tile hb*NB + ib
 #pragma unroll
@@ -1358,20 +1288,6 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
   }
 }
 
-// one wave per output element: rows of the slab strided over the lanes, wave reduction, one add
-__global__ __launch_bounds__(256) void th_dT_finalize_kernel(const float* __restrict__ slab, int nblk, int hh2, float* __restrict__ dT1,
-                                                              float* __restrict__ dT2) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= 2 * hh2) return;
-  const int lane = threadIdx.x & 63;
-  float a = 0.f;
-  for (int r = lane; r < nblk; r += 64) a += slab[(size_t)r * 2 * hh2 + i];
-  a = wave_sum(a);
-  if (lane == 0) {
-    if (i < hh2) dT1[i] += a; else dT2[i - hh2] += a;
-  }
-}
-
 }  // namespace
 
 static bool attn_force_general() {
@@ -1544,3 +1460,25 @@ extern "C" int savit_th_attention_bwd(const void* qkv, const float* T1, const fl
   SAVIT_LAUNCH_RET();
 }
 
+// dV from P' (p_buf) and dO, dQ and dK from dS (ds_buf): the MFMA half of the talking-heads backward on tensors the fused row kernel
+// (th_fused.hip) materialised.
+extern "C" int savit_th_attention_bwd_products(const void* qkv, const void* p_buf, const void* ds_buf, const void* d_o, void* dqkv, int B, int N,
+                                               int H, int head_dim, int ld_qkv, int Np, float dq_scale, void* stream) {
+  ThParams p{};
+  int rc = th_fill(p, qkv, B, N, H, head_dim, ld_qkv, Np);
+  if (rc) return rc;
+  SAVIT_CHECK_ARG(p_buf && ds_buf && d_o && dqkv && ((uintptr_t)d_o % 16) == 0 && ((uintptr_t)dqkv % 16) == 0);
+  if (B == 0) return SAVIT_OK;
+  const int threads = 64 * (p.nt < 8 ? p.nt : 8);
+  const size_t lds = (size_t)p.nt * 32 * ROWB + (size_t)(threads / 64) * 32 * ROWB;
+  hipError_t e = hipFuncSetAttribute((const void*)th_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  e = hipFuncSetAttribute((const void*)th_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  p.o = (bf16_t*)const_cast<void*>(d_o); p.dqkv = (bf16_t*)dqkv; p.dq_scale = dq_scale;
+  p.sbuf = (bf16_t*)const_cast<void*>(p_buf);
+  hipLaunchKernelGGL(th_bwd_kernel<2>, dim3(B * H), dim3(threads), lds, (hipStream_t)stream, p);
+  p.sbuf = (bf16_t*)const_cast<void*>(ds_buf);
+  hipLaunchKernelGGL(th_bwd_kernel<1>, dim3(B * H), dim3(threads), lds, (hipStream_t)stream, p);
+  SAVIT_LAUNCH_RET();
+}

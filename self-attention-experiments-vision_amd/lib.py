@@ -63,6 +63,13 @@ _SIGNATURES = {
     "savit_th_attention_fwd": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
     "savit_th_attention_bwd": (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_float, c_void_p, c_long, c_void_p]),
     "savit_th_attention_bwd_workspace_bytes": (c_long, [c_int, c_int, c_int]),
+    "savit_th_fused_supported": (c_int, [c_int, c_int, c_int]),
+    "savit_th_fused_preferred": (c_int, [c_int, c_int, c_int]),
+    "savit_th_fused_fwd_workspace_bytes": (c_long, [c_int, c_int, c_int, c_int]),
+    "savit_th_fused_bwd_workspace_bytes": (c_long, [c_int, c_int, c_int, c_int]),
+    "savit_th_fused_attention_fwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_long, c_void_p]),
+    "savit_th_fused_attention_bwd": (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_float, c_void_p, c_long, c_void_p]),
+    "savit_th_attention_bwd_products": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float, c_void_p]),
     "savit_cls_pos_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p]),
     "savit_pos_cls_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "savit_transpose_bf16": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,

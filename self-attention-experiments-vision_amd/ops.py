@@ -474,6 +474,53 @@ def th_attention_bwd(qkv, T1, T2, s_buf, p_buf, d_o, dT1, dT2, B: int, N: int, H
     return dqkv
 
 
+def th_fused_supported(N: int, H: int, head_dim: int) -> bool:
+    """True when the fused talking-heads kernels (S / P' in LDS) cover this geometry."""
+    return bool(_lib.load().savit_th_fused_supported(N, H, head_dim))
+
+
+def th_fused_attention_fwd(qkv: torch.Tensor, T1: torch.Tensor, T2: torch.Tensor, B: int, N: int, H: int, head_dim: int = 48,
+                           workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused talking-heads attention forward (csrc/th_fused.hip): returns o bf16 [B*N, d]; nothing is kept for backward."""
+    _chk(qkv, bf16, "qkv", 2)
+    _chk(T1, f32, "T1", 2)
+    _chk(T2, f32, "T2", 2)
+    rows, cols, ld = _rows2d(qkv, "qkv")
+    d = H * head_dim
+    if rows < B * N or cols < 3 * d or tuple(T1.shape) != (H, H) or tuple(T2.shape) != (H, H) or not T1.is_contiguous() or not T2.is_contiguous():
+        raise ValueError("th_fused_attention_fwd: bad shapes")
+    L = _lib.load()
+    if not L.savit_th_fused_supported(N, H, head_dim):
+        raise ValueError(f"th_fused_attention_fwd: geometry N={N} H={H} head_dim={head_dim} is not covered (use th_attention_fwd)")
+    need = L.savit_th_fused_fwd_workspace_bytes(B, N, H, head_dim)
+    if workspace is None:
+        workspace = torch.empty((max(need, 16),), dtype=torch.uint8, device=qkv.device)
+    o = torch.empty((B * N, d), dtype=bf16, device=qkv.device)
+    _lib.check(L.savit_th_fused_attention_fwd(_p(qkv), _p(T1), _p(T2), _p(o), B, N, H, head_dim, ld, _p(workspace), workspace.numel(), _stream()),
+               "savit_th_fused_attention_fwd")
+    return o
+
+
+def th_fused_attention_bwd(qkv, T1, T2, d_o, dT1, dT2, B: int, N: int, H: int, dq_scale: float, head_dim: int = 48):
+    """Backward of th_fused_attention_fwd from QKV and dO alone.  dT1/dT2 accumulate.  Returns dqkv bf16 [B*N, ld]."""
+    for name, t, dt in (("qkv", qkv, bf16), ("d_o", d_o, bf16), ("T1", T1, f32), ("T2", T2, f32), ("dT1", dT1, f32), ("dT2", dT2, f32)):
+        _chk(t, dt, name)
+    rows, cols, ld = _rows2d(qkv, "qkv")
+    d = H * head_dim
+    if tuple(d_o.shape) != (B * N, d) or not d_o.is_contiguous() or dT1.numel() != H * H or dT2.numel() != H * H:
+        raise ValueError("th_fused_attention_bwd: bad shapes")
+    L = _lib.load()
+    Np = (N + 7) // 8 * 8
+    p_buf = torch.empty((B, H, N, Np), dtype=bf16, device=qkv.device)
+    ds_buf = torch.empty_like(p_buf)
+    dqkv = torch.empty((rows, cols), dtype=bf16, device=qkv.device)
+    need = L.savit_th_fused_bwd_workspace_bytes(B, N, H, head_dim)
+    ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=qkv.device)
+    _lib.check(L.savit_th_fused_attention_bwd(_p(qkv), _p(T1), _p(T2), _p(d_o), _p(p_buf), _p(ds_buf), _p(dqkv), _p(dT1), _p(dT2), B, N, H, head_dim,
+                                              ld, Np, float(dq_scale), _p(ws), ws.numel(), _stream()), "savit_th_fused_attention_bwd")
+    return dqkv
+
+
 # --------------------------------------------------------------------------------------------- input path (row f-2)
 IMAGENET_1K_MEAN, IMAGENET_1K_STD = (0.475, 0.452, 0.398), (0.232, 0.228, 0.229)      # data/constants.py:7-8
 IMAGENET_21K_MEAN, IMAGENET_21K_STD = (0.494, 0.473, 0.415), (0.228, 0.224, 0.230)    # data/constants.py:9-10

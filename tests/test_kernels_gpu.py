@@ -563,6 +563,63 @@ def test_talking_heads_attention(ops, B, N, H, hd):
     assert rel(host(dT2), t2.grad.numpy()) < 2e-2, rel(host(dT2), t2.grad.numpy())
 
 
+@pytest.mark.parametrize("B,N,H,hd", [(2, 196, 8, 48), (1, 196, 4, 48), (2, 50, 6, 48), (1, 33, 2, 64), (1, 197, 8, 48), (3, 208, 8, 64), (2, 17, 8, 48)])
+def test_fused_talking_heads_attention(ops, B, N, H, hd):
+    """csrc/th_fused.hip (S / P' in LDS) against the same fp64 autograd reference and tolerances as the materialising kernels, and
+    against those kernels themselves (same roundings: bf16 S, P', dP', dS)."""
+    assert ops.th_fused_supported(N, H, hd)
+    rng = np.random.default_rng(B + N + H)
+    d = H * hd
+    qkv = rb(rng.standard_normal((B * N, 3 * d)))
+    qkv[:, :d] = rb(qkv[:, :d] / np.sqrt(hd) * 2.0)
+    T1 = (np.linalg.qr(rng.standard_normal((H, H)))[0] + 0.1 * rng.standard_normal((H, H))).astype(np.float32)
+    T2 = (np.linalg.qr(rng.standard_normal((H, H)))[0] + 0.1 * rng.standard_normal((H, H))).astype(np.float32)
+    d_o = rb(rng.standard_normal((B * N, d)))
+    t = torch.tensor(qkv.astype(np.float64), requires_grad=True)
+    t1 = torch.tensor(T1.astype(np.float64), requires_grad=True)
+    t2 = torch.tensor(T2.astype(np.float64), requires_grad=True)
+    x = t.view(B, N, 3, H, hd)
+    q, k, v = x[:, :, 0].permute(0, 2, 1, 3), x[:, :, 1].permute(0, 2, 1, 3), x[:, :, 2].permute(0, 2, 1, 3)
+    s_raw = q @ k.transpose(-1, -2)
+    s_rnd = s_raw + (s_raw.detach().float().bfloat16().double() - s_raw.detach())
+    sc = torch.einsum("hi,bhqk->biqk", t1, s_rnd)
+    w = torch.einsum("hi,bhqk->biqk", t2, torch.softmax(sc, dim=-1))
+    o_t = (w @ v).permute(0, 2, 1, 3).reshape(B * N, d)
+    o_t.backward(torch.tensor(d_o.astype(np.float64)))
+    qkv_d, T1d, T2d = dev(qkv, bf16), dev(T1), dev(T2)
+    o = ops.th_fused_attention_fwd(qkv_d, T1d, T2d, B, N, H, head_dim=hd)
+    assert np.isfinite(host(o)).all()
+    assert rel(host(o), o_t.detach().numpy()) < 5e-3, rel(host(o), o_t.detach().numpy())
+    dT1 = torch.zeros((H, H), device="cuda")
+    dT2 = torch.zeros((H, H), device="cuda")
+    dqkv = ops.th_fused_attention_bwd(qkv_d, T1d, T2d, dev(d_o, bf16), dT1, dT2, B, N, H, dq_scale=1.0, head_dim=hd)
+    out, g = host(dqkv), t.grad.numpy()
+    assert np.isfinite(out).all()
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        assert rel(out[:, sl], g[:, sl]) < 2e-2, (name, rel(out[:, sl], g[:, sl]))
+    assert rel(host(dT1), t1.grad.numpy()) < 2e-2, rel(host(dT1), t1.grad.numpy())
+    assert rel(host(dT2), t2.grad.numpy()) < 2e-2, rel(host(dT2), t2.grad.numpy())
+    # the materialising path computes the same function with the same roundings (different MFMA shapes: not bitwise)
+    o_m, s_buf, p_buf = ops.th_attention_fwd(qkv_d, T1d, T2d, B, N, H, head_dim=hd)
+    assert rel(host(o), host(o_m)) < 2e-3, rel(host(o), host(o_m))
+    dT1m = torch.zeros((H, H), device="cuda")
+    dT2m = torch.zeros((H, H), device="cuda")
+    dqkv_m = ops.th_attention_bwd(qkv_d, T1d, T2d, s_buf, p_buf, dev(d_o, bf16), dT1m, dT2m, B, N, H, dq_scale=1.0, head_dim=hd)
+    assert rel(out, host(dqkv_m)) < 4e-3, rel(out, host(dqkv_m))
+    assert rel(host(dT1), host(dT1m)) < 2e-3 and rel(host(dT2), host(dT2m)) < 2e-3
+    # accumulation into dT1 / dT2 and run-to-run determinism
+    dqkv2 = ops.th_fused_attention_bwd(qkv_d, T1d, T2d, dev(d_o, bf16), dT1, dT2, B, N, H, dq_scale=1.0, head_dim=hd)
+    assert torch.equal(dqkv2, dqkv)
+    assert rel(host(dT1), 2 * t1.grad.numpy()) < 2e-2
+
+
+def test_fused_talking_heads_geometry_gate(ops):
+    assert not ops.th_fused_supported(196, 16, 48) and not ops.th_fused_supported(209, 8, 48) and not ops.th_fused_supported(196, 8, 32)
+    with pytest.raises(ValueError, match="not covered"):
+        ops.th_fused_attention_fwd(torch.zeros(2 * 196, 3 * 16 * 48, dtype=bf16, device="cuda"), torch.eye(16, device="cuda"),
+                                   torch.eye(16, device="cuda"), 2, 196, 16, head_dim=48)
+
+
 # ------------------------------------------------------------------------------------------ LayerScale backward (row a9)
 @pytest.mark.parametrize("rows,d,rps,with_bias", [(2 * 196, 384, 196, True), (5 * 197, 192, 197, False), (7, 768, 1, True), (64, 4096, 1, True)])
 def test_layerscale_bwd(ops, rows, d, rps, with_bias):

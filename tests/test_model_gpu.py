@@ -191,8 +191,19 @@ CAIT_CASES = {
 }
 
 
+@pytest.fixture(params=["materialising", "fused"])
+def th_path(request, monkeypatch):
+    """Both talking-heads paths of the CaiT engine: the default materialising kernels and the opt-in fused ones (SAVIT_TH_FUSED=1,
+    csrc/th_fused.hip; geometries they do not cover - 16 heads - keep the materialising kernels)."""
+    if request.param == "fused":
+        monkeypatch.setenv("SAVIT_TH_FUSED", "1")
+    else:
+        monkeypatch.delenv("SAVIT_TH_FUSED", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("case,B,training", [("tiny_cait", 32, False), ("tiny_cait", 32, True), ("xxs2", 2, True), ("m1", 2, True)])
-def test_cait_forward_backward_parity(pkg, case, B, training):
+def test_cait_forward_backward_parity(pkg, th_path, case, B, training):
     """Talking-heads SA + LayerScale + stochastic depth + class attention end to end vs the fp32 oracle / fp32 autograd.
     Training mode uses explicit per-sample keep masks (the JAX rng stream cannot be reproduced).  The tiny model runs 32 images: the
     gradient of its 2 x 2 talking-heads matrices is a strongly cancelling sum over (image, query, key) of bf16-rounded scores times
@@ -208,6 +219,7 @@ def test_cait_forward_backward_parity(pkg, case, B, training):
     labels = rng.integers(0, oc.num_classes, B)
     masks = (rng.random((oc.num_layers + oc.num_layers_token_only, 2, B)) < 0.7).astype(np.float32) if training else None
     eng = CaiTEngine(mc, B)
+    assert eng.th_fused == (th_path == "fused" and mc.num_heads <= 8)
     eng.load_params(params)
     logits = eng.forward(torch.as_tensor(images).cuda(), is_training=training,
                          keep_masks=None if masks is None else torch.as_tensor(masks)).float().cpu().numpy()
