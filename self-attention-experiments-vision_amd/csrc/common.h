@@ -108,6 +108,21 @@ __device__ __forceinline__ float wave_sum(float v) {
   permlane32_swap(a, b);
   return a + b;
 }
+// v_permlane32_swap on raw dwords, and the store-widening exchange built on it: a lane (row, half) of a swapped-layout MFMA tile
+// holds columns 8g + 4*half .. +3 of its row as one 8-byte piece per g.  Given the pieces of g0 (a) and g0 + 1 (b), the two lanes
+// of a row trade one piece each, after which lane half = 0 holds columns 8*g0 .. 8*g0+7 and lane half = 1 columns 8*(g0+1) .. :
+// one 16-byte store per lane at column 8*(g0 + half) instead of two 8-byte ones (store issue, not bandwidth, bounds these tails).
+__device__ __forceinline__ void permlane32_swap_u32(uint32_t& a, uint32_t& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = r0;
+  b = r1;
+}
+__device__ __forceinline__ uint4 merge_row_halves(uint2 a, uint2 b) {
+  permlane32_swap_u32(a.x, b.x);
+  permlane32_swap_u32(a.y, b.y);
+  return make_uint4(a.x, a.y, b.x, b.y);
+}
 __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_mov<0xB1>(v));
   v = fmaxf(v, dpp_mov<0x4E>(v));

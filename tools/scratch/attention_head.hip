@@ -58,23 +58,6 @@ __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int s) {
   return r.v;
 }
 
-// One row of a swapped-layout output tile pair (lane = (row, half); acc[eb] registers 4g .. 4g+3 = columns 32*eb + 8*g + 4*half ..)
-// scaled, rounded to bf16 and stored as 16-byte pieces: the two lanes of a row trade 8-byte pieces first (merge_row_halves,
-// common.h; 8-byte stores made the epilogues store-issue-bound: attention backward 146 -> 139 us at DeiT-B's layer).  Columns
-// >= hd are skipped (hd is a multiple of 16).  Both lanes of a row must be active.
-__device__ __forceinline__ void store_row_tile(bf16_t* row, const f32x16 (&acc)[2], int half, int hd, float sc) {
-#pragma unroll
-  for (int eb = 0; eb < 2; ++eb)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; g4 += 2) {
-      const int e0 = 32 * eb + 8 * g4;
-      if (e0 < hd)
-        *reinterpret_cast<uint4*>(row + e0 + 8 * half) = merge_row_halves(
-            make_uint2(pack_bf16x2(acc[eb][4 * g4] * sc, acc[eb][4 * g4 + 1] * sc), pack_bf16x2(acc[eb][4 * g4 + 2] * sc, acc[eb][4 * g4 + 3] * sc)),
-            make_uint2(pack_bf16x2(acc[eb][4 * g4 + 4] * sc, acc[eb][4 * g4 + 5] * sc), pack_bf16x2(acc[eb][4 * g4 + 6] * sc, acc[eb][4 * g4 + 7] * sc)));
-    }
-}
-
 // Stage `rows` (multiple of 8*NW... handled by caller loop) token rows of one [token][64] slice into an LDS image.
 // src column offset `col0` (elements) inside rows of length ld; token t maps to global row row_base + t; t >= N -> zeros.
 template <int NW, int NT>
@@ -89,12 +72,6 @@ __device__ __forceinline__ void stage_image(char* img, __amdgpu_buffer_rsrc_t sr
     if (t < N) voff = (uint32_t)(((size_t)(row_base + t) * ld + col0 + c * 8) * 2);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(img + inst * 1024), 16, voff, 0, 0, 0);
   }
-}
-
-__device__ __forceinline__ bf16x8 load_row_frag_global(const bf16_t* base, size_t row, int ld, int col, bool valid) {
-  bf16x8 z = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-  if (valid) z = *reinterpret_cast<const bf16x8*>(base + row * ld + col);
-  return z;
 }
 
 struct AttnParams {
@@ -223,7 +200,14 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_kernel(const AttnParams p) {
     if (q < p.N) {
       const float inv = 1.0f / l;
       bf16_t* orow = p.o + (size_t)(row_base + q) * p.d + hh * HD;
-      store_row_tile(orow, oacc, half, HD, inv);
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int e = 32 * eb + 8 * g4 + 4 * half;
+          *reinterpret_cast<uint2*>(orow + e) = make_uint2(pack_bf16x2(oacc[eb][4 * g4] * inv, oacc[eb][4 * g4 + 1] * inv),
+                                                           pack_bf16x2(oacc[eb][4 * g4 + 2] * inv, oacc[eb][4 * g4 + 3] * inv));
+        }
       if (half == 0 && p.lse != nullptr) p.lse[((size_t)b * p.H + hh) * p.N + q] = m + __logf(l);
     }
     cur ^= 1;
@@ -335,7 +319,15 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
     }
     if (q < p.N) {
       bf16_t* drow = p.dqkv + (size_t)(row_base + q) * p.ld + hh * HD;
-      store_row_tile(drow, dq, half, HD, p.dq_scale);
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int e = 32 * eb + 8 * g4 + 4 * half;
+          *reinterpret_cast<uint2*>(drow + e) =
+              make_uint2(pack_bf16x2(dq[eb][4 * g4] * p.dq_scale, dq[eb][4 * g4 + 1] * p.dq_scale),
+                         pack_bf16x2(dq[eb][4 * g4 + 2] * p.dq_scale, dq[eb][4 * g4 + 3] * p.dq_scale));
+        }
     }
   }
   __syncthreads();  // every wave's delta is in del_s
@@ -403,8 +395,16 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
     if (key < p.N) {
       bf16_t* krow = p.dqkv + (size_t)(row_base + key) * p.ld + p.d + hh * HD;
       bf16_t* vrow = krow + p.d;
-      store_row_tile(krow, dk, half, HD, 1.0f);
-      store_row_tile(vrow, dv, half, HD, 1.0f);
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int e = 32 * eb + 8 * g4 + 4 * half;
+          *reinterpret_cast<uint2*>(krow + e) = make_uint2(pack_bf16x2(dk[eb][4 * g4], dk[eb][4 * g4 + 1]),
+                                                           pack_bf16x2(dk[eb][4 * g4 + 2], dk[eb][4 * g4 + 3]));
+          *reinterpret_cast<uint2*>(vrow + e) = make_uint2(pack_bf16x2(dv[eb][4 * g4], dv[eb][4 * g4 + 1]),
+                                                           pack_bf16x2(dv[eb][4 * g4 + 2], dv[eb][4 * g4 + 3]));
+        }
     }
   }
 }
@@ -438,6 +438,11 @@ struct AttnParams2 {
   int hd;   // 48 or 64
 };
 
+__device__ __forceinline__ bf16x8 load_row_frag_global(const bf16_t* base, size_t row, int ld, int col, bool valid) {
+  bf16x8 z = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  if (valid) z = *reinterpret_cast<const bf16x8*>(base + row * ld + col);
+  return z;
+}
 
 __global__ __launch_bounds__(512) void attn_fwd2_kernel(const AttnParams2 pp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -538,7 +543,15 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const AttnParams2 pp) {
     if (q < p.N) {
       const float inv = 1.0f / l;
       bf16_t* orow = p.o + (size_t)(row_base + q) * p.d + hh * hd;
-      store_row_tile(orow, oacc, half, hd, inv);
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int e = 32 * eb + 8 * g4 + 4 * half;
+          if (e < hd)
+            *reinterpret_cast<uint2*>(orow + e) = make_uint2(pack_bf16x2(oacc[eb][4 * g4] * inv, oacc[eb][4 * g4 + 1] * inv),
+                                                             pack_bf16x2(oacc[eb][4 * g4 + 2] * inv, oacc[eb][4 * g4 + 3] * inv));
+        }
       if (half == 0 && p.lse != nullptr) p.lse[((size_t)b * p.H + hh) * p.N + q] = m + __logf(l);
     }
   }
@@ -634,7 +647,16 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
     }
     if (q < p.N) {
       bf16_t* drow = p.dqkv + (size_t)(row_base + q) * p.ld + hh * hd;
-      store_row_tile(drow, dq, half, hd, p.dq_scale);
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int e = 32 * eb + 8 * g4 + 4 * half;
+          if (e < hd)
+            *reinterpret_cast<uint2*>(drow + e) =
+                make_uint2(pack_bf16x2(dq[eb][4 * g4] * p.dq_scale, dq[eb][4 * g4 + 1] * p.dq_scale),
+                           pack_bf16x2(dq[eb][4 * g4 + 2] * p.dq_scale, dq[eb][4 * g4 + 3] * p.dq_scale));
+        }
     }
   }
   __syncthreads();  // pass A reads of K,V are done everywhere; delta is complete
@@ -701,8 +723,18 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
     if (key < p.N) {
       bf16_t* krow = p.dqkv + (size_t)(row_base + key) * p.ld + p.d + hh * hd;
       bf16_t* vrow = krow + p.d;
-      store_row_tile(krow, dk, half, hd, 1.0f);
-      store_row_tile(vrow, dv, half, hd, 1.0f);
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int e = 32 * eb + 8 * g4 + 4 * half;
+          if (e < hd) {
+            *reinterpret_cast<uint2*>(krow + e) = make_uint2(pack_bf16x2(dk[eb][4 * g4], dk[eb][4 * g4 + 1]),
+                                                             pack_bf16x2(dk[eb][4 * g4 + 2], dk[eb][4 * g4 + 3]));
+            *reinterpret_cast<uint2*>(vrow + e) = make_uint2(pack_bf16x2(dv[eb][4 * g4], dv[eb][4 * g4 + 1]),
+                                                             pack_bf16x2(dv[eb][4 * g4 + 2], dv[eb][4 * g4 + 3]));
+          }
+        }
     }
   }
 }
@@ -855,7 +887,15 @@ __global__ __launch_bounds__(512) void th_pv_kernel(const ThParams p) {
     }
     if (q < p.N) {
       bf16_t* orow = p.o + (size_t)(row_base + q) * p.d + hh * hd;
-      store_row_tile(orow, oacc, half, hd, 1.0f);
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int e = 32 * eb + 8 * g4 + 4 * half;
+          if (e < hd)
+            *reinterpret_cast<uint2*>(orow + e) = make_uint2(pack_bf16x2(oacc[eb][4 * g4], oacc[eb][4 * g4 + 1]),
+                                                             pack_bf16x2(oacc[eb][4 * g4 + 2], oacc[eb][4 * g4 + 3]));
+        }
     }
   }
 }
@@ -934,7 +974,15 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
       }
       if (q < p.N) {
         bf16_t* drow = p.dqkv + (size_t)(row_base + q) * p.ld + hh * hd;
-      store_row_tile(drow, dq, half, hd, p.dq_scale);
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int e = 32 * eb + 8 * g4 + 4 * half;
+            if (e < hd)
+              *reinterpret_cast<uint2*>(drow + e) = make_uint2(pack_bf16x2(dq[eb][4 * g4] * p.dq_scale, dq[eb][4 * g4 + 1] * p.dq_scale),
+                                                               pack_bf16x2(dq[eb][4 * g4 + 2] * p.dq_scale, dq[eb][4 * g4 + 3] * p.dq_scale));
+          }
       }
     }
   }
@@ -988,7 +1036,15 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
     }
     if (key < p.N) {
       bf16_t* grow = p.dqkv + (size_t)(row_base + key) * p.ld + (PV ? 2 : 1) * p.d + hh * hd;
-      store_row_tile(grow, acc, half, hd, 1.0f);
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int e = 32 * eb + 8 * g4 + 4 * half;
+          if (e < hd)
+            *reinterpret_cast<uint2*>(grow + e) = make_uint2(pack_bf16x2(acc[eb][4 * g4], acc[eb][4 * g4 + 1]),
+                                                             pack_bf16x2(acc[eb][4 * g4 + 2], acc[eb][4 * g4 + 3]));
+        }
     }
   }
 }
@@ -1320,11 +1376,6 @@ extern "C" int savit_attention_bwd(const void* qkv, const void* o, const void* d
     hipLaunchKernelGGL(attn_bwd2_kernel, dim3(B * H), dim3(64 * (nt < 8 ? nt : 8)), lds, (hipStream_t)stream, pp);
     SAVIT_LAUNCH_RET();
   }
-  // One (batch, head) item per workgroup.  A persistent variant that double-buffers the K,V / Q,dO image pairs across items (LDS-DMA
-  // of the next item under the current pass, counted vmcnt waits, buffer stores) was built and measured in round 2 and dropped: with
-  // the passes compiled out the data movement of this kernel is 45 us of loads + 47 us of stores, the two passes with the loads hidden
-  // take 123 us, and everything together ran 148 us against 139 us here - the passes, not the data movement, bound this backward
-  // (seven waves on four SIMDs run their LDS -> MFMA -> exp -> MFMA chains nearly serially).
   ATTN_DISPATCH(attn_bwd_kernel, (size_t)4 * NT * 32 * ROWB + (size_t)2 * NT * 32 * sizeof(float), B * H)
   SAVIT_LAUNCH_RET();
 }

@@ -6,7 +6,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import savit_amd  # noqa: E402,F401
 from savit_amd import lib  # noqa: E402
 
