@@ -18,6 +18,9 @@ shapes only.  What *is* pinned (tests/test_oracle.py):
   * agreement (<=1e-6 rel, fp32) with an independent PyTorch-CPU composition
     (oracle/torch_ref.py) that shares no code with this file;
   * frozen golden outputs under tests/golden/ (made by tests/golden/make_golden.py).
+  * the ViT path against HuggingFace transformers' ViTForImageClassification, an implementation of the same
+    published architecture that shares nothing with this file (tests/test_oracle_hf_pin.py: fp64 logits
+    <1e-10, gradients <1e-8).  Not the reference: the status above stands.
 
 Third-party semantics restated here (not vendored in /root/reference): flax.linen
 (unpinned git, ~0.3.4; requirements.txt:16), jax ~=0.2.13 (requirements.txt:7), optax
