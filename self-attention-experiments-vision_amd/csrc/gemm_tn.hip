@@ -1216,6 +1216,9 @@ extern "C" int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue) {
   //    the other reads fragments and issues LDS-DMA): wide outputs on large grids with K >= 768 - measured against the next best
   //    tile with cold operands (tools/gemm_epi_bench.py): fc1+GELU 172 -> 155 us, fc2 input-gradient+GELU' 179 -> 171 us, qkv 117 -> 111 us,
   //    ViT-L shapes 4-6 % over the pair kernel.  Narrow outputs (N = 768) keep 192x128: 297 tiles of 256x256 are 1.16 rounds.
+  //    K = 384 (DeiT-S, CaiT-S at 256 images) stays with the pair kernels: with cold operands the ping-pong tile is 7-11 % faster on
+  //    those shapes too (SAVIT_EPI_SHAPE=50432,384,1536 tools/gemm_epi_bench.py), inside the training step - warm operands, same box,
+  //    alternating runs - DeiT-S lost 1.4 % (17.63 -> 17.38 k img/s) and CaiT-S24, TNT, Mixer did not move.
   if (big && N >= 1024 && K >= 768 && epilogue != SAVIT_EPI_PATCH) return 20;
   if (big && (epilogue == SAVIT_EPI_BIAS_GELU || K >= 1024)) return 13;
   if (N % 128 == 0 && M >= 1536 && epilogue != SAVIT_EPI_PATCH) {

@@ -1,11 +1,12 @@
-"""Fused-epilogue GEMM timings on the DeiT-B shapes per tile variant (dev tool).  Usage: gemm_epi_bench.py tile [tile ...]"""
+"""Fused-epilogue GEMM timings on the DeiT-B shapes per tile variant (dev tool).  Usage: gemm_epi_bench.py tile [tile ...]
+(SAVIT_EPI_SHAPE="M,d,F" selects another model: e.g. 50432,384,1536 = DeiT-S at 256 images; tile 0 = the library's own choice)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import savit_amd
 from savit_amd import ops
 bf16 = torch.bfloat16
-M, d, F = 25216, 768, 3072
+M, d, F = (int(v) for v in os.environ.get("SAVIT_EPI_SHAPE", "25216,768,3072").split(","))
 def mk(epi, N, K):
     A = torch.randn(M, K, device="cuda").to(bf16); Bt = (torch.randn(N, K, device="cuda") / K ** 0.5).to(bf16)
     bias = torch.randn(N, device="cuda")
