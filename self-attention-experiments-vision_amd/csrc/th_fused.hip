@@ -494,8 +494,7 @@ extern "C" int savit_th_fused_attention_bwd(const void* qkv, const float* T1, co
   if (B == 0) return SAVIT_OK;
   p.d_o = (const bf16_t*)d_o; p.pbuf = (bf16_t*)p_buf; p.dsbuf = (bf16_t*)ds_buf; p.slab = (float*)workspace; p.Np = Np;
   p.qtiles = (N + 15) / 16;
-  size_t lds = (size_t)2 * H * 16 * THF_PIT * 2;
-  { const char* e = getenv("SAVIT_THF_LDS_MIN"); if (e && (size_t)atol(e) > lds) lds = (size_t)atol(e); }
+  const size_t lds = (size_t)2 * H * 16 * THF_PIT * 2;
   { const char* e = getenv("SAVIT_THF_DEBUG"); p.debug = e ? atoi(e) : 0; }
   const int nblk = B * p.qtiles;
   THF_DISPATCH(th_fused_bwd_rows_kernel, nblk, lds)
