@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os as _os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -125,7 +126,8 @@ def stochastic_depth_seed(seed: int, rank: int, step: int) -> int:
 
 
 class CaiTEngine:
-    def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True):
+    def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True,
+                 th_fused: "bool | None" = None):
         if cfg.kind != "cait":
             raise ValueError("CaiTEngine needs a CaiT config")
         if cfg.head_dim not in (48, 64) or cfg.num_heads not in (2, 4, 6, 8, 16):
@@ -163,8 +165,12 @@ class CaiTEngine:
         self.br1, self.br2 = ([e(M, d, dt=bf16) for _ in range(NL)] for _ in range(2))
         self.qkv = [e(M, 3 * d, dt=bf16) for _ in range(NL)]
         # talking-heads attention: the materialising kernels (S and P' [B,H,N,Np] saved per layer for backward), or with
-        # SAVIT_TH_FUSED=1 the fused ones (S / P' in LDS, nothing kept per layer; slower on MI355X: see csrc/th_fused.hip)
-        self.th_fused = bool(self.L.savit_th_fused_preferred(N, H, cfg.head_dim))
+        # th_fused=True (or SAVIT_TH_FUSED=1, read HERE - the library reads no environment) the fused ones (S / P' in LDS, nothing kept
+        # per layer; slower on MI355X: see csrc/th_fused.hip).  Default: what the library prefers for this geometry.
+        if th_fused is None:
+            env = _os.environ.get("SAVIT_TH_FUSED")
+            th_fused = (env != "0") if env is not None else bool(self.L.savit_th_fused_preferred(N, H, cfg.head_dim))
+        self.th_fused = bool(th_fused) and bool(self.L.savit_th_fused_supported(N, H, cfg.head_dim))
         if self.th_fused:
             self.sbuf, self.pbuf = [], []
             self.th_pbuf = e(B, H, N, self.Np, dt=bf16)  # backward scratch: P' (dsbuf below takes dS)
@@ -214,7 +220,6 @@ class CaiTEngine:
         self._fwd_plan = self._bwd_plan = self._cast_plan = None
         self.bwd_hooks: Dict[str, object] = {}
         self.weights_stale = True
-        import os as _os
         self.overlap_wgrad = _os.environ.get("SAVIT_OVERLAP_WGRAD", "1") != "0"
         self.n_side_streams = int(_os.environ.get("SAVIT_SIDE_STREAMS", "1"))
         self.wgrad_cu_share = float(_os.environ.get("SAVIT_WGRAD_CU_SHARE", "0.56"))

@@ -22,7 +22,6 @@
 #include "common.h"
 #include "savit.h"
 #include "th_rows.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -1234,8 +1233,9 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
 
 }  // namespace
 
+// development switch (SAVIT_EXPERIMENTS builds only): run the general online-softmax kernels where the resident ones would be chosen
 static bool attn_force_general() {
-  static const bool f = [] { const char* e = getenv("SAVIT_ATTN_GENERAL"); return e && atoi(e) != 0; }();
+  static const bool f = SAVIT_EXP_ENV_INT("SAVIT_ATTN_GENERAL", 0) != 0;
   return f;
 }
 
@@ -1271,10 +1271,7 @@ static int persistent_grid(int items, size_t lds_bytes, int threads) {
     constexpr int NT = NTV;                                                                                    \
     const size_t lds = (LDS_EXPR);                                                                             \
     auto kfn = KERNEL<NTV>;                                                                                    \
-    if (lds > 48 * 1024) {                                                                                     \
-      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      if (e != hipSuccess) return (int)e;                                                                      \
-    }                                                                                                          \
+    SAVIT_LDS_ONCE(kfn);                                                                                \
     hipLaunchKernelGGL(kfn, dim3(GRID), dim3(64 * NTV), lds, (hipStream_t)stream, p);                          \
   } break;
 
@@ -1291,8 +1288,7 @@ extern "C" int savit_attention_fwd(const void* qkv, void* o, float* lse, int B, 
   if (head_dim != HD || nt > 8 || attn_force_general()) {
     AttnParams2 pp{p, nt, head_dim};
     const size_t lds = (size_t)2 * nt * 32 * ROWB;
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    SAVIT_LDS_ONCE(attn_fwd2_kernel);
     hipLaunchKernelGGL(attn_fwd2_kernel, dim3(B * H), dim3(64 * (nt < 8 ? nt : 8)), lds, (hipStream_t)stream, pp);
     SAVIT_LAUNCH_RET();
   }
@@ -1315,8 +1311,7 @@ extern "C" int savit_attention_bwd(const void* qkv, const void* o, const void* d
   if (head_dim != HD || nt > 8 || attn_force_general()) {
     AttnParams2 pp{p, nt, head_dim};
     const size_t lds = (size_t)2 * nt * 32 * ROWB + (size_t)2 * nt * 32 * sizeof(float);
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    SAVIT_LDS_ONCE(attn_bwd2_kernel);
     hipLaunchKernelGGL(attn_bwd2_kernel, dim3(B * H), dim3(64 * (nt < 8 ? nt : 8)), lds, (hipStream_t)stream, pp);
     SAVIT_LAUNCH_RET();
   }
@@ -1364,10 +1359,8 @@ extern "C" int savit_th_attention_fwd(const void* qkv, const float* T1, const fl
   const size_t lds = (size_t)p.nt * 32 * ROWB;
   const int threads = 64 * (p.nt < 8 ? p.nt : 8);
   const size_t lds_scores = lds + (size_t)(threads / 64) * 32 * ROWB;  // + one 32-row tile per wave for the coalesced S stores
-  hipError_t e = hipFuncSetAttribute((const void*)th_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scores);
-  if (e != hipSuccess) return (int)e;
-  e = hipFuncSetAttribute((const void*)th_pv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
+  SAVIT_LDS_ONCE(th_scores_kernel);
+  SAVIT_LDS_ONCE(th_pv_kernel);
   hipLaunchKernelGGL(th_scores_kernel, dim3(B * H), dim3(threads), lds_scores, (hipStream_t)stream, p);
   long rows = (long)B * N, blocks = (rows + 3) / 4;
   if (blocks > 16384) blocks = 16384;
@@ -1387,10 +1380,8 @@ extern "C" int savit_th_attention_bwd(const void* qkv, const float* T1, const fl
   if (B == 0) return SAVIT_OK;
   const int threads = 64 * (p.nt < 8 ? p.nt : 8);
   const size_t lds = (size_t)p.nt * 32 * ROWB + (size_t)(threads / 64) * 32 * ROWB;  // staged image + one 32-row tile per wave
-  hipError_t e = hipFuncSetAttribute((const void*)th_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
-  e = hipFuncSetAttribute((const void*)th_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
+  SAVIT_LDS_ONCE(th_bwd_kernel<0>);
+  SAVIT_LDS_ONCE(th_bwd_kernel<1>);
   // 1) dP' (into ds_buf) and dV from P' (p_buf) and dO
   p.o = (bf16_t*)const_cast<void*>(d_o); p.dqkv = (bf16_t*)dqkv; p.dq_scale = dq_scale;
   p.sbuf = (bf16_t*)p_buf;   // pass B input: P'
@@ -1420,10 +1411,8 @@ extern "C" int savit_th_attention_bwd_products(const void* qkv, const void* p_bu
   if (B == 0) return SAVIT_OK;
   const int threads = 64 * (p.nt < 8 ? p.nt : 8);
   const size_t lds = (size_t)p.nt * 32 * ROWB + (size_t)(threads / 64) * 32 * ROWB;
-  hipError_t e = hipFuncSetAttribute((const void*)th_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
-  e = hipFuncSetAttribute((const void*)th_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
+  SAVIT_LDS_ONCE(th_bwd_kernel<2>);
+  SAVIT_LDS_ONCE(th_bwd_kernel<1>);
   p.o = (bf16_t*)const_cast<void*>(d_o); p.dqkv = (bf16_t*)dqkv; p.dq_scale = dq_scale;
   p.sbuf = (bf16_t*)const_cast<void*>(p_buf);
   hipLaunchKernelGGL(th_bwd_kernel<2>, dim3(B * H), dim3(threads), lds, (hipStream_t)stream, p);

@@ -41,6 +41,26 @@ __device__ __forceinline__ void nt_store_u4(void* p, uint4 v) {
 
 #define SAVIT_LAUNCH_RET() return (int)hipGetLastError()
 
+// Kernels that use more than the default 64 KB of dynamic LDS need their limit raised.  That is done ONCE per kernel symbol (a
+// function-local static: initialised thread-safely, C++11) to the CU's whole 160 KB - a limit, not an allocation: each launch still
+// passes the bytes it uses - instead of a driver call in front of every launch.
+#define SAVIT_LDS_ONCE(kfn)                                                                                                    \
+  do {                                                                                                                         \
+    static const hipError_t lds_once_ =                                                                                        \
+        hipFuncSetAttribute((const void*)(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
+    if (lds_once_ != hipSuccess) return (int)lds_once_;                                                                        \
+  } while (0)
+
+// Development switches (ablation tiles that compute wrong results on purpose, SAVIT_* environment overrides of the tile / split
+// heuristics, phases compiled out for timing) exist only in builds that define SAVIT_EXPERIMENTS - tools/build_variant.sh does, the
+// Makefile of the product library does not: libsavit.so reads no environment variable and has no run-time ablation path.
+#ifdef SAVIT_EXPERIMENTS
+#include <stdlib.h>
+#define SAVIT_EXP_ENV_INT(name, dflt) ([] { const char* e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }())
+#else
+#define SAVIT_EXP_ENV_INT(name, dflt) (dflt)
+#endif
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 // round-to-nearest-even; a plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)

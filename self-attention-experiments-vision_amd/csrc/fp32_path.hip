@@ -212,8 +212,7 @@ extern "C" int savit_attention_fwd_f32(const float* qkv, float* o, int B, int N,
   if (B == 0) return SAVIT_OK;
   const size_t lds = ((size_t)N * (head_dim + 1) + (size_t)N * head_dim + 4 * AF_KPL * 64) * sizeof(float);
   SAVIT_CHECK_ARG(lds <= 160 * 1024);
-  hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
+  SAVIT_LDS_ONCE(attn_fwd_f32_kernel);
   hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, qkv, o, B, N, H, head_dim, ld_qkv);
   SAVIT_LAUNCH_RET();
 }

@@ -16,7 +16,6 @@
 //     share A row-panels.
 #include "common.h"
 #include "savit.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -832,7 +831,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_tn_pair_tail_kernel(co
 //   barrier after the last reader's lgkmcnt(0).  RAW: K-tile t+1 is complete in LDS once every wave has passed the vmcnt(4) of
 //   L(t,p3) (all but the four DMAs of K-tile t+2 have landed) and the barrier behind it; its first read is in L(t+1,p0), which
 //   for both groups lies behind a barrier that every wave reaches after that wait.
-template <int EPI, int ABL = 0>  // ABL: timing-only ablation builds (tools/gemm_pp_check.py): 1 no main-loop DMA, 2 no LDS reads, 4 no barriers, 8 no MFMA
+template <int EPI, int ABL = 0>  // ABL != 0: timing-only ablations, instantiated in SAVIT_EXPERIMENTS builds only: 1 no main-loop DMA, 2 no LDS reads, 4 no barriers, 8 no MFMA
 __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, RB = 128;
   constexpr int UNIT = 64 * RB, BUF = (BM + BN) * RB;
@@ -902,12 +901,14 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(const GemmParams p) {
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 af[4][2], bf[4][2];
 
+#ifdef SAVIT_EXPERIMENTS
   if (p.desync_sleep > 0 && blockIdx.x < 256u) {  // the first round only: later workgroups inherit the phase of the CU they land on
     // spread the workgroups of a round over phase groups: with every CU in its epilogue at the same moment the output stores of
     // a round queue behind one another at the memory side while the matrix pipes idle (and the reverse during the main loops)
     const int n = (int)(blockIdx.x % (unsigned)p.desync_phases) * p.desync_sleep;
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);  // ~1 us per unit
   }
+#endif
   // prologue: all of K-tile 0 and the four units of K-tile 1 that L(-1,p2), L(-1,p3) would have issued
 #pragma unroll
   for (int u = 0; u < 8; ++u) dma(0, u);
@@ -1000,9 +1001,9 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(const GemmParams p) {
 // row panels per group of the ping-pong kernel's tile order: as many 256-row A-panels (256 x K x 2 B) as fit in about 3 MB of the
 // XCD's 4 MB L2, at most 8 (K = 768: 8, K = 1024: 6, K >= 3072: 1 = plain row-major order).  Measured on DeiT-B with cold operands
 // (tools/gemm_epi_bench.py, G = 1 -> 8): qkv 104 -> 97 us, fc1+GELU 156 -> 145 us; the GELU' epilogue, which also READS a [M, N]
-// tensor, is best at 4 (177 -> 172 us; 186 us at 8: fewer concurrent tiles per row of that tensor).  SAVIT_PP_ROW_GROUP overrides.
+// tensor, is best at 4 (177 -> 172 us; 186 us at 8: fewer concurrent tiles per row of that tensor).
 inline int pp_row_group(int K, int tiles_m, int epilogue) {
-  static const int force = [] { const char* e = getenv("SAVIT_PP_ROW_GROUP"); return e ? atoi(e) : 0; }();
+  static const int force = SAVIT_EXP_ENV_INT("SAVIT_PP_ROW_GROUP", 0);  // SAVIT_EXPERIMENTS builds only
   int g = force > 0 ? force : (int)((3l << 20) / ((long)256 * K * 2));
   if (g < 1) g = 1;
   if (g > 8) g = 8;
@@ -1011,6 +1012,7 @@ inline int pp_row_group(int K, int tiles_m, int epilogue) {
   return g;
 }
 
+#ifdef SAVIT_EXPERIMENTS
 template <int ABL>
 int launch_pp_ablation(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
@@ -1018,31 +1020,30 @@ int launch_pp_ablation(const GemmParams& p0, hipStream_t s) {
   p.tiles_n = (p.a.N + 255) / 256;
   p.row_group = pp_row_group(p.a.K, p.tiles_m, p.a.epilogue);
   auto kfn = gemm_tn_pp_kernel<SAVIT_EPI_BF16, ABL>;
-  hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128);
-  if (e != hipSuccess) return (int)e;
+  SAVIT_LDS_ONCE(kfn);
   hipLaunchKernelGGL(kfn, dim3(p.tiles_m * p.tiles_n), dim3(512), 2 * 512 * 128, s, p);
   SAVIT_LAUNCH_RET();
 }
+#endif
 
 int launch_pp(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
   p.tiles_m = (p.a.M + 255) / 256;
   p.tiles_n = (p.a.N + 255) / 256;
-  {
-    const char* e1 = getenv("SAVIT_PP_PHASES");
-    const char* e2 = getenv("SAVIT_PP_SLEEP");
-    p.desync_phases = e1 ? atoi(e1) : 1;
-    p.desync_sleep = e2 ? atoi(e2) : 0;
-    if (p.desync_phases < 1) p.desync_phases = 1;
+#ifdef SAVIT_EXPERIMENTS
+  {  // staggered-start experiment (measured neutral to -10 %: DESIGN.md 6.2); read once
+    static const int ph = SAVIT_EXP_ENV_INT("SAVIT_PP_PHASES", 1), sl = SAVIT_EXP_ENV_INT("SAVIT_PP_SLEEP", 0);
+    p.desync_phases = ph < 1 ? 1 : ph;
+    p.desync_sleep = sl;
   }
+#endif
   p.row_group = pp_row_group(p.a.K, p.tiles_m, p.a.epilogue);
   const dim3 grid(p.tiles_m * p.tiles_n);
   const size_t lds = 2 * 512 * 128;
 #define SAVIT_LAUNCH_EPI(E)                                                                            \
   case E: {                                                                                            \
     auto kfn = gemm_tn_pp_kernel<E>;                                                                   \
-    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    if (e != hipSuccess) return (int)e;                                                                \
+    SAVIT_LDS_ONCE(kfn);                                                                                \
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, p);                                               \
   } break;
   switch (p.a.epilogue) {
@@ -1067,10 +1068,7 @@ int launch_pair(const GemmParams& p0, hipStream_t s) {
 #define SAVIT_LAUNCH_EPI(E)                                                                            \
   case E: {                                                                                            \
     auto kfn = gemm_tn_pair_kernel<BM, BN, WGM, WGN, ND, E>;                                           \
-    if (lds > 48 * 1024) {                                                                             \
-      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      if (e != hipSuccess) return (int)e;                                                              \
-    }                                                                                                  \
+    SAVIT_LDS_ONCE(kfn);                                                                                \
     hipLaunchKernelGGL(kfn, grid, dim3(64 * WGM * WGN), lds, s, p);                                   \
   } break;
   switch (p.a.epilogue) {
@@ -1120,10 +1118,7 @@ int launch_pair_tail(const GemmParams& p0, hipStream_t s) {
 #define SAVIT_LAUNCH_EPI(E)                                                                            \
   case E: {                                                                                            \
     auto kfn = gemm_tn_pair_tail_kernel<BM, BM2, BN, WGM, WGN, ND, E>;                                 \
-    if (lds > 48 * 1024) {                                                                             \
-      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      if (e != hipSuccess) return (int)e;                                                              \
-    }                                                                                                  \
+    SAVIT_LDS_ONCE(kfn);                                                                                \
     hipLaunchKernelGGL(kfn, grid, dim3(64 * WGM * WGN), lds, s, p);                                   \
   } break;
   switch (p.a.epilogue) {
@@ -1147,10 +1142,7 @@ int launch_ring(const GemmParams& p0, hipStream_t s) {
 #define SAVIT_LAUNCH_EPI(E)                                                                            \
   case E: {                                                                                            \
     auto kfn = gemm_tn_ring_kernel<BM, BN, WGM, WGN, S, E, LATE>;                                            \
-    if (lds > 48 * 1024) {                                                                             \
-      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      if (e != hipSuccess) return (int)e;                                                              \
-    }                                                                                                  \
+    SAVIT_LDS_ONCE(kfn);                                                                                \
     hipLaunchKernelGGL(kfn, grid, block, lds, s, p);                                                   \
   } break;
   switch (p.a.epilogue) {
@@ -1176,10 +1168,7 @@ int launch_tile(const GemmParams& p0, hipStream_t s) {
 #define SAVIT_LAUNCH_EPI(E)                                                                            \
   case E: {                                                                                            \
     auto kfn = gemm_tn_kernel<BM, BN, WGM, WGN, E>;                                                    \
-    if (lds > 48 * 1024) {                                                                             \
-      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      if (e != hipSuccess) return (int)e;                                                              \
-    }                                                                                                  \
+    SAVIT_LDS_ONCE(kfn);                                                                                \
     hipLaunchKernelGGL(kfn, grid, block, lds, s, p);                                                   \
   } break;
   switch (p.a.epilogue) {
@@ -1207,7 +1196,7 @@ extern "C" int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue) {
   //    amortised - grids of at least two rounds with K >= 1024 (ViT-L: every product 5-20 % faster than 192x128), or the
   //    GELU-forward epilogue (two outputs).
   //  * 128x128: small or ragged problems (few rows, N not a multiple of 128).
-  static const int force = [] { const char* e = getenv("SAVIT_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  static const int force = SAVIT_EXP_ENV_INT("SAVIT_GEMM_TILE", 0);  // SAVIT_EXPERIMENTS builds only
   if (force > 0) return force;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
   const bool big = (t256 >= 512 && N % 128 == 0);
@@ -1225,7 +1214,7 @@ extern "C" int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue) {
     //  * 192x128 with the LAST partial round cut into 128-row tiles (tile 18) when that saves at least 7 % of a round count:
     //    DeiT-B's N = 768 products are 792 tiles on 512 slots (2 rounds, the second at 55 %) -> 510 tall + 420 short tiles.
     int bp, sp;
-    static const bool no_tail = getenv("SAVIT_NO_TAIL_SPLIT") != nullptr;  // development aid (A/B runs)
+    static const bool no_tail = SAVIT_EXP_ENV_INT("SAVIT_NO_TAIL_SPLIT", 0) != 0;  // SAVIT_EXPERIMENTS builds only (A/B runs)
     if (!no_tail && epilogue != SAVIT_EPI_DGELU && tail_split_plan(M, N, 192, 128, 128, 512, &bp, &sp)) return 18;
     return 17;
   }
@@ -1356,7 +1345,8 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
     case 17: return a.K % 64 ? SAVIT_EINVAL : launch_pair<192, 128, 2, 2, 2>(p, s);
     case 18: return a.K % 64 ? SAVIT_EINVAL : launch_pair_tail<192, 128, 128, 2, 2, 2>(p, s);  // 17 with 128-row tiles for the last partial round
     case 20: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp(p, s);
-    // timing-only ablations of tile 20 (wrong results by construction; SAVIT_EPI_BF16 only)
+#ifdef SAVIT_EXPERIMENTS
+    // timing-only ablations of tile 20 (wrong results by construction; SAVIT_EPI_BF16 only) - never in the product library
     case 101: return launch_pp_ablation<1>(p, s);
     case 102: return launch_pp_ablation<2>(p, s);
     case 103: return launch_pp_ablation<3>(p, s);
@@ -1365,6 +1355,7 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
     case 108: return launch_pp_ablation<8>(p, s);
     case 109: return launch_pp_ablation<9>(p, s);
     case 110: return launch_pp_ablation<10>(p, s);
+#endif
     default: return SAVIT_EINVAL;
   }
 }

@@ -16,7 +16,6 @@
 //     fp32 gradient with global_atomic_add_f32 (order-dependent in the last bits, like any atomic sum).
 #include "common.h"
 #include "savit.h"
-#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -30,7 +29,7 @@ struct WgradParams {
   int M, Kin, Nout, ldx, lddy, lddw;
   int tiles_i, tiles_j, splits, tiles_per_split;
   int patch, img_size, tokens, token_offset, grid_side, chunks_per_prow;
-  int abl;  // timing-only ablation (SAVIT_WGRAD_ABL): 1 = skip the epilogue
+  int abl;  // SAVIT_EXPERIMENTS builds only: timing ablation (SAVIT_WGRAD_ABL): 1 = skip the epilogue
   float* slab;       // non-null: every split stores its partial tile to slab + split * slab_stride (dense [Kin, Nout]) with plain
   long slab_stride;  // stores and wgrad_reduce_kernel sums the splits into dW: no atomics, bitwise reproducible
   int no_reduce;     // slab form only: leave the ordered sum to a later savit_gemm_wgrad_reduce call
@@ -403,7 +402,9 @@ __global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_ring_kernel(cons
   frag_wait(f0);  // nothing may stay in flight into the epilogue
 #undef SAVIT_ISSUE_FRAGS
 #undef SAVIT_TR_READ
+#ifdef SAVIT_EXPERIMENTS
   if ((p.abl & 1) && p.M > 0) return;  // timing-only: the accumulators stay live (the condition is a run-time value)
+#endif
 
   const int jl = lane & 31, hi5 = lane >> 5;
   if (p.slab != nullptr) {
@@ -494,17 +495,11 @@ int launch_wgrad_ring(WgradParams p, hipStream_t s, int slots, long ws_bytes) {
   const size_t lds = (size_t)S * TS * (BI + BJ) * 2;
   if (p.patch) {
     auto kfn = gemm_wgrad_ring_kernel<BI, BJ, WGI, WGJ, S, true>;
-    if (lds > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-    }
+    SAVIT_LDS_ONCE(kfn);
     hipLaunchKernelGGL(kfn, grid, block, lds, s, p);
   } else {
     auto kfn = gemm_wgrad_ring_kernel<BI, BJ, WGI, WGJ, S, false>;
-    if (lds > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-    }
+    SAVIT_LDS_ONCE(kfn);
     hipLaunchKernelGGL(kfn, grid, block, lds, s, p);
   }
   if (p.no_reduce && !use_slab) return SAVIT_EINVAL;  // the caller asked for partials only and gave no (or too small a) workspace
@@ -544,17 +539,11 @@ int launch_wgrad(WgradParams p, hipStream_t s) {
   const size_t lds = 2 * TK * (BI + BJ) * 2;
   if (p.patch) {
     auto kfn = gemm_wgrad_kernel<BI, BJ, WGI, WGJ, true>;
-    if (lds > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-    }
+    SAVIT_LDS_ONCE(kfn);
     hipLaunchKernelGGL(kfn, grid, block, lds, s, p);
   } else {
     auto kfn = gemm_wgrad_kernel<BI, BJ, WGI, WGJ, false>;
-    if (lds > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-    }
+    SAVIT_LDS_ONCE(kfn);
     hipLaunchKernelGGL(kfn, grid, block, lds, s, p);
   }
   SAVIT_LAUNCH_RET();
@@ -575,8 +564,8 @@ extern "C" int savit_gemm_wgrad_auto_variant(int Kin, int Nout, int patch) {
 }
 
 static int wgrad_variant(int Kin, int Nout, int patch) {
-  // SAVIT_WGRAD_VARIANT (development aid): 0 = auto, 1..4 = ring kernels, 9 = the 2-stage kernel
-  static const int variant = [] { const char* e = getenv("SAVIT_WGRAD_VARIANT"); return e ? atoi(e) : 0; }();
+  // SAVIT_WGRAD_VARIANT (SAVIT_EXPERIMENTS builds only): 0 = auto, 1..4 = ring kernels, 9 = the 2-stage kernel
+  static const int variant = SAVIT_EXP_ENV_INT("SAVIT_WGRAD_VARIANT", 0);
   return variant ? variant : savit_gemm_wgrad_auto_variant(Kin, Nout, patch);
 }
 
@@ -649,7 +638,7 @@ static int wgrad_dispatch(const void* X, const void* dY, float* dW, int M, int K
   p.X = (const bf16_t*)X; p.dY = (const bf16_t*)dY; p.dW = dW;
   p.M = M; p.Kin = Kin; p.Nout = Nout; p.ldx = ldx; p.lddy = lddy; p.lddw = lddw; p.splits = splits;
   p.patch = patch; p.img_size = img_size; p.tokens = tokens; p.token_offset = token_offset;
-  { const char* e = getenv("SAVIT_WGRAD_ABL"); p.abl = e ? atoi(e) : 0; }
+  p.abl = SAVIT_EXP_ENV_INT("SAVIT_WGRAD_ABL", 0);
   p.slab = (float*)workspace;
   p.no_reduce = no_reduce;
   if (patch) {

@@ -23,7 +23,6 @@
 #include "common.h"
 #include "savit.h"
 #include "th_rows.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -43,8 +42,14 @@ struct ThFusedParams {
   const float* T2;
   float* slab;         // backward: [workgroups][2*H*H]
   int B, N, H, ld, d, hd, Np, qtiles;
-  int debug;  // development aid (SAVIT_THF_DEBUG), bit mask of phases to skip: 1 = rows, 2 = scores, 4 = P'V (forward) / row copy-out (backward)
+  int debug;  // SAVIT_EXPERIMENTS builds only (SAVIT_THF_DEBUG): bit mask of phases to skip: 1 = rows, 2 = scores, 4 = P'V (forward) / row copy-out (backward)
 };
+
+#ifdef SAVIT_EXPERIMENTS
+#define THF_SKIP(p, bit) (((p).debug & (bit)) != 0)
+#else
+#define THF_SKIP(p, bit) false
+#endif
 
 __device__ __forceinline__ uint2 pack4(const f32x4& a) { return make_uint2(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])); }
 
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(512) void th_fused_fwd_kernel(const ThFusedParams p
 
   // ---- 1. scores
   const auto srdQ = image_rsrc(p.qkv, row_base, p.ld, p.N);
-  for (int item = wave; item < ((p.debug & 2) ? 0 : 2 * H); item += nwv) {
+  for (int item = wave; item < (THF_SKIP(p, 2) ? 0 : 2 * H); item += nwv) {
     const int h = item >> 1, qb = item & 1;
     const int q = q0 + 16 * qb + fr;
     const uint32_t xoff = q < p.N ? (uint32_t)(((size_t)q * p.ld + h * HDV + 8 * kg) * 2) : THF_OOB;
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(512) void th_fused_fwd_kernel(const ThFusedParams p
 
   // ---- 2. rows: mix, softmax, mix; P' over S
   for (int r = wave; r < QT; r += nwv) {
-    if (q0 + r >= p.N || (p.debug & 1)) continue;
+    if (q0 + r >= p.N || THF_SKIP(p, 1)) continue;
     bf16_t* row = SB + r * THF_PIT + 4 * lane;
     float s[H][TH_KPL], pr[H][TH_KPL];
 #pragma unroll
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(512) void th_fused_fwd_kernel(const ThFusedParams p
 
   // ---- 3. O_g^T[e][q] = sum_key V_g^T[e][key] P'_g[q][key]
   constexpr int NEB = HDV / 16;
-  for (int item = wave; item < ((p.debug & 4) ? 0 : 2 * H); item += nwv) {
+  for (int item = wave; item < (THF_SKIP(p, 4) ? 0 : 2 * H); item += nwv) {
     const int g = item >> 1, qb = item & 1;
     const int q = q0 + 16 * qb + fr;
     const bf16_t* prow = SB + g * HS + (16 * qb + fr) * THF_PIT + 8 * kg;
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(512) void th_fused_bwd_rows_kernel(const ThFusedPar
   // ---- 1. S = Q K^T and dP' = dO V^T
   const auto srdQ = image_rsrc(p.qkv, row_base, p.ld, p.N);
   const auto srdD = image_rsrc(p.d_o, row_base, p.d, p.N);
-  for (int item = wave; item < ((p.debug & 2) ? 0 : 2 * H); item += nwv) {
+  for (int item = wave; item < (THF_SKIP(p, 2) ? 0 : 2 * H); item += nwv) {
     const int h = item >> 1;
     const int q = q0 + fr;
     const uint32_t tile_pitch = (uint32_t)(16 * p.ld * 2);
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(512) void th_fused_bwd_rows_kernel(const ThFusedPar
   // ---- 2. rows
   float acc1 = 0.f, acc2 = 0.f;  // lane l accumulates dT1 / dT2 entry (h = l >> 3, i = l & 7)
   for (int r = wave; r < QT; r += nwv) {
-    if (q0 + r >= p.N || (p.debug & 1)) continue;
+    if (q0 + r >= p.N || THF_SKIP(p, 1)) continue;
     bf16_t* srow = SB + r * THF_PIT + 4 * lane;
     bf16_t* drow = DB + r * THF_PIT + 4 * lane;
     const bool in_row = 4 * lane < THF_KW;
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(512) void th_fused_bwd_rows_kernel(const ThFusedPar
 
   // ---- 3. dS and P' rows -> HBM in 16-byte chunks
   const int npc = p.Np / 8;
-  for (int i = threadIdx.x; i < ((p.debug & 4) ? 0 : 2 * H * QT * npc); i += blockDim.x) {
+  for (int i = threadIdx.x; i < (THF_SKIP(p, 4) ? 0 : 2 * H * QT * npc); i += blockDim.x) {
     const int c = i % npc, rowi = i / npc;
     const int which = rowi / (H * QT), hr = rowi - which * (H * QT);
     const int h = hr / QT, r = hr - h * QT;
@@ -412,11 +417,11 @@ extern "C" int savit_th_fused_supported(int N, int H, int head_dim) { return thf
 // 1 when a caller with both paths available should take the fused one.  Measured on MI355X at the CaiT-S24 layer (256 images, 8 heads
 // of 48, N = 196; tools/thf_bench.py): forward 240 us fused vs 253 us materialising, backward 660 vs 500 us - the 160 KB of LDS cap
 // the query tile at 32 (forward) / 16 (backward) rows of all heads, so K / V are re-read from L2 7 / 13 times per image (0.8 / 1.1 GB
-// per layer: 72 / 142 us), and the row phase is the same VALU work as the materialising row kernels.  Default: off; SAVIT_TH_FUSED=1
+// per layer: 72 / 142 us), and the row phase is the same VALU work as the materialising row kernels.  Default: off; the engine's `th_fused=True` (or SAVIT_TH_FUSED=1 read by cait_engine.py)
 // selects the fused kernels (they keep no S / P' per layer: 7.5 GB less HBM at CaiT-S24, 256 images).
 extern "C" int savit_th_fused_preferred(int N, int H, int head_dim) {
-  const char* e = getenv("SAVIT_TH_FUSED");  // read per call: engines ask once, at construction
-  return e && atoi(e) != 0 && thf_ok(N, H, head_dim) ? 1 : 0;
+  (void)N; (void)H; (void)head_dim;
+  return 0;  // no geometry measured so far runs faster fused; callers that want the fused kernels ask for them (CaiTEngine(th_fused=True))
 }
 
 // bytes of the V^T scratch the forward needs (shared by all layers)
@@ -435,20 +440,18 @@ extern "C" long savit_th_fused_bwd_workspace_bytes(int B, int N, int H, int head
   {                                                                                                                       \
     const void* kfn = nullptr;                                                                                            \
     switch (H * 100 + head_dim) {                                                                                         \
-      case 248: kfn = (const void*)KERNEL<2, 48>; break;                                                                  \
-      case 264: kfn = (const void*)KERNEL<2, 64>; break;                                                                  \
-      case 448: kfn = (const void*)KERNEL<4, 48>; break;                                                                  \
-      case 464: kfn = (const void*)KERNEL<4, 64>; break;                                                                  \
-      case 648: kfn = (const void*)KERNEL<6, 48>; break;                                                                  \
-      case 664: kfn = (const void*)KERNEL<6, 64>; break;                                                                  \
-      case 848: kfn = (const void*)KERNEL<8, 48>; break;                                                                  \
-      case 864: kfn = (const void*)KERNEL<8, 64>; break;                                                                  \
+      case 248: { kfn = (const void*)KERNEL<2, 48>; SAVIT_LDS_ONCE(kfn); } break;                                       \
+      case 264: { kfn = (const void*)KERNEL<2, 64>; SAVIT_LDS_ONCE(kfn); } break;                                       \
+      case 448: { kfn = (const void*)KERNEL<4, 48>; SAVIT_LDS_ONCE(kfn); } break;                                       \
+      case 464: { kfn = (const void*)KERNEL<4, 64>; SAVIT_LDS_ONCE(kfn); } break;                                       \
+      case 648: { kfn = (const void*)KERNEL<6, 48>; SAVIT_LDS_ONCE(kfn); } break;                                       \
+      case 664: { kfn = (const void*)KERNEL<6, 64>; SAVIT_LDS_ONCE(kfn); } break;                                       \
+      case 848: { kfn = (const void*)KERNEL<8, 48>; SAVIT_LDS_ONCE(kfn); } break;                                       \
+      case 864: { kfn = (const void*)KERNEL<8, 64>; SAVIT_LDS_ONCE(kfn); } break;                                       \
       default: return SAVIT_EINVAL;                                                                                       \
     }                                                                                                                     \
-    hipError_t e_ = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS));                     \
-    if (e_ != hipSuccess) return (int)e_;                                                                                 \
     void* args_[] = {(void*)&p};                                                                                          \
-    e_ = hipLaunchKernel(kfn, dim3(GRID), dim3(512), args_, (LDS), (hipStream_t)stream);                                  \
+    hipError_t e_ = hipLaunchKernel(kfn, dim3(GRID), dim3(512), args_, (LDS), (hipStream_t)stream);                                  \
     if (e_ != hipSuccess) return (int)e_;                                                                                 \
   }
 
@@ -471,7 +474,7 @@ extern "C" int savit_th_fused_attention_fwd(const void* qkv, const float* T1, co
                   workspace_bytes >= savit_th_fused_fwd_workspace_bytes(B, N, H, head_dim));
   if (B == 0) return SAVIT_OK;
   p.o = (bf16_t*)o; p.vt = (bf16_t*)workspace;
-  { const char* e = getenv("SAVIT_THF_DEBUG"); p.debug = e ? atoi(e) : 0; }
+  p.debug = SAVIT_EXP_ENV_INT("SAVIT_THF_DEBUG", 0);
   p.qtiles = (N + 31) / 32;
   const size_t lds_vt = (size_t)THF_KEYS * (head_dim / 2 + 1) * 4;
   hipLaunchKernelGGL(th_vt_kernel, dim3(B * H), dim3(256), lds_vt, (hipStream_t)stream, p);
@@ -495,7 +498,7 @@ extern "C" int savit_th_fused_attention_bwd(const void* qkv, const float* T1, co
   p.d_o = (const bf16_t*)d_o; p.pbuf = (bf16_t*)p_buf; p.dsbuf = (bf16_t*)ds_buf; p.slab = (float*)workspace; p.Np = Np;
   p.qtiles = (N + 15) / 16;
   const size_t lds = (size_t)2 * H * 16 * THF_PIT * 2;
-  { const char* e = getenv("SAVIT_THF_DEBUG"); p.debug = e ? atoi(e) : 0; }
+  p.debug = SAVIT_EXP_ENV_INT("SAVIT_THF_DEBUG", 0);
   const int nblk = B * p.qtiles;
   THF_DISPATCH(th_fused_bwd_rows_kernel, nblk, lds)
   hipLaunchKernelGGL(th_dT_finalize_kernel, dim3((2 * H * H + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk, H * H, dT1,

@@ -89,6 +89,33 @@ def test_shape_contracts_are_checked_on_the_host(built):
     assert L.savit_gemm_bf16_tn(ctypes.byref(a), None) == EINVAL
 
 
+def test_product_library_has_no_experiment_switches(built):
+    """the shipped library reads no environment variable, has no run-time ablation path, and rejects the
+    timing-only tile ids (they exist only in tools/build_variant.sh builds, which define SAVIT_EXPERIMENTS)."""
+    import subprocess
+
+    so = built.lib.LIB_PATH
+    text = subprocess.run(["strings", so], check=True, capture_output=True, text=True).stdout
+    bad = [ln for ln in text.splitlines() if re.search(r"SAVIT_\w*(ABL|DEBUG|TILE|VARIANT|PP_|NO_TAIL|GENERAL|FUSED)", ln)]
+    assert not bad, bad
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", so], check=True, capture_output=True, text=True).stdout
+    assert "getenv" not in undefined, "libsavit.so imports getenv"
+    L = built.lib.load()
+    P = 0x1000
+    a = built.lib.GemmArgs()
+    a.A, a.Bt, a.C, a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.epilogue, a.rows_per_sample = P, P, P, 4096, 4096, 4096, 4096, 4096, 4096, 0, 1
+    for tile in (100, 101, 102, 103, 104, 107, 108, 109, 110, 255):
+        a.tile = tile
+        assert L.savit_gemm_bf16_tn(ctypes.byref(a), None) == 1001, tile
+    # no per-launch driver calls: the dynamic-LDS limit is raised once per kernel symbol (SAVIT_LDS_ONCE), never inline
+    csrc = os.path.join(ROOT, "self-attention-experiments-vision_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith(".hip"):
+            s = open(os.path.join(csrc, f)).read()
+            assert "hipFuncSetAttribute" not in s, f"{f}: per-launch hipFuncSetAttribute"
+            assert "getenv" not in s, f"{f}: getenv in the library"
+
+
 def _device_isa(obj_name, tmp_path):
     """Disassemble the gfx950 code object embedded in csrc/<obj_name> (llvm-objdump --offloading extracts next to its input)."""
     import shutil

@@ -193,12 +193,9 @@ CAIT_CASES = {
 
 @pytest.fixture(params=["materialising", "fused"])
 def th_path(request, monkeypatch):
-    """Both talking-heads paths of the CaiT engine: the default materialising kernels and the opt-in fused ones (SAVIT_TH_FUSED=1,
-    csrc/th_fused.hip; geometries they do not cover - 16 heads - keep the materialising kernels)."""
-    if request.param == "fused":
-        monkeypatch.setenv("SAVIT_TH_FUSED", "1")
-    else:
-        monkeypatch.delenv("SAVIT_TH_FUSED", raising=False)
+    """Both talking-heads paths of the CaiT engine: the default materialising kernels and the opt-in fused ones
+    (CaiTEngine(th_fused=True), csrc/th_fused.hip; geometries they do not cover - 16 heads - keep the materialising kernels)."""
+    monkeypatch.delenv("SAVIT_TH_FUSED", raising=False)
     return request.param
 
 
@@ -218,7 +215,7 @@ def test_cait_forward_backward_parity(pkg, th_path, case, B, training):
     images = vit_ref.bf16_round(rng.standard_normal((B, oc.img_size, oc.img_size, 3)).astype(np.float32))
     labels = rng.integers(0, oc.num_classes, B)
     masks = (rng.random((oc.num_layers + oc.num_layers_token_only, 2, B)) < 0.7).astype(np.float32) if training else None
-    eng = CaiTEngine(mc, B)
+    eng = CaiTEngine(mc, B, th_fused=(th_path == "fused"))
     assert eng.th_fused == (th_path == "fused" and mc.num_heads <= 8)
     eng.load_params(params)
     logits = eng.forward(torch.as_tensor(images).cuda(), is_training=training,
