@@ -158,6 +158,8 @@ def make_step(eng, cfg, B, world, rank, sync):
     if cfg.kind == "cait":
         eng.gen.manual_seed(42 + rank)  # per-rank stochastic-depth masks
 
+    exposed = []  # per step: (event after the last backward launch, event after sync.wait() returned) on the compute stream
+
     def step(i):
         img, lab = batches[i & 1]
         if cfg.kind == "cait":
@@ -166,10 +168,34 @@ def make_step(eng, cfg, B, world, rank, sync):
             eng.forward(img)
         eng.loss_backward(lab, label_smoothing=0.1)
         if sync is not None:
-            sync.wait()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()   # behind the last backward kernel
+            sync.wait()   # the compute stream waits here for the bucket all-reduces still in flight
+            e1.record()
+            exposed.append((e0, e1))
         eng.optimizer_step(lr=lr, weight_decay=wd, max_norm=1.0, grad_scale=(sync.grad_scale if sync else 1.0))
 
+    step.exposed = exposed
     return step, batches
+
+
+def rank_identity(local_rank: int) -> dict:
+    """What this rank actually runs on - gathered over all ranks into the N > 1 JSON line, so that the line itself shows that N
+    different GPUs took part."""
+    import torch
+
+    p = torch.cuda.get_device_properties(local_rank)
+    ident = {"rank": int(os.environ.get("RANK", "0")), "local_rank": local_rank, "device": torch.cuda.current_device(), "name": p.name,
+             "pci_bus_id": None, "uuid": None, "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))}
+    try:
+        ident["pci_bus_id"] = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}"
+    except AttributeError:
+        pass
+    try:
+        ident["uuid"] = str(p.uuid)
+    except AttributeError:
+        pass
+    return ident
 
 
 def init_bench_params(eng, cfg):
@@ -303,6 +329,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    del step.exposed[:]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -319,6 +346,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(eng.loss.item())
+    dist_info = None
+    if dist is not None:
+        # self-evidence of the multi-GPU run: the backend torch.distributed reports, its world size, every rank's device identity
+        # (all-gathered) and the all-reduce time NOT hidden behind backward (HIP events on the compute stream, max over ranks)
+        ids = [None] * world
+        dist.all_gather_object(ids, rank_identity(local_rank))
+        ex = torch.tensor([sum(a.elapsed_time(b) for a, b in step.exposed) / max(1, len(step.exposed))], device="cuda", dtype=torch.float64)
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ids,
+                     "distinct_devices": len({(d.get("pci_bus_id"), d.get("uuid"), d.get("device")) for d in ids}),
+                     "gradient_bytes_per_step": int(eng.grads.numel() * 4), "buckets": len(sync.buckets),
+                     "allreduce_exposed_ms": round(float(ex.item()), 4)}
 
     out = None
     if rank == 0:
@@ -334,7 +373,8 @@ def main():
             "config": {"workload": f"{args.model} ({'DeiT-B/16' if args.model == 'vit_b_patch16' else args.model}) {S}x{S} train step: "
                                    "fwd + label-smoothed CE + bwd + grad all-reduce + AdamW",
                        "images_per_gpu": B, "global_batch": B * world, "seq_len": cfg.seq_len, "parallelism": f"dp{world}",
-                       "final_loss": round(loss, 4)},
+                       "final_loss": round(loss, 4), **({"distributed": dist_info} if dist_info else {})},
+            **({"allreduce_exposed_ms": dist_info["allreduce_exposed_ms"]} if dist_info else {}),
             "step_roofline": {"bound": "mfma", "achieved": round(per_gpu * fpi / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(per_gpu * fpi / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "flops_per_image": fpi},
         }

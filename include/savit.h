@@ -190,8 +190,9 @@ long savit_th_attention_bwd_workspace_bytes(int B, int N, int H);
  * backward; backward recomputes S / P from QKV, materialises only dS and P' (bf16 [B,H,N,Np] scratch shared by all layers) and
  * finishes with savit_th_attention_bwd_products (dV = P'^T dO, dQ = dS K * dq_scale, dK = dS^T Q).  Covered: H in {2,4,6,8},
  * head_dim 48 / 64, N <= 208 (savit_th_fused_supported); other geometries use the entries above.  savit_th_fused_preferred says
- * which path a caller that has both should take (measured: the materialising kernels are faster on MI355X; SAVIT_TH_FUSED=1
- * selects the fused ones, which keep no per-layer S / P').
+ * which path a caller that has both should take (measured: the materialising kernels are faster on MI355X, so it returns 0; the
+ * library itself reads no environment variable - the Python engine takes CaiTEngine(th_fused=True) or SAVIT_TH_FUSED=1 - and the
+ * fused kernels keep no per-layer S / P').
  * Workspaces: forward = V^T scratch, backward = dT1/dT2 partial slab (sizes from the *_workspace_bytes functions). */
 int savit_th_fused_supported(int N, int H, int head_dim);
 int savit_th_fused_preferred(int N, int H, int head_dim);

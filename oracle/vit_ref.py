@@ -157,14 +157,21 @@ def bf16_round(x: np.ndarray) -> np.ndarray:
 
 
 class Policy:
+    """'engine' (test infrastructure for the HIP engines, not a property of the reference): bf16 like 'bf16', but rounding where
+    the build's FUSED kernels round instead of after every op of the reference's graph - one rounding per Dense after bias / query
+    scale (the GEMM epilogue), attention scores and softmax statistics in fp32 with exp(S - max) rounded to bf16 only as the MFMA
+    operand of P.V, LayerScale in fp32.  With it the block-level parity bars measure kernel error (summation order, rounding-boundary
+    flips) instead of the distance between two rounding policies (missing 5)."""
+
     def __init__(self, mode: str = "f32"):
-        assert mode in ("f64", "f32", "bf16")
+        assert mode in ("f64", "f32", "bf16", "engine")
         self.mode = mode
         self.acc = np.float64 if mode == "f64" else np.float32
+        self.fused = mode == "engine"
 
     def lo(self, x):
         """Cast to the module `dtype` (what jnp.asarray(x, self.dtype) does)."""
-        if self.mode == "bf16":
+        if self.mode in ("bf16", "engine"):
             return bf16_round(x)
         return np.asarray(x, dtype=self.acc)
 
@@ -181,6 +188,9 @@ class Policy:
 def dense(pol: Policy, x, kernel, bias=None):
     """flax nn.Dense: y = asarray(x,dtype) @ asarray(kernel,dtype) (+ asarray(bias,dtype)).
     Kernel layout is [in, out].  Call sites: ff.py:26-31, patch_embed.py:23-25, vit.py:96-98."""
+    if pol.fused:  # the GEMM epilogue: fp32 accumulator + bias, ONE rounding
+        y = np.matmul(pol.lo(x), pol.lo(kernel))
+        return pol.lo(y + pol.lo(bias)) if bias is not None else pol.lo(y)
     y = pol.lo(np.matmul(pol.lo(x), pol.lo(kernel)))
     if bias is not None:
         y = pol.lo(y + pol.lo(bias))
@@ -244,9 +254,24 @@ def attention_block(pol: Policy, p: dict, xq, xkv, num_heads: int, talking: bool
     wk = np.asarray(p["keys"]["kernel"]).reshape(d, d)
     wv = np.asarray(p["values"]["kernel"]).reshape(d, d)
     wo = np.asarray(p["DenseGeneral_0"]["kernel"]).reshape(d, -1)
-    q = dense(pol, xq, wq).reshape(B, Nq, H, hd)  # attention.py:35
     k = dense(pol, xkv, wk).reshape(B, -1, H, hd)  # :36
     v = dense(pol, xkv, wv).reshape(B, -1, H, hd)  # :37
+    if pol.fused:
+        # engine rounding points (csrc/gemm_tn.hip alpha epilogue, csrc/attention.hip, csrc/class_attention.hip): the query scale is
+        # applied to the fp32 accumulator and rounded once; S stays fp32 (talking heads: S is a bf16 tensor in HBM, P' the bf16
+        # operand of P'.V); P = exp(S - max) is rounded to bf16 as an MFMA operand, its row sum is taken from the unrounded values
+        q = pol.lo(np.matmul(pol.lo(xq), pol.lo(wq)) * pol.acc(1.0 / math.sqrt(hd))).reshape(B, Nq, H, hd)
+        s = np.einsum("bqhd,bkhd->bhqk", q, k)
+        hp = Policy("f32")
+        if talking:
+            s = talking_heads(hp, p["TalkingHeadsBlock_0"]["talking_heads_transform"], pol.lo(s))
+            w = pol.lo(talking_heads(hp, p["TalkingHeadsBlock_1"]["talking_heads_transform"], softmax_last(hp, s)))
+            o = pol.lo(np.einsum("bhqk,bkhd->bqhd", w, v))
+        else:
+            e = np.exp(s - s.max(axis=-1, keepdims=True))
+            o = pol.lo(np.einsum("bhqk,bkhd->bqhd", pol.lo(e), v) / e.sum(axis=-1)[..., None].transpose(0, 2, 1, 3))
+        return dense(pol, o.reshape(B, Nq, d), wo)
+    q = dense(pol, xq, wq).reshape(B, Nq, H, hd)  # attention.py:35
     q = pol.lo(q / pol.acc(math.sqrt(hd)))  # :39  (weak-typed scalar: stays in dtype)
     s = pol.lo(np.einsum("bqhd,bkhd->bhqk", q, k))  # :41
     if talking:
@@ -303,6 +328,8 @@ def vit_forward(params: dict, images, cfg: Cfg, mode: str = "f32", is_training: 
 
 def layer_scale(pol: Policy, p: dict, x):
     """LayerScaleBlock  (models/layers/normalizations/layerscale.py:18-23)."""
+    if pol.fused:  # the residual epilogue multiplies the bf16 branch by the fp32 parameter in fp32 and adds it to the fp32 stream
+        return pol.hi(x) * pol.hi(p["layerscale"])
     return pol.lo(pol.hi(x) * pol.lo(p["layerscale"]))
 
 

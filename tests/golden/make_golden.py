@@ -103,10 +103,11 @@ def make_block(name):
     cfg, params, images, labels = block_inputs(cfg_kw, seed)
     logits64 = vit_ref.forward(params, images, cfg, mode="f64")
     logits_bf16 = vit_ref.forward(params, images, cfg, mode="bf16")
+    logits_engine = vit_ref.forward(params, images, cfg, mode="engine")
     loss64 = vit_ref.loss_fn(logits64, labels, 0.1)
     _, _, grads = torch_ref.loss_and_grads(params, images, labels, cfg, 0.1, dtype=torch.float64)
     out = {"cfg": np.array(json.dumps(cfg_kw)), "seed": np.int64(seed), "labels": labels.astype(np.int64), "logits": logits64.astype(np.float64),
-           "logits_bf16": logits_bf16.astype(np.float32), "loss": np.float64(loss64)}
+           "logits_bf16": logits_bf16.astype(np.float32), "logits_engine": logits_engine.astype(np.float32), "loss": np.float64(loss64)}
     out.update(checksums(params, images))
     srng = np.random.default_rng(seed + 2)
     for k, g in grads.items():
@@ -120,10 +121,28 @@ def make_block(name):
     print(name, "loss", float(loss64), "bytes", os.path.getsize(path))
 
 
+def add_engine_logits(name):
+    """Round 3: a third logits array - the oracle with the ENGINE's rounding points (vit_ref.Policy('engine')) - added to a block
+    fixture written in round 2.  Every array already in the file is kept byte for byte."""
+    path = os.path.join(HERE, name + ".npz")
+    old = dict(np.load(path))
+    if "logits_engine" in old:
+        return
+    cfg_kw, seed = BLOCKS[name]
+    cfg, params, images, labels = block_inputs(cfg_kw, seed)
+    for k, v in checksums(params, images).items():
+        np.testing.assert_allclose(v, old[k], rtol=1e-12, atol=1e-12, err_msg=k)
+    assert np.allclose(vit_ref.forward(params, images, cfg, mode="bf16"), old["logits_bf16"], rtol=0, atol=0)
+    old["logits_engine"] = vit_ref.forward(params, images, cfg, mode="engine").astype(np.float32)
+    np.savez_compressed(path, **old)
+    print(name, "+ logits_engine", "bytes", os.path.getsize(path))
+
+
 if __name__ == "__main__":
     for _name in BLOCKS:
         if not os.path.exists(os.path.join(HERE, _name + ".npz")):
             make_block(_name)
+        add_engine_logits(_name)
     make(TINY_VIT, "tiny_vit.npz", 1234)
     make(TINY_CAIT, "tiny_cait.npz", 4321)
     if not os.path.exists(os.path.join(HERE, "tiny_mixer.npz")):  # added later: the two fixtures above are never rewritten

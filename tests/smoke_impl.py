@@ -25,6 +25,6 @@ def run():
     ref = vit_ref.forward(params, images, oc, mode="f32")
     r = float(np.linalg.norm(logits - ref) / np.linalg.norm(ref))
     loss_ref, _, g_ref = torch_ref.loss_and_grads(params, images, labels, oc, 0.1)
-    assert np.isfinite(logits).all() and r < 3e-2, f"logits rel-L2 {r}"
+    assert np.isfinite(logits).all() and r < 1.3e-2, f"logits rel-L2 {r}"
     assert abs(loss - loss_ref) < 3e-2 * max(1.0, abs(loss_ref)), (loss, loss_ref)
     print(f"smoke: logits rel-L2 vs fp32 oracle {r:.2e}; loss {loss:.4f} (oracle {loss_ref:.4f})")

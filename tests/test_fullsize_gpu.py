@@ -68,7 +68,7 @@ def test_rows_are_independent_and_permutation_equivariant(deit_b):
     small.params, small.w, small.weights_stale = eng.params, eng.w, False
     sub = small.forward(img[32:48].contiguous())
     err = float((sub - full[32:48]).norm() / full[32:48].norm())
-    assert err < 2e-3, err
+    assert err < 1e-6, err  # measured 0: every output element sums its K products in the same order whatever the grid
 
 
 def test_mean_gradient_is_linear_over_sub_batches(deit_b):
@@ -92,12 +92,12 @@ def test_mean_gradient_is_linear_over_sub_batches(deit_b):
         acc += half.grads
     acc *= 0.5
     rel = float((acc - g_full).norm() / g_full.norm())
-    assert rel < 2e-3, rel
-    # and the backward pass repeats to fp32 summation order (weight gradients are split-K atomics)
+    assert rel < 2e-5, rel  # fp32 summation order only (measured 4e-7 ... 1.3e-6 on the BASELINE configs)
+    # and the backward pass repeats BITWISE: no atomics anywhere on the path (weight gradients, bias / LayerNorm column sums)
     eng.forward(img)
     eng.loss_backward(lab, label_smoothing=0.1)
     torch.cuda.synchronize()
-    assert float((eng.grads - g_full).norm() / g_full.norm()) < 1e-5
+    assert torch.equal(eng.grads, g_full)
 
 
 def test_loss_descends_on_a_fixed_batch(deit_b):
@@ -173,6 +173,34 @@ def test_cait_s24_full_size_properties():
     eng.loss_backward(lab)
     torch.cuda.synchronize()
     assert torch.isfinite(eng.grads).all() and float(eng.grads.abs().max()) > 0
+    # a 16-image engine reproduces rows of the 256-image batch, and the mean gradient is the mean of the two half-batch gradients
+    # (eval mode: stochastic depth is the identity, so the identity is exact up to fp32 summation order) - as for the ViT configs
+    small = CaiTEngine(cfg, 16)
+    small.params, small.w, small.weights_stale = eng.params, eng.w, False
+    got = small.forward(img[64:80].contiguous(), is_training=False)
+    err = float((got - full[64:80]).norm() / full[64:80].norm())
+    assert err < 1e-6, err
+    del small
+    eng.forward(img, is_training=False)
+    eng.loss_backward(lab)
+    torch.cuda.synchronize()
+    g_full = eng.grads.clone()
+    eng.forward(img, is_training=False)
+    eng.loss_backward(lab)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.grads, g_full)  # the whole backward pass is bitwise reproducible
+    half = CaiTEngine(cfg, B // 2)
+    half.params, half.w, half.weights_stale = eng.params, eng.w, False
+    acc = torch.zeros_like(g_full)
+    for lo in (0, B // 2):
+        half.forward(img[lo:lo + B // 2].contiguous(), is_training=False)
+        half.loss_backward(lab[lo:lo + B // 2].contiguous())
+        torch.cuda.synchronize()
+        acc += half.grads
+    acc *= 0.5
+    rel = float((acc - g_full).norm() / g_full.norm())
+    print(f"[cait_s_24 B={B}] sub-batch rows {err:.2e}, half-batch gradient linearity {rel:.2e}")
+    assert rel < 2e-5, rel
 
 
 def _full_workload_properties(model, img_size, B, sub, seed):

@@ -6,6 +6,11 @@ are regenerated from the fixture's seed and pinned by the stored checksums; expe
 gradients (norm + 2048 sampled entries per tensor) are stored.  No oracle forward runs here: the stored numbers are the judge.
 (The d = 32 tiny_*.npz fixtures are narrower than the engines' minimum width; tests/test_oracle.py uses them to pin the oracle.)
 
+Round 3: every fixture also stores `logits_engine`, the oracle evaluated with the ENGINE's rounding points (vit_ref.Policy("engine"):
+one rounding per fused GEMM epilogue, fp32 scores and softmax statistics, bf16 P only as the MFMA operand).  Against that array the
+engine's distance is summation order plus rounding-boundary flips - a bar that a small kernel error would break, which the two
+policy-distance bars above it cannot (missing 5).
+
 Bars = ~1.5x the values measured on MI355X (printed by the tests):
   logits vs fp64 oracle            7.4e-3 - 9.7e-3 measured on the single blocks (the bf16-emulating oracle itself: 8.8e-3 - 1.0e-2)
   logits vs bf16-emulating oracle  7.6e-3 - 8.6e-3 measured: two bf16 evaluations that round at the same places but sum in different
@@ -72,6 +77,13 @@ BLOCK_BARS = {  # measured (gpurun_out/r2d/parity.log):          logits f64 | bf
 }
 
 
+# engine vs the oracle evaluated with the engine's own rounding points (`logits_engine`): ~1.5x measured (round 3)
+ENGINE_POLICY_BARS = {
+    "block_d192_n197": 4e-3, "block_d384_n197": 4e-3, "block_d768_n197": 4e-3, "block_d1024_n577": 4e-3, "block_cait_d384_n196": 4e-3,
+    "e2e_vit_d128": 4e-3, "e2e_cait_d128": 4e-3, "e2e_mixer_d128": 1e-2, "e2e_tnt_d128": 1.5e-2,
+}
+
+
 @pytest.mark.parametrize("name", sorted(make_golden.BLOCKS))
 def test_real_width_block_fixture(name):
     if not torch.cuda.is_available():
@@ -90,11 +102,15 @@ def test_real_width_block_fixture(name):
     logits = (eng.forward(x, is_training=False) if cfg.kind == "cait" else eng.forward(x)).float().cpu().numpy()
     b64, bbf, bgn, bgs = BLOCK_BARS[name]
     r64, rbf, r_emul = rel(logits, fx["logits"]), rel(logits, fx["logits_bf16"]), rel(fx["logits_bf16"], fx["logits"])
-    print(f"[{name}] logits rel-L2: engine vs fp64 {r64:.2e}, engine vs bf16-emulation {rbf:.2e} (bf16-emulation vs fp64 {r_emul:.2e})")
+    reng = rel(logits, fx["logits_engine"])
+    print(f"[{name}] logits rel-L2: engine vs fp64 {r64:.2e}, engine vs bf16-emulation {rbf:.2e} (bf16-emulation vs fp64 {r_emul:.2e}), "
+          f"engine vs engine-policy oracle {reng:.2e}")
     assert np.isfinite(logits).all()
     bad = []  # every figure is printed before the first failure is raised
     if not (r64 < b64 and rbf < bbf):
         bad.append(("logits", r64, rbf))
+    if not reng < ENGINE_POLICY_BARS[name]:
+        bad.append(("logits vs engine-policy oracle", reng, ENGINE_POLICY_BARS[name]))
     loss = float(eng.loss_backward(torch.as_tensor(labels).cuda(), 0.1))
     if not abs(loss - float(fx["loss"])) < 5e-3 * max(1.0, abs(float(fx["loss"]))):
         bad.append(("loss", loss, float(fx["loss"])))

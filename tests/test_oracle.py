@@ -257,6 +257,7 @@ def test_block_fixtures_pin_the_oracle(name):
     assert rel(logits, fx["logits"]) < 1e-9
     assert abs(vit_ref.loss_fn(logits, labels, 0.1) - float(fx["loss"])) < 1e-9
     assert rel(vit_ref.forward(params, images, cfg, mode="bf16"), fx["logits_bf16"]) < 1e-6
+    assert rel(vit_ref.forward(params, images, cfg, mode="engine"), fx["logits_engine"]) < 1e-6  # the engine-rounding policy (round 3)
     if name == "block_d192_n197":
         _, _, grads = torch_ref.loss_and_grads(params, images, labels, cfg, 0.1, dtype=torch.float64)
         for k, g in grads.items():
