@@ -50,6 +50,8 @@ EPI_OF = {"qkv": 0, "proj": 2, "fc1": 1, "fc2": 2, "fc2.dgrad": 3, "fc1.dgrad": 
 def kernel_symbol(label: str, lib, M: int, d: int, F: int) -> str:
     """Launch label of the engine's plan -> the kernel symbol rocprofv3 reports (template arguments as in csrc/)."""
     parts = label.split(".")
+    if label.startswith("wgrad.group"):
+        return "gemm_wgrad_group_kernel<256,256,2,4,4>" if d % 256 == 0 and F % 256 == 0 else "gemm_wgrad_group_kernel<128,128,2,2,4>"
     op = ".".join(parts[1:]) if parts[0].startswith("l") and parts[0][1:].isdigit() else label
     shapes = {"qkv": (3 * d, d), "proj": (d, d), "fc1": (F, d), "fc2": (d, F), "fc2.dgrad": (F, d), "fc1.dgrad": (d, F),
               "proj.dgrad": (d, d), "qkv.dgrad": (d, 3 * d)}
@@ -70,6 +72,8 @@ def kernel_symbol(label: str, lib, M: int, d: int, F: int) -> str:
 
 
 def kernel_class(label: str) -> str:
+    if label.startswith("wgrad.group"):
+        return "gemm_wgrad"
     if label.endswith(".wgrad.reduce"):
         return "wgrad_reduce"
     if label.endswith(".wgrad") or label == "Wpe.wgrad":
@@ -397,6 +401,8 @@ def main():
             if c in ("gemm_tn", "gemm_wgrad") and len(parts) >= 2 and parts[0].startswith("l"):
                 key = {"Wqkv": "qkv", "Wo": "proj", "W1": "fc1", "W2": "fc2", "tW1": "tok", "tW2": "tok"}.get(parts[1], parts[1])
                 fl = gemm_flops.get(key, 0.0)
+            elif label.startswith("wgrad.group"):
+                fl = getattr(eng, "group_flops", {}).get(label, 0.0)
             elif label in ("patch_embed", "Wpe.wgrad"):
                 fl = 2.0 * B * cfg.n_patches * cfg.patch_dim * d
             elif label.startswith("head"):
@@ -410,6 +416,8 @@ def main():
             parts = label.split(".")
             key = {"Wqkv": "qkv", "Wo": "proj", "W1": "fc1", "W2": "fc2", "tW1": "tok", "tW2": "tok"}.get(parts[1], parts[1]) if len(parts) >= 2 else ""
             fl = gemm_flops.get(key, 0.0) if sym.startswith("gemm") and parts[0].startswith("l") else 0.0
+            if label.startswith("wgrad.group"):
+                fl = getattr(eng, "group_flops", {}).get(label, 0.0)
             sym_ms[sym] = sym_ms.get(sym, 0.0) + t_ms
             sym_n[sym] = sym_n.get(sym, 0) + 1
             sym_fl[sym] = sym_fl.get(sym, 0.0) + fl
@@ -429,7 +437,11 @@ def main():
                 if pm:
                     out["roofline"]["traffic"] = pm["traffic_bytes"]
                     out["roofline"]["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, FETCH doubled)"
-                    if dom.startswith("gemm_wgrad_ring_kernel<256"):
+                    if dom.startswith("gemm_wgrad_group_kernel"):
+                        # operands read once (X and dY of every weight of the group) + dW read and written once (fp32)
+                        g = getattr(eng, "wgrad_group", 1)
+                        out["roofline"]["algorithmic_bytes_per_launch"] = int(g * sum(2 * M * (a + b_) + 8 * a * b_ for a, b_ in ((d, 3 * d), (d, d), (d, F), (F, d))))
+                    elif dom.startswith("gemm_wgrad_ring_kernel<256"):
                         # operands read once + the split partials written once (slab form; the reduce kernel is its own row of the profile)
                         sp = max(1, eng.L.savit_gemm_wgrad_workspace_bytes(M, d, F, 0, 0) // (d * F * 4))
                         out["roofline"]["algorithmic_bytes_per_launch"] = int(sum(2 * M * (a + b_) + 4 * a * b_ * sp for a, b_ in ((d, 3 * d), (d, F), (F, d))) / 3)

@@ -11,6 +11,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) int int32x4_t;  // a buffer descriptor as an inline-asm SGPR operand
 
 // Non-temporal ("nt") accesses for data with no reuse in the near future: a tensor saved for backward, or the last read of one.
 // They keep the 256 MB memory-side cache for the tensors the NEXT kernel reads (measured: storing the pre-GELU activation nt
@@ -44,11 +45,17 @@ __device__ __forceinline__ void nt_store_u4(void* p, uint4 v) {
 // Kernels that use more than the default 64 KB of dynamic LDS need their limit raised.  That is done ONCE per kernel symbol (a
 // function-local static: initialised thread-safely, C++11) to the CU's whole 160 KB - a limit, not an allocation: each launch still
 // passes the bytes it uses - instead of a driver call in front of every launch.
-#define SAVIT_LDS_ONCE(kfn)                                                                                                    \
-  do {                                                                                                                         \
-    static const hipError_t lds_once_ =                                                                                        \
-        hipFuncSetAttribute((const void*)(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
-    if (lds_once_ != hipSuccess) return (int)lds_once_;                                                                        \
+inline hipError_t savit_raise_lds_limit(const void* kfn) {
+  hipFuncAttributes at{};
+  const hipError_t e = hipFuncGetAttributes(&at, kfn);
+  if (e != hipSuccess) return e;
+  // the limit covers dynamic LDS only: a kernel's static __shared__ arrays come out of the same 160 KB
+  return hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)at.sharedSizeBytes);
+}
+#define SAVIT_LDS_ONCE(kfn)                                                                  \
+  do {                                                                                       \
+    static const hipError_t lds_once_ = savit_raise_lds_limit((const void*)(kfn));           \
+    if (lds_once_ != hipSuccess) return (int)lds_once_;                                      \
   } while (0)
 
 // Development switches (ablation tiles that compute wrong results on purpose, SAVIT_* environment overrides of the tile / split

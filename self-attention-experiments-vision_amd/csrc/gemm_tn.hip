@@ -16,6 +16,7 @@
 //     share A row-panels.
 #include "common.h"
 #include "savit.h"
+#include <type_traits>
 
 namespace {
 
@@ -998,6 +999,454 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(const GemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Streaming variant (tile 30): PERSISTENT workgroups, 256 x 128 tiles, and the epilogue of tile t runs UNDER the MFMAs of tile t+1.
+// Why: with K = 768 a tile is 12 K-tiles of matrix work and then a burst of HBM traffic (fc1 + GELU writes 310 MB: ~60 us at the
+// HBM rate next to ~75 us of MFMA time).  Every kernel above runs the two back to back - all CUs compute, then all CUs store - and a
+// launch costs their SUM (141 us).  Overlap inside a workgroup needs the finished tile to live somewhere while the next one
+// accumulates: a 256 x 256 tile cannot (128 accumulator registers per wave, 128 KB as bf16), a 256 x 128 tile can - its 64 fp32
+// accumulators per wave pack into 32 registers of bf16 at the tile boundary, and those are drained 8 rows at a time through a 2-KB
+// per-wave LDS park (transposition to whole 128-B lines, as in epilogue_lds) while the next tile's MFMAs issue.
+//   * one workgroup (8 waves = 4 (M) x 2 (N), wave tile 64 x 64) per CU walks over its tiles; the K-pipeline never drains at a tile
+//     boundary: a ring of 3 K-tile slots (48 KB each: 256 A rows + 128 Bt rows of 128 B, pair_tile's swizzle), the LDS-DMA of K-tile
+//     t+2 - possibly the NEXT tile's operands - is issued during K-tile t;
+//   * main loop = the ping-pong schedule of gemm_tn_pp_kernel: waves 0-3 (M-half 0) and their SIMD partners 4-7 (M-half 1) run the
+//     same program ONE BARRIER apart; a K-tile is two phases (column halves of the wave tile), each [load segment | barrier |
+//     16 MFMAs | barrier], so one group's load segment - fragment reads, LDS-DMA issue, and the epilogue work below - runs beside
+//     the other group's MFMA segment.  K-tile t, per wave:
+//       L(t,0): read the B fragments of columns 0-31 and all A fragments of slot t%3 | epilogue stage 2 and stage 0
+//       L(t,1): read the B fragments of columns 32-63 | issue the 6 DMA pieces of K-tile t+2 into slot (t+2)%3 | epilogue stage 1 |
+//               s_waitcnt vmcnt: K-tile t+1 has landed
+//     Hazards (group B = one barrier behind group A; interval n = between barriers n and n+1; A runs L(t,0) in interval 4t):
+//       WAR: slot (t+2)%3 held K-tile t-1, last read by group B in its L(t-1,1) (interval 4t-1), complete behind the lgkmcnt(0) that
+//            follows barrier 4t; the DMA is issued in L(t,1): interval 4t+2 (A) / 4t+3 (B) - at least one barrier later.
+//       RAW: every wave waits for its own pieces of K-tile t+1 in L(t,1) and then passes barrier 4t+3 (A) / 4t+4 (B); the first read
+//            of K-tile t+1 is group A's L(t+1,0) in interval 4t+4, behind a barrier every wave reached after that wait.
+//   * the previous tile's epilogue is cut into 8 chunks (8 rows x 64 columns per wave) of 3 stages, one stage per load segment:
+//       stage 0: park a 16-row slice of the packed accumulators (every second chunk; inline-asm ds_write_b64) and request the
+//                chunk's rows back row-contiguous (ds_read_b128; + the GELU' pre-activation rows that an LDS-DMA left in the park);
+//       stage 1: first half of the math; LDS-DMA of the NEXT chunk's pre-activation rows (or, behind the last chunk, of the bias
+//                of the tile being accumulated) into the half of the park this chunk is done with;
+//       stage 2: second half of the math, 16-byte buffer stores of whole 128-B lines (+ the column-sum slab row of GELU').
+//     Load segments are not interleaved with MFMAs by the compiler (the MFMA segments are fenced), so they may branch: chunk and
+//     stage are run-time state, only the slice index of the parked registers is a compile-time switch;
+//   * every vector-memory operation is an LDS-DMA or a store, so hipcc has no load result to wait for and inserts no vmcnt wait (for
+//     a register-destination load it drains the whole ring; an inline-asm load left its destination registers open to compiler
+//     copies while the data was in flight: measured, wrong rows now and then).  The counted wait of L(t,1) accounts for what the
+//     epilogue issued since the pieces it waits for: stores of this K-tile's stage 2, the DMA of its stage 1, the 6 pieces of t+2;
+//   * rows >= M and the "no previous tile yet" case are handled by the buffer descriptors' bounds checks (loads return 0, stores are
+//     dropped): no branches on them.
+// Same K order per output element as every other TN kernel: results are bitwise those of tiles 13 / 17 / 20.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_tn_stream_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 128, RB = 128, ND = 3, G = 6;
+  constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, SLOT = A_BYTES + B_BYTES;
+  constexpr int PARK = ND * SLOT;  // 8 x 2 KB behind the ring
+  constexpr bool GELU = (EPI == SAVIT_EPI_BIAS_GELU), DG = (EPI == SAVIT_EPI_DGELU);
+  static_assert(EPI == SAVIT_EPI_BF16 || GELU || DG, "epilogues of the streaming kernel");
+  constexpr int ES = GELU ? 2 : 1;  // stores of a chunk's stage 2 (the last chunk of GELU' adds the two slab stores)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const savit_gemm_args& a = p.a;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;  // waves 0-3: rows 0-127 (group A), waves 4-7: rows 128-255 (group B, their SIMD partners)
+  const int grp = wave >> 2;
+
+  // ---- this workgroup's tiles: XCD x owns a contiguous run of the tile list; its `per` workgroups take consecutive tiles, round by round
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int xbase = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int xlen = q8 + (xcd < r8 ? 1 : 0);
+  const int NT = wslot < xlen ? (xlen - wslot + per - 1) / per : 0;
+  if (NT == 0) return;
+  auto tile_rc = [&](int k, int& row0, int& col0) {
+    const int tid = xbase + wslot + k * per;
+    const int Gr = p.row_group, perg = Gr * p.tiles_n;
+    const int g = tid / perg, rem = tid - g * perg;
+    const int rows_g = (p.tiles_m - g * Gr) < Gr ? (p.tiles_m - g * Gr) : Gr;
+    const int tn = rem / rows_g;
+    row0 = (g * Gr + (rem - tn * rows_g)) * BM;
+    col0 = tn * BN;
+  };
+  const int KP = a.K / 64;    // K-tiles per tile (>= 9: stream_ok)
+  const int total = NT * KP;  // K-tiles this workgroup computes
+
+  // ---- LDS-DMA side (runs two K-tiles ahead of the MFMAs)
+  const int lrow = lane >> 3, pch = lane & 7;
+  uint32_t a_voff[4], b_voff[2];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int r = (wave * 4 + g) * 8 + lrow;
+    a_voff[g] = (uint32_t)r * (uint32_t)(a.lda * 2) + (uint32_t)((pch ^ ((r >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int r = (wave * 2 + g) * 8 + lrow;
+    b_voff[g] = (uint32_t)r * (uint32_t)(a.ldb * 2) + (uint32_t)((pch ^ ((r >> 1) & 7)) << 4);
+  }
+  int d_k = 0, d_pp = 0, d_slot = 0;
+  __amdgpu_buffer_rsrc_t srdA, srdB;
+  auto dma_set_tile = [&](int k) {
+    int r0, c0;
+    tile_rc(k, r0, c0);
+    const size_t ta = (size_t)(a.M - r0) * a.lda * 2, tb = (size_t)(a.N - c0) * a.ldb * 2;
+    srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(a.A) + (size_t)r0 * a.lda), 0,
+                                             (uint32_t)(ta > 0xfffffff0ull ? 0xfffffff0ull : ta), 0x00020000);
+    srdB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(a.Bt) + (size_t)c0 * a.ldb), 0,
+                                             (uint32_t)(tb > 0xfffffff0ull ? 0xfffffff0ull : tb), 0x00020000);
+  };
+  auto dma_ktile = [&]() {  // the 6 pieces of K-tile (d_k, d_pp) into slot d_slot, then advance
+    char* base = smem + d_slot * SLOT;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (__attribute__((address_space(3))) void*)(base + (wave * 4 + g) * 1024), 16, a_voff[g], d_pp * RB, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave * 2 + g) * 1024), 16, b_voff[g],
+                                               d_pp * RB, 0, 0);
+    d_slot = (d_slot + 1 == ND) ? 0 : d_slot + 1;
+    if (++d_pp == KP) {
+      d_pp = 0;
+      if (++d_k < NT) dma_set_tile(d_k);
+    }
+  };
+
+  // ---- fragment addressing (as pair_tile)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = (fr >> 1) & 7;
+  const int foff0 = fr * RB + ((fq ^ sw) << 4), foff1 = fr * RB + (((fq + 4) ^ sw) << 4);
+  const int a_row = (wm * 64) * RB, b_row = A_BYTES + (wn * 64) * RB;
+
+  // ---- epilogue side
+  const __amdgpu_buffer_rsrc_t srdC = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (uint32_t)((size_t)a.M * a.ldc * 2), 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t srdC2 =
+      __builtin_amdgcn_make_buffer_rsrc(GELU ? a.C2 : a.C, 0, (uint32_t)((size_t)a.M * a.ldc * 2), 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t srdSlab = __builtin_amdgcn_make_buffer_rsrc(
+      DG && a.colsum ? (void*)a.colsum : a.C, 0, (uint32_t)(DG && a.colsum ? (size_t)a.colsum_rows * a.N * 4 : 0), 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t srdAux = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(DG ? a.aux : (const void*)a.C), 0, (uint32_t)(DG ? (size_t)a.M * a.ldaux * 2 : 0), 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t srdBias = __builtin_amdgcn_make_buffer_rsrc(
+      GELU ? (void*)const_cast<float*>(a.bias) : a.C, 0, (uint32_t)(GELU ? (size_t)a.N * 4 : 0), 0x00020000);
+  const int rrow = lane >> 3, rcol = lane & 7;  // drain mapping: 8 rows x 8 lanes x 16 B
+  // The 2-KB park of a wave is two 1-KB halves (rows 0-7 / rows 8-15 of a 16-row slice).  Once a chunk has read its half, that half
+  // is free until the next slice is parked: the LDS-DMA of the NEXT chunk's pre-activation rows (GELU') lands there - lane L's 16
+  // bytes at L * 16, read back by the same lane - and, behind a tile's last chunk, the 64 bias values of the tile being accumulated
+  // (GELU), read at the tile boundary.  The park is written and read with INLINE-ASM LDS instructions: for a ds_write / ds_read it
+  // can see, hipcc puts `s_waitcnt vmcnt(0)` in front whenever an LDS-DMA is in flight (it cannot prove they do not alias), which
+  // drained the ring at every chunk.  LDS operations of one wave execute in order.
+  const uint32_t park0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem) + (uint32_t)(PARK + wave * 2048);
+  const uint32_t park_w = park0 + (uint32_t)(fr * 128 + (fq & 1) * 8);                      // + swizzled 16-B unit of column block j
+  const uint32_t park_r = park0 + (uint32_t)(rrow * 128 + ((rcol ^ (rrow & 7)) << 4));      // rows 0-7 (+ 1024: rows 8-15, same swizzle)
+  [[maybe_unused]] char* const park_ptr = smem + PARK + wave * 2048;
+  int c_row0, c_col0;                            // tile being accumulated
+  int o_row0 = a.M, o_col0 = 0;                  // tile being drained (none yet: every row out of range)
+  tile_rc(0, c_row0, c_col0);
+
+  f32x4 acc[4][4];
+  uint2 old[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      old[i][j] = make_uint2(0u, 0u);
+    }
+  u32x4 rawv = {0u, 0u, 0u, 0u};                        // the chunk's 8 bf16 values per lane (stage 0 -> 2)
+  [[maybe_unused]] u32x4 auxv = {0u, 0u, 0u, 0u};       // GELU': the pre-activation at the same positions
+  [[maybe_unused]] uint32_t half_out[2] = {0u, 0u};     // stage 1's packed results (second output of GELU / output of GELU')
+  [[maybe_unused]] float cs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // ---- epilogue stages of chunk c (rows 16 (c >> 1) + 8 (c & 1) .. + 7 of this wave's 64 x 64 tile of the tile in `old`)
+  auto stage0 = [&](const int c, const bool tail) {
+    const int h = c & 1;
+    if constexpr (DG) {
+      // the pre-activation rows the previous chunk's stage 1 requested: behind that LDS-DMA only the 6 pieces of one K-tile and
+      // the previous chunk's stores
+      if (tail) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + ES) : "memory");
+      }
+      // an even chunk's rows sit in the upper half (read BEFORE the slice overwrites it), an odd chunk's in the lower one
+      asm volatile("ds_read_b128 %0, %1" : "=v"(auxv) : "v"(park0 + (uint32_t)((h ? 0 : 1024) + lane * 16)) : "memory");
+    }
+    if (h == 0) {
+      // the parked slice is a compile-time register index: each case holds its own (volatile asm) stores, so the switch cannot be
+      // turned into a run-time indexed array (which hipcc would move to scratch memory)
+      auto park_slice = [&](const uint2(&sl)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // lane: row fr, columns 16 j + 4 fq .. + 3 -> 8 bytes at unit (2 j + (fq >> 1)) ^ (row & 7)
+          const u32x2 v = {sl[j].x, sl[j].y};
+          asm volatile("ds_write_b64 %0, %1" ::"v"(park_w + (uint32_t)((((2 * j + (fq >> 1)) ^ (fr & 7)) << 4))), "v"(v) : "memory");
+        }
+      };
+      switch (c >> 1) {
+        case 0: park_slice(old[0]); break;
+        case 1: park_slice(old[1]); break;
+        case 2: park_slice(old[2]); break;
+        default: park_slice(old[3]); break;
+      }
+    }
+    asm volatile("ds_read_b128 %0, %1" : "=v"(rawv) : "v"(park_r + (uint32_t)(h * 1024)) : "memory");
+    // waited for HERE, inside the branch: a destination register of an inline-asm read must not cross a control-flow join while the
+    // data is in flight (the compiler may copy it there).  ~one LDS round trip per chunk, before this segment's fragment reads.
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rawv), "+v"(auxv)::"memory");
+  };
+  auto stage1 = [&](const int c) {
+    if constexpr (GELU) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const f32x2 gv = gelu_tanh2(unpack_bf16x2(rawv[k]));
+        half_out[k] = pack_bf16x2(gv.x, gv.y);
+      }
+      if (c == 7 && lane < 16)
+        // the bias of the tile being ACCUMULATED (64 columns of this wave = 16 lanes x 16 B) into the lower half, which nobody reads
+        // again before the next tile's first slice is parked; consumed at the tile boundary
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdBias, (__attribute__((address_space(3))) void*)park_ptr, 16,
+                                                 (uint32_t)(c_col0 + wn * 64 + 4 * lane) * 4u, 0, 0, 0);
+    } else if constexpr (DG) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const f32x2 dv = unpack_bf16x2(rawv[k]) * gelu_tanh_grad2(unpack_bf16x2(auxv[k]));
+        half_out[k] = pack_bf16x2(dv.x, dv.y);
+      }
+      // the NEXT chunk's pre-activation rows (chunk 0 of the tile being accumulated behind this tile's last chunk) into the half
+      // this chunk has finished with (its reads completed behind the last barrier)
+      const int cn = (c + 1) & 7;
+      const int nrow = (c == 7 ? c_row0 : o_row0) + wm * 64 + 16 * (cn >> 1) + 8 * (cn & 1) + rrow;
+      const int ncol = (c == 7 ? c_col0 : o_col0) + wn * 64 + 8 * rcol;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdAux, (__attribute__((address_space(3))) void*)(park_ptr + ((c & 1) ? 1024 : 0)), 16,
+                                               (uint32_t)nrow * (uint32_t)(a.ldaux * 2) + (uint32_t)(ncol * 2), 0, 0, 0);
+    }
+  };
+  auto stage2 = [&](const int c) {
+    const int pr = 8 * (c & 1) + rrow;
+    const int row = o_row0 + wm * 64 + 16 * (c >> 1) + pr, col = o_col0 + wn * 64 + 8 * rcol;
+    const uint32_t voff = (uint32_t)row * (uint32_t)(a.ldc * 2) + (uint32_t)(col * 2);
+    if constexpr (EPI == SAVIT_EPI_BF16) {
+      __builtin_amdgcn_raw_buffer_store_b128(rawv, srdC, voff, 0, 0);
+    } else if constexpr (GELU) {
+      uint32_t gw[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const f32x2 gv = gelu_tanh2(unpack_bf16x2(rawv[2 + k]));
+        gw[k] = pack_bf16x2(gv.x, gv.y);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(rawv, srdC, voff, 0, 2);  // nt: read again in backward only
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{half_out[0], half_out[1], gw[0], gw[1]}, srdC2, voff, 0, 0);
+    } else {
+      uint32_t ow[4] = {half_out[0], half_out[1], 0u, 0u};
+#pragma unroll
+      for (int k = 2; k < 4; ++k) {
+        const f32x2 dv = unpack_bf16x2(rawv[k]) * gelu_tanh_grad2(unpack_bf16x2(auxv[k]));
+        ow[k] = pack_bf16x2(dv.x, dv.y);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x2 r = unpack_bf16x2(ow[k]);  // the column sum adds the bf16-rounded values, as the stored tensor holds them
+        cs8[2 * k] += r.x;
+        cs8[2 * k + 1] += r.y;
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{ow[0], ow[1], ow[2], ow[3]}, srdC, voff, 0, 0);
+      if (c == 7) {
+        // fold the 8 row groups (lanes with equal lane & 7 own the same 8 columns), then lanes 0-7 write this (row tile, wave row)'s
+        // partial (other lanes and the "no tile yet" placeholder store out of range: dropped; the offsets must not wrap to 0)
+        float s8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float v = cs8[k];
+          v += __shfl_xor(v, 32, 64);
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 8, 64);
+          s8[k] = v;
+          cs8[k] = 0.f;
+        }
+        const bool live = lane < 8 && o_row0 < a.M;
+        const uint32_t soff = live ? ((uint32_t)((o_row0 / BM) * 4 + wm) * (uint32_t)a.N + (uint32_t)col) * 4u : 0xffffff00u;
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(s8[0]), __float_as_uint(s8[1]), __float_as_uint(s8[2]), __float_as_uint(s8[3])},
+                                               srdSlab, soff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(s8[4]), __float_as_uint(s8[5]), __float_as_uint(s8[6]), __float_as_uint(s8[7])},
+                                               srdSlab, soff + 16u, 0, 0);
+      }
+    }
+  };
+
+  // ---- prologue: K-tiles 0 and 1 in flight, K-tile 0 landed
+  dma_set_tile(0);
+  dma_ktile();
+  dma_ktile();
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // group B runs one barrier behind group A
+
+  bf16x8 af[4][2], bq[2][2];
+#define STREAM_READ_A()                                                                              \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+    af[i][0] = *reinterpret_cast<const bf16x8*>(cur + a_row + i * 16 * RB + foff0);                \
+    af[i][1] = *reinterpret_cast<const bf16x8*>(cur + a_row + i * 16 * RB + foff1);                \
+  }
+#define STREAM_READ_B(Q)                                                                             \
+  _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                               \
+    bq[jj][0] = *reinterpret_cast<const bf16x8*>(cur + b_row + (2 * (Q) + jj) * 16 * RB + foff0);  \
+    bq[jj][1] = *reinterpret_cast<const bf16x8*>(cur + b_row + (2 * (Q) + jj) * 16 * RB + foff1);  \
+  }
+#define STREAM_COMPUTE(Q)                                                                            \
+  __builtin_amdgcn_s_barrier();                                                                      \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+  __builtin_amdgcn_sched_barrier(0);                                                                 \
+  __builtin_amdgcn_s_setprio(1);                                                                     \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
+      _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                             \
+        acc[i][2 * (Q) + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[jj][ks], af[i][ks], acc[i][2 * (Q) + jj], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                     \
+  __builtin_amdgcn_sched_barrier(0);                                                                 \
+  __builtin_amdgcn_s_barrier();
+
+  int slot = 0;  // ring slot of the K-tile being computed
+  int t = 0;     // its index among this workgroup's K-tiles
+  for (int k = 0; k < NT; ++k) {
+    int c_next = 0;      // next chunk to start (stage 0) ...
+    int pp_next = 0;     // ... in the L(.,0) of this K-tile of the tile
+    int c_run = -1;      // chunk between stage 0 and stage 2
+    for (int pp = 0; pp < KP; ++pp) {
+      const char* cur = smem + slot * SLOT;
+      const bool tail = t + 2 >= total;  // no K-tile left to request: the counts below do not apply, wait for everything
+      // ---- L(t,0)
+      int n_st = 0;  // stores issued in this segment
+      if (c_run >= 0) {  // stage 2 of the chunk whose stages 0 and 1 ran in the previous K-tile
+        stage2(c_run);
+        n_st = (DG && c_run == 7) ? ES + 2 : ES;
+        c_run = -1;
+      }
+      const bool start = (c_next < 8 && pp == pp_next);
+      if (start) stage0(c_next, tail);
+      STREAM_READ_B(0)
+      __builtin_amdgcn_sched_barrier(0);
+      STREAM_READ_A()
+      STREAM_COMPUTE(0)
+      // ---- L(t,1)
+      STREAM_READ_B(1)
+      int n_x = 0;  // the epilogue's own LDS-DMA in this segment
+      if (start) {
+        stage1(c_next);
+        n_x = (DG || (GELU && c_next == 7)) ? 1 : 0;
+        c_run = c_next;
+        ++c_next;
+        pp_next = (c_next * KP) >> 3;
+      }
+      if (!tail) dma_ktile();
+      // K-tile t+1 must have landed; in flight may stay: this segment's 6 pieces and epilogue DMA, the stores of L(t,0)
+      if (tail) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        switch (n_st + n_x) {
+          case 0: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+          case 1: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+          case 3: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        }
+      }
+      STREAM_COMPUTE(1)
+      slot = (slot + 1 == ND) ? 0 : slot + 1;
+      ++t;
+    }
+    // ---- tile boundary (every chunk of the previous tile has finished: its last stage 2 ran in L(.,0) of a K-tile of this tile):
+    // scale / bias, ONE rounding to bf16 (where the reference's graph rounds), accumulators restart from zero
+    [[maybe_unused]] u32x4 biasv[4];
+    if constexpr (GELU) {
+      // the bias the last chunk's stage 1 requested (behind it at least one K-tile's 6 pieces and that chunk's two stores)
+      if (k + 1 == NT) {  // last tile: the ring's requests have run out, the count below does not apply
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + ES) : "memory");
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(biasv[j]) : "v"(park0 + (uint32_t)((16 * j + 4 * fq) * 4)) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(biasv[0]), "+v"(biasv[1]), "+v"(biasv[2]), "+v"(biasv[3])::"memory");
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      [[maybe_unused]] float bb[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (GELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bb[q] = a.round_bias_bf16 ? round_bf16(__uint_as_float(biasv[j][q])) : __uint_as_float(biasv[j][q]);
+      }
+      const float sc = (EPI == SAVIT_EPI_BF16 && c_col0 + wn * 64 + 16 * j + 4 * fq < a.alpha_cols) ? a.alpha : 1.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = acc[i][j];
+        if constexpr (EPI == SAVIT_EPI_BF16) v = v * sc;
+        old[i][j] = make_uint2(pack_bf16x2(v[0] + bb[0], v[1] + bb[1]), pack_bf16x2(v[2] + bb[2], v[3] + bb[3]));
+        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    o_row0 = c_row0;
+    o_col0 = c_col0;
+    if (k + 1 < NT) {
+      tile_rc(k + 1, c_row0, c_col0);
+    } else {
+      c_row0 = a.M;  // nothing follows: the last chunk's look-ahead request falls out of range
+    }
+  }
+#undef STREAM_READ_A
+#undef STREAM_READ_B
+#undef STREAM_COMPUTE
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count
+  // ---- drain the last tile (nothing left to overlap with)
+  for (int c = 0; c < 8; ++c) {
+    stage0(c, true);
+    stage1(c);
+    stage2(c);
+  }
+}
+
+int launch_stream(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  p.tiles_m = (p.a.M + 255) / 256;
+  p.tiles_n = p.a.N / 128;
+  p.row_group = p.tiles_m < 4 ? p.tiles_m : 4;  // 32 concurrent tiles per XCD = 4 A-panels x 8 W-panels (K = 768: 1.5 MB + 1.5 MB of L2)
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  const int ntiles = p.tiles_m * p.tiles_n;
+  int per = (cus + 7) / 8;  // workgroups per XCD: one per CU
+  if (per > (ntiles + 7) / 8) per = (ntiles + 7) / 8;
+  const dim3 grid(8 * per);
+  const size_t lds = 3 * (256 + 128) * 128 + 8 * 2048;
+#define SAVIT_LAUNCH_EPI(E)                                   \
+  case E: {                                                   \
+    auto kfn = gemm_tn_stream_kernel<E>;                      \
+    SAVIT_LDS_ONCE(kfn);                                      \
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, p);      \
+  } break;
+  switch (p.a.epilogue) {
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_BF16)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_BIAS_GELU)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_DGELU)
+    default: return SAVIT_EINVAL;
+  }
+#undef SAVIT_LAUNCH_EPI
+  SAVIT_LAUNCH_RET();
+}
+
+// what the streaming kernel takes: its three epilogues in their hot-path forms, whole 128-column tiles, at least 9 K-tiles per tile
+inline bool stream_ok(const savit_gemm_args& a) {
+  if (a.K % 64 != 0 || a.K < 576 || a.N % 128 != 0 || a.lda < a.K || a.M < 1) return false;
+  // 32-bit buffer offsets, also for the rows of a ragged last tile and of the "no tile yet" placeholder (row index < M + 512)
+  if ((size_t)(a.M + 512) * a.ldc * 2 > 0xffffffe0ull || a.ldc % 8 != 0 || a.rowscale != nullptr || a.colscale != nullptr) return false;
+  if (a.epilogue == SAVIT_EPI_BF16) return a.bias == nullptr;
+  if (a.epilogue == SAVIT_EPI_BIAS_GELU) return a.bias != nullptr && a.C2 != nullptr;
+  if (a.epilogue == SAVIT_EPI_DGELU) return a.aux != nullptr && a.ldaux % 8 == 0 && (size_t)(a.M + 512) * a.ldaux * 2 <= 0xffffffe0ull &&
+                                            (a.colsum == nullptr || a.colsum_rows > 0);
+  return false;
+}
+
 // row panels per group of the ping-pong kernel's tile order: as many 256-row A-panels (256 x K x 2 B) as fit in about 3 MB of the
 // XCD's 4 MB L2, at most 8 (K = 768: 8, K = 1024: 6, K >= 3072: 1 = plain row-major order).  Measured on DeiT-B with cold operands
 // (tools/gemm_epi_bench.py, G = 1 -> 8): qkv 104 -> 97 us, fc1+GELU 156 -> 145 us; the GELU' epilogue, which also READS a [M, N]
@@ -1276,6 +1725,7 @@ inline bool tile_geometry(int tile, int* bm, int* wgm) {
     case 3: *bm = 256; *wgm = 4; return true;
     case 17: case 18: *bm = 192; *wgm = 2; return true;
     case 20: *bm = 256; *wgm = 2; return true;
+    case 30: *bm = 256; *wgm = 4; return true;
     default: return false;
   }
 }
@@ -1345,6 +1795,7 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
     case 17: return a.K % 64 ? SAVIT_EINVAL : launch_pair<192, 128, 2, 2, 2>(p, s);
     case 18: return a.K % 64 ? SAVIT_EINVAL : launch_pair_tail<192, 128, 128, 2, 2, 2>(p, s);  // 17 with 128-row tiles for the last partial round
     case 20: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp(p, s);
+    case 30: return stream_ok(a) ? launch_stream(p, s) : SAVIT_EINVAL;
 #ifdef SAVIT_EXPERIMENTS
     // timing-only ablations of tile 20 (wrong results by construction; SAVIT_EPI_BF16 only) - never in the product library
     case 101: return launch_pp_ablation<1>(p, s);

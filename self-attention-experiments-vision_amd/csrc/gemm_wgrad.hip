@@ -33,6 +33,7 @@ struct WgradParams {
   float* slab;       // non-null: every split stores its partial tile to slab + split * slab_stride (dense [Kin, Nout]) with plain
   long slab_stride;  // stores and wgrad_reduce_kernel sums the splits into dW: no atomics, bitwise reproducible
   int no_reduce;     // slab form only: leave the ordered sum to a later savit_gemm_wgrad_reduce call
+  int rmw;           // grouped launches (one workgroup per output tile, no split): dW += tile with plain loads / stores
 };
 
 __device__ __forceinline__ bf16x4 ds_read_tr16_b64(const char* p) {
@@ -209,8 +210,9 @@ __global__ __launch_bounds__(64 * WGI * WGJ) void gemm_wgrad_kernel(const WgradP
 // flight across the per-stage barrier) and register-prefetched transposed fragments (the fragments of k-step t+1 are
 // read from LDS while the MFMAs of k-step t issue).  One barrier per stage, placed between its two k-steps: every read
 // of a stage's slot is issued before that barrier, so the slot is refilled right after it.
+// One output tile (ti, tj) of one token range (`split`): the body shared by the single-problem kernel and the grouped one.
 template <int BI, int BJ, int WGI, int WGJ, int S, bool PATCH>
-__global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_ring_kernel(const WgradParams p) {
+__device__ __forceinline__ void wgrad_ring_tile(const WgradParams& p, const int split, const int ti, const int tj, char* smem) {
   constexpr int NW = WGI * WGJ;
   constexpr int TS = 32;  // tokens per stage
   constexpr int WTI = BI / WGI, WTJ = BJ / WGJ;
@@ -220,19 +222,10 @@ __global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_ring_kernel(cons
   constexpr int X_INSTR = X_BYTES / 1024 / NW, Y_INSTR = Y_BYTES / 1024 / NW, G = X_INSTR + Y_INSTR;
   static_assert(X_BYTES % (1024 * NW) == 0 && Y_BYTES % (1024 * NW) == 0, "tile/wave mismatch");
   static_assert(G * (S - 1) <= 63, "vmcnt immediate");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wi = wave / WGJ, wj = wave % WGJ;
-  // 1-D grid, XCD-aware: consecutive remapped ids = the tiles of ONE token range (split), so the workgroups that
-  // stream the same X / dY rows sit on the same XCD and share them through its L2 (measured before the remap: 653 MB
-  // of L2 misses per launch for 194 MB of operands - every XCD re-fetched every token range).
-  const int ntile = p.tiles_i * p.tiles_j;
-  const int wid = xcd_remap(blockIdx.x, ntile * p.splits);
-  const int split = wid / ntile;
-  const int tid = wid - split * ntile;
-  const int ti = tid / p.tiles_j, tj = tid - ti * p.tiles_j;
   const int i0 = ti * BI, j0 = tj * BJ;
   const int st_total = (p.M + TS - 1) / TS;
   const int st_begin = split * p.tiles_per_split;  // in 32-token stages
@@ -407,6 +400,28 @@ __global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_ring_kernel(cons
 #endif
 
   const int jl = lane & 31, hi5 = lane >> 5;
+  if (p.rmw) {
+    // the tile IS the whole sum over the tokens (no split): dW += tile, read-modify-write with plain accesses (one accumulator
+    // register = 2 rows x 128 B: whole lines per wave-instruction); no other workgroup touches these elements
+#pragma unroll
+    for (int a = 0; a < II; ++a)
+#pragma unroll
+      for (int b = 0; b < JJ; ++b) {
+        const int j = j0 + wj * WTJ + 32 * b + jl;
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = i0 + wi * WTI + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi5;
+          old[r] = (i < p.Kin && j < p.Nout) ? p.dW[(size_t)i * p.lddw + j] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = i0 + wi * WTI + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi5;
+          if (i < p.Kin && j < p.Nout) p.dW[(size_t)i * p.lddw + j] = old[r] + acc[a][b][r];
+        }
+      }
+    return;
+  }
   if (p.slab != nullptr) {
     // one accumulator register = 2 rows x 128 B: whole lines per wave-instruction, the shape plain dword stores run at the HBM rate with
     float* out = p.slab + (size_t)split * p.slab_stride;
@@ -434,6 +449,63 @@ __global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_ring_kernel(cons
         if (i < p.Kin && j < p.Nout) atomicAdd(p.dW + (size_t)i * p.lddw + j, acc[a][b][r]);
       }
     }
+}
+
+template <int BI, int BJ, int WGI, int WGJ, int S, bool PATCH>
+__global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_ring_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // 1-D grid, XCD-aware: consecutive remapped ids = the tiles of ONE token range (split), so the workgroups that
+  // stream the same X / dY rows sit on the same XCD and share them through its L2 (measured before the remap: 653 MB
+  // of L2 misses per launch for 194 MB of operands - every XCD re-fetched every token range).
+  const int ntile = p.tiles_i * p.tiles_j;
+  const int wid = xcd_remap(blockIdx.x, ntile * p.splits);
+  const int split = wid / ntile;
+  const int tid = wid - split * ntile;
+  const int ti = tid / p.tiles_j;
+  wgrad_ring_tile<BI, BJ, WGI, WGJ, S, PATCH>(p, split, ti, tid - ti * p.tiles_j, smem);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Grouped launch: the weight gradients of SEVERAL Dense kernels (the four of an encoder layer, of one or more layers) in ONE grid,
+// one workgroup per 256 x 256 (or 128 x 128) output tile, each reducing over ALL tokens.  A single weight gradient has too few
+// output tiles for the chip (DeiT-B's W1: 36 tiles of 256 x 256 on 256 CUs), which is why the single-problem launch splits the
+// token range 7 ways - and then pays for it: 7 partial slabs of the whole matrix written and read again (65 MB per launch, 1.75 x
+// the algorithmic traffic) plus an ordered-sum launch.  Together the four gradients of two DeiT-B layers are 216 tiles: one tile
+// per workgroup fills 84 % of the CUs with NO split, no slab, no second launch, the long reduction (788 stages) amortises the
+// prologue, and the result is still a fixed-order sum (bitwise reproducible).  The weight gradients have no consumer before the
+// optimizer step, so the engine is free to compute them a layer or two after their operands are produced.
+constexpr int WGRAD_GROUP_MAX = 16;
+struct WgradGroupParams {
+  int n;
+  int tile_end[WGRAD_GROUP_MAX];  // tiles of problems 0 .. i (prefix sums)
+  struct {
+    const bf16_t* X;
+    const bf16_t* dY;
+    float* dW;
+    int M, Kin, Nout, ldx, lddy, lddw;
+  } pr[WGRAD_GROUP_MAX];
+};
+
+template <int BI, int BJ, int WGI, int WGJ, int S>
+__global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_group_kernel(const WgradGroupParams g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // XCD-aware: each XCD takes a contiguous run of the tile list (problem-major, then row tile, then column tile), i.e. tiles that
+  // stream the same X columns / dY columns of the same problem share them through that XCD's L2
+  const int wid = xcd_remap(blockIdx.x, g.tile_end[g.n - 1]);
+  int pi = 0;
+  while (wid >= g.tile_end[pi]) ++pi;  // uniform: scalar loop over at most WGRAD_GROUP_MAX entries
+  const int t = wid - (pi ? g.tile_end[pi - 1] : 0);
+  WgradParams p{};
+  p.X = g.pr[pi].X; p.dY = g.pr[pi].dY; p.dW = g.pr[pi].dW;
+  p.M = g.pr[pi].M; p.Kin = g.pr[pi].Kin; p.Nout = g.pr[pi].Nout;
+  p.ldx = g.pr[pi].ldx; p.lddy = g.pr[pi].lddy; p.lddw = g.pr[pi].lddw;
+  p.tiles_i = (p.Kin + BI - 1) / BI;
+  p.tiles_j = (p.Nout + BJ - 1) / BJ;
+  p.splits = 1;
+  p.tiles_per_split = (p.M + 31) / 32;
+  p.rmw = 1;
+  const int ti = t / p.tiles_j;
+  wgrad_ring_tile<BI, BJ, WGI, WGJ, S, false>(p, 0, ti, t - ti * p.tiles_j, smem);
 }
 
 // dW[i, j] += sum over splits of slab[s][i][j], splits added in index order (fixed order: the result is bitwise reproducible).
@@ -662,4 +734,42 @@ static int wgrad_dispatch(const void* X, const void* dY, float* dW, int M, int K
       p.slab = nullptr;
       return launch_wgrad<128, 128, 2, 2>(p, (hipStream_t)stream);
   }
+}
+
+// ---- grouped weight gradients (see gemm_wgrad_group_kernel)
+extern "C" int savit_gemm_wgrad_group_tiles(int Kin, int Nout, int tile) {
+  if (Kin <= 0 || Nout <= 0 || (tile != 128 && tile != 256)) return 0;
+  return ((Kin + tile - 1) / tile) * ((Nout + tile - 1) / tile);
+}
+
+extern "C" int savit_gemm_bf16_wgrad_grouped(const savit_wgrad_problem* problems, int count, int tile, void* stream) {
+  SAVIT_CHECK_ARG(problems != nullptr && count >= 1 && count <= WGRAD_GROUP_MAX && (tile == 128 || tile == 256));
+  WgradGroupParams g{};
+  int tiles = 0, n = 0;
+  for (int i = 0; i < count; ++i) {
+    const savit_wgrad_problem& q = problems[i];
+    SAVIT_CHECK_ARG(q.X && q.dY && q.dW && q.M >= 0 && q.Kin > 0 && q.Nout > 0 && q.lddw >= q.Nout);
+    SAVIT_CHECK_ARG(q.Kin % 8 == 0 && q.Nout % 8 == 0 && q.ldx % 8 == 0 && q.ldx >= q.Kin && q.lddy % 8 == 0 && q.lddy >= q.Nout);
+    SAVIT_CHECK_ARG(((uintptr_t)q.X % 16) == 0 && ((uintptr_t)q.dY % 16) == 0 && ((uintptr_t)q.dW % 4) == 0);
+    SAVIT_CHECK_ARG((size_t)q.M * q.ldx * 2 <= 0xffffffe0ull && (size_t)q.M * q.lddy * 2 <= 0xffffffe0ull);  // 32-bit buffer offsets
+    if (q.M == 0) continue;  // nothing to add
+    tiles += savit_gemm_wgrad_group_tiles(q.Kin, q.Nout, tile);
+    g.tile_end[n] = tiles;
+    g.pr[n].X = (const bf16_t*)q.X; g.pr[n].dY = (const bf16_t*)q.dY; g.pr[n].dW = q.dW;
+    g.pr[n].M = q.M; g.pr[n].Kin = q.Kin; g.pr[n].Nout = q.Nout; g.pr[n].ldx = q.ldx; g.pr[n].lddy = q.lddy; g.pr[n].lddw = q.lddw;
+    ++n;
+  }
+  if (n == 0) return SAVIT_OK;
+  g.n = n;
+  for (int i = n; i < WGRAD_GROUP_MAX; ++i) g.tile_end[i] = tiles;
+  if (tile == 256) {
+    auto kfn = gemm_wgrad_group_kernel<256, 256, 2, 4, 4>;
+    SAVIT_LDS_ONCE(kfn);
+    hipLaunchKernelGGL(kfn, dim3(tiles), dim3(512), (size_t)4 * 32 * (256 + 256) * 2, (hipStream_t)stream, g);
+  } else {
+    auto kfn = gemm_wgrad_group_kernel<128, 128, 2, 2, 4>;
+    SAVIT_LDS_ONCE(kfn);
+    hipLaunchKernelGGL(kfn, dim3(tiles), dim3(256), (size_t)4 * 32 * (128 + 128) * 2, (hipStream_t)stream, g);
+  }
+  SAVIT_LAUNCH_RET();
 }

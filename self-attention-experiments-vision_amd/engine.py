@@ -152,7 +152,7 @@ class _Plan:
         self.calls: List[Tuple[Callable, tuple, str]] = []
         self.keep: List[object] = []  # ctypes structs that must outlive the plan
         self.ws_requests: List[Tuple[int, int, int, int]] = []  # (call index, workspace key, bytes, argument position): add_wgrad
-        self.hook_alias: Dict[str, str] = {}     # launch label -> label whose hook fires behind THIS launch instead (add_wgrad)
+        self.hook_alias: Dict[str, List[str]] = {}  # launch label -> labels whose hooks fire behind THIS launch instead (add_wgrad, wgrad groups)
         self.side: Dict[int, int] = {}           # call index -> side-launch ordinal (stream = ordinal % number of side streams)
         self.guard: Dict[int, List[int]] = {}    # main call index -> side call indices that must have finished first
         self._readers: Dict[int, List[int]] = {}  # buffer address -> side calls reading it (build-time bookkeeping)
@@ -177,11 +177,21 @@ class _Plan:
         """The hook to run right behind the launch `label`: a label that has an alias target fires there, not here."""
         if not hooks:
             return None
-        if label in self.hook_alias:
-            return hooks.get(self.hook_alias[label])
-        if label in self.hook_alias.values():
+        names = self.hook_alias.get(label)
+        if names is None:
+            if any(label in v for v in self.hook_alias.values()):
+                return None  # deferred: fires behind another launch
+            return hooks.get(label)
+        cbs = [hooks[n] for n in names if n in hooks]
+        if not cbs:
             return None
-        return hooks.get(label)
+        if len(cbs) == 1:
+            return cbs[0]
+
+        def fire():
+            for cb in cbs:
+                cb()
+        return fire
 
     def run(self, stream: int):
         for fn, args, label in self.calls:
@@ -249,7 +259,25 @@ def add_wgrad(eng, plan: _Plan, label: str, X, dY, dW, Mr, Kin, Nout, ldx, lddy,
     plan.ws_requests.append((len(plan.calls) - 1, key, need, -2))
     plan.add(eng.L.savit_gemm_wgrad_reduce, (None, nsplit, Kin, Nout, dW, lddw), label + ".reduce", side=side, same_side_stream=True)
     plan.ws_requests.append((len(plan.calls) - 1, key, need, 0))
-    plan.hook_alias[label + ".reduce"] = label  # a hook registered for `label` (DDP bucket trigger) fires behind the reduce
+    plan.hook_alias[label + ".reduce"] = [label]  # a hook registered for `label` (DDP bucket trigger) fires behind the reduce
+
+
+def add_wgrad_group(eng, plan: _Plan, label: str, problems: list, tile: int, deferred_hooks: list, side: bool = True):
+    """Record ONE grouped weight-gradient launch (savit_gemm_bf16_wgrad_grouped) for `problems` = [(X, dY, dW, M, Kin, Nout, ldx, lddy,
+    lddw)]: one workgroup per output tile over all tokens - no split, no slabs, no reduce launch.  `deferred_hooks`: labels of
+    earlier launches whose hooks (DDP bucket triggers) must wait for these gradients; they fire behind this launch."""
+    arr = (_lib.WgradProblem * len(problems))()
+    flops = 0.0
+    for q, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw) in zip(arr, problems):
+        q.X, q.dY, q.dW, q.M, q.Kin, q.Nout, q.ldx, q.lddy, q.lddw = X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw
+        flops += 2.0 * Mr * Kin * Nout
+    plan.keep.append(arr)
+    plan.add(eng.L.savit_gemm_bf16_wgrad_grouped, (arr, len(problems), tile), label, side=side, reads=tuple(q[1] for q in problems) if side else ())
+    if deferred_hooks:
+        plan.hook_alias[label] = list(deferred_hooks)
+    if not hasattr(eng, "group_flops"):
+        eng.group_flops = {}
+    eng.group_flops[label] = flops
 
 
 def finalize_wgrad_ws(eng, plan: _Plan):
@@ -325,8 +353,11 @@ class ViTEngine:
         self.fstats = e(2, self.B)
         # ---- backward scratch
         self.dres = e(M, d)
-        # scratch that the side-stream weight-gradient GEMMs read is rotated, so the main chain rarely has to wait for them
-        depth = max(2, int(os.environ.get("SAVIT_RING_DEPTH", "2")))  # layers the side streams may lag behind the main chain
+        # Weight gradients of `wgrad_group` consecutive layers are computed by ONE grouped launch (add_wgrad_group) once the last of
+        # them has produced its cotangents: those cotangent buffers therefore rotate through rings `wgrad_group` layers deep (also
+        # what lets side-stream weight-gradient GEMMs lag behind the main chain).
+        self.wgrad_tile, self.wgrad_group = self._wgrad_group_plan()
+        depth = max(2, int(os.environ.get("SAVIT_RING_DEPTH", "2")), self.wgrad_group)
         self.dres_b_ring = [e(M, d, dt=bf16) for _ in range(2 * depth)]
         self.dres_b = self.dres_b_ring[0]
         self.d_u_ring = [e(M, F, dt=bf16) for _ in range(depth)]
@@ -490,9 +521,27 @@ class ViTEngine:
         gp = lambda n: self._off_ptr(self.grads, n)  # noqa: E731
         ws, wsb = self.ln_ws.data_ptr(), self.ln_ws.numel()
 
-        def wgrad(label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0)):
+        group: List[tuple] = []       # pending problems of the current weight-gradient group
+        group_layers: List[int] = []  # layers they belong to
+
+        def wgrad(label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0), layer=None):
             # no later launch consumes dW: side stream.  X is a saved activation (stable until the next forward), dY is scratch
+            if layer is not None and self.wgrad_group > 0:
+                group.append((X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw))
+                if layer not in group_layers:
+                    group_layers.append(layer)
+                return
             self._add_wgrad(P, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, self._wgrad_splits(Kin, Nout, patch[0]), patch)
+
+        def flush_group(last: bool):
+            # called between a layer's last input-gradient GEMM and its ln1.bwd (which overwrites the oldest ring slot): every
+            # cotangent of the group's layers is still intact.  The DDP triggers of the group's EARLIER layers ('l{j}.ln1.bwd', already
+            # launched) fire behind this launch; the current layer's own trigger follows naturally.
+            if group and (last or len(group_layers) >= self.wgrad_group):
+                add_wgrad_group(self, P, f"wgrad.group.l{group_layers[0]}-l{group_layers[-1]}", list(group), self.wgrad_tile,
+                                [f"l{j}.ln1.bwd" for j in group_layers[:-1]])
+                group.clear()
+                group_layers.clear()
 
         ring, ri = [t.data_ptr() for t in self.dres_b_ring], 0
         # ---- head: dWh, d z_cls, final LayerNorm backward into the (zeroed) residual gradient
@@ -507,14 +556,14 @@ class ViTEngine:
             w = lambda n, l=l: self.w[n][l].data_ptr()  # noqa: E731
             d_u, dqkv = self.d_u_ring[l % len(self.d_u_ring)].data_ptr(), self.dqkv_ring[l % len(self.dqkv_ring)].data_ptr()
             # FFN branch: x_{l+1} = x_mid + gelu(h2 W1 + b1) W2 + b2     (ff.py:26-33, vit.py:26-31)
-            wgrad(f"l{l}.W2.wgrad", self.a[l].data_ptr(), ring[ri], gp(f"l{l}.W2"), M, F, d, F, d, d)
+            wgrad(f"l{l}.W2.wgrad", self.a[l].data_ptr(), ring[ri], gp(f"l{l}.W2"), M, F, d, F, d, d, layer=l)
             # db1 = column sums of d_u: per-row-tile partials (plain stores) + a finalize launch; ~200 row tiles adding into the
             # same F addresses with atomics serialise at the memory side (16 us of this 180 us launch), and this is reproducible
             self._gemm(P, f"l{l}.fc2.dgrad", writes=(d_u,), A=ring[ri], Bt=w("W2_n"), C=d_u, aux=self.u[l].data_ptr(),
                        colsum=self.colsum_slab.data_ptr(), colsum_rows=self.colsum_slab.shape[0], M=M, N=F, K=d, lda=d, ldb=d, ldc=F,
                        ldaux=F, epilogue=_lib.EPI_DGELU)
             P.add(L.savit_colsum_finalize, (self.colsum_slab.data_ptr(), self.colsum_slab.shape[0], F, gp(f"l{l}.b1"), 1), f"l{l}.b1.grad")
-            wgrad(f"l{l}.W1.wgrad", self.h2[l].data_ptr(), d_u, gp(f"l{l}.W1"), M, d, F, d, F, F)
+            wgrad(f"l{l}.W1.wgrad", self.h2[l].data_ptr(), d_u, gp(f"l{l}.W1"), M, d, F, d, F, F, layer=l)
             self._gemm(P, f"l{l}.fc1.dgrad", A=d_u, Bt=w("W1_n"), C=self.d_h.data_ptr(), M=M, N=d, K=F, lda=F, ldb=F,
                        ldc=d, epilogue=_lib.EPI_BF16)
             ri = (ri + 1) % len(ring)
@@ -522,15 +571,16 @@ class ViTEngine:
                                           self.dres.data_ptr(), self.dres.data_ptr(), ring[ri], gp(f"l{l}.ln2_g"),
                                           gp(f"l{l}.ln2_b"), None, M, d, d, d, self.rp, ws, wsb), f"l{l}.ln2.bwd", writes=(ring[ri],))
             # attention branch: x_mid = x_l + attn(LN1(x_l)) Wo     (attention.py:21-67, vit.py:19-24)
-            wgrad(f"l{l}.Wo.wgrad", self.o[l].data_ptr(), ring[ri], gp(f"l{l}.Wo"), M, d, d, d, d, d)
+            wgrad(f"l{l}.Wo.wgrad", self.o[l].data_ptr(), ring[ri], gp(f"l{l}.Wo"), M, d, d, d, d, d, layer=l)
             self._gemm(P, f"l{l}.proj.dgrad", A=ring[ri], Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=M, N=d, K=d, lda=d, ldb=d,
                        ldc=d, epilogue=_lib.EPI_BF16)
             P.add(L.savit_attention_bwd, (self.qkv[l].data_ptr(), self.o[l].data_ptr(), self.d_o.data_ptr(), self.lse[l].data_ptr(),
                                           dqkv, B, N, H, cfg.head_dim, 3 * d, 1.0 / math.sqrt(cfg.head_dim)), f"l{l}.attn.bwd",
                   writes=(dqkv,))
-            wgrad(f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), dqkv, gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d)
+            wgrad(f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), dqkv, gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d, layer=l)
             self._gemm(P, f"l{l}.qkv.dgrad", A=dqkv, Bt=w("Wqkv_n"), C=self.d_h.data_ptr(), M=M, N=d, K=3 * d, lda=3 * d,
                        ldb=3 * d, ldc=d, epilogue=_lib.EPI_BF16)
+            flush_group(last=(l == 0))
             ri = (ri + 1) % len(ring)
             P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
                                           self.dres.data_ptr(), self.dres.data_ptr(), ring[ri], gp(f"l{l}.ln1_g"),
@@ -546,6 +596,30 @@ class ViTEngine:
     def _add_wgrad(self, plan: "_Plan", label: str, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, splits: int, patch=(0, 0, 0, 0),
                    side: bool = True):
         add_wgrad(self, plan, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, splits, patch, side)
+
+    def _wgrad_group_plan(self) -> Tuple[int, int]:
+        """(tile, layers per grouped weight-gradient launch); (0, 0) = one launch per weight (split over the tokens, slabs + reduce).
+        A layer's four weight gradients are d x 3d, d x d, d x F, F x d: with 256 x 256 tiles DeiT-B has 108 tiles per layer, ViT-L 192 -
+        too few for 256 CUs one layer at a time, so layers are grouped until the tiles fill whole rounds of the CUs: the smallest
+        group size (at most 4 layers) with the best fill.  SAVIT_WGRAD_GROUP=0 / N overrides (0 = off)."""
+        cfg = self.cfg
+        d, F = cfg.embed_dim, cfg.hidden
+        env = os.environ.get("SAVIT_WGRAD_GROUP", "auto")
+        if env == "0" or (d % 256 or F % 256) and env == "auto":
+            return 0, 0  # narrower models keep the per-weight launches (128 x 128 tiles, measured per model: DESIGN.md)
+        tile = 256 if (d % 256 == 0 and F % 256 == 0) else 128
+        per_layer = sum(int(self.L.savit_gemm_wgrad_group_tiles(a, b, tile)) for a, b in ((d, 3 * d), (d, d), (d, F), (F, d)))
+        if env != "auto":
+            return tile, max(1, min(int(env), cfg.num_layers, 16 // 4))
+        n_cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        slots = n_cus * (1 if tile == 256 else 2)
+        best, best_fill = 1, 0.0
+        for g in range(1, min(4, cfg.num_layers) + 1):
+            t = g * per_layer
+            fill = t / (-(-t // slots) * slots)
+            if fill > best_fill + 0.02:
+                best, best_fill = g, fill
+        return tile, best
 
     def _wgrad_splits(self, Kin: int, Nout: int, patch: int) -> int:
         """K-splits of a weight-gradient GEMM.  On its own a launch wants every CU (0 = the library's choice); beside the

@@ -29,6 +29,12 @@ class GemmArgs(Structure):
     ]
 
 
+class WgradProblem(Structure):
+    """Mirror of `savit_wgrad_problem` (include/savit.h)."""
+    _fields_ = [("X", c_void_p), ("dY", c_void_p), ("dW", c_void_p), ("M", c_int), ("Kin", c_int), ("Nout", c_int), ("ldx", c_int),
+                ("lddy", c_int), ("lddw", c_int)]
+
+
 # name -> (restype, argtypes); every symbol include/savit.h declares must be here (tests check both ways)
 _SIGNATURES = {
     "savit_abi_version": (c_int, []),
@@ -57,6 +63,8 @@ _SIGNATURES = {
                                               c_void_p, c_long, c_void_p]),
     "savit_gemm_wgrad_reduce": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "savit_gemm_wgrad_split_count": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "savit_gemm_bf16_wgrad_grouped": (c_int, [POINTER(WgradProblem), c_int, c_int, c_void_p]),
+    "savit_gemm_wgrad_group_tiles": (c_int, [c_int, c_int, c_int]),
     "savit_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "savit_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                     c_void_p]),

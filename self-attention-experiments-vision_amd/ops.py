@@ -250,6 +250,23 @@ def gemm_wgrad(X: torch.Tensor, dY: torch.Tensor, dW: torch.Tensor, splits: int 
     return dW
 
 
+def gemm_wgrad_grouped(problems, tile: int = 256):
+    """dW_i += X_i^T @ dY_i for every (X_i, dY_i, dW_i) of `problems` in ONE launch, one workgroup per tile x tile output tile, each
+    reducing over all rows (no split, no slabs; savit_gemm_bf16_wgrad_grouped).  At most 16 problems."""
+    arr = (_lib.WgradProblem * len(problems))()
+    for q, (X, dY, dW) in zip(arr, problems):
+        _chk(X, bf16, "X", 2)
+        _chk(dY, bf16, "dY", 2)
+        _chk(dW, f32, "dW", 2)
+        Kin, Nout, lddw = _rows2d(dW, "dW")
+        Mv, kx, ldx = _rows2d(X, "X")
+        ry, cy, lddy = _rows2d(dY, "dY")
+        if kx < Kin or cy < Nout or ry < Mv:
+            raise ValueError("operand shapes do not match dW")
+        q.X, q.dY, q.dW, q.M, q.Kin, q.Nout, q.ldx, q.lddy, q.lddw = _p(X), _p(dY), _p(dW), Mv, Kin, Nout, ldx, lddy, lddw
+    _lib.check(_lib.load().savit_gemm_bf16_wgrad_grouped(arr, len(problems), int(tile), _stream()), "savit_gemm_bf16_wgrad_grouped")
+
+
 def wgrad_workspace(M: int, Kin: int, Nout: int, splits: int = 0, patch: int = 0, device="cuda") -> torch.Tensor:
     """Scratch for gemm_wgrad(..., workspace=...): one partial [Kin, Nout] fp32 slab per split of the reduction over M."""
     n = int(_lib.load().savit_gemm_wgrad_workspace_bytes(int(M), int(Kin), int(Nout), int(splits), int(patch)))

@@ -77,10 +77,17 @@ BLOCK_BARS = {  # measured (gpurun_out/r2d/parity.log):          logits f64 | bf
 }
 
 
-# engine vs the oracle evaluated with the engine's own rounding points (`logits_engine`): ~1.5x measured (round 3)
+# engine vs the oracle evaluated with the engine's own rounding points (`logits_engine`): ~1.5x measured (round 3; MI355X:
+# d768 4.48e-3, d1024 5.58e-3, CaiT block 6.26e-3, e2e CaiT 4.96e-3, the rest < 4e-3).  These are NOT at the "summation order" level
+# (1e-6) the policy was built to expose, and cannot be: evaluating this very policy on the CPU with fp64 instead of fp32 accumulation -
+# identical rounding points, only the summation precision differs - moves the logits of the same blocks by 3.4e-3 (d 192) and 4.7e-3
+# (d 768).  A 1e-6 difference flips one bf16 rounding in 4 000; every flip is a 4e-3 perturbation of that element, which flips 1 in
+# 100 of the next tensor's roundings, and so on: within the half dozen rounding stages of ONE encoder block any two evaluations
+# decorrelate to the bf16 noise floor.  Parity below that floor is a per-kernel property (tests/test_kernels_gpu.py: each kernel
+# against exact math with its own operand roundings emulated, 1e-4 ... 1e-3).
 ENGINE_POLICY_BARS = {
-    "block_d192_n197": 4e-3, "block_d384_n197": 4e-3, "block_d768_n197": 4e-3, "block_d1024_n577": 4e-3, "block_cait_d384_n196": 4e-3,
-    "e2e_vit_d128": 4e-3, "e2e_cait_d128": 4e-3, "e2e_mixer_d128": 1e-2, "e2e_tnt_d128": 1.5e-2,
+    "block_d192_n197": 4e-3, "block_d384_n197": 4e-3, "block_d768_n197": 6.8e-3, "block_d1024_n577": 8.4e-3,
+    "block_cait_d384_n196": 9.4e-3, "e2e_vit_d128": 4e-3, "e2e_cait_d128": 7.5e-3, "e2e_mixer_d128": 1e-2, "e2e_tnt_d128": 1.5e-2,
 }
 
 

@@ -235,7 +235,7 @@ def test_gemm_dgelu_colsum_slab_is_deterministic(ops, tile):
         ops.gemm_tn(dev(dy, bf16), dev(W2, bf16), dU, 3, aux=dev(u, bf16), colsum=slab[:-1], tile=tile)
 
 
-def _epi_case(ops, rng_seed, M, N, K, epi, tile):
+def _epi_case(ops, rng_seed, M, N, K, epi, tile, plain_bias=True):
     """One launch of every fused epilogue on seeded operands; returns (outputs, fp64 reference of the main output)."""
     g = torch.Generator(device="cuda").manual_seed(rng_seed)
     A = torch.randn(M, K, device="cuda", generator=g).to(bf16)
@@ -244,7 +244,13 @@ def _epi_case(ops, rng_seed, M, N, K, epi, tile):
     ref = (A.double() @ Bt.double().T).cpu().numpy()
     bias_r = rb(bias.cpu().numpy())
     kw, outs = {}, []
-    if epi == 0:
+    if epi == 0 and not plain_bias:  # the qkv form: no bias, the first third of the columns scaled (attention.py:39)
+        C = torch.full((M, N), float("nan"), device="cuda", dtype=bf16)
+        kw = dict(alpha=0.125, alpha_cols=N // 3 // 128 * 128)
+        want = ref.copy()
+        want[:, :kw["alpha_cols"]] *= 0.125
+        want = rb(want)
+    elif epi == 0:
         C = torch.full((M, N), float("nan"), device="cuda", dtype=bf16)
         kw = dict(bias=bias)
         want = rb(ref + bias_r)
@@ -301,6 +307,33 @@ def test_gemm_large_grid_tiles_vs_oracle_and_each_other(ops, epi, M, N, K):
                 assert torch.equal(x, y), (a, b, i)
     if epi != 3:
         assert torch.equal(got[17][0], got[13][0])  # 192x128 and 256x256 tiles also agree bit for bit (same K order)
+
+
+@pytest.mark.parametrize("epi", [0, 1, 3])
+@pytest.mark.parametrize("M,N,K", [(19700, 1536, 768), (3001, 1024, 512), (300, 128, 1024), (25216, 2304, 768), (6000, 768, 2304),
+                                   (777, 3072, 640)])
+def test_gemm_stream_tile(ops, epi, M, N, K):
+    """Tile 30 - the persistent 256 x 128 kernel that drains tile t's epilogue between the MFMAs of tile t + 1 - on its three
+    epilogues (qkv: scaled columns, no bias; fc1: bias + GELU, two outputs; fc2 input gradient: GELU' x cotangent + column-sum
+    slab): against exact fp64 math on the same bf16 operands and BITWISE against the 256 x 256 pair kernel (tile 13, same K order).
+    Shapes: K-loops of 8, 10, 12, 16 and 36 pairs (every pattern of chunk pairs next to / apart from each other), a ragged last row
+    tile, fewer tiles than CUs, one column tile, and seven tiles per workgroup (the continuous pipeline across tile boundaries)."""
+    got = {}
+    for tile in (13, 30):
+        outs, want = _epi_case(ops, 77 * epi + K, M, N, K, epi, tile, plain_bias=False)
+        assert all(torch.isfinite(o.float()).all() for o in outs), (tile, "an output element was not written")
+        e = rel(host(outs[0]), want)
+        assert e < 1e-3, (tile, e)
+        got[tile] = outs
+    for i, (x, y) in enumerate(zip(got[13], got[30])):
+        if epi == 3 and i == 1:
+            assert rel(host(x).sum(0), host(y).sum(0)) < 1e-6  # slabs of different heights: compare the column sums
+        else:
+            assert torch.equal(x, y), (i, int((x != y).sum()))
+    # the same launch again: bitwise repeatable
+    outs2, _ = _epi_case(ops, 77 * epi + K, M, N, K, epi, 30, plain_bias=False)
+    for x, y in zip(got[30], outs2):
+        assert torch.equal(x, y)
 
 
 def test_gemm_f32_head(ops):
@@ -372,6 +405,38 @@ def test_wgrad_slab_reduction(ops, M, Kin, Nout, splits):
     dW2 = base.clone()
     ops.gemm_wgrad(X, dY, dW2, splits=splits, workspace=small)
     assert rel(host(dW2) - host(base), ref) < 2e-5
+
+
+@pytest.mark.parametrize("tile", [256, 128])
+def test_wgrad_grouped_matches_fp64_and_is_reproducible(ops, tile):
+    """savit_gemm_bf16_wgrad_grouped: several weight gradients in one launch, one workgroup per output tile over ALL tokens.  Each
+    dW: the fp64 product within fp32 summation error, accumulated onto its old value, bitwise repeatable; ragged Kin / Nout (tiles
+    that hang over the matrix edge), a column slice of a wider dY (lddy > Nout), different M per problem."""
+    rng = np.random.default_rng(tile)
+    shapes = [(1999, 768, 1024), (1999, 256, 256), (3001, 192, 576), (517, 384, 1000), (64, 128, 128), (2048, 1024, 256)]
+    probs, refs, bases = [], [], []
+    for i, (M, Kin, Nout) in enumerate(shapes):
+        X = dev(_mk(rng, M, Kin), bf16)
+        wide = dev(_mk(rng, M, Nout + 64), bf16)
+        dY = wide[:, 32:32 + Nout] if i % 2 else dev(_mk(rng, M, Nout), bf16)
+        base = torch.randn((Kin, Nout), dtype=torch.float32, device="cuda")
+        probs.append((X, dY, base.clone()))
+        bases.append(base)
+        refs.append(host(X).astype(np.float64).T @ host(dY).astype(np.float64))
+    ops.gemm_wgrad_grouped(probs, tile=tile)
+    for (X, dY, dW), base, ref in zip(probs, bases, refs):
+        assert rel(host(dW) - host(base), ref) < 2e-5
+    again = [(X, dY, base.clone()) for (X, dY, _), base in zip(probs, bases)]
+    ops.gemm_wgrad_grouped(again, tile=tile)
+    for (_, _, a), (_, _, b) in zip(probs, again):
+        assert torch.equal(a, b)
+    ops.gemm_wgrad_grouped(probs, tile=tile)  # accumulates
+    for (X, dY, dW), base, ref in zip(probs, bases, refs):
+        assert rel(host(dW) - host(base), 2 * ref) < 2e-5
+    with pytest.raises(ValueError):
+        ops.gemm_wgrad_grouped(probs * 3, tile=tile)  # more than 16 problems
+    with pytest.raises(ValueError):
+        ops.gemm_wgrad_grouped(probs[:1], tile=192)
 
 
 def test_wgrad_padded_dy_columns(ops):
