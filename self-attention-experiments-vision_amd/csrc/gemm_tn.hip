@@ -1447,6 +1447,207 @@ inline bool stream_ok(const savit_gemm_args& a) {
   return false;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Ping-pong variant with 320-row tiles (tile 21: 320 x 256 x 64, 8 waves = 2 (M) x 4 (N), wave tile 160 x 64).  Why 320: the N = 768
+// products of DeiT-B (proj, fc2 and the three input-gradient GEMMs that end in d columns: 5 of the 8 TN GEMMs of a layer) have
+// M = 25 216 rows: 256-row tiles are 99 x 3 = 297 workgroups - 1.16 rounds of the 256 CUs, so the 192 x 128 tiles ran instead
+// (792 + tail) and paid for it in operand feed: (192 + 128) x 128 B per 4-wave K-tile step = 52 B per MFMA-pipe cycle and CU against
+// 31 for 256 x 256 - and the L2 -> LDS path of a CU (about 70 GB/s), not the matrix pipe, is what bounds these kernels.
+// 320-row tiles are 79 x 3 = 237 workgroups: ONE round at 93 % fill, no tail, and 72 KB per 2 560 pipe cycles = 28 B per cycle.
+// Same structure and proofs as gemm_tn_pp_kernel; what changes:
+//   LDS: 2 buffers x 72 KB; a buffer = 9 units of 64 rows: A0..A4 (rows 0-319) and B0..B3 (B(wc) = the Bt rows of N-quarter wc).
+//   M-half h = rows 160 h .. +159, quadrant rows 80 (5 row blocks of 16): 20 MFMAs per phase.  Unit reads by phase: A0 p0 (rows 0-63:
+//   M-half 0, first quadrant); A1 p0 + p2 (rows 64-79 / 80-127); A2 p2 (M-half 0) + p0 (rows 160-191: M-half 1); A3 p0 + p2; A4 p2;
+//   B units p0 (columns 0-31 of the wave) + p1.
+//   Load segments:  p0: read A(qm 0) [10 x ds_read_b128] + B(qn 0) [4]      | DMA A1, A2 of K-tile t+1
+//                   p1: read B(qn 1) [4]                                      | DMA A3, A4 of K-tile t+1
+//                   p2: read A(qm 1) [10]                                     | DMA A0 of K-tile t+2
+//                   p3: -                                                     | DMA B0..B3 of K-tile t+2 ; s_waitcnt vmcnt(5)
+//   WAR (a unit is overwritten two phases after its last read or later): A1..A4 of K-tile t+1 replace K-tile t-1's, last read in
+//   (t-1, p2), written from (t, p0) on; A0 of t+2 replaces K-tile t's A0, read in (t, p0) only, written in (t, p2); B of t+2 replaces
+//   K-tile t's, last read (t, p1), written (t, p3).  RAW: K-tile t+1 is complete behind the vmcnt(5) of (t, p3) - all but A0 and the
+//   four B units of K-tile t+2 have landed - and the barrier after it; its first read is in (t+1, p0).
+//   Epilogue: the wave's 160 x 64 tile is parked in the staging LDS in two 80-row halves (10 KB per wave each).
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_tn_pp320_kernel(const GemmParams p) {
+  constexpr int BM = 320, BN = 256, RB = 128;
+  constexpr int UNIT = 64 * RB, NUA = 5, BUF = 9 * UNIT;
+  constexpr int WTM = 160, WTN = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const savit_gemm_args& a = p.a;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int tid = xcd_remap(blockIdx.x, nwg);
+  int tm, tn;
+  {
+    const int G = p.row_group, per = G * p.tiles_n;
+    const int g = tid / per, rem = tid - g * per;
+    const int rows_g = (p.tiles_m - g * G) < G ? (p.tiles_m - g * G) : G;
+    tn = rem / rows_g;
+    tm = g * G + (rem - tn * rows_g);
+  }
+  const int row0 = tm * BM, col0 = tn * BN;
+
+  const bf16_t* Abase = reinterpret_cast<const bf16_t*>(a.A) + (size_t)row0 * a.lda;
+  const bf16_t* Bbase = reinterpret_cast<const bf16_t*>(a.Bt) + (size_t)col0 * a.ldb;
+  uint32_t a_bytes, b_bytes;
+  {
+    const size_t ta = (size_t)(a.M - row0) * a.lda * 2, tb = (size_t)(a.N - col0) * a.ldb * 2;
+    a_bytes = (uint32_t)(ta > 0xfffffff0ull ? 0xfffffff0ull : ta);
+    b_bytes = (uint32_t)(tb > 0xfffffff0ull ? 0xfffffff0ull : tb);
+  }
+  const auto srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Abase), 0, a_bytes, 0x00020000);
+  const auto srdB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bbase), 0, b_bytes, 0x00020000);
+
+  // LDS-DMA geometry: one wave-instruction = 8 rows x 128 B; this wave owns rows wave*8 .. +7 of every unit
+  const int lrow = lane >> 3, pch = lane & 7;
+  const int ur = wave * 8 + lrow;
+  const int uc = (pch ^ ((ur >> 1) & 7)) * 16;
+  const uint32_t a_voff = (uint32_t)ur * (uint32_t)(a.lda * 2) + (uint32_t)uc;
+  const uint32_t b_voff = (uint32_t)ur * (uint32_t)(a.ldb * 2) + (uint32_t)uc;
+  const uint32_t a_unit = 64u * (uint32_t)(a.lda * 2), b_unit = 64u * (uint32_t)(a.ldb * 2);
+  const int KT = a.K / 64;
+  auto dma = [&](int kt, int u) {  // unit u (compile-time; 0-4 = A0..A4, 5-8 = B0..B3) of K-tile kt into buffer kt & 1
+    if (kt >= KT) return;
+    char* dst = smem + (kt & 1) * BUF + u * UNIT + wave * 1024;
+    if (u < NUA)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (__attribute__((address_space(3))) void*)dst, 16, a_voff + (uint32_t)u * a_unit, kt * RB, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (__attribute__((address_space(3))) void*)dst, 16, b_voff + (uint32_t)(u - NUA) * b_unit, kt * RB, 0, 0);
+  };
+
+  // fragment read offsets: row = 16 i + (lane & 15) from a base that is a multiple of 16, logical chunk = 4 ks + (lane >> 4)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = (fr >> 1) & 7;
+  const int foff0 = fr * RB + ((fq ^ sw) << 4);
+  const int foff1 = fr * RB + (((fq + 4) ^ sw) << 4);
+  const int a_base = (WTM * wr) * RB, b_base = NUA * UNIT + (WTN * wc) * RB;
+
+  f32x4 acc[10][4];
+#pragma unroll
+  for (int i = 0; i < 10; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[5][2], bf[4][2];
+
+  // prologue: all of K-tile 0 and the five units of K-tile 1 that L(-1,p2), L(-1,p3) would have issued
+#pragma unroll
+  for (int u = 0; u < 9; ++u) dma(0, u);
+  dma(1, 0); dma(1, 5); dma(1, 6); dma(1, 7); dma(1, 8);
+  if (KT > 1) {
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // M-half 1 runs one barrier behind M-half 0
+
+#define PP5_READ_A(QM)                                                                                         \
+  _Pragma("unroll") for (int i = 0; i < 5; ++i) {                                                              \
+    af[i][0] = *reinterpret_cast<const bf16x8*>(cur + a_base + (80 * (QM) + 16 * i) * RB + foff0);             \
+    af[i][1] = *reinterpret_cast<const bf16x8*>(cur + a_base + (80 * (QM) + 16 * i) * RB + foff1);             \
+  }
+#define PP5_READ_B(QN)                                                                                         \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
+    bf[2 * (QN) + j][0] = *reinterpret_cast<const bf16x8*>(cur + b_base + (2 * (QN) + j) * 16 * RB + foff0);  \
+    bf[2 * (QN) + j][1] = *reinterpret_cast<const bf16x8*>(cur + b_base + (2 * (QN) + j) * 16 * RB + foff1);  \
+  }
+#define PP5_COMPUTE(QM, QN)                                                                                    \
+  __builtin_amdgcn_s_barrier();                                                                                \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                                                           \
+  __builtin_amdgcn_s_setprio(1);                                                                               \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+        acc[5 * (QM) + i][2 * (QN) + j] =                                                                      \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[2 * (QN) + j][ks], af[i][ks], acc[5 * (QM) + i][2 * (QN) + j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                               \
+  __builtin_amdgcn_sched_barrier(0);                                                                           \
+  __builtin_amdgcn_s_barrier();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const char* cur = smem + (kt & 1) * BUF;
+    // ---- phase 0: quadrant (0,0)
+    PP5_READ_B(0)
+    __builtin_amdgcn_sched_barrier(0);
+    PP5_READ_A(0)
+    dma(kt + 1, 1); dma(kt + 1, 2);
+    PP5_COMPUTE(0, 0)
+    // ---- phase 1: quadrant (0,1)
+    PP5_READ_B(1)
+    dma(kt + 1, 3); dma(kt + 1, 4);
+    PP5_COMPUTE(0, 1)
+    // ---- phase 2: quadrant (1,1)
+    PP5_READ_A(1)
+    dma(kt + 2, 0);
+    PP5_COMPUTE(1, 1)
+    // ---- phase 3: quadrant (1,0); K-tile kt+1 must be complete behind this phase's first barrier
+    dma(kt + 2, 5); dma(kt + 2, 6); dma(kt + 2, 7); dma(kt + 2, 8);
+    if (kt + 2 < KT) {
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PP5_COMPUTE(1, 0)
+  }
+#undef PP5_READ_A
+#undef PP5_READ_B
+#undef PP5_COMPUTE
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count: every wave is past its last LDS read after this one
+
+  if constexpr (epi_uses_lds<EPI>()) {
+    // two 80-row halves through this wave's 10-KB slice of the (now idle) staging LDS
+    epilogue_lds<EPI, 80, WTN, 5, 4>(p, reinterpret_cast<f32x4(&)[5][4]>(acc[0]), smem + wave * (80 * WTN * 2), row0 + wr * WTM, col0 + wc * WTN, lane,
+                                     (tm * 2 + wr) * 2);
+    epilogue_lds<EPI, 80, WTN, 5, 4>(p, reinterpret_cast<f32x4(&)[5][4]>(acc[5]), smem + wave * (80 * WTN * 2), row0 + wr * WTM + 80, col0 + wc * WTN,
+                                     lane, (tm * 2 + wr) * 2 + 1);
+  } else {
+    const int mrow = row0 + wr * WTM + fr;
+    const int ncol = col0 + wc * WTN + fq * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 10; ++i) epilogue_store<EPI>(p, mrow + i * 16, ncol + j * 16, acc[i][j], csum);
+    }
+  }
+}
+
+int launch_pp320(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  p.tiles_m = (p.a.M + 319) / 320;
+  p.tiles_n = (p.a.N + 255) / 256;
+  // (row panels per group: as for the 256-row kernel; see pp_row_group below)
+  int g = (int)((3l << 20) / ((long)320 * p.a.K * 2));
+  if (g < 1) g = 1;
+  if (g > 8) g = 8;
+  if (p.a.epilogue == SAVIT_EPI_DGELU && g > 4) g = 4;
+  if (g > p.tiles_m) g = p.tiles_m;
+  p.row_group = g;
+  const dim3 grid(p.tiles_m * p.tiles_n);
+  const size_t lds = 2 * 9 * 64 * 128;
+#define SAVIT_LAUNCH_EPI(E)                                                                            \
+  case E: {                                                                                            \
+    auto kfn = gemm_tn_pp320_kernel<E>;                                                                \
+    SAVIT_LDS_ONCE(kfn);                                                                               \
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, p);                                               \
+  } break;
+  switch (p.a.epilogue) {
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_BF16)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_BIAS_GELU)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_RESID)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_DGELU)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_F32)
+    default: return SAVIT_EINVAL;
+  }
+#undef SAVIT_LAUNCH_EPI
+  SAVIT_LAUNCH_RET();
+}
+
 // row panels per group of the ping-pong kernel's tile order: as many 256-row A-panels (256 x K x 2 B) as fit in about 3 MB of the
 // XCD's 4 MB L2, at most 8 (K = 768: 8, K = 1024: 6, K >= 3072: 1 = plain row-major order).  Measured on DeiT-B with cold operands
 // (tools/gemm_epi_bench.py, G = 1 -> 8): qkv 104 -> 97 us, fc1+GELU 156 -> 145 us; the GELU' epilogue, which also READS a [M, N]
@@ -1657,6 +1858,28 @@ extern "C" int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue) {
   //    K = 384 (DeiT-S, CaiT-S at 256 images) stays with the pair kernels: with cold operands the ping-pong tile is 7-11 % faster on
   //    those shapes too (SAVIT_EPI_SHAPE=50432,384,1536 tools/gemm_epi_bench.py), inside the training step - warm operands, same box,
   //    alternating runs - DeiT-S lost 1.4 % (17.63 -> 17.38 k img/s) and CaiT-S24, TNT, Mixer did not move.
+  if (K >= 768 && N % 256 == 0 && M >= 4096 && epilogue != SAVIT_EPI_PATCH) {
+    //  * 320x256 ping-pong (tile 21, round 3) against 256x256 (tile 20) and 192x128 (17 / 18): what a launch costs is (rounds of
+    //    workgroups over the CUs) x (rows of a tile), weighted by what the tile's operand feed costs - the L2 -> LDS path of a CU, not
+    //    the matrix pipe, bounds these kernels, and a 192x128 tile moves 1.7x the bytes per flop of a 256-wide one (measured: the same
+    //    product 1.35x slower per flop at equal fill).  DeiT-B (M = 25 216): N = 768 is 237 tiles of 320 rows = ONE round (297 of 256
+    //    rows = two; 792 + tail of 192x128): fc1 input gradient 142 -> 98 us, fc2 + residual 166 -> 121, qkv input gradient 112 -> 80,
+    //    proj + residual 69 -> 58; N = 2304: 3 rounds of 320 rows against 4 of 256: qkv 108 -> 96 us; N = 3072: 4 x 320 = 5 x 256, the
+    //    320-row tile moves 10 % fewer bytes: fc1 + GELU 147 -> 143, GELU' 167 -> 162 (tools/gemm_epi_bench.py, cold operands).
+    static const int cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      return n;
+    }();
+    const long tn = N / 256;
+    const long r256 = (((long)(M + 255) / 256 * tn + cus - 1) / cus) * 256;
+    const long r320 = (((long)(M + 319) / 320 * tn + cus - 1) / cus) * 320;
+    // 192x128, two workgroups per CU, the last partial round cut into 128-row tiles: rounds in thirds of a tile time
+    const long t192 = (long)((M + 191) / 192) * (N / 128);
+    const long c192 = ((t192 * 3 + 2L * cus - 1) / (2L * cus)) * 64 * 135 / 100;
+    const long best = r320 <= r256 ? r320 : r256;
+    if (best <= c192 || (big && N >= 1024)) return r320 <= r256 ? 21 : 20;
+  }
   if (big && N >= 1024 && K >= 768 && epilogue != SAVIT_EPI_PATCH) return 20;
   if (big && (epilogue == SAVIT_EPI_BIAS_GELU || K >= 1024)) return 13;
   if (N % 128 == 0 && M >= 1536 && epilogue != SAVIT_EPI_PATCH) {
@@ -1725,6 +1948,7 @@ inline bool tile_geometry(int tile, int* bm, int* wgm) {
     case 3: *bm = 256; *wgm = 4; return true;
     case 17: case 18: *bm = 192; *wgm = 2; return true;
     case 20: *bm = 256; *wgm = 2; return true;
+    case 21: *bm = 320; *wgm = 4; return true;
     case 30: *bm = 256; *wgm = 4; return true;
     default: return false;
   }
@@ -1773,7 +1997,7 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
   int tile = a.tile;
   if (tile == 0) {
     tile = savit_gemm_tn_auto_tile_epi(a.M, a.N, a.K, a.epilogue);
-    if (tile == 20 && a.lda < a.K) tile = 13;  // the ping-pong kernel does not take the aliased-row operand form
+    if ((tile == 20 || tile == 21) && a.lda < a.K) tile = 13;  // the ping-pong kernels do not take the aliased-row operand form
   }
   if (a.colsum != nullptr && a.colsum_rows != 0) SAVIT_CHECK_ARG(a.colsum_rows == savit_gemm_colsum_rows(a.M, a.N, a.K, tile));
   switch (tile) {
@@ -1795,6 +2019,7 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
     case 17: return a.K % 64 ? SAVIT_EINVAL : launch_pair<192, 128, 2, 2, 2>(p, s);
     case 18: return a.K % 64 ? SAVIT_EINVAL : launch_pair_tail<192, 128, 128, 2, 2, 2>(p, s);  // 17 with 128-row tiles for the last partial round
     case 20: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp(p, s);
+    case 21: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp320(p, s);
     case 30: return stream_ok(a) ? launch_stream(p, s) : SAVIT_EINVAL;
 #ifdef SAVIT_EXPERIMENTS
     // timing-only ablations of tile 20 (wrong results by construction; SAVIT_EPI_BF16 only) - never in the product library
