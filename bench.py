@@ -439,8 +439,10 @@ def main():
                     out["roofline"]["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, FETCH doubled)"
                     if dom.startswith("gemm_wgrad_group_kernel"):
                         # operands read once (X and dY of every weight of the group) + dW read and written once (fp32)
-                        g = getattr(eng, "wgrad_group", 1)
-                        out["roofline"]["algorithmic_bytes_per_launch"] = int(g * sum(2 * M * (a + b_) + 8 * a * b_ for a, b_ in ((d, 3 * d), (d, d), (d, F), (F, d))))
+                        # (every weight gradient of the model, spread over the grouped launches: each takes one tile per CU)
+                        n_div = len(getattr(eng, "wgrad_divert", ()))
+                        per_layer = sum(2 * M * (a + b_) + 8 * a * b_ for a, b_ in ((d, 3 * d), (d, d), (d, F), (F, d)))
+                        out["roofline"]["algorithmic_bytes_per_launch"] = int((cfg.num_layers * per_layer - n_div * (4 * M * d + 8 * d * d)) / sym_n[dom])
                     elif dom.startswith("gemm_wgrad_ring_kernel<256"):
                         # operands read once + the split partials written once (slab form; the reduce kernel is its own row of the profile)
                         sp = max(1, eng.L.savit_gemm_wgrad_workspace_bytes(M, d, F, 0, 0) // (d * F * 4))

@@ -164,6 +164,8 @@ typedef struct savit_wgrad_problem {
   const void* dY;
   float* dW;
   int M, Kin, Nout, ldx, lddy, lddw;
+  int tile_begin, tile_count; /* a range of the weight's output tiles (row-major over tile x tile blocks of dW); 0, 0 = all of them.
+                                 Lets a caller cut launches at exact multiples of the CU count: a weight may span two launches. */
 } savit_wgrad_problem;
 int savit_gemm_bf16_wgrad_grouped(const savit_wgrad_problem* problems, int count, int tile, void* stream);
 int savit_gemm_wgrad_group_tiles(int Kin, int Nout, int tile);

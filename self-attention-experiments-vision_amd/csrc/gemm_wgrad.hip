@@ -483,6 +483,7 @@ struct WgradGroupParams {
     const bf16_t* dY;
     float* dW;
     int M, Kin, Nout, ldx, lddy, lddw;
+    int tile_begin;  // first output tile of this entry (an entry may cover a RANGE of a weight's tiles: the rest runs in another launch)
   } pr[WGRAD_GROUP_MAX];
 };
 
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_group_kernel(con
   const int wid = xcd_remap(blockIdx.x, g.tile_end[g.n - 1]);
   int pi = 0;
   while (wid >= g.tile_end[pi]) ++pi;  // uniform: scalar loop over at most WGRAD_GROUP_MAX entries
-  const int t = wid - (pi ? g.tile_end[pi - 1] : 0);
+  const int t = wid - (pi ? g.tile_end[pi - 1] : 0) + g.pr[pi].tile_begin;
   WgradParams p{};
   p.X = g.pr[pi].X; p.dY = g.pr[pi].dY; p.dW = g.pr[pi].dW;
   p.M = g.pr[pi].M; p.Kin = g.pr[pi].Kin; p.Nout = g.pr[pi].Nout;
@@ -753,8 +754,12 @@ extern "C" int savit_gemm_bf16_wgrad_grouped(const savit_wgrad_problem* problems
     SAVIT_CHECK_ARG(((uintptr_t)q.X % 16) == 0 && ((uintptr_t)q.dY % 16) == 0 && ((uintptr_t)q.dW % 4) == 0);
     SAVIT_CHECK_ARG((size_t)q.M * q.ldx * 2 <= 0xffffffe0ull && (size_t)q.M * q.lddy * 2 <= 0xffffffe0ull);  // 32-bit buffer offsets
     if (q.M == 0) continue;  // nothing to add
-    tiles += savit_gemm_wgrad_group_tiles(q.Kin, q.Nout, tile);
+    const int all = savit_gemm_wgrad_group_tiles(q.Kin, q.Nout, tile);
+    const int cnt = q.tile_count > 0 ? q.tile_count : all - q.tile_begin;
+    SAVIT_CHECK_ARG(q.tile_begin >= 0 && cnt >= 1 && q.tile_begin + cnt <= all);
+    tiles += cnt;
     g.tile_end[n] = tiles;
+    g.pr[n].tile_begin = q.tile_begin;
     g.pr[n].X = (const bf16_t*)q.X; g.pr[n].dY = (const bf16_t*)q.dY; g.pr[n].dW = q.dW;
     g.pr[n].M = q.M; g.pr[n].Kin = q.Kin; g.pr[n].Nout = q.Nout; g.pr[n].ldx = q.ldx; g.pr[n].lddy = q.lddy; g.pr[n].lddw = q.lddw;
     ++n;

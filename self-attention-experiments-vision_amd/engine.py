@@ -262,22 +262,55 @@ def add_wgrad(eng, plan: _Plan, label: str, X, dY, dW, Mr, Kin, Nout, ldx, lddy,
     plan.hook_alias[label + ".reduce"] = [label]  # a hook registered for `label` (DDP bucket trigger) fires behind the reduce
 
 
-def add_wgrad_group(eng, plan: _Plan, label: str, problems: list, tile: int, deferred_hooks: list, side: bool = True):
-    """Record ONE grouped weight-gradient launch (savit_gemm_bf16_wgrad_grouped) for `problems` = [(X, dY, dW, M, Kin, Nout, ldx, lddy,
-    lddw)]: one workgroup per output tile over all tokens - no split, no slabs, no reduce launch.  `deferred_hooks`: labels of
-    earlier launches whose hooks (DDP bucket triggers) must wait for these gradients; they fire behind this launch."""
-    arr = (_lib.WgradProblem * len(problems))()
+def add_wgrad_group(eng, plan: _Plan, label: str, entries: list, tile: int, deferred_hooks: list, side: bool = True):
+    """Record ONE grouped weight-gradient launch (savit_gemm_bf16_wgrad_grouped).  entries = [(problem, tile_begin, tile_count)] with
+    problem = (X, dY, dW, M, Kin, Nout, ldx, lddy, lddw): one workgroup per output tile over all tokens - no split, no slabs, no reduce
+    launch.  `deferred_hooks`: labels of earlier launches whose hooks (DDP bucket triggers) must wait for these gradients; they fire
+    behind this launch."""
+    arr = (_lib.WgradProblem * len(entries))()
     flops = 0.0
-    for q, (X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw) in zip(arr, problems):
-        q.X, q.dY, q.dW, q.M, q.Kin, q.Nout, q.ldx, q.lddy, q.lddw = X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw
-        flops += 2.0 * Mr * Kin * Nout
+    for q, ((X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw), t0, tc) in zip(arr, entries):
+        q.X, q.dY, q.dW, q.M, q.Kin, q.Nout, q.ldx, q.lddy, q.lddw, q.tile_begin, q.tile_count = X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, t0, tc
+        flops += 2.0 * Mr * tile * tile * tc  # (whole tiles: Kin, Nout are multiples of the tile on this path)
     plan.keep.append(arr)
-    plan.add(eng.L.savit_gemm_bf16_wgrad_grouped, (arr, len(problems), tile), label, side=side, reads=tuple(q[1] for q in problems) if side else ())
+    plan.add(eng.L.savit_gemm_bf16_wgrad_grouped, (arr, len(entries), tile), label, side=side,
+             reads=tuple(sorted({e[0][1] for e in entries})) if side else ())
     if deferred_hooks:
         plan.hook_alias[label] = list(deferred_hooks)
     if not hasattr(eng, "group_flops"):
         eng.group_flops = {}
     eng.group_flops[label] = flops
+
+
+class WgradQueue:
+    """FIFO of weight-gradient output tiles waiting for a grouped launch.  A launch takes exactly `cap` tiles (one per CU: a full
+    round of workgroups), cutting a weight between two launches where it must; what is left at the end goes out as the last launch."""
+
+    def __init__(self, cap: int):
+        self.cap = cap
+        self.items: List[list] = []  # [problem, layer, tiles, next tile]
+
+    def push(self, problem, layer: int, tiles: int):
+        self.items.append([problem, layer, tiles, 0])
+
+    def pending(self) -> int:
+        return sum(it[2] - it[3] for it in self.items)
+
+    def take(self, n: int):
+        """-> (entries [(problem, tile_begin, tile_count)], layers whose LAST pending tile is in this launch, oldest layer touched)"""
+        entries, done, oldest = [], [], None
+        while n > 0 and self.items:
+            it = self.items[0]
+            c = min(n, it[2] - it[3])
+            entries.append((it[0], it[3], c))
+            oldest = it[1] if oldest is None else max(oldest, it[1])
+            it[3] += c
+            n -= c
+            if it[3] == it[2]:
+                self.items.pop(0)
+                if not any(o[1] == it[1] for o in self.items):
+                    done.append(it[1])
+        return entries, done, oldest
 
 
 def finalize_wgrad_ws(eng, plan: _Plan):
@@ -353,11 +386,12 @@ class ViTEngine:
         self.fstats = e(2, self.B)
         # ---- backward scratch
         self.dres = e(M, d)
-        # Weight gradients of `wgrad_group` consecutive layers are computed by ONE grouped launch (add_wgrad_group) once the last of
-        # them has produced its cotangents: those cotangent buffers therefore rotate through rings `wgrad_group` layers deep (also
-        # what lets side-stream weight-gradient GEMMs lag behind the main chain).
-        self.wgrad_tile, self.wgrad_group = self._wgrad_group_plan()
-        depth = max(2, int(os.environ.get("SAVIT_RING_DEPTH", "2")), self.wgrad_group)
+        # Weight gradients wait in a FIFO of output tiles and go out in grouped launches of exactly one tile per CU (add_wgrad_group,
+        # WgradQueue), up to `wgrad_lag` layers after their cotangents were produced: those cotangent buffers therefore rotate through
+        # rings that deep (also what lets side-stream weight-gradient GEMMs lag behind the main chain).
+        self.wgrad_tile, self.wgrad_cap, self.wgrad_divert, self.wgrad_lag = self._wgrad_group_plan()
+        self.wgrad_group = self.wgrad_lag  # (layers a launch reaches back: bench.py's label for the grouping)
+        depth = max(2, int(os.environ.get("SAVIT_RING_DEPTH", "2")), self.wgrad_lag + 1 if self.wgrad_tile else 0)
         self.dres_b_ring = [e(M, d, dt=bf16) for _ in range(2 * depth)]
         self.dres_b = self.dres_b_ring[0]
         self.d_u_ring = [e(M, F, dt=bf16) for _ in range(depth)]
@@ -521,27 +555,26 @@ class ViTEngine:
         gp = lambda n: self._off_ptr(self.grads, n)  # noqa: E731
         ws, wsb = self.ln_ws.data_ptr(), self.ln_ws.numel()
 
-        group: List[tuple] = []       # pending problems of the current weight-gradient group
-        group_layers: List[int] = []  # layers they belong to
+        queue = WgradQueue(self.wgrad_cap) if self.wgrad_tile else None
+        n_launch = [0]
 
         def wgrad(label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0), layer=None):
             # no later launch consumes dW: side stream.  X is a saved activation (stable until the next forward), dY is scratch
-            if layer is not None and self.wgrad_group > 0:
-                group.append((X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw))
-                if layer not in group_layers:
-                    group_layers.append(layer)
+            if queue is not None and layer is not None and not (layer in self.wgrad_divert and label.endswith(".Wo.wgrad")):
+                queue.push((X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw), layer, int(L.savit_gemm_wgrad_group_tiles(Kin, Nout, self.wgrad_tile)))
                 return
             self._add_wgrad(P, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, self._wgrad_splits(Kin, Nout, patch[0]), patch)
 
-        def flush_group(last: bool):
+        def flush_group(layer: int, last: bool):
             # called between a layer's last input-gradient GEMM and its ln1.bwd (which overwrites the oldest ring slot): every
-            # cotangent of the group's layers is still intact.  The DDP triggers of the group's EARLIER layers ('l{j}.ln1.bwd', already
-            # launched) fire behind this launch; the current layer's own trigger follows naturally.
-            if group and (last or len(group_layers) >= self.wgrad_group):
-                add_wgrad_group(self, P, f"wgrad.group.l{group_layers[0]}-l{group_layers[-1]}", list(group), self.wgrad_tile,
-                                [f"l{j}.ln1.bwd" for j in group_layers[:-1]])
-                group.clear()
-                group_layers.clear()
+            # cotangent of the last `wgrad_lag` + 1 layers is still intact.  A launch takes one tile per CU; the DDP trigger
+            # ('l{j}.ln1.bwd') of an EARLIER layer whose last tile is in it fires behind it, the current layer's own follows naturally.
+            while queue is not None and queue.pending() > 0 and (queue.pending() >= queue.cap or last):
+                entries, done, oldest = queue.take(queue.cap)
+                assert oldest - layer <= self.wgrad_lag, "weight-gradient queue reaches back further than the cotangent rings"
+                add_wgrad_group(self, P, f"wgrad.group.{n_launch[0]}.l{oldest}-l{layer}", entries, self.wgrad_tile,
+                                [f"l{j}.ln1.bwd" for j in done if j != layer])
+                n_launch[0] += 1
 
         ring, ri = [t.data_ptr() for t in self.dres_b_ring], 0
         # ---- head: dWh, d z_cls, final LayerNorm backward into the (zeroed) residual gradient
@@ -580,7 +613,7 @@ class ViTEngine:
             wgrad(f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), dqkv, gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d, layer=l)
             self._gemm(P, f"l{l}.qkv.dgrad", A=dqkv, Bt=w("Wqkv_n"), C=self.d_h.data_ptr(), M=M, N=d, K=3 * d, lda=3 * d,
                        ldb=3 * d, ldc=d, epilogue=_lib.EPI_BF16)
-            flush_group(last=(l == 0))
+            flush_group(l, last=(l == 0))
             ri = (ri + 1) % len(ring)
             P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
                                           self.dres.data_ptr(), self.dres.data_ptr(), ring[ri], gp(f"l{l}.ln1_g"),
@@ -597,29 +630,40 @@ class ViTEngine:
                    side: bool = True):
         add_wgrad(self, plan, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, splits, patch, side)
 
-    def _wgrad_group_plan(self) -> Tuple[int, int]:
-        """(tile, layers per grouped weight-gradient launch); (0, 0) = one launch per weight (split over the tokens, slabs + reduce).
+    def _wgrad_group_plan(self):
+        """(tile, tiles per launch, layers whose Wo keeps the per-weight path, layers a launch reaches back); tile 0 = one launch per
+        weight (token range split over workgroups, partial slabs + ordered reduce).
         A layer's four weight gradients are d x 3d, d x d, d x F, F x d: with 256 x 256 tiles DeiT-B has 108 tiles per layer, ViT-L 192 -
-        too few for 256 CUs one layer at a time, so layers are grouped until the tiles fill whole rounds of the CUs: the smallest
-        group size (at most 4 layers) with the best fill.  SAVIT_WGRAD_GROUP=0 / N overrides (0 = off)."""
+        too few for 256 CUs one weight (or one layer) at a time.  They wait in a FIFO and leave in launches of exactly one tile per CU,
+        a weight cut between two launches where needed: every launch is a full round.  DeiT-B: 12 x 108 = 1 296 tiles = 5 rounds + 16
+        tiles - so the d x d gradients of the last two layers (18 tiles) keep the per-weight path and the rest is 5 launches (4 x 256 +
+        254); ViT-L: 24 x 192 = 18 x 256 exactly.  SAVIT_WGRAD_GROUP=0 turns the grouping off."""
         cfg = self.cfg
-        d, F = cfg.embed_dim, cfg.hidden
+        d, F, NL = cfg.embed_dim, cfg.hidden, cfg.num_layers
         env = os.environ.get("SAVIT_WGRAD_GROUP", "auto")
-        if env == "0" or (d % 256 or F % 256) and env == "auto":
-            return 0, 0  # narrower models keep the per-weight launches (128 x 128 tiles, measured per model: DESIGN.md)
-        tile = 256 if (d % 256 == 0 and F % 256 == 0) else 128
-        per_layer = sum(int(self.L.savit_gemm_wgrad_group_tiles(a, b, tile)) for a, b in ((d, 3 * d), (d, d), (d, F), (F, d)))
-        if env != "auto":
-            return tile, max(1, min(int(env), cfg.num_layers, 16 // 4))
-        n_cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
-        slots = n_cus * (1 if tile == 256 else 2)
-        best, best_fill = 1, 0.0
-        for g in range(1, min(4, cfg.num_layers) + 1):
-            t = g * per_layer
-            fill = t / (-(-t // slots) * slots)
-            if fill > best_fill + 0.02:
-                best, best_fill = g, fill
-        return tile, best
+        if env == "0" or d % 256 or F % 256:
+            return 0, 0, frozenset(), 0  # narrower models keep the per-weight launches (128 x 128 tiles)
+        tile = 256
+        sizes = [(n, int(self.L.savit_gemm_wgrad_group_tiles(a, b, tile))) for n, a, b in (("W2", F, d), ("W1", d, F), ("Wo", d, d), ("Wqkv", d, 3 * d))]
+        per_layer = sum(t for _, t in sizes)
+        cap = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        total = NL * per_layer
+        rounds = -(-total // cap)
+        need = total - (rounds - 1) * cap  # tiles in the last, partial round
+        wo = dict(sizes)["Wo"]
+        divert = frozenset()
+        if rounds >= 2 and need <= 0.12 * cap and -(-need // wo) <= NL:
+            divert = frozenset(range(-(-need // wo)))  # the layers processed LAST (0, 1, ...): their d x d gradients run per weight
+        # dry run of the queue: how many layers does a launch reach back?
+        q, lag = WgradQueue(cap), 0
+        for l in range(NL - 1, -1, -1):
+            for n, t in sizes:
+                if not (n == "Wo" and l in divert):
+                    q.push(None, l, t)
+            while q.pending() > 0 and (q.pending() >= cap or l == 0):
+                _, _, oldest = q.take(cap)
+                lag = max(lag, oldest - l)
+        return tile, cap, divert, lag
 
     def _wgrad_splits(self, Kin: int, Nout: int, patch: int) -> int:
         """K-splits of a weight-gradient GEMM.  On its own a launch wants every CU (0 = the library's choice); beside the

@@ -32,7 +32,7 @@ class GemmArgs(Structure):
 class WgradProblem(Structure):
     """Mirror of `savit_wgrad_problem` (include/savit.h)."""
     _fields_ = [("X", c_void_p), ("dY", c_void_p), ("dW", c_void_p), ("M", c_int), ("Kin", c_int), ("Nout", c_int), ("ldx", c_int),
-                ("lddy", c_int), ("lddw", c_int)]
+                ("lddy", c_int), ("lddw", c_int), ("tile_begin", c_int), ("tile_count", c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/savit.h declares must be here (tests check both ways)

@@ -254,7 +254,10 @@ def gemm_wgrad_grouped(problems, tile: int = 256):
     """dW_i += X_i^T @ dY_i for every (X_i, dY_i, dW_i) of `problems` in ONE launch, one workgroup per tile x tile output tile, each
     reducing over all rows (no split, no slabs; savit_gemm_bf16_wgrad_grouped).  At most 16 problems."""
     arr = (_lib.WgradProblem * len(problems))()
-    for q, (X, dY, dW) in zip(arr, problems):
+    for q, pr in zip(arr, problems):
+        X, dY, dW = pr[:3]
+        if len(pr) == 5:  # (X, dY, dW, tile_begin, tile_count): a range of the weight's output tiles
+            q.tile_begin, q.tile_count = int(pr[3]), int(pr[4])
         _chk(X, bf16, "X", 2)
         _chk(dY, bf16, "dY", 2)
         _chk(dW, f32, "dW", 2)

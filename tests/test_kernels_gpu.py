@@ -433,6 +433,17 @@ def test_wgrad_grouped_matches_fp64_and_is_reproducible(ops, tile):
     ops.gemm_wgrad_grouped(probs, tile=tile)  # accumulates
     for (X, dY, dW), base, ref in zip(probs, bases, refs):
         assert rel(host(dW) - host(base), 2 * ref) < 2e-5
+    # a weight's tiles cut over two launches (what the engine does to make every launch an exact multiple of the CU count)
+    X, dY, base = probs[0][0], probs[0][1], bases[0]
+    nt = ops._lib.load().savit_gemm_wgrad_group_tiles(768, 1024, tile)
+    halves = base.clone()
+    ops.gemm_wgrad_grouped([(X, dY, halves, 0, 5)], tile=tile)
+    ops.gemm_wgrad_grouped([(X, dY, halves, 5, nt - 5), (probs[1][0], probs[1][1], bases[1].clone())], tile=tile)
+    whole = base.clone()
+    ops.gemm_wgrad_grouped([(X, dY, whole)], tile=tile)
+    assert torch.equal(halves, whole)
+    with pytest.raises(ValueError):
+        ops.gemm_wgrad_grouped([(X, dY, halves, 5, nt)], tile=tile)  # range past the last tile
     with pytest.raises(ValueError):
         ops.gemm_wgrad_grouped(probs * 3, tile=tile)  # more than 16 problems
     with pytest.raises(ValueError):
