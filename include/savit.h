@@ -314,6 +314,39 @@ int savit_gemm_f32(const float* A, const float* W, float* C, const float* bias, 
 int savit_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, int rows, int d, long x_stride, long y_stride,
                             float eps, void* stream);
 int savit_attention_fwd_f32(const float* qkv, float* o, int B, int N, int H, int head_dim, int ld_qkv, void* stream);
+
+/* ---- fp32 arithmetic mode, general form (round 3): what the reference computes when create_model's dtype stays at its float32
+ * default - which is ALWAYS the case for CaiT (models/create_model.py:50-213 do not forward dtype; cait.py:147-154) - and what
+ * simple_train.py:72-90 differentiates.  Exact fp32 products (v_mfma_f32_32x32x2_f32), written for exactness and generality.
+ * savit_gemm_f32_ex: for every batch z = outer * inner + in (pointer offsets outer * s?o + in * s?i elements; aux / C2 / U follow C):
+ *     v = alpha_on_first_alpha_cols * (A . W) + bias ;  C2 = v if C2 ;  act 1: v = gelu_tanh(v), act 2: v = v * gelu_tanh'(U)
+ *     C = (accumulate ? C : 0) + colscale[n] * rowscale[m / rows_per_sample] * v + aux
+ *   A is [M, K] (transA: stored [K, M]), W is [K, N] (transW: stored [N, K]).  Serves Dense forward (attention.py:29-37,60-63,
+ *   ff.py:26-31), its input-gradient (transW) and weight-gradient (transA, accumulate) products, Q K^T / P V and their VJPs per
+ *   (image, head), LayerScale (layerscale.py:23) and stochastic depth (stochastic_depth.py:16-27) as colscale / rowscale.
+ * savit_softmax_rows_f32 / _bwd_f32: nn.softmax over the last axis (attention.py:48) and dS = P (dP - sum_k dP P).
+ * savit_head_mix_f32: TalkingHeadsBlock (talking_heads.py:13) y[b,i,e] = sum_h T[h,i] x[b,h,e], e over the N x N score positions.
+ * savit_layernorm_bwd_f32: VJP of nn.LayerNorm(dtype=float32); dx (+ add, the residual cotangent), dgamma / dbeta accumulated.
+ * savit_colsum_f32: out[n] += sum_m x[m,n] (Dense bias gradients).  savit_softmax_xent_grad_f32: d(mean label-smoothed CE)/dlogits
+ *   in fp32 (train.py:83-90), scaled by grad_scale (1 / batch). */
+typedef struct savit_gemm_f32_args {
+  const float* A; const float* W; float* C; const float* bias; const float* aux; const float* colscale; const float* rowscale;
+  float* C2; const float* U;
+  int M, N, K, lda, ldw, ldc, ldaux;
+  int transA, transW, batch, inner;
+  long sAo, sAi, sWo, sWi, sCo, sCi;
+  float alpha; int alpha_cols; int act; int accumulate; int rows_per_sample;
+  int aux_row_mod; /* > 0: aux is a table [aux_row_mod, ldaux] shared by all batches, row m % aux_row_mod (position embeddings) */
+} savit_gemm_f32_args;
+int savit_gemm_f32_ex(const savit_gemm_f32_args* args, void* stream);
+int savit_softmax_rows_f32(const float* x, float* y, long rows, int N, int ld, void* stream);
+int savit_softmax_rows_bwd_f32(const float* p, const float* dp, float* ds, long rows, int N, int ld, void* stream);
+int savit_head_mix_f32(const float* T, const float* x, float* y, int B, int H, long elems, void* stream);
+int savit_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* add, float* dx, float* dgamma, float* dbeta, int rows,
+                            int d, long x_stride, long dy_stride, float eps, void* stream);
+int savit_colsum_f32(const float* x, float* out, int M, int N, int ld, void* stream);
+int savit_softmax_xent_grad_f32(const float* logits, const int* labels, float label_smoothing, float grad_scale, float* dlogits, int B, int C,
+                                void* stream);
 int savit_patchify_f32(const float* images, float* patches, int B, int img_size, int patch, void* stream);
 int savit_assemble_tokens_f32(const float* tok, const float* cls, const float* pos, float* x0, int B, int N, int d, void* stream);
 

@@ -187,6 +187,264 @@ __global__ __launch_bounds__(256) void assemble_tokens_f32_kernel(const float* _
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- round 3
+// The general form of the fp32 product, for everything the forward-only kernels above do not cover: batched (grid.z, a batch index
+// split into an outer and an inner part with their own strides: (image, head) for attention), either operand transposed in place
+// (the input-gradient products dY.W^T, the weight-gradient products X^T.dY, Q.K^T, dS^T.Q, P^T.dO), epilogue
+//   v = alpha_on_first_alpha_cols * (A.W) + bias ; [C2 = v (pre-activation saved)] ; act 1: v = gelu_tanh(v) ; act 2: v = v * gelu'(U) ;
+//   v = colscale[n] * rowscale[m / rows_per_sample] * v ; v += aux ; C = (accumulate ? C : 0) + v
+// (ff.py:26-33 and its VJP, LayerScale layerscale.py:23, stochastic depth stochastic_depth.py:16-27, residual adds vit.py:24,31).
+// Exact fp32 on v_mfma_f32_32x32x2_f32 like gemm_f32_kernel; written for exactness and generality, not speed.
+struct GemmF32ExParams {
+  const float* A; const float* W; float* C; const float* bias; const float* aux; const float* colscale; const float* rowscale;
+  float* C2; const float* U;
+  int M, N, K, lda, ldw, ldc, ldaux;
+  int transA, transW;                 // A stored [K, M] / W stored [N, K]
+  int inner;                          // batch z = outer * inner + in
+  long sAo, sAi, sWo, sWi, sCo, sCi;  // element strides of the batch parts (aux, C2, U follow C)
+  float alpha; int alpha_cols; int act; int accumulate; int rows_per_sample;
+  int aux_row_mod;  // > 0: aux is a [aux_row_mod, ldaux] table shared by all batches, row m % aux_row_mod (position embeddings)
+};
+
+__device__ __forceinline__ float gelu_tanh_exact(float v) {
+  const float z = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+  return 0.5f * v * (1.0f + tanhf(z));
+}
+__device__ __forceinline__ float gelu_tanh_grad_exact(float v) {
+  const float z = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+  const float t = tanhf(z);
+  return 0.5f * (1.0f + t) + 0.5f * v * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * v * v);
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_ex_kernel(const GemmF32ExParams p) {
+  __shared__ float As[GB * A_LD];
+  __shared__ float Bs[GK * B_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int row0 = blockIdx.y * GB, col0 = blockIdx.x * GB;
+  const int zo = blockIdx.z / p.inner, zi = blockIdx.z - zo * p.inner;
+  const float* A = p.A + zo * p.sAo + zi * p.sAi;
+  const float* W = p.W + zo * p.sWo + zi * p.sWi;
+  const long coff = zo * p.sCo + zi * p.sCi;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int li = lane & 31, lk = lane >> 5;
+  for (int k0 = 0; k0 < p.K; k0 += GK) {
+    // A tile 64 (m) x 32 (k): 8 elements per thread, walking the operand's contiguous index fastest
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int e = tid + 256 * r;
+      int row, kc;
+      if (p.transA) { row = e & 63; kc = e >> 6; } else { kc = e & 31; row = e >> 5; }
+      const int m = row0 + row, k = k0 + kc;
+      float v = 0.f;
+      if (m < p.M && k < p.K) v = p.transA ? A[(size_t)k * p.lda + m] : A[(size_t)m * p.lda + k];
+      As[row * A_LD + kc] = v;
+    }
+    // W tile 32 (k) x 64 (n)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int e = tid + 256 * r;
+      int kr, nc;
+      if (p.transW) { kr = e & 31; nc = e >> 5; } else { nc = e & 63; kr = e >> 6; }
+      const int k = k0 + kr, n = col0 + nc;
+      float v = 0.f;
+      if (k < p.K && n < p.N) v = p.transW ? W[(size_t)n * p.ldw + k] : W[(size_t)k * p.ldw + n];
+      Bs[kr * B_LD + nc] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < GK / 2; ++s) {
+      const float a = As[(wm * 32 + li) * A_LD + 2 * s + lk];
+      const float b = Bs[(2 * s + lk) * B_LD + wn * 32 + li];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int n = col0 + wn * 32 + li;
+  if (n >= p.N) return;
+  const float bn = p.bias ? p.bias[n] : 0.f;
+  const float sc = n < p.alpha_cols ? p.alpha : 1.0f;
+  const float cs = p.colscale ? p.colscale[n] : 1.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+    if (m >= p.M) continue;
+    const size_t o = (size_t)coff + (size_t)m * p.ldc + n;
+    float v = acc[r] * sc + bn;
+    if (p.C2) p.C2[o] = v;
+    if (p.act == 1) v = gelu_tanh_exact(v);
+    if (p.act == 2) v *= gelu_tanh_grad_exact(p.U[o]);
+    v *= cs;
+    if (p.rowscale) v *= p.rowscale[m / p.rows_per_sample];
+    if (p.aux) v += p.aux_row_mod > 0 ? p.aux[(size_t)(m % p.aux_row_mod) * p.ldaux + n] : p.aux[(size_t)coff + (size_t)m * p.ldaux + n];
+    p.C[o] = p.accumulate ? p.C[o] + v : v;
+  }
+}
+
+// softmax over the last axis (attention.py:48) of `rows` rows of N values, and its VJP dS = P (dP - sum_k dP P); one wave per row
+__global__ __launch_bounds__(256) void softmax_rows_f32_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int N, int ld) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ld;
+  float* yr = y + row * ld;
+  float m = -INFINITY;
+  for (int c = lane; c < N; c += 64) m = fmaxf(m, xr[c]);
+  m = wave_max(m);
+  float l = 0.f;
+  for (int c = lane; c < N; c += 64) l += expf(xr[c] - m);
+  l = wave_sum(l);
+  const float inv = 1.0f / l;
+  for (int c = lane; c < N; c += 64) yr[c] = expf(xr[c] - m) * inv;
+}
+__global__ __launch_bounds__(256) void softmax_rows_bwd_f32_kernel(const float* __restrict__ pr, const float* __restrict__ dp, float* __restrict__ ds, long rows,
+                                                                    int N, int ld) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = pr + row * ld;
+  const float* d = dp + row * ld;
+  float s = 0.f;
+  for (int c = lane; c < N; c += 64) s += p[c] * d[c];
+  s = wave_sum(s);
+  for (int c = lane; c < N; c += 64) ds[row * ld + c] = p[c] * (d[c] - s);
+}
+
+// talking heads (talking_heads.py:13): y[b, i, e] = sum_h T[h, i] x[b, h, e] over e = the N x N positions; H <= 16
+__global__ __launch_bounds__(256) void head_mix_f32_kernel(const float* __restrict__ T, const float* __restrict__ x, float* __restrict__ y, int B, int H, long E) {
+  const long total = (long)B * E;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / E, e = i - b * E;
+    float xv[16];
+    for (int h = 0; h < H; ++h) xv[h] = x[((size_t)b * H + h) * E + e];
+    for (int o = 0; o < H; ++o) {
+      float a = 0.f;
+      for (int h = 0; h < H; ++h) a = fmaf(T[h * H + o], xv[h], a);
+      y[((size_t)b * H + o) * E + e] = a;
+    }
+  }
+}
+
+// nn.LayerNorm(dtype=float32) VJP: dx = rstd (g - mean(g) - xhat mean(g xhat)) [+ add], g = gamma dy; dgamma += sum dy xhat, dbeta += sum dy.
+// One wave per row, LNB_ROWS rows per wave; a lane keeps the dgamma / dbeta partials of its columns (lane + 64 j) in registers, the four
+// waves fold them in LDS, and the block issues ONE atomic per column (d <= 64 LNB_COLS; wider rows take the per-row atomics).
+// add and dx may be the same buffer (the residual cotangent updated in place): neither is __restrict__.
+constexpr int LNB_ROWS = 8, LNB_COLS = 16;
+template <bool WIDE>
+__global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* add, float* dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int d,
+                                                          long x_stride, long dy_stride, float eps) {
+  __shared__ float sg[WIDE ? 1 : 64 * LNB_COLS], sb[WIDE ? 1 : 64 * LNB_COLS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float pg[LNB_COLS], pb[LNB_COLS];
+#pragma unroll
+  for (int j = 0; j < LNB_COLS; ++j) pg[j] = pb[j] = 0.f;
+  if constexpr (!WIDE) {
+    for (int c = threadIdx.x; c < d; c += 256) sg[c] = sb[c] = 0.f;
+    __syncthreads();
+  }
+  for (int rr = 0; rr < LNB_ROWS; ++rr) {
+    const int row = (blockIdx.x * 4 + wave) * LNB_ROWS + rr;
+    if (row >= rows) break;
+    const float* xr = x + (size_t)row * x_stride;
+    const float* gr = dy + (size_t)row * dy_stride;
+    float s = 0.f, s2 = 0.f;
+    for (int c = lane; c < d; c += 64) {
+      const float v = xr[c];
+      s += v;
+      s2 += v * v;
+    }
+    s = wave_sum(s);
+    s2 = wave_sum(s2);
+    const float mean = s / (float)d;
+    const float rstd = 1.0f / sqrtf(s2 / (float)d - mean * mean + eps);
+    float a = 0.f, b = 0.f;
+    for (int c = lane; c < d; c += 64) {
+      const float g = gamma[c] * gr[c], xh = (xr[c] - mean) * rstd;
+      a += g;
+      b += g * xh;
+    }
+    a = wave_sum(a) / (float)d;
+    b = wave_sum(b) / (float)d;
+    if constexpr (WIDE) {
+      for (int c = lane; c < d; c += 64) {
+        const float xh = (xr[c] - mean) * rstd;
+        float v = rstd * (gamma[c] * gr[c] - a - xh * b);
+        if (add) v += add[(size_t)row * x_stride + c];
+        dx[(size_t)row * x_stride + c] = v;
+        atomicAdd(dgamma + c, gr[c] * xh);
+        atomicAdd(dbeta + c, gr[c]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < LNB_COLS; ++j) {
+        const int c = lane + 64 * j;
+        if (c < d) {
+          const float xh = (xr[c] - mean) * rstd;
+          float v = rstd * (gamma[c] * gr[c] - a - xh * b);
+          if (add) v += add[(size_t)row * x_stride + c];
+          dx[(size_t)row * x_stride + c] = v;
+          pg[j] += gr[c] * xh;
+          pb[j] += gr[c];
+        }
+      }
+    }
+  }
+  if constexpr (!WIDE) {
+#pragma unroll
+    for (int j = 0; j < LNB_COLS; ++j) {
+      const int c = lane + 64 * j;
+      if (c < d) {
+        atomicAdd(&sg[c], pg[j]);
+        atomicAdd(&sb[c], pb[j]);
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+      atomicAdd(dgamma + c, sg[c]);
+      atomicAdd(dbeta + c, sb[c]);
+    }
+  }
+}
+
+// out[n] += sum_m x[m, n] (bias gradients); out[i] = a[i] + b[i]; dlogits of train.py:83-90 in fp32
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N, int ld) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int chunk = (M + gridDim.y - 1) / gridDim.y;
+  const int m0 = blockIdx.y * chunk, m1 = min(M, m0 + chunk);
+  float s = 0.f;
+  for (int m = m0; m < m1; ++m) s += x[(size_t)m * ld + n];
+  atomicAdd(out + n, s);
+}
+__global__ __launch_bounds__(256) void xent_grad_f32_kernel(const float* __restrict__ logits, const int* __restrict__ labels, float alpha, float scale,
+                                                             float* __restrict__ dz, int B, int C) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const float* z = logits + (size_t)row * C;
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, z[c]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) s += expf(z[c] - m);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  s = red[0] + red[1] + red[2] + red[3];
+  const int l = labels[row];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float y = (1.0f - alpha) * (c == l ? 1.f : 0.f) + alpha / (float)C;
+    dz[(size_t)row * C + c] = (expf(z[c] - m) / s - y) * scale;
+  }
+}
+
 }  // namespace
 
 extern "C" int savit_gemm_f32(const float* A, const float* W, float* C, const float* bias, const float* aux, int M, int N, int K, int lda, int ldw,
@@ -234,5 +492,69 @@ extern "C" int savit_assemble_tokens_f32(const float* tok, const float* cls, con
   long blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(assemble_tokens_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tok, cls, pos, x0, B, N, d);
+  SAVIT_LAUNCH_RET();
+}
+
+// ---- round 3: the general fp32 entries (header: include/savit.h)
+extern "C" int savit_gemm_f32_ex(const savit_gemm_f32_args* g, void* stream) {
+  SAVIT_CHECK_ARG(g && g->A && g->W && g->C && g->M >= 0 && g->N > 0 && g->K > 0 && g->batch >= 1 && g->inner >= 1 && g->batch % g->inner == 0);
+  SAVIT_CHECK_ARG(g->lda >= (g->transA ? g->M : g->K) && g->ldw >= (g->transW ? g->K : g->N) && g->ldc >= g->N && (g->aux == nullptr || g->ldaux >= g->N));
+  SAVIT_CHECK_ARG((g->act != 2 || g->U != nullptr) && (g->rowscale == nullptr || g->rows_per_sample >= 1) && g->act >= 0 && g->act <= 2 && g->aux_row_mod >= 0);
+  if (g->M == 0) return SAVIT_OK;
+  GemmF32ExParams p{g->A, g->W, g->C, g->bias, g->aux, g->colscale, g->rowscale, g->C2, g->U, g->M, g->N, g->K, g->lda, g->ldw, g->ldc, g->ldaux,
+                    g->transA, g->transW, g->inner, g->sAo, g->sAi, g->sWo, g->sWi, g->sCo, g->sCi, g->alpha, g->alpha_cols, g->act, g->accumulate,
+                    g->rows_per_sample > 0 ? g->rows_per_sample : 1, g->aux_row_mod};
+  hipLaunchKernelGGL(gemm_f32_ex_kernel, dim3((g->N + GB - 1) / GB, (g->M + GB - 1) / GB, g->batch), dim3(256), 0, (hipStream_t)stream, p);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_softmax_rows_f32(const float* x, float* y, long rows, int N, int ld, void* stream) {
+  SAVIT_CHECK_ARG(x && y && rows >= 0 && N > 0 && ld >= N);
+  if (rows == 0) return SAVIT_OK;
+  hipLaunchKernelGGL(softmax_rows_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, N, ld);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_softmax_rows_bwd_f32(const float* p, const float* dp, float* ds, long rows, int N, int ld, void* stream) {
+  SAVIT_CHECK_ARG(p && dp && ds && rows >= 0 && N > 0 && ld >= N);
+  if (rows == 0) return SAVIT_OK;
+  hipLaunchKernelGGL(softmax_rows_bwd_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, dp, ds, rows, N, ld);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_head_mix_f32(const float* T, const float* x, float* y, int B, int H, long elems, void* stream) {
+  SAVIT_CHECK_ARG(T && x && y && x != y && B >= 0 && H >= 1 && H <= 16 && elems > 0);
+  if (B == 0) return SAVIT_OK;
+  long blocks = ((long)B * elems + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(head_mix_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, T, x, y, B, H, elems);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* add, float* dx, float* dgamma, float* dbeta,
+                                       int rows, int d, long x_stride, long dy_stride, float eps, void* stream) {
+  SAVIT_CHECK_ARG(dy && x && gamma && dx && dgamma && dbeta && rows >= 0 && d > 0 && x_stride >= d && dy_stride >= d);
+  if (rows == 0) return SAVIT_OK;
+  const dim3 grid((rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS));
+  if (d <= 64 * LNB_COLS)
+    hipLaunchKernelGGL(ln_bwd_f32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, gamma, add, dx, dgamma, dbeta, rows, d, x_stride, dy_stride, eps);
+  else
+    hipLaunchKernelGGL(ln_bwd_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, gamma, add, dx, dgamma, dbeta, rows, d, x_stride, dy_stride, eps);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_colsum_f32(const float* x, float* out, int M, int N, int ld, void* stream) {
+  SAVIT_CHECK_ARG(x && out && M >= 0 && N > 0 && ld >= N);
+  if (M == 0) return SAVIT_OK;
+  const int split = M >= 4096 ? 32 : (M >= 256 ? 8 : 1);
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 255) / 256, split), dim3(256), 0, (hipStream_t)stream, x, out, M, N, ld);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_softmax_xent_grad_f32(const float* logits, const int* labels, float label_smoothing, float grad_scale, float* dlogits, int B, int C,
+                                           void* stream) {
+  SAVIT_CHECK_ARG(logits && labels && dlogits && B >= 0 && C > 0);
+  if (B == 0) return SAVIT_OK;
+  hipLaunchKernelGGL(xent_grad_f32_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, labels, label_smoothing, grad_scale, dlogits, B, C);
   SAVIT_LAUNCH_RET();
 }

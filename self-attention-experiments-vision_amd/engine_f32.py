@@ -1,16 +1,22 @@
-"""fp32 arithmetic mode of the ViT forward path (forward + loss).
+"""fp32 arithmetic mode: what the reference computes when `create_model`'s dtype stays at its default.
 
 The reference's `create_model(model_name, num_classes=1000, dtype=jnp.float32)` defaults to float32
-(/root/reference/models/create_model.py:6-8) and BASELINE config 1 is ViT-Tiny/16 in fp32: with dtype=float32 every Dense,
-LayerNorm, softmax and GELU of models/vit.py:73-99 computes and returns fp32.  This engine runs that graph on the GPU with the
-fp32 kernels of csrc/fp32_path.hip (exact fp32-input MFMA products on the fp32 master weights in place - no bf16 anywhere).
-It shares the parameter layout (ParamLayout: flat fp32 buffer, Flax-shaped views) with the bf16 training engine, so a tree moves
-between the two unchanged.  Training (backward, optimizer) is the bf16 MFMA engine's job: `loss_backward` raises here.
-Limits: the ViT family, seq_len <= 256, head_dim <= 64 (every 224x224 create_model ViT)."""
+(/root/reference/models/create_model.py:6-8), BASELINE config 1 is ViT-Tiny/16 in fp32 trained by simple_train.py:72-90, and for
+CaiT the reference ALWAYS computes in fp32: create_model.py:50-213 do not forward `dtype` and cait.py:147-154 builds the encoder
+without it.  With dtype=float32 every Dense, LayerNorm, softmax and GELU computes and returns fp32.
+
+Engines here run that graph on the GPU with the fp32 kernels of csrc/fp32_path.hip (exact fp32-input MFMA products on the fp32
+master weights in place - no bf16 anywhere; scores materialised per (image, head), so any sequence length):
+  ViTEngineF32   forward, loss, BACKWARD (every parameter gradient) and the AdamW step - a config-1 train step in fp32;
+  CaiTEngineF32  forward (+ loss): talking-heads attention, LayerScale, stochastic depth (explicit keep masks), class attention.
+They share the parameter layouts (ParamLayout / CaiTLayout: flat fp32 buffer, Flax-shaped views) with the bf16 training engines, so
+a tree moves between the two unchanged.  These paths are written for exactness and generality (the fp32 MFMA runs at 1/16 of the
+bf16 rate); throughput work lives in the bf16 engines."""
 from __future__ import annotations
 
+import ctypes
 import math
-from typing import Optional
+from typing import Dict, List, Optional
 
 import torch
 
@@ -21,95 +27,70 @@ from .engine import ParamLayout, _Plan, _copy_tree
 f32 = torch.float32
 
 
-class ViTEngineF32:
-    def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda"):
-        if cfg.kind != "vit":
-            raise NotImplementedError("fp32 arithmetic is implemented for the ViT family; the other families compute in bf16 "
-                                      "(pass dtype=torch.bfloat16 to create_model)")
-        if cfg.seq_len > 256 or cfg.head_dim > 64:
-            raise NotImplementedError("fp32 attention keeps one head's K and V in LDS: seq_len <= 256, head_dim <= 64")
+class _F32Base:
+    """Plan helpers shared by the fp32 engines."""
+
+    def _init_common(self, cfg: ModelConfig, batch: int, device: str):
         if not torch.cuda.is_available():
-            raise RuntimeError("ViTEngineF32 needs a GPU: there is no CPU path")
+            raise RuntimeError(f"{type(self).__name__} needs a GPU: there is no CPU path")
         self.L = _lib.load()
         self.cfg, self.B, self.dev = cfg, int(batch), torch.device(device)
-        self.layout = ParamLayout(cfg)
-        d, F, C, N, NL = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers
-        self.M = M = self.B * N
-        e = lambda *s: torch.empty(*s, dtype=f32, device=self.dev)  # noqa: E731
         self.params = torch.zeros(self.layout.total, dtype=f32, device=self.dev)
-        self.grads = None
-        self.w = {}
+        self.grads: Optional[torch.Tensor] = None
+        self.w: Dict[str, torch.Tensor] = {}
         self.adam_m = self.adam_v = None
+        self.step_count = 0
         self.weights_stale = False
-        self.images = e(self.B, cfg.img_size, cfg.img_size, 3)
-        self.patches = e(self.B * cfg.n_patches, cfg.patch_dim)
-        self.tok = e(self.B * cfg.n_patches, d)
-        self.x = e(M, d)
-        self.xmid = e(M, d)
-        self.h = e(M, d)
-        self.qkv = e(M, 3 * d)
-        self.o = e(M, d)
-        self.a = e(M, F)
-        self.zcls = e(self.B, d)
-        self.logits = e(self.B, C)
+        C = cfg.num_classes
+        self.logits = torch.empty(self.B, C, dtype=f32, device=self.dev)
+        self.dlogits = torch.empty(self.B, C, dtype=f32, device=self.dev)
         self.labels = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
         self.loss = torch.zeros(1, dtype=f32, device=self.dev)
-        self.loss_rows, self.top1, self.top5 = e(self.B), e(self.B), e(self.B)
-        self._plan: Optional[_Plan] = None
+        self.loss_rows = torch.empty(self.B, dtype=f32, device=self.dev)
+        self.top1 = torch.empty(self.B, dtype=f32, device=self.dev)
+        self.top5 = torch.empty(self.B, dtype=f32, device=self.dev)
+        self.gnorm_sq = torch.zeros(1, dtype=f32, device=self.dev)
+
+    def e(self, *shape) -> torch.Tensor:
+        return torch.empty(*shape, dtype=f32, device=self.dev)
 
     # ---- parameters (same tree as the bf16 engine)
     def param_tree(self) -> dict:
         return self.layout.flax_tree(self.params)
 
+    def grad_tree(self) -> dict:
+        if self.grads is None:
+            self.grads = torch.zeros_like(self.params)
+        return self.layout.flax_tree(self.grads)
+
     def load_params(self, tree: dict):
         _copy_tree(self.param_tree()["params"], tree["params"] if "params" in tree else tree)
 
-    def init_params(self, seed: int = 0):
-        from .engine import ViTEngine
+    def _off(self, name: str, buf: Optional[torch.Tensor] = None) -> int:
+        return (self.params if buf is None else buf).data_ptr() + self.layout.off[name][0] * 4
 
-        ViTEngine.init_params(self, seed)  # reference initialisers; touches only .params / .layout / .cfg / .weights_stale
+    def _gemm(self, P: _Plan, label: str, A, W, C, M, N, K, lda, ldw, ldc, **kw):
+        """C = epi(A . W) through savit_gemm_f32_ex; kw: bias, aux, ldaux, colscale, rowscale, rows_per_sample, C2, U, transA, transW,
+        batch, inner, sA=(outer, inner), sW=(..), sC=(..), alpha, alpha_cols, act, accumulate, aux_row_mod."""
+        g = _lib.GemmF32Args()
+        g.A, g.W, g.C, g.M, g.N, g.K, g.lda, g.ldw, g.ldc = A, W, C, M, N, K, lda, ldw, ldc
+        g.bias, g.aux, g.colscale, g.rowscale, g.C2, g.U = (kw.get(k) for k in ("bias", "aux", "colscale", "rowscale", "C2", "U"))
+        g.ldaux = kw.get("ldaux", ldc)
+        g.transA, g.transW = int(kw.get("transA", 0)), int(kw.get("transW", 0))
+        g.batch, g.inner = int(kw.get("batch", 1)), int(kw.get("inner", 1))
+        g.sAo, g.sAi = kw.get("sA", (0, 0))
+        g.sWo, g.sWi = kw.get("sW", (0, 0))
+        g.sCo, g.sCi = kw.get("sC", (0, 0))
+        g.alpha, g.alpha_cols = float(kw.get("alpha", 1.0)), int(kw.get("alpha_cols", 0))
+        g.act, g.accumulate, g.rows_per_sample = int(kw.get("act", 0)), int(kw.get("accumulate", 0)), int(kw.get("rows_per_sample", 1))
+        g.aux_row_mod = int(kw.get("aux_row_mod", 0))
+        P.keep.append(g)
+        P.add(self.L.savit_gemm_f32_ex, (ctypes.byref(g),), label)
 
-    def _off(self, name: str) -> int:
-        return self.params.data_ptr() + self.layout.off[name][0] * 4
-
-    def _build_plan(self) -> _Plan:
-        P, L, cfg = _Plan(), self.L, self.cfg
-        d, F, C, N, NL, H, B, M = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers, cfg.num_heads, self.B, self.M
-        pp = self._off
-        x, xm, h = self.x.data_ptr(), self.xmid.data_ptr(), self.h.data_ptr()
-
-        def gemm(label, A, W, Cc, M_, N_, K_, lda, ldw, ldc, bias=None, aux=None, ldaux=0, alpha=1.0, alpha_cols=0, gelu=0):
-            P.add(L.savit_gemm_f32, (A, W, Cc, bias, aux, M_, N_, K_, lda, ldw, ldc, ldaux, alpha, alpha_cols, gelu), label)
-
-        P.add(L.savit_patchify_f32, (self.images.data_ptr(), self.patches.data_ptr(), B, cfg.img_size, cfg.patch), "patchify")
-        gemm("patch_embed", self.patches.data_ptr(), pp("Wpe"), self.tok.data_ptr(), B * cfg.n_patches, d, cfg.patch_dim, cfg.patch_dim, d, d)
-        P.add(L.savit_assemble_tokens_f32, (self.tok.data_ptr(), pp("cls"), pp("pos"), x, B, N, d), "tokens")
-        for l in range(NL):
-            P.add(L.savit_layernorm_fwd_f32, (x, pp(f"l{l}.ln1_g"), pp(f"l{l}.ln1_b"), h, M, d, d, d, 1e-6), f"l{l}.ln1")
-            gemm(f"l{l}.qkv", h, pp(f"l{l}.Wqkv"), self.qkv.data_ptr(), M, 3 * d, d, d, 3 * d, 3 * d, alpha=1.0 / math.sqrt(cfg.head_dim),
-                 alpha_cols=d)
-            P.add(L.savit_attention_fwd_f32, (self.qkv.data_ptr(), self.o.data_ptr(), B, N, H, cfg.head_dim, 3 * d), f"l{l}.attn")
-            gemm(f"l{l}.proj", self.o.data_ptr(), pp(f"l{l}.Wo"), xm, M, d, d, d, d, d, aux=x, ldaux=d)
-            P.add(L.savit_layernorm_fwd_f32, (xm, pp(f"l{l}.ln2_g"), pp(f"l{l}.ln2_b"), h, M, d, d, d, 1e-6), f"l{l}.ln2")
-            gemm(f"l{l}.fc1", h, pp(f"l{l}.W1"), self.a.data_ptr(), M, F, d, d, F, F, bias=pp(f"l{l}.b1"), gelu=1)
-            gemm(f"l{l}.fc2", self.a.data_ptr(), pp(f"l{l}.W2"), x, M, d, F, F, d, d, bias=pp(f"l{l}.b2"), aux=xm, ldaux=d)
-        P.add(L.savit_layernorm_fwd_f32, (x, pp("lnf_g"), pp("lnf_b"), self.zcls.data_ptr(), B, d, N * d, d, 1e-6), "lnf")  # cls rows only
-        gemm("head", self.zcls.data_ptr(), pp("Wh"), self.logits.data_ptr(), B, C, d, d, C, C, bias=pp("bh"))
-        return P
-
-    def set_images(self, images: torch.Tensor):
-        S = self.cfg.img_size
-        if not images.is_cuda or tuple(images.shape) != (self.B, S, S, 3):
-            raise ValueError(f"images must be a GPU tensor [B={self.B},{S},{S},3] (NHWC)")
-        self.images.copy_(images.to(f32))
-
-    def forward(self, images: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if images is not None:
-            self.set_images(images)
-        if self._plan is None:
-            self._plan = self._build_plan()
-        self._plan.run(torch.cuda.current_stream().cuda_stream)
-        return self.logits
+    def _scores(self, P: _Plan, label: str, q_ptr, k_ptr, S, Nq, Nk, H, hd, ldq, ldk, q_img_stride, k_img_stride):
+        """S[b, h] = Q[b, h] K[b, h]^T (attention.py:41) for every (image, head): [B * H, Nq, Nk]."""
+        self._gemm(P, label, q_ptr, k_ptr, S.data_ptr(), Nq, Nk, hd, ldq, ldk, Nk, transW=1, batch=self.B * H, inner=H,
+                   sA=(q_img_stride, hd), sW=(k_img_stride, hd), sC=(H * Nq * Nk, Nq * Nk))
 
     def loss_fn(self, labels: torch.Tensor, label_smoothing: float = 0.1) -> torch.Tensor:
         """train.py:83-90 on the fp32 logits (one-hot, label smoothing, softmax cross-entropy, mean); also fills top1 / top5."""
@@ -121,8 +102,311 @@ class ViTEngineF32:
                                              self.B, self.cfg.num_classes, torch.cuda.current_stream().cuda_stream), "savit_softmax_xent")
         return self.loss
 
+
+class ViTEngineF32(_F32Base):
+    def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda"):
+        if cfg.kind != "vit":
+            raise NotImplementedError("ViTEngineF32 handles the ViT family (CaiT: CaiTEngineF32)")
+        self.layout = ParamLayout(cfg)
+        self._init_common(cfg, batch, device)
+        d, F, N, NL, H = cfg.embed_dim, cfg.hidden, cfg.seq_len, cfg.num_layers, cfg.num_heads
+        self.M = M = self.B * N
+        e = self.e
+        self.images = e(self.B, cfg.img_size, cfg.img_size, 3)
+        self.patches = e(self.B * cfg.n_patches, cfg.patch_dim)
+        self.tok = e(self.B * cfg.n_patches, d)
+        # activations, saved per layer (a train step differentiates through all of them; simple_train.py:84-85)
+        self.x = [e(M, d) for _ in range(NL + 1)]
+        self.xmid = [e(M, d) for _ in range(NL)]
+        self.h1 = [e(M, d) for _ in range(NL)]
+        self.h2 = [e(M, d) for _ in range(NL)]
+        self.qkv = [e(M, 3 * d) for _ in range(NL)]
+        self.p = [e(self.B * H, N, N) for _ in range(NL)]   # softmax probabilities (attention.py:48)
+        self.o = [e(M, d) for _ in range(NL)]
+        self.u = [e(M, F) for _ in range(NL)]               # pre-GELU
+        self.a = [e(M, F) for _ in range(NL)]
+        self.s = e(self.B * H, N, N)                        # scores / dP / dS scratch
+        self.zcls = e(self.B, d)
+        # backward scratch
+        self.dres = e(M, d)
+        self.d_a = e(M, F)
+        self.d_h = e(M, d)
+        self.d_o = e(M, d)
+        self.dqkv = e(M, 3 * d)
+        self.d_z = e(self.B, d)
+        self._fwd: Optional[_Plan] = None
+        self._bwd: Optional[_Plan] = None
+
+    def init_params(self, seed: int = 0):
+        from .engine import ViTEngine
+
+        ViTEngine.init_params(self, seed)  # reference initialisers; touches only .params / .layout / .cfg / .weights_stale
+
+    def _build_fwd(self) -> _Plan:
+        P, L, cfg = _Plan(), self.L, self.cfg
+        d, F, C, N, NL, H, B, M, hd = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers, cfg.num_heads, self.B, self.M, cfg.head_dim
+        pp = self._off
+        P.add(L.savit_patchify_f32, (self.images.data_ptr(), self.patches.data_ptr(), B, cfg.img_size, cfg.patch), "patchify")
+        self._gemm(P, "patch_embed", self.patches.data_ptr(), pp("Wpe"), self.tok.data_ptr(), B * cfg.n_patches, d, cfg.patch_dim, cfg.patch_dim, d, d)
+        P.add(L.savit_assemble_tokens_f32, (self.tok.data_ptr(), pp("cls"), pp("pos"), self.x[0].data_ptr(), B, N, d), "tokens")
+        for l in range(NL):
+            x, xm, qkv = self.x[l].data_ptr(), self.xmid[l].data_ptr(), self.qkv[l].data_ptr()
+            P.add(L.savit_layernorm_fwd_f32, (x, pp(f"l{l}.ln1_g"), pp(f"l{l}.ln1_b"), self.h1[l].data_ptr(), M, d, d, d, 1e-6), f"l{l}.ln1")
+            self._gemm(P, f"l{l}.qkv", self.h1[l].data_ptr(), pp(f"l{l}.Wqkv"), qkv, M, 3 * d, d, d, 3 * d, 3 * d, alpha=1.0 / math.sqrt(hd), alpha_cols=d)
+            self._scores(P, f"l{l}.scores", qkv, qkv + 4 * d, self.s, N, N, H, hd, 3 * d, 3 * d, N * 3 * d, N * 3 * d)
+            P.add(L.savit_softmax_rows_f32, (self.s.data_ptr(), self.p[l].data_ptr(), B * H * N, N, N), f"l{l}.softmax")
+            self._gemm(P, f"l{l}.pv", self.p[l].data_ptr(), qkv + 8 * d, self.o[l].data_ptr(), N, hd, N, N, 3 * d, d, batch=B * H, inner=H,
+                       sA=(H * N * N, N * N), sW=(N * 3 * d, hd), sC=(N * d, hd))
+            self._gemm(P, f"l{l}.proj", self.o[l].data_ptr(), pp(f"l{l}.Wo"), xm, M, d, d, d, d, d, aux=x, ldaux=d)
+            P.add(L.savit_layernorm_fwd_f32, (xm, pp(f"l{l}.ln2_g"), pp(f"l{l}.ln2_b"), self.h2[l].data_ptr(), M, d, d, d, 1e-6), f"l{l}.ln2")
+            self._gemm(P, f"l{l}.fc1", self.h2[l].data_ptr(), pp(f"l{l}.W1"), self.a[l].data_ptr(), M, F, d, d, F, F, bias=pp(f"l{l}.b1"), act=1,
+                       C2=self.u[l].data_ptr())
+            self._gemm(P, f"l{l}.fc2", self.a[l].data_ptr(), pp(f"l{l}.W2"), self.x[l + 1].data_ptr(), M, d, F, F, d, d, bias=pp(f"l{l}.b2"), aux=xm, ldaux=d)
+        P.add(L.savit_layernorm_fwd_f32, (self.x[NL].data_ptr(), pp("lnf_g"), pp("lnf_b"), self.zcls.data_ptr(), B, d, N * d, d, 1e-6), "lnf")  # cls rows only
+        self._gemm(P, "head", self.zcls.data_ptr(), pp("Wh"), self.logits.data_ptr(), B, C, d, d, C, C, bias=pp("bh"))
+        return P
+
+    def _build_bwd(self) -> _Plan:
+        """Reverse-mode gradient of the forward plan (jax.value_and_grad at simple_train.py:84-85): every product is the transposed
+        form of its forward GEMM, weight gradients accumulate into self.grads."""
+        P, L, cfg = _Plan(), self.L, self.cfg
+        d, F, C, N, NL, H, B, M, hd = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers, cfg.num_heads, self.B, self.M, cfg.head_dim
+        pp = self._off
+        gp = lambda n: self._off(n, self.grads)  # noqa: E731
+        dres, d_a, d_h, d_o, dqkv, s = (t.data_ptr() for t in (self.dres, self.d_a, self.d_h, self.d_o, self.dqkv, self.s))
+        dl = self.dlogits.data_ptr()
+
+        def wgrad(label, X, dY, dW, Mr, Kin, Nout, ldx, lddy):  # dW[Kin, Nout] += X[Mr, Kin]^T dY[Mr, Nout]
+            self._gemm(P, label, X, dY, dW, Kin, Nout, Mr, ldx, lddy, Nout, transA=1, accumulate=1)
+
+        def dgrad(label, dY, W, dX, Mr, Kin, Nout, lddy, ldx, **kw):  # dX[Mr, Kin] = dY[Mr, Nout] W[Kin, Nout]^T
+            self._gemm(P, label, dY, W, dX, Mr, Kin, Nout, lddy, Nout, ldx, transW=1, **kw)
+
+        # head (vit.py:95-98) and the final LayerNorm on the cls rows (vit.py:57)
+        wgrad("head.wgrad", self.zcls.data_ptr(), dl, gp("Wh"), B, d, C, d, C)
+        P.add(L.savit_colsum_f32, (dl, gp("bh"), B, C, C), "head.bgrad")
+        dgrad("head.dgrad", dl, pp("Wh"), self.d_z.data_ptr(), B, d, C, C, d)
+        P.add(L.savit_layernorm_bwd_f32, (self.d_z.data_ptr(), self.x[NL].data_ptr(), pp("lnf_g"), None, dres, gp("lnf_g"), gp("lnf_b"), B, d, N * d, d,
+                                          1e-6), "lnf.bwd")
+        for l in range(NL - 1, -1, -1):
+            qkv = self.qkv[l].data_ptr()
+            # x_{l+1} = x_mid + gelu(h2 W1 + b1) W2 + b2   (ff.py:26-33, vit.py:26-31)
+            wgrad(f"l{l}.W2.wgrad", self.a[l].data_ptr(), dres, gp(f"l{l}.W2"), M, F, d, F, d)
+            P.add(L.savit_colsum_f32, (dres, gp(f"l{l}.b2"), M, d, d), f"l{l}.b2.grad")
+            dgrad(f"l{l}.fc2.dgrad", dres, pp(f"l{l}.W2"), d_a, M, F, d, d, F, act=2, U=self.u[l].data_ptr())  # * gelu'(u)
+            wgrad(f"l{l}.W1.wgrad", self.h2[l].data_ptr(), d_a, gp(f"l{l}.W1"), M, d, F, d, F)
+            P.add(L.savit_colsum_f32, (d_a, gp(f"l{l}.b1"), M, F, F), f"l{l}.b1.grad")
+            dgrad(f"l{l}.fc1.dgrad", d_a, pp(f"l{l}.W1"), d_h, M, d, F, F, d)
+            P.add(L.savit_layernorm_bwd_f32, (d_h, self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), dres, dres, gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b"), M, d, d, d,
+                                              1e-6), f"l{l}.ln2.bwd")
+            # x_mid = x_l + attn(LN1(x_l)) Wo   (attention.py:21-67, vit.py:19-24)
+            wgrad(f"l{l}.Wo.wgrad", self.o[l].data_ptr(), dres, gp(f"l{l}.Wo"), M, d, d, d, d)
+            dgrad(f"l{l}.proj.dgrad", dres, pp(f"l{l}.Wo"), d_o, M, d, d, d, d)
+            bh = dict(batch=B * H, inner=H)
+            # dP = dO V^T ; dV = P^T dO ; dS = P (dP - sum dP P) ; dQ = dS K / sqrt(hd) ; dK = dS^T Q
+            self._gemm(P, f"l{l}.dP", d_o, qkv + 8 * d, s, N, N, hd, d, 3 * d, N, transW=1, sA=(N * d, hd), sW=(N * 3 * d, hd), sC=(H * N * N, N * N), **bh)
+            self._gemm(P, f"l{l}.dV", self.p[l].data_ptr(), d_o, dqkv + 8 * d, N, hd, N, N, d, 3 * d, transA=1, sA=(H * N * N, N * N), sW=(N * d, hd),
+                       sC=(N * 3 * d, hd), **bh)
+            P.add(L.savit_softmax_rows_bwd_f32, (self.p[l].data_ptr(), s, s, B * H * N, N, N), f"l{l}.softmax.bwd")
+            self._gemm(P, f"l{l}.dQ", s, qkv + 4 * d, dqkv, N, hd, N, N, 3 * d, 3 * d, sA=(H * N * N, N * N), sW=(N * 3 * d, hd), sC=(N * 3 * d, hd),
+                       alpha=1.0 / math.sqrt(hd), alpha_cols=hd, **bh)
+            self._gemm(P, f"l{l}.dK", s, qkv, dqkv + 4 * d, N, hd, N, N, 3 * d, 3 * d, transA=1, sA=(H * N * N, N * N), sW=(N * 3 * d, hd),
+                       sC=(N * 3 * d, hd), **bh)
+            wgrad(f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), dqkv, gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d)
+            dgrad(f"l{l}.qkv.dgrad", dqkv, pp(f"l{l}.Wqkv"), d_h, M, d, 3 * d, 3 * d, d)
+            P.add(L.savit_layernorm_bwd_f32, (d_h, self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), dres, dres, gp(f"l{l}.ln1_g"), gp(f"l{l}.ln1_b"), M, d, d, d,
+                                              1e-6), f"l{l}.ln1.bwd")
+        # embeddings: dpos, dcls (vit.py:81-85, position_embed.py:56), dWpe per image (patch_embed.py:23-25: token rows 1.. of each image)
+        P.add(L.savit_pos_cls_grad, (dres, gp("pos"), gp("cls"), B, N, d, 1), "pos_cls.grad")
+        P.add(_gather_patch_rows, (self,), "dtok.gather")  # the patch rows of dx0 (token 0 of each image is cls), contiguous
+        wgrad("Wpe.wgrad", self.patches.data_ptr(), self.tok.data_ptr(), gp("Wpe"), B * cfg.n_patches, cfg.patch_dim, d, cfg.patch_dim, d)
+        return P
+
+    def set_images(self, images: torch.Tensor):
+        S = self.cfg.img_size
+        if not images.is_cuda or tuple(images.shape) != (self.B, S, S, 3):
+            raise ValueError(f"images must be a GPU tensor [B={self.B},{S},{S},3] (NHWC)")
+        self.images.copy_(images.to(f32))
+
+    def forward(self, images: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if images is not None:
+            self.set_images(images)
+        if self._fwd is None:
+            self._fwd = self._build_fwd()
+        self._fwd.run(torch.cuda.current_stream().cuda_stream)
+        return self.logits
+
+    def loss_backward(self, labels: torch.Tensor, label_smoothing: float = 0.1, zero_grads: bool = True) -> torch.Tensor:
+        """Loss (train.py:83-90 / simple_train.py:76-83) + the full backward pass into self.grads (fp32)."""
+        if self.grads is None:
+            self.grads = torch.zeros_like(self.params)
+        elif zero_grads:
+            self.grads.zero_()
+        s = torch.cuda.current_stream().cuda_stream
+        self.loss_fn(labels, label_smoothing)
+        _lib.check(self.L.savit_softmax_xent_grad_f32(self.logits.data_ptr(), self.labels.data_ptr(), float(label_smoothing), 1.0 / self.B,
+                                                      self.dlogits.data_ptr(), self.B, self.cfg.num_classes, s), "savit_softmax_xent_grad_f32")
+        self.dres.zero_()
+        if self._bwd is None:
+            self._bwd = self._build_bwd()
+        self._bwd.run(s)
+        return self.loss
+
+    def optimizer_step(self, lr: float, weight_decay: float = 0.0, max_norm: float = 0.0, b1: float = 0.9, b2: float = 0.999,
+                       eps: float = 1e-8, grad_scale: float = 1.0):
+        """optax chain of simple_train.py:25-27 / train.py:25-27 (clip, Adam, weight decay, -lr) on the fp32 parameters."""
+        if self.adam_m is None:
+            self.adam_m, self.adam_v = torch.zeros_like(self.params), torch.zeros_like(self.params)
+        s = torch.cuda.current_stream().cuda_stream
+        self.step_count += 1
+        ss = None
+        if max_norm and max_norm > 0:
+            self.gnorm_sq.zero_()
+            _lib.check(self.L.savit_sumsq(self.grads.data_ptr(), self.grads.numel(), self.gnorm_sq.data_ptr(), s), "savit_sumsq")
+            ss = self.gnorm_sq.data_ptr()
+        _lib.check(self.L.savit_adamw_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
+                                           self.params.numel(), float(lr), float(b1), float(b2), float(eps), float(weight_decay),
+                                           self.step_count, ss, float(max_norm or 0.0), float(grad_scale), s), "savit_adamw_step")
+
+    def refresh_weights(self):  # the fp32 products read the master weights in place
+        self.weights_stale = False
+
+
+class CaiTEngineF32(_F32Base):
+    """cait.py:140-183 in fp32 - the arithmetic the reference ALWAYS uses for CaiT (its create_model branch ignores dtype)."""
+
+    def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda"):
+        if cfg.kind != "cait":
+            raise ValueError("CaiTEngineF32 needs a CaiT config")
+        if cfg.num_heads > 16:
+            raise NotImplementedError("savit_head_mix_f32 handles up to 16 heads")
+        from .cait_engine import CaiTLayout
+
+        self.layout = CaiTLayout(cfg)
+        self._init_common(cfg, batch, device)
+        d, F, N, H = cfg.embed_dim, cfg.hidden, cfg.n_patches, cfg.num_heads
+        B = self.B
+        self.M, self.Mc = B * N, B * (N + 1)
+        e = self.e
+        self.images = e(B, cfg.img_size, cfg.img_size, 3)
+        self.patches = e(self.M, cfg.patch_dim)
+        self.x, self.xmid, self.h = e(self.M, d), e(self.M, d), e(self.M, d)
+        self.qkv, self.o, self.a = e(self.M, 3 * d), e(self.M, d), e(self.M, F)
+        self.s, self.s2 = e(B * H, N, N), e(B * H, N, N)
+        # class-attention stage: [cls ; x] rows, cls stream, its 1 x (N + 1) scores
+        self.xc, self.hc = e(self.Mc, d), e(self.Mc, d)
+        self.cls, self.clsmid, self.hq = e(B, d), e(B, d), e(B, d)
+        self.qc, self.kvc, self.oc, self.ac = e(B, d), e(self.Mc, 2 * d), e(B, d), e(B, F)
+        self.sc, self.pc = e(B * H, 1, N + 1), e(B * H, 1, N + 1)
+        self.zcls = e(B, d)
+        self.keep: Optional[torch.Tensor] = None  # [(L + Lc), 2, B] keep masks / keep_prob of a training-mode forward, or None
+        self.gen = torch.Generator(device=self.dev)
+        self._plans: Dict[bool, _Plan] = {}
+
+    def init_params(self, seed: int = 0):
+        from .cait_engine import CaiTEngine
+
+        CaiTEngine.init_params(self, seed)
+
+    def _build(self, training: bool) -> _Plan:
+        P, L, cfg = _Plan(), self.L, self.cfg
+        d, F, C, N, NL, NC, H, B, M, Mc, hd = (cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.n_patches, cfg.num_layers, cfg.num_layers_token_only,
+                                              cfg.num_heads, self.B, self.M, self.Mc, cfg.head_dim)
+        pp = self._off
+        x, xm, h, qkv, o, a, s, s2 = (t.data_ptr() for t in (self.x, self.xmid, self.h, self.qkv, self.o, self.a, self.s, self.s2))
+        sd = training and cfg.stoch_depth_rate > 0
+
+        def rs(block, which):  # stochastic depth as the per-image row scale of the residual epilogue (stochastic_depth.py:16-27)
+            return dict(rowscale=self.keep[block, which].data_ptr()) if sd else {}
+
+        P.add(L.savit_patchify_f32, (self.images.data_ptr(), self.patches.data_ptr(), B, cfg.img_size, cfg.patch), "patchify")
+        self._gemm(P, "patch_embed", self.patches.data_ptr(), pp("Wpe"), x, M, d, cfg.patch_dim, cfg.patch_dim, d, d, aux=pp("pos"), ldaux=d,
+                   aux_row_mod=N)  # + pos_embed, shared by the images (cait.py:143-145, position_embed.py:56)
+        for l in range(NL):
+            P.add(L.savit_layernorm_fwd_f32, (x, pp(f"l{l}.ln1_g"), pp(f"l{l}.ln1_b"), h, M, d, d, d, 1e-6), f"l{l}.ln1")
+            self._gemm(P, f"l{l}.qkv", h, pp(f"l{l}.Wqkv"), qkv, M, 3 * d, d, d, 3 * d, 3 * d, alpha=1.0 / math.sqrt(hd), alpha_cols=d)
+            self._scores(P, f"l{l}.scores", qkv, qkv + 4 * d, self.s, N, N, H, hd, 3 * d, 3 * d, N * 3 * d, N * 3 * d)
+            P.add(L.savit_head_mix_f32, (pp(f"l{l}.T1"), s, s2, B, H, N * N), f"l{l}.th1")          # attention.py:44-46
+            P.add(L.savit_softmax_rows_f32, (s2, s2, B * H * N, N, N), f"l{l}.softmax")               # :48
+            P.add(L.savit_head_mix_f32, (pp(f"l{l}.T2"), s2, s, B, H, N * N), f"l{l}.th2")          # :50-52
+            self._gemm(P, f"l{l}.pv", s, qkv + 8 * d, o, N, hd, N, N, 3 * d, d, batch=B * H, inner=H, sA=(H * N * N, N * N), sW=(N * 3 * d, hd),
+                       sC=(N * d, hd))
+            self._gemm(P, f"l{l}.proj", o, pp(f"l{l}.Wo"), xm, M, d, d, d, d, d, aux=x, ldaux=d, colscale=pp(f"l{l}.ls1"), rows_per_sample=N, **rs(l, 0))
+            P.add(L.savit_layernorm_fwd_f32, (xm, pp(f"l{l}.ln2_g"), pp(f"l{l}.ln2_b"), h, M, d, d, d, 1e-6), f"l{l}.ln2")
+            self._gemm(P, f"l{l}.fc1", h, pp(f"l{l}.W1"), a, M, F, d, d, F, F, bias=pp(f"l{l}.b1"), act=1)
+            self._gemm(P, f"l{l}.fc2", a, pp(f"l{l}.W2"), x, M, d, F, F, d, d, bias=pp(f"l{l}.b2"), aux=xm, ldaux=d, colscale=pp(f"l{l}.ls2"),
+                       rows_per_sample=N, **rs(l, 1))
+        # class-attention stage (cait.py:157-173): cls starts as the parameter; x is frozen
+        xc, hc, cls, clsm, hq = (t.data_ptr() for t in (self.xc, self.hc, self.cls, self.clsmid, self.hq))
+        qc, kvc, oc, ac, sc, pc = (t.data_ptr() for t in (self.qc, self.kvc, self.oc, self.ac, self.sc, self.pc))
+        Nk = N + 1
+        for c in range(NC):
+            P.add(_concat_rows, (self, ), f"c{c}.concat")  # xc = [cls ; x] (cait.py:98): device-side row copies
+            P.add(L.savit_layernorm_fwd_f32, (xc, pp(f"c{c}.ln1_g"), pp(f"c{c}.ln1_b"), hc, Mc, d, d, d, 1e-6), f"c{c}.ln1")
+            # q from row 0 only (cait.py:13-15), k and v from all N + 1 rows
+            self._gemm(P, f"c{c}.q", hc, pp(f"c{c}.Wqkv"), qc, B, d, d, Nk * d, 3 * d, d, alpha=1.0 / math.sqrt(hd), alpha_cols=d)
+            self._gemm(P, f"c{c}.kv", hc, pp(f"c{c}.Wqkv") + 4 * d, kvc, Mc, 2 * d, d, d, 3 * d, 2 * d)
+            self._scores(P, f"c{c}.scores", qc, kvc, self.sc, 1, Nk, H, hd, d, 2 * d, d, Nk * 2 * d)
+            P.add(L.savit_softmax_rows_f32, (sc, pc, B * H, Nk, Nk), f"c{c}.softmax")
+            self._gemm(P, f"c{c}.pv", pc, kvc + 4 * d, oc, 1, hd, Nk, Nk, 2 * d, d, batch=B * H, inner=H, sA=(H * Nk, Nk), sW=(Nk * 2 * d, hd), sC=(d, hd))
+            self._gemm(P, f"c{c}.proj", oc, pp(f"c{c}.Wo"), clsm, B, d, d, d, d, d, aux=cls, ldaux=d, colscale=pp(f"c{c}.ls1"), rows_per_sample=1,
+                       **rs(NL + c, 0))
+            P.add(L.savit_layernorm_fwd_f32, (clsm, pp(f"c{c}.ln2_g"), pp(f"c{c}.ln2_b"), hq, B, d, d, d, 1e-6), f"c{c}.ln2")
+            self._gemm(P, f"c{c}.fc1", hq, pp(f"c{c}.W1"), ac, B, F, d, d, F, F, bias=pp(f"c{c}.b1"), act=1)
+            self._gemm(P, f"c{c}.fc2", ac, pp(f"c{c}.W2"), cls, B, d, F, F, d, d, bias=pp(f"c{c}.b2"), aux=clsm, ldaux=d, colscale=pp(f"c{c}.ls2"),
+                       rows_per_sample=1, **rs(NL + c, 1))
+        # final LayerNorm over [cls ; x], of which only row 0 reaches the head (cait.py:175-182)
+        P.add(L.savit_layernorm_fwd_f32, (cls, pp("lnf_g"), pp("lnf_b"), self.zcls.data_ptr(), B, d, d, d, 1e-6), "lnf")
+        self._gemm(P, "head", self.zcls.data_ptr(), pp("Wh"), self.logits.data_ptr(), B, C, d, d, C, C, bias=pp("bh"))
+        return P
+
+    def set_images(self, images: torch.Tensor):
+        S = self.cfg.img_size
+        if not images.is_cuda or tuple(images.shape) != (self.B, S, S, 3):
+            raise ValueError(f"images must be a GPU tensor [B={self.B},{S},{S},3] (NHWC)")
+        self.images.copy_(images.to(f32))
+
+    def forward(self, images: Optional[torch.Tensor] = None, is_training: bool = False, keep_masks: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """keep_masks [(L + Lc), 2, B] of 0 / 1 (tests); drawn from the engine's generator in training mode when absent."""
+        cfg = self.cfg
+        if images is not None:
+            self.set_images(images)
+        training = bool(is_training) and cfg.stoch_depth_rate > 0
+        if training:
+            keep = 1.0 - cfg.stoch_depth_rate
+            nb = cfg.num_layers + cfg.num_layers_token_only
+            if keep_masks is None:
+                keep_masks = torch.floor(keep + torch.rand(nb, 2, self.B, device=self.dev, generator=self.gen))
+            if self.keep is None:
+                self.keep = torch.empty(nb, 2, self.B, dtype=f32, device=self.dev)
+            self.keep.copy_(keep_masks.to(device=self.dev, dtype=f32) / keep)
+        if training not in self._plans:
+            if training and self.keep is None:
+                raise RuntimeError("keep masks missing")
+            self._plans[training] = self._build(training)
+        # the cls stream starts from the parameter (cait.py:157-160)
+        self.cls.copy_(self.layout.view(self.params, "cls").view(1, -1).expand(self.B, -1))
+        self._plans[training].run(torch.cuda.current_stream().cuda_stream)
+        return self.logits
+
     def loss_backward(self, *a, **k):
-        raise NotImplementedError("fp32 arithmetic covers forward + loss; training runs on the bf16 MFMA engine "
+        raise NotImplementedError("CaiT fp32 arithmetic covers forward + loss; CaiT training runs on the bf16 MFMA engine "
                                   "(create_model(..., dtype=torch.bfloat16))")
 
     optimizer_step = backward_from_dlogits = loss_backward
+
+
+def _concat_rows(eng: "CaiTEngineF32", stream: int) -> int:
+    """xc = concat([cls, x], axis=1) (cait.py:98): two strided device copies on the current stream (memory plumbing, no arithmetic)."""
+    B, N, d = eng.B, eng.cfg.n_patches, eng.cfg.embed_dim
+    xc = eng.xc.view(B, N + 1, d)
+    xc[:, 0].copy_(eng.cls)
+    xc[:, 1:].copy_(eng.x.view(B, N, d))
+    return 0
+
+
+def _gather_patch_rows(eng: "ViTEngineF32", stream: int) -> int:
+    """tok = dx0[:, 1:, :] (the cotangent of the patch embeddings, vit.py:81-84): one strided device copy on the current stream."""
+    B, N, d = eng.B, eng.cfg.seq_len, eng.cfg.embed_dim
+    eng.tok.view(B, N - 1, d).copy_(eng.dres.view(B, N, d)[:, 1:])
+    return 0

@@ -35,6 +35,17 @@ class WgradProblem(Structure):
                 ("lddy", c_int), ("lddw", c_int), ("tile_begin", c_int), ("tile_count", c_int)]
 
 
+class GemmF32Args(Structure):
+    """Mirror of `savit_gemm_f32_args` (include/savit.h)."""
+    _fields_ = [("A", c_void_p), ("W", c_void_p), ("C", c_void_p), ("bias", c_void_p), ("aux", c_void_p), ("colscale", c_void_p),
+                ("rowscale", c_void_p), ("C2", c_void_p), ("U", c_void_p),
+                ("M", c_int), ("N", c_int), ("K", c_int), ("lda", c_int), ("ldw", c_int), ("ldc", c_int), ("ldaux", c_int),
+                ("transA", c_int), ("transW", c_int), ("batch", c_int), ("inner", c_int),
+                ("sAo", c_long), ("sAi", c_long), ("sWo", c_long), ("sWi", c_long), ("sCo", c_long), ("sCi", c_long),
+                ("alpha", c_float), ("alpha_cols", c_int), ("act", c_int), ("accumulate", c_int), ("rows_per_sample", c_int),
+                ("aux_row_mod", c_int)]
+
+
 # name -> (restype, argtypes); every symbol include/savit.h declares must be here (tests check both ways)
 _SIGNATURES = {
     "savit_abi_version": (c_int, []),
@@ -111,6 +122,13 @@ _SIGNATURES = {
                                c_int, c_int, c_void_p]),
     "savit_layernorm_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_long, c_float, c_void_p]),
     "savit_attention_fwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "savit_gemm_f32_ex": (c_int, [POINTER(GemmF32Args), c_void_p]),
+    "savit_softmax_rows_f32": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "savit_softmax_rows_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "savit_head_mix_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p]),
+    "savit_layernorm_bwd_f32": (c_int, [c_void_p] * 7 + [c_int, c_int, c_long, c_long, c_float, c_void_p]),
+    "savit_colsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "savit_softmax_xent_grad_f32": (c_int, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int, c_int, c_void_p]),
     "savit_patchify_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "savit_assemble_tokens_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
