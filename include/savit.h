@@ -337,6 +337,7 @@ typedef struct savit_gemm_f32_args {
   long sAo, sAi, sWo, sWi, sCo, sCi;
   float alpha; int alpha_cols; int act; int accumulate; int rows_per_sample;
   int aux_row_mod; /* > 0: aux is a table [aux_row_mod, ldaux] shared by all batches, row m % aux_row_mod (position embeddings) */
+  const float* rowbias; /* nullable: v += rowbias[m] before the activation (a Dense bias of a product computed transposed) */
 } savit_gemm_f32_args;
 int savit_gemm_f32_ex(const savit_gemm_f32_args* args, void* stream);
 int savit_softmax_rows_f32(const float* x, float* y, long rows, int N, int ld, void* stream);

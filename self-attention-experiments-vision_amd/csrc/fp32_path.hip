@@ -205,6 +205,7 @@ struct GemmF32ExParams {
   long sAo, sAi, sWo, sWi, sCo, sCi;  // element strides of the batch parts (aux, C2, U follow C)
   float alpha; int alpha_cols; int act; int accumulate; int rows_per_sample;
   int aux_row_mod;  // > 0: aux is a [aux_row_mod, ldaux] table shared by all batches, row m % aux_row_mod (position embeddings)
+  const float* rowbias;  // nullable: + rowbias[m] (a Dense bias when the product is computed transposed: MLP-Mixer token mixing)
 };
 
 __device__ __forceinline__ float gelu_tanh_exact(float v) {
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(256) void gemm_f32_ex_kernel(const GemmF32ExParams 
     if (m >= p.M) continue;
     const size_t o = (size_t)coff + (size_t)m * p.ldc + n;
     float v = acc[r] * sc + bn;
+    if (p.rowbias) v += p.rowbias[m];
     if (p.C2) p.C2[o] = v;
     if (p.act == 1) v = gelu_tanh_exact(v);
     if (p.act == 2) v *= gelu_tanh_grad_exact(p.U[o]);
@@ -503,7 +505,7 @@ extern "C" int savit_gemm_f32_ex(const savit_gemm_f32_args* g, void* stream) {
   if (g->M == 0) return SAVIT_OK;
   GemmF32ExParams p{g->A, g->W, g->C, g->bias, g->aux, g->colscale, g->rowscale, g->C2, g->U, g->M, g->N, g->K, g->lda, g->ldw, g->ldc, g->ldaux,
                     g->transA, g->transW, g->inner, g->sAo, g->sAi, g->sWo, g->sWi, g->sCo, g->sCi, g->alpha, g->alpha_cols, g->act, g->accumulate,
-                    g->rows_per_sample > 0 ? g->rows_per_sample : 1, g->aux_row_mod};
+                    g->rows_per_sample > 0 ? g->rows_per_sample : 1, g->aux_row_mod, g->rowbias};
   hipLaunchKernelGGL(gemm_f32_ex_kernel, dim3((g->N + GB - 1) / GB, (g->M + GB - 1) / GB, g->batch), dim3(256), 0, (hipStream_t)stream, p);
   SAVIT_LAUNCH_RET();
 }

@@ -71,7 +71,7 @@ class _F32Base:
 
     def _gemm(self, P: _Plan, label: str, A, W, C, M, N, K, lda, ldw, ldc, **kw):
         """C = epi(A . W) through savit_gemm_f32_ex; kw: bias, aux, ldaux, colscale, rowscale, rows_per_sample, C2, U, transA, transW,
-        batch, inner, sA=(outer, inner), sW=(..), sC=(..), alpha, alpha_cols, act, accumulate, aux_row_mod."""
+        batch, inner, sA=(outer, inner), sW=(..), sC=(..), alpha, alpha_cols, act, accumulate, aux_row_mod, rowbias."""
         g = _lib.GemmF32Args()
         g.A, g.W, g.C, g.M, g.N, g.K, g.lda, g.ldw, g.ldc = A, W, C, M, N, K, lda, ldw, ldc
         g.bias, g.aux, g.colscale, g.rowscale, g.C2, g.U = (kw.get(k) for k in ("bias", "aux", "colscale", "rowscale", "C2", "U"))
@@ -83,7 +83,7 @@ class _F32Base:
         g.sCo, g.sCi = kw.get("sC", (0, 0))
         g.alpha, g.alpha_cols = float(kw.get("alpha", 1.0)), int(kw.get("alpha_cols", 0))
         g.act, g.accumulate, g.rows_per_sample = int(kw.get("act", 0)), int(kw.get("accumulate", 0)), int(kw.get("rows_per_sample", 1))
-        g.aux_row_mod = int(kw.get("aux_row_mod", 0))
+        g.aux_row_mod, g.rowbias = int(kw.get("aux_row_mod", 0)), kw.get("rowbias")
         P.keep.append(g)
         P.add(self.L.savit_gemm_f32_ex, (ctypes.byref(g),), label)
 
@@ -396,6 +396,164 @@ class CaiTEngineF32(_F32Base):
     optimizer_step = backward_from_dlogits = loss_backward
 
 
+class _ForwardOnlyF32(_F32Base):
+    """Shared by the forward (+ loss) fp32 engines of the families that train on the bf16 MFMA engines."""
+
+    def set_images(self, images: torch.Tensor):
+        S = self.cfg.img_size
+        if not images.is_cuda or tuple(images.shape) != (self.B, S, S, 3):
+            raise ValueError(f"images must be a GPU tensor [B={self.B},{S},{S},3] (NHWC)")
+        self.images.copy_(images.to(f32))
+
+    def forward(self, images: Optional[torch.Tensor] = None, is_training: bool = False) -> torch.Tensor:
+        if images is not None:
+            self.set_images(images)
+        if self._plan is None:
+            self._plan = self._build()
+        self._plan.run(torch.cuda.current_stream().cuda_stream)
+        return self.logits
+
+    def loss_backward(self, *a, **k):
+        raise NotImplementedError(f"{type(self).__name__}: fp32 arithmetic covers forward + loss; this family trains on the bf16 MFMA engine "
+                                  "(create_model(..., dtype=torch.bfloat16))")
+
+    optimizer_step = backward_from_dlogits = loss_backward
+
+
+class MixerEngineF32(_ForwardOnlyF32):
+    """mlp_mixer.py:44-64 in fp32.  Token mixing (MixerBlock :17-24: FFBlock on the transposed activation) reads the [n, d]
+    activation of an image as its transposed operand in place and produces the second product already transposed back
+    (x[b] += tW2^T a[b]^T, the Dense bias then runs along the rows) - no transposed copy exists."""
+
+    def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda"):
+        from .mixer_engine import MixerLayout
+
+        self.layout = MixerLayout(cfg)
+        self._init_common(cfg, batch, device)
+        d, F, n, B = cfg.embed_dim, cfg.hidden, cfg.n_patches, self.B
+        self.M = B * n
+        e = self.e
+        self.images = e(B, cfg.img_size, cfg.img_size, 3)
+        self.patches = e(self.M, cfg.patch_dim)
+        self.x, self.h, self.a = e(self.M, d), e(self.M, d), e(self.M, F)
+        self.at = e(B, d, self.layout.Fp)  # token-mixing hidden activation, [image, channel, Ft]
+        self.ones = torch.ones(n, dtype=f32, device=self.dev)
+        self.zmean = e(B, d)
+        self._plan: Optional[_Plan] = None
+
+    def init_params(self, seed: int = 0):
+        from .mixer_engine import MixerEngine
+
+        MixerEngine.init_params(self, seed)
+
+    def _build(self) -> _Plan:
+        P, L, cfg, lay = _Plan(), self.L, self.cfg, self.layout
+        d, F, C, n, NL, B, M = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.n_patches, cfg.num_layers, self.B, self.M
+        Ft, Lp, Fp = cfg.tokens_hidden, lay.Lp, lay.Fp
+        pp = self._off
+        x, h, a, at = (t.data_ptr() for t in (self.x, self.h, self.a, self.at))
+        P.add(L.savit_patchify_f32, (self.images.data_ptr(), self.patches.data_ptr(), B, cfg.img_size, cfg.patch), "patchify")
+        self._gemm(P, "patch_embed", self.patches.data_ptr(), pp("Wpe"), x, M, d, cfg.patch_dim, cfg.patch_dim, d, d, bias=pp("bpe"))
+        for l in range(NL):
+            P.add(L.savit_layernorm_fwd_f32, (x, pp(f"l{l}.ln1_g"), pp(f"l{l}.ln1_b"), h, M, d, d, d, 1e-6), f"l{l}.ln1")
+            # a[b] [d, Ft] = gelu(h[b]^T tW1 + tb1)
+            self._gemm(P, f"l{l}.tok.fc1", h, pp(f"l{l}.tW1"), at, d, Ft, n, d, Fp, Fp, transA=1, bias=pp(f"l{l}.tb1"), act=1, batch=B,
+                       sA=(n * d, 0), sC=(d * Fp, 0))
+            # x[b] [n, d] += tW2^T a[b]^T + tb2 along the rows
+            self._gemm(P, f"l{l}.tok.fc2", pp(f"l{l}.tW2"), at, x, n, d, Ft, Lp, Fp, d, transA=1, transW=1, rowbias=pp(f"l{l}.tb2"), accumulate=1,
+                       batch=B, sW=(d * Fp, 0), sC=(n * d, 0))
+            P.add(L.savit_layernorm_fwd_f32, (x, pp(f"l{l}.ln2_g"), pp(f"l{l}.ln2_b"), h, M, d, d, d, 1e-6), f"l{l}.ln2")
+            self._gemm(P, f"l{l}.fc1", h, pp(f"l{l}.W1"), a, M, F, d, d, F, F, bias=pp(f"l{l}.b1"), act=1)
+            self._gemm(P, f"l{l}.fc2", a, pp(f"l{l}.W2"), x, M, d, F, F, d, d, bias=pp(f"l{l}.b2"), accumulate=1)
+        P.add(L.savit_layernorm_fwd_f32, (x, pp("lnf_g"), pp("lnf_b"), h, M, d, d, d, 1e-6), "lnf")
+        # mean over the tokens (mlp_mixer.py:61-62) as (1 / n) 1^T z[b]
+        self._gemm(P, "token_mean", self.ones.data_ptr(), h, self.zmean.data_ptr(), 1, d, n, n, d, d, batch=B, sW=(n * d, 0), sC=(d, 0), alpha=1.0 / n,
+                   alpha_cols=d)
+        self._gemm(P, "head", self.zmean.data_ptr(), pp("Wh"), self.logits.data_ptr(), B, C, d, d, C, C, bias=pp("bh"))
+        return P
+
+
+class TNTEngineF32(_ForwardOnlyF32):
+    """tnt.py:150-193 in fp32: the pixel stream [B n npx, di] and the patch stream [B (n + 1), do] (EncoderBlock :66-93).  The inner
+    attention kernels are stored head-padded to 16 columns (tnt_engine.TNTLayout); the pad columns are zero, so the products over
+    the padded head width are exact."""
+
+    def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda"):
+        from .tnt_engine import HDP, TNTLayout
+
+        self.layout = lay = TNTLayout(cfg)
+        self._init_common(cfg, batch, device)
+        do, Fo, N, n, npx, di, Hi, Ho = cfg.embed_dim, cfg.hidden, cfg.seq_len, cfg.n_patches, cfg.n_pixels, cfg.inner_embed_dim, cfg.inner_num_heads, cfg.num_heads
+        B = self.B
+        self.HDP = HDP
+        self.Mi, self.Ms, self.Mo = B * n * npx, B * n, B * N
+        e = self.e
+        self.images = e(B, cfg.img_size, cfg.img_size, 3)
+        self.pix = e(self.Mi, lay.pix_in)
+        self.patches = e(self.Ms, cfg.patch_dim)
+        self.tok = e(self.Ms, do)
+        self.xi, self.hi, self.qkvi, self.oi, self.ai = e(self.Mi, di), e(self.Mi, di), e(self.Mi, 3 * lay.dap), e(self.Mi, lay.dap), e(self.Mi, lay.Fi)
+        self.si = e(self.Ms * Hi, npx, npx)
+        self.xo, self.outer, self.ho, self.xmid = e(self.Mo, do), e(self.Mo, do), e(self.Mo, do), e(self.Mo, do)
+        self.qkvo, self.oo, self.ao = e(self.Mo, 3 * do), e(self.Mo, do), e(self.Mo, Fo)
+        self.so = e(B * Ho, N, N)
+        self._plan: Optional[_Plan] = None
+
+    def init_params(self, seed: int = 0):
+        from .tnt_engine import TNTEngine
+
+        TNTEngine.init_params(self, seed)
+
+    def _build(self) -> _Plan:
+        P, L, cfg, lay = _Plan(), self.L, self.cfg, self.layout
+        do, Fo, C, N, NL, n, npx = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers, cfg.n_patches, cfg.n_pixels
+        di, Hi, Ho, Fi, dap, HDP, B = cfg.inner_embed_dim, cfg.inner_num_heads, cfg.num_heads, lay.Fi, lay.dap, self.HDP, self.B
+        hdi, hdo = di // Hi, do // Ho
+        Mi, Ms, Mo = self.Mi, self.Ms, self.Mo
+        pp = self._off
+        xi, hi, qkvi, oi, ai, si = (t.data_ptr() for t in (self.xi, self.hi, self.qkvi, self.oi, self.ai, self.si))
+        xo, outer, ho, xmid, qkvo, oo, ao, so = (t.data_ptr() for t in (self.xo, self.outer, self.ho, self.xmid, self.qkvo, self.oo, self.ao, self.so))
+        ln = L.savit_layernorm_fwd_f32
+        # embeddings: pixel tokens (tnt.py:17-33,155-158) and patch tokens + cls + position (tnt.py:160-167)
+        P.add(_gather_pixels, (self,), "pixel_gather")
+        self._gemm(P, "pixel_embed", self.pix.data_ptr(), pp("Wpx"), xi, Mi, di, lay.pix_in, lay.pix_in, di, di, bias=pp("bpx"), aux=pp("ppos"), ldaux=di,
+                   aux_row_mod=npx)
+        P.add(L.savit_patchify_f32, (self.images.data_ptr(), self.patches.data_ptr(), B, cfg.img_size, cfg.patch), "patchify")
+        self._gemm(P, "patch_embed", self.patches.data_ptr(), pp("Wpe"), self.tok.data_ptr(), Ms, do, cfg.patch_dim, cfg.patch_dim, do, do, bias=pp("bpa"))
+        P.add(L.savit_assemble_tokens_f32, (self.tok.data_ptr(), pp("cls"), pp("pos"), xo, B, N, do), "tokens")
+        for l in range(NL):
+            p = f"l{l}."
+            # inner block on the pixel stream (tnt.py:68-80): sequences of npx pixel tokens, Hi heads padded to HDP columns
+            P.add(ln, (xi, pp(p + "iln1_g"), pp(p + "iln1_b"), hi, Mi, di, di, di, 1e-6), p + "iln1")
+            self._gemm(P, p + "iqkv", hi, pp(p + "iWqkv"), qkvi, Mi, 3 * dap, di, di, 3 * dap, 3 * dap, alpha=1.0 / math.sqrt(hdi), alpha_cols=dap)
+            self._gemm(P, p + "iscores", qkvi, qkvi + 4 * dap, si, npx, npx, HDP, 3 * dap, 3 * dap, npx, transW=1, batch=Ms * Hi, inner=Hi,
+                       sA=(npx * 3 * dap, HDP), sW=(npx * 3 * dap, HDP), sC=(Hi * npx * npx, npx * npx))
+            P.add(L.savit_softmax_rows_f32, (si, si, Ms * Hi * npx, npx, npx), p + "isoftmax")
+            self._gemm(P, p + "ipv", si, qkvi + 8 * dap, oi, npx, HDP, npx, npx, 3 * dap, dap, batch=Ms * Hi, inner=Hi, sA=(Hi * npx * npx, npx * npx),
+                       sW=(npx * 3 * dap, HDP), sC=(npx * dap, HDP))
+            self._gemm(P, p + "iproj", oi, pp(p + "iWo"), xi, Mi, di, dap, dap, di, di, accumulate=1)
+            P.add(ln, (xi, pp(p + "iln2_g"), pp(p + "iln2_b"), hi, Mi, di, di, di, 1e-6), p + "iln2")
+            self._gemm(P, p + "ifc1", hi, pp(p + "iW1"), ai, Mi, Fi, di, di, Fi, Fi, bias=pp(p + "ib1"), act=1)
+            self._gemm(P, p + "ifc2", ai, pp(p + "iW2"), xi, Mi, di, Fi, Fi, di, di, bias=pp(p + "ib2"), accumulate=1)
+            # Inner2Outer (tnt.py:40-51,82-84): outer[b, 1 + j] = pixels[b, j].flatten() Wio + bio + patches[b, 1 + j]; outer[b, 0] = patches[b, 0]
+            P.add(_copy_cls_rows, (self,), p + "i2o.cls")
+            self._gemm(P, p + "i2o", xi, pp(p + "Wio"), outer + 4 * do, n, do, npx * di, npx * di, do, do, bias=pp(p + "bio"), aux=xo + 4 * do, ldaux=do,
+                       batch=B, sA=(n * npx * di, 0), sC=(N * do, 0))
+            # outer block (tnt.py:85-92): attention reads the Inner2Outer sum, its residual adds the patch stream (tnt.py:86)
+            P.add(ln, (outer, pp(p + "ln1_g"), pp(p + "ln1_b"), ho, Mo, do, do, do, 1e-6), p + "ln1")
+            self._gemm(P, p + "qkv", ho, pp(p + "Wqkv"), qkvo, Mo, 3 * do, do, do, 3 * do, 3 * do, alpha=1.0 / math.sqrt(hdo), alpha_cols=do)
+            self._scores(P, p + "scores", qkvo, qkvo + 4 * do, self.so, N, N, Ho, hdo, 3 * do, 3 * do, N * 3 * do, N * 3 * do)
+            P.add(L.savit_softmax_rows_f32, (so, so, B * Ho * N, N, N), p + "softmax")
+            self._gemm(P, p + "pv", so, qkvo + 8 * do, oo, N, hdo, N, N, 3 * do, do, batch=B * Ho, inner=Ho, sA=(Ho * N * N, N * N), sW=(N * 3 * do, hdo),
+                       sC=(N * do, hdo))
+            self._gemm(P, p + "proj", oo, pp(p + "Wo"), xmid, Mo, do, do, do, do, do, aux=xo, ldaux=do)
+            P.add(ln, (xmid, pp(p + "ln2_g"), pp(p + "ln2_b"), ho, Mo, do, do, do, 1e-6), p + "ln2")
+            self._gemm(P, p + "fc1", ho, pp(p + "W1"), ao, Mo, Fo, do, do, Fo, Fo, bias=pp(p + "b1"), act=1)
+            self._gemm(P, p + "fc2", ao, pp(p + "W2"), xo, Mo, do, Fo, Fo, do, do, bias=pp(p + "b2"), aux=xmid, ldaux=do)
+        self._gemm(P, "head", xo, pp("Wh"), self.logits.data_ptr(), B, C, do, N * do, C, C, bias=pp("bh"))  # cls rows, no final LayerNorm (tnt.py:188-192)
+        return P
+
+
 def _concat_rows(eng: "CaiTEngineF32", stream: int) -> int:
     """xc = concat([cls, x], axis=1) (cait.py:98): two strided device copies on the current stream (memory plumbing, no arithmetic)."""
     B, N, d = eng.B, eng.cfg.n_patches, eng.cfg.embed_dim
@@ -409,4 +567,21 @@ def _gather_patch_rows(eng: "ViTEngineF32", stream: int) -> int:
     """tok = dx0[:, 1:, :] (the cotangent of the patch embeddings, vit.py:81-84): one strided device copy on the current stream."""
     B, N, d = eng.B, eng.cfg.seq_len, eng.cfg.embed_dim
     eng.tok.view(B, N - 1, d).copy_(eng.dres.view(B, N, d)[:, 1:])
+    return 0
+
+
+def _gather_pixels(eng: "TNTEngineF32", stream: int) -> int:
+    """PixelEmbedBlock's rearrangement (tnt.py:24-29): every patch as its (P / t)^2 pixel tokens of c t t features - one permuted device
+    copy on the current stream (memory plumbing, no arithmetic)."""
+    cfg, B = eng.cfg, eng.B
+    g, t = cfg.img_size // cfg.patch, cfg.transformed_patch
+    s = cfg.patch // t
+    eng.pix.view(B, g, g, s, s, 3, t, t).copy_(eng.images.view(B, g, s, t, g, s, t, 3).permute(0, 1, 4, 2, 5, 7, 3, 6))
+    return 0
+
+
+def _copy_cls_rows(eng: "TNTEngineF32", stream: int) -> int:
+    """outer[:, 0] = patches[:, 0]: Inner2Outer pads a zero row for cls (tnt.py:48-50)."""
+    B, N, do = eng.B, eng.cfg.seq_len, eng.cfg.embed_dim
+    eng.outer.view(B, N, do)[:, 0].copy_(eng.xo.view(B, N, do)[:, 0])
     return 0

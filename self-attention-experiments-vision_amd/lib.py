@@ -43,7 +43,7 @@ class GemmF32Args(Structure):
                 ("transA", c_int), ("transW", c_int), ("batch", c_int), ("inner", c_int),
                 ("sAo", c_long), ("sAi", c_long), ("sWo", c_long), ("sWi", c_long), ("sCo", c_long), ("sCi", c_long),
                 ("alpha", c_float), ("alpha_cols", c_int), ("act", c_int), ("accumulate", c_int), ("rows_per_sample", c_int),
-                ("aux_row_mod", c_int)]
+                ("aux_row_mod", c_int), ("rowbias", c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/savit.h declares must be here (tests check both ways)

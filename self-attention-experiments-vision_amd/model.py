@@ -37,14 +37,10 @@ class ViT:
     """models/vit.py:61-99 behind the HIP engine.  Stateless w.r.t. parameters in `apply` (the caller owns the
     tree, as with Flax); `init` / `bind` attach a tree for the `model(images, is_training)` form."""
 
-    FP32_OK = True  # fp32 engines: ViT (forward, backward, optimizer) and CaiT (forward + loss)
-
     def __init__(self, cfg: ModelConfig, dtype=torch.float32):
         if dtype not in (torch.bfloat16, torch.float32):
-            raise NotImplementedError("dtype must be torch.bfloat16 (the MFMA training path) or torch.float32 (exact fp32 arithmetic)")
-        if dtype == torch.float32 and not self.FP32_OK:
-            raise NotImplementedError(f"{type(self).__name__}: fp32 arithmetic is implemented for the ViT and CaiT families; this family "
-                                      "computes in bf16 - pass dtype=torch.bfloat16 (the reference's create_model default is float32)")
+            raise NotImplementedError("dtype must be torch.bfloat16 (the MFMA training path) or torch.float32 (exact fp32 arithmetic: every "
+                                      "family's forward + loss, and the ViT train step)")
         assert cfg.embed_dim % cfg.num_heads == 0  # vit.py:75
         self.cfg = cfg
         self.dtype = dtype
@@ -130,7 +126,7 @@ class CaiT(ViT):
     (stochastic_depth.py:16-27) from the engine's generator; pass `rngs={'stochastic_depth': seed}` to seed it (the reference needs
     that rng stream too and forgets to pass it, defect B7)."""
 
-    FP32_OK = True  # the reference computes CaiT in fp32 whatever dtype is passed (create_model.py:50-213 drop it)
+    # NOTE: the reference computes CaiT in fp32 whatever dtype is passed (create_model.py:50-213 drop it)
 
     def _new_engine(self, batch: int):
         if self.dtype == torch.float32:
@@ -157,9 +153,11 @@ class CaiT(ViT):
 class MLPMixer(ViT):
     """models/mlp_mixer.py:34-64 behind mixer_engine.MixerEngine.  No stochastic layer: is_training selects nothing."""
 
-    FP32_OK = False
-
     def _new_engine(self, batch: int):
+        if self.dtype == torch.float32:
+            from .engine_f32 import MixerEngineF32
+
+            return MixerEngineF32(self.cfg, batch)
         from .mixer_engine import MixerEngine
 
         return MixerEngine(self.cfg, batch)
@@ -168,9 +166,11 @@ class MLPMixer(ViT):
 class TNT(ViT):
     """models/tnt.py:136-193 behind tnt_engine.TNTEngine.  Every dropout rate is 0: is_training selects nothing."""
 
-    FP32_OK = False
-
     def _new_engine(self, batch: int):
+        if self.dtype == torch.float32:
+            from .engine_f32 import TNTEngineF32
+
+            return TNTEngineF32(self.cfg, batch)
         from .tnt_engine import TNTEngine
 
         return TNTEngine(self.cfg, batch)

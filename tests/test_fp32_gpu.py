@@ -130,12 +130,33 @@ def test_vit_tiny_fp32_forward_and_loss_vs_oracle(L):
     assert sum(v.numel() for v in _leaves(p2["params"])) == 5_708_008
 
 
-def test_other_families_state_the_bf16_restriction(L):
+@pytest.mark.parametrize("name", ["mixer_s_patch32", "tnt_s_patch16"])
+def test_mixer_and_tnt_fp32_default_dtype_vs_oracle(L, name):
+    """create_model(name) at the reference's default dtype for the two remaining families (models/mlp_mixer.py:44-64, models/tnt.py:150-193):
+    logits within 2e-5 of the fp32 oracle; training stays on the bf16 engines and says so."""
     from savit_amd.model import create_model
 
-    for name in ("mixer_s_patch32", "tnt_s_patch16"):
-        with pytest.raises(NotImplementedError, match="dtype=torch.bfloat16"):
-            create_model(name)  # the reference default, float32
+    model = create_model(name)
+    assert model.dtype == torch.float32
+    oc = vit_ref.get_cfg(name)
+    rng = np.random.default_rng(51)
+    params = vit_ref.init_params(oc, seed=11, randomize=True)
+    images = rng.standard_normal((3, 224, 224, 3)).astype(np.float32)
+    logits = model.apply(params, torch.as_tensor(images).cuda(), is_training=False)
+    assert logits.dtype == torch.float32 and tuple(logits.shape) == (3, 1000)
+    ref32 = vit_ref.forward(params, images, oc, mode="f32")
+    ref64 = vit_ref.forward(params, images, oc, mode="f64")
+    r32, r64 = rel(logits.cpu().numpy(), ref32), rel(logits.cpu().numpy(), ref64)
+    print(f"[fp32 {name}] logits rel-L2: engine vs fp32 oracle {r32:.2e}, vs fp64 oracle {r64:.2e} (fp32 oracle vs fp64 {rel(ref32, ref64):.2e})")
+    assert r32 < 2e-5 and r64 < 2e-5
+    labels = rng.integers(0, 1000, 3)
+    loss = float(model.engine(3).loss_fn(torch.as_tensor(labels).cuda(), 0.1))
+    assert abs(loss - vit_ref.loss_fn(ref64, labels, 0.1)) < 2e-5 * max(1.0, abs(loss))
+    with pytest.raises(NotImplementedError, match="dtype=torch.bfloat16"):
+        model.engine(3).loss_backward(torch.as_tensor(labels).cuda())
+    # the reference initialisers through the same boundary (mlp_mixer_test.py / tnt_test.py shapes)
+    out, _ = create_model(name).init_with_output(0, torch.ones(2, 224, 224, 3, device="cuda"), is_training=False)
+    assert tuple(out.shape) == (2, 1000) and bool(torch.isfinite(out).all())
 
 
 def _gemm_ex(L, **kw):
