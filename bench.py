@@ -432,7 +432,7 @@ def main():
         # covers this kernel and this is the headline workload; null otherwise.
         try:
             if args.model == "vit_b_patch16" and B == 128:
-                src = next(f for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                src = next(f for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
                 pm = json.load(open(os.path.join(ROOT, "profiles", src)))["kernels"].get(dom)
                 if pm:
                     out["roofline"]["traffic"] = pm["traffic_bytes"]

@@ -26,6 +26,15 @@ cp $(find $OUT/serial -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_serial_ke
 cp $(find $OUT/overlap -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_overlap_kernel_stats.csv
 tail -1 $OUT/serial_bench.json > $OUT/${TAG}_serial_bench.json
 tail -1 $OUT/overlap_bench.json > $OUT/${TAG}_overlap_bench.json
+# BASELINE config 4 (CaiT-S24, 256 images): kernel stats of the same bench harness
+C="$GRAFT_REPO_ROOT/bench.py --model cait_s_24 --batch 256 --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cait -o c -- python3 $C > $OUT/cait_bench.json 2> $OUT/cait.err
+echo cait done
+cd $GRAFT_REPO_ROOT
+cp $(find $OUT/cait -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_cait_s24_kernel_stats.csv
+tail -1 $OUT/cait_bench.json > $OUT/${TAG}_cait_s24_bench.json
+rm -rf $OUT/cait
 # the raw traces are large: keep only the summaries
 rm -rf $OUT/serial $OUT/overlap $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma
 cat $OUT/pmc_summary.txt; cat $OUT/mfma_summary.txt; head -12 $OUT/${TAG}_serial_kernel_stats.csv
