@@ -153,11 +153,12 @@ int savit_gemm_wgrad_split_count(int M, int Kin, int Nout, int splits, int patch
 /* Kernel the wgrad heuristic picks: 1 = 128x128 ring (4 waves), 3 = 256x256 ring (8 waves). */
 int savit_gemm_wgrad_auto_variant(int Kin, int Nout, int patch);
 
-/* Grouped weight gradients: dW_i += X_i^T dY_i for up to 16 independent Dense kernels in ONE launch - the reverse-mode products of
+/* Grouped weight gradients: dW_i += X_i^T dY_i for up to 64 independent Dense kernels in ONE launch - the reverse-mode products of
  * attention.py:29-37,60-63 and ff.py:26-31 for one or more encoder layers (train.py:94-95).  One workgroup per `tile` x `tile`
  * (256 or 128) output tile reduces over ALL M tokens: no token split, no partial slabs, no second launch; every dW element is one
  * fixed-order sum added to its old value (bitwise reproducible).  A weight gradient has no consumer before the optimizer step, so a
  * caller may group across layers until the tiles fill the CUs (savit_gemm_wgrad_group_tiles = tiles of one kernel).
+ * Kin / Nout need not be multiples of the tile: edge tiles compute the full tile and store the part inside dW.
  * X_i bf16 [M_i, ldx], dY_i bf16 [M_i, lddy], dW_i fp32 [Kin_i, lddw]; Kin, Nout, ldx, lddy multiples of 8; M_i * pitch * 2 < 4 GiB. */
 typedef struct savit_wgrad_problem {
   const void* X;

@@ -27,7 +27,7 @@ import torch
 
 from . import lib as _lib
 from .config import ModelConfig
-from .engine import _Plan, _align, _copy_tree, add_wgrad, finalize_wgrad_ws
+from .engine import WgradQueue, _Plan, _align, _copy_tree, add_wgrad, add_wgrad_group, finalize_wgrad_ws
 
 bf16 = torch.bfloat16
 f32 = torch.float32
@@ -198,10 +198,14 @@ class CaiTEngine:
         # ---- backward scratch
         self.dres, self.dres_b = e(M, d), e(M, d, dt=bf16)
         self.d_h, self.d_o = e(M, d, dt=bf16), e(M, d, dt=bf16)
-        # scratch the side-stream weight-gradient GEMMs read is rotated, so the main chain rarely waits for them
-        self.dbr_ring = [e(M, d, dt=bf16) for _ in range(4)]
-        self.d_u_ring = [e(M, F, dt=bf16) for _ in range(2)]
-        self.dqkv_ring = [e(M, 3 * d, dt=bf16) for _ in range(2)]
+        # The SA layers' weight gradients wait in a FIFO of 256 x 256 output tiles and leave in grouped launches of one tile per CU
+        # (engine.WgradQueue; a launch reaches back `wgrad_lag` layers), so the cotangents they read rotate through rings that deep.
+        self.n_cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        self.wgrad_tile, self.wgrad_lag = self._wgrad_group_plan()
+        depth = max(2, self.wgrad_lag + 1)
+        self.dbr_ring = [e(M, d, dt=bf16) for _ in range(2 * depth)]
+        self.d_u_ring = [e(M, F, dt=bf16) for _ in range(depth)]
+        self.dqkv_ring = [e(M, 3 * d, dt=bf16) for _ in range(depth)]
         self.dbr, self.d_u, self.dqkv = self.dbr_ring[0], self.d_u_ring[0], self.dqkv_ring[0]
         self.dsbuf = e(B, H, N, self.Np, dt=bf16)
         self.colsum_slab = e(max(1, self.L.savit_gemm_colsum_rows(M, F, d, 0)), F)
@@ -223,7 +227,6 @@ class CaiTEngine:
         self.overlap_wgrad = _os.environ.get("SAVIT_OVERLAP_WGRAD", "1") != "0"
         self.n_side_streams = int(_os.environ.get("SAVIT_SIDE_STREAMS", "1"))
         self.wgrad_cu_share = float(_os.environ.get("SAVIT_WGRAD_CU_SHARE", "0.56"))
-        self.n_cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
         self._side_streams = []
         self._building_serial = False
         self._bwd_plan_serial = None
@@ -285,6 +288,26 @@ class CaiTEngine:
         a.round_bias_bf16 = self.rp
         plan.keep.append(a)
         plan.add(self.L.savit_gemm_bf16_tn, (ctypes.byref(a),), label, writes=writes)
+
+    def _layer_wgrad_tiles(self, tile: int):
+        d, F = self.cfg.embed_dim, self.cfg.hidden
+        return [int(self.L.savit_gemm_wgrad_group_tiles(a, b, tile)) for a, b in ((F, d), (d, F), (d, d), (d, 3 * d))]  # W2, W1, Wo, Wqkv
+
+    def _wgrad_group_plan(self):
+        """(tile, layers a launch reaches back) of the SA layers' grouped weight gradients (engine.ViTEngine._wgrad_group_plan has the
+        reasoning; CaiT-S24: 38 tiles per layer, a launch of 256 every ~7 layers); tile 0 (SAVIT_WGRAD_GROUP=0) = one launch per weight."""
+        if _os.environ.get("SAVIT_WGRAD_GROUP", "auto") == "0":
+            return 0, 0
+        tile = 256
+        sizes = self._layer_wgrad_tiles(tile)
+        q, lag = WgradQueue(self.n_cus), 0
+        for l in range(self.cfg.num_layers - 1, -1, -1):
+            for t in sizes:
+                q.push(None, l, t)
+            while q.pending() > 0 and (q.due() or l == 0):
+                _, _, oldest = q.take(q.cap)
+                lag = max(lag, oldest - l)
+        return tile, lag
 
     def _wgrad(self, plan, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0), side=False):
         """side=True (the big SA-layer weight gradients): no later launch consumes dW, so `_Plan.run_overlapped` issues it on a
@@ -432,24 +455,43 @@ class CaiTEngine:
                                                  self.dcls.data_ptr(), self.dcls.data_ptr(), None, gp(f"c{c}.ln1_g"), gp(f"c{c}.ln1_b"), None, B, d,
                                                  d, d, self.rp, 1, N + 1, 0, ws, wsb), f"c{c}.ln1c.bwd")
         P.add(L.savit_pos_cls_grad, (self.dcls.data_ptr(), gp("cls"), None, B, 1, d, 0), "cls.grad")
-        # ---- SA layers (reverse).  Their weight-gradient GEMMs go to the side stream; dbr / d_u / dqkv rotate through small rings.
+        # ---- SA layers (reverse).  Their weight gradients wait in the tile FIFO (grouped launches of one tile per CU) or, ungrouped, go
+        # to the side stream; dbr / d_u / dqkv rotate through rings as deep as a launch reaches back.
+        queue = WgradQueue(self.n_cus) if self.wgrad_tile else None
+        n_launch = [0]
+
+        def wgrad_l(label, layer, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw):
+            if queue is None:
+                return self._wgrad(P, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, side=True)
+            queue.push((X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw), layer, int(L.savit_gemm_wgrad_group_tiles(Kin, Nout, self.wgrad_tile)))
+
+        def flush_group(layer: int, last: bool):
+            # after a layer's last input-gradient GEMM, before anything overwrites the oldest ring slots; the DDP trigger of an EARLIER
+            # layer ('l{j}.ln1.bwd') whose last tile is in a launch fires behind that launch
+            while queue is not None and queue.pending() > 0 and (queue.due() or last):
+                entries, done, oldest = queue.take(queue.cap)
+                assert oldest - layer <= self.wgrad_lag, "weight-gradient queue reaches back further than the cotangent rings"
+                add_wgrad_group(self, P, f"wgrad.group.{n_launch[0]}.l{oldest}-l{layer}", entries, self.wgrad_tile,
+                                [f"l{j}.ln1.bwd" for j in done if j != layer], side=False)
+                n_launch[0] += 1
+
         ring, ri = [t.data_ptr() for t in self.dbr_ring], 0
         for l in range(NL - 1, -1, -1):
             st = self.stats[l]
             w = lambda n, l=l: self.w[n][l].data_ptr()  # noqa: E731
             sd0, sd1 = self.sd[2 * l].data_ptr(), self.sd[2 * l + 1].data_ptr()
-            d_u, dqkv = self.d_u_ring[l % 2].data_ptr(), self.dqkv_ring[l % 2].data_ptr()
+            d_u, dqkv = self.d_u_ring[l % len(self.d_u_ring)].data_ptr(), self.dqkv_ring[l % len(self.dqkv_ring)].data_ptr()
             ri = (ri + 1) % len(ring)
             P.add(L.savit_layerscale_bwd, (self.dres.data_ptr(), self.br2[l].data_ptr(), pp(f"l{l}.ls2"), sd1, N, ring[ri], gp(f"l{l}.ls2"),
                                            gp(f"l{l}.b2"), M, d, d, ws, wsb), f"l{l}.ls2.bwd", writes=(ring[ri],))
-            self._wgrad(P, f"l{l}.W2.wgrad", self.a[l].data_ptr(), ring[ri], gp(f"l{l}.W2"), M, F, d, F, d, d, side=True)
+            wgrad_l(f"l{l}.W2.wgrad", l, self.a[l].data_ptr(), ring[ri], gp(f"l{l}.W2"), M, F, d, F, d, d)
             # bias gradient: per-row-tile partial sums to a slab + finalize, as in the ViT engine (atomic column sums cost this launch
             # 160 instead of 117 us at CaiT-S24: 50 k rows adding into 1536 addresses)
             self._gemm(P, f"l{l}.fc2.dgrad", writes=(d_u,), A=ring[ri], Bt=w("W2_n"), C=d_u, aux=self.u[l].data_ptr(),
                        colsum=self.colsum_slab.data_ptr(), colsum_rows=self.colsum_slab.shape[0], M=M, N=F, K=d, lda=d, ldb=d, ldc=F,
                        ldaux=F, epilogue=_lib.EPI_DGELU)
             P.add(L.savit_colsum_finalize, (self.colsum_slab.data_ptr(), self.colsum_slab.shape[0], F, gp(f"l{l}.b1"), 1), f"l{l}.b1.grad")
-            self._wgrad(P, f"l{l}.W1.wgrad", self.h2[l].data_ptr(), d_u, gp(f"l{l}.W1"), M, d, F, d, F, F, side=True)
+            wgrad_l(f"l{l}.W1.wgrad", l, self.h2[l].data_ptr(), d_u, gp(f"l{l}.W1"), M, d, F, d, F, F)
             self._gemm(P, f"l{l}.fc1.dgrad", A=d_u, Bt=w("W1_n"), C=self.d_h.data_ptr(), M=M, N=d, K=F, lda=F, ldb=F, ldc=d,
                        epilogue=_lib.EPI_BF16)
             P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(),
@@ -458,7 +500,7 @@ class CaiTEngine:
             ri = (ri + 1) % len(ring)
             P.add(L.savit_layerscale_bwd, (self.dres.data_ptr(), self.br1[l].data_ptr(), pp(f"l{l}.ls1"), sd0, N, ring[ri], gp(f"l{l}.ls1"),
                                            None, M, d, d, ws, wsb), f"l{l}.ls1.bwd", writes=(ring[ri],))
-            self._wgrad(P, f"l{l}.Wo.wgrad", self.o[l].data_ptr(), ring[ri], gp(f"l{l}.Wo"), M, d, d, d, d, d, side=True)
+            wgrad_l(f"l{l}.Wo.wgrad", l, self.o[l].data_ptr(), ring[ri], gp(f"l{l}.Wo"), M, d, d, d, d, d)
             self._gemm(P, f"l{l}.proj.dgrad", A=ring[ri], Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=M, N=d, K=d, lda=d, ldb=d, ldc=d,
                        epilogue=_lib.EPI_BF16)
             if self.th_fused:
@@ -469,9 +511,10 @@ class CaiTEngine:
                 P.add(L.savit_th_attention_bwd, (self.qkv[l].data_ptr(), pp(f"l{l}.T1"), pp(f"l{l}.T2"), self.sbuf[l].data_ptr(),
                                                  self.pbuf[l].data_ptr(), self.d_o.data_ptr(), self.dsbuf.data_ptr(), dqkv, gp(f"l{l}.T1"),
                                                  gp(f"l{l}.T2"), B, N, H, hd, 3 * d, Np, dqs, ws, wsb), f"l{l}.th_attn.bwd", writes=(dqkv,))
-            self._wgrad(P, f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), dqkv, gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d, side=True)
+            wgrad_l(f"l{l}.Wqkv.wgrad", l, self.h1[l].data_ptr(), dqkv, gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d)
             self._gemm(P, f"l{l}.qkv.dgrad", A=dqkv, Bt=w("Wqkv_n"), C=self.d_h.data_ptr(), M=M, N=d, K=3 * d, lda=3 * d, ldb=3 * d,
                        ldc=d, epilogue=_lib.EPI_BF16)
+            flush_group(l, last=(l == 0))
             P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
                                           self.dres.data_ptr(), self.dres.data_ptr(), self.dres_b.data_ptr(), gp(f"l{l}.ln1_g"), gp(f"l{l}.ln1_b"),
                                           None, M, d, d, d, self.rp, ws, wsb), f"l{l}.ln1.bwd")

@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_ring_kernel(cons
 // per workgroup fills 84 % of the CUs with NO split, no slab, no second launch, the long reduction (788 stages) amortises the
 // prologue, and the result is still a fixed-order sum (bitwise reproducible).  The weight gradients have no consumer before the
 // optimizer step, so the engine is free to compute them a layer or two after their operands are produced.
-constexpr int WGRAD_GROUP_MAX = 16;
+constexpr int WGRAD_GROUP_MAX = 64;  // entries per launch (the kernel-argument block stays under 4 KB)
 struct WgradGroupParams {
   int n;
   int tile_end[WGRAD_GROUP_MAX];  // tiles of problems 0 .. i (prefix sums)

@@ -271,7 +271,7 @@ def add_wgrad_group(eng, plan: _Plan, label: str, entries: list, tile: int, defe
     flops = 0.0
     for q, ((X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw), t0, tc) in zip(arr, entries):
         q.X, q.dY, q.dW, q.M, q.Kin, q.Nout, q.ldx, q.lddy, q.lddw, q.tile_begin, q.tile_count = X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, t0, tc
-        flops += 2.0 * Mr * tile * tile * tc  # (whole tiles: Kin, Nout are multiples of the tile on this path)
+        flops += 2.0 * Mr * Kin * Nout * tc / (-(-Kin // tile) * -(-Nout // tile))  # the weight's flops, by its share of tiles in this launch
     plan.keep.append(arr)
     plan.add(eng.L.savit_gemm_bf16_wgrad_grouped, (arr, len(entries), tile), label, side=side,
              reads=tuple(sorted({e[0][1] for e in entries})) if side else ())
@@ -286,6 +286,8 @@ class WgradQueue:
     """FIFO of weight-gradient output tiles waiting for a grouped launch.  A launch takes exactly `cap` tiles (one per CU: a full
     round of workgroups), cutting a weight between two launches where it must; what is left at the end goes out as the last launch."""
 
+    MAX_ENTRIES = 64  # savit_gemm_bf16_wgrad_grouped takes at most this many (weight, tile range) entries per launch
+
     def __init__(self, cap: int):
         self.cap = cap
         self.items: List[list] = []  # [problem, layer, tiles, next tile]
@@ -296,10 +298,14 @@ class WgradQueue:
     def pending(self) -> int:
         return sum(it[2] - it[3] for it in self.items)
 
+    def due(self) -> bool:
+        """A launch's worth is waiting: a full round of tiles, or as many entries as one launch takes (narrow models)."""
+        return self.pending() >= self.cap or len(self.items) >= self.MAX_ENTRIES
+
     def take(self, n: int):
         """-> (entries [(problem, tile_begin, tile_count)], layers whose LAST pending tile is in this launch, oldest layer touched)"""
         entries, done, oldest = [], [], None
-        while n > 0 and self.items:
+        while n > 0 and self.items and len(entries) < self.MAX_ENTRIES:
             it = self.items[0]
             c = min(n, it[2] - it[3])
             entries.append((it[0], it[3], c))
@@ -569,7 +575,7 @@ class ViTEngine:
             # called between a layer's last input-gradient GEMM and its ln1.bwd (which overwrites the oldest ring slot): every
             # cotangent of the last `wgrad_lag` + 1 layers is still intact.  A launch takes one tile per CU; the DDP trigger
             # ('l{j}.ln1.bwd') of an EARLIER layer whose last tile is in it fires behind it, the current layer's own follows naturally.
-            while queue is not None and queue.pending() > 0 and (queue.pending() >= queue.cap or last):
+            while queue is not None and queue.pending() > 0 and (queue.due() or last):
                 entries, done, oldest = queue.take(queue.cap)
                 assert oldest - layer <= self.wgrad_lag, "weight-gradient queue reaches back further than the cotangent rings"
                 add_wgrad_group(self, P, f"wgrad.group.{n_launch[0]}.l{oldest}-l{layer}", entries, self.wgrad_tile,
@@ -633,7 +639,8 @@ class ViTEngine:
     def _wgrad_group_plan(self):
         """(tile, tiles per launch, layers whose Wo keeps the per-weight path, layers a launch reaches back); tile 0 = one launch per
         weight (token range split over workgroups, partial slabs + ordered reduce).
-        A layer's four weight gradients are d x 3d, d x d, d x F, F x d: with 256 x 256 tiles DeiT-B has 108 tiles per layer, ViT-L 192 -
+        A layer's four weight gradients are d x 3d, d x d, d x F, F x d (edge tiles where a side is not a multiple of 256: DeiT-S's
+        d = 384 takes 38 tiles per layer, 71 % of them inside a matrix): with 256 x 256 tiles DeiT-B has 108 tiles per layer, ViT-L 192 -
         too few for 256 CUs one weight (or one layer) at a time.  They wait in a FIFO and leave in launches of exactly one tile per CU,
         a weight cut between two launches where needed: every launch is a full round.  DeiT-B: 12 x 108 = 1 296 tiles = 5 rounds + 16
         tiles - so the d x d gradients of the last two layers (18 tiles) keep the per-weight path and the rest is 5 launches (4 x 256 +
@@ -641,8 +648,8 @@ class ViTEngine:
         cfg = self.cfg
         d, F, NL = cfg.embed_dim, cfg.hidden, cfg.num_layers
         env = os.environ.get("SAVIT_WGRAD_GROUP", "auto")
-        if env == "0" or d % 256 or F % 256:
-            return 0, 0, frozenset(), 0  # narrower models keep the per-weight launches (128 x 128 tiles)
+        if env == "0" or d % 8 or F % 8:
+            return 0, 0, frozenset(), 0
         tile = 256
         sizes = [(n, int(self.L.savit_gemm_wgrad_group_tiles(a, b, tile))) for n, a, b in (("W2", F, d), ("W1", d, F), ("Wo", d, d), ("Wqkv", d, 3 * d))]
         per_layer = sum(t for _, t in sizes)
@@ -660,7 +667,7 @@ class ViTEngine:
             for n, t in sizes:
                 if not (n == "Wo" and l in divert):
                     q.push(None, l, t)
-            while q.pending() > 0 and (q.pending() >= cap or l == 0):
+            while q.pending() > 0 and (q.due() or l == 0):
                 _, _, oldest = q.take(cap)
                 lag = max(lag, oldest - l)
         return tile, cap, divert, lag

@@ -252,7 +252,7 @@ def gemm_wgrad(X: torch.Tensor, dY: torch.Tensor, dW: torch.Tensor, splits: int 
 
 def gemm_wgrad_grouped(problems, tile: int = 256):
     """dW_i += X_i^T @ dY_i for every (X_i, dY_i, dW_i) of `problems` in ONE launch, one workgroup per tile x tile output tile, each
-    reducing over all rows (no split, no slabs; savit_gemm_bf16_wgrad_grouped).  At most 16 problems."""
+    reducing over all rows (no split, no slabs; savit_gemm_bf16_wgrad_grouped).  At most 64 problems."""
     arr = (_lib.WgradProblem * len(problems))()
     for q, pr in zip(arr, problems):
         X, dY, dW = pr[:3]
