@@ -266,8 +266,24 @@ def time_config1_fp32(steps=20, warmup=3):
         eng.loss_fn(lab)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    return {"model": "vit_ti_patch16", "dtype": "f32", "images_per_gpu": 8, "steps": steps, "warmup": warmup, "value": round(8 * steps / el, 1),
-            "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 3), "final_loss": round(float(eng.loss.item()), 4)}
+    res = {"model": "vit_ti_patch16", "dtype": "f32", "images_per_gpu": 8, "steps": steps, "warmup": warmup, "value": round(8 * steps / el, 1),
+           "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 3), "final_loss": round(float(eng.loss.item()), 4)}
+    # the whole fp32 train step of simple_train.py:72-90 (forward, loss, backward, clip + Adam): what cpu_baseline.value times on the host
+    def train_step():
+        eng.forward(img)
+        eng.loss_backward(lab, 0.1)
+        eng.optimizer_step(lr=3e-3 * 8 / 512.0, weight_decay=0.0, max_norm=1.0)
+    for _ in range(warmup):
+        train_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        train_step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    res["train_step"] = {"value": round(8 * steps / el, 1), "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 3),
+                         "final_loss": round(float(eng.loss.item()), 4)}
+    return res
 
 
 def main():
@@ -461,7 +477,7 @@ def main():
         out["other_configs"] = {}
         for model, ob, osz, name in OTHER_CONFIGS:
             out["other_configs"][name] = time_other_config(model, ob, osz)
-        out["other_configs"]["1. ViT-Ti/16 224^2 fp32, batch 8, forward + loss (fp32-input MFMA path)"] = time_config1_fp32()
+        out["other_configs"]["1. ViT-Ti/16 224^2 fp32, batch 8, forward + loss; train_step = + backward + Adam (fp32-input MFMA path)"] = time_config1_fp32()
 
     # ---- CPU baseline leg (rank 0, N=1 only): the oracle's torch-CPU restatement of BASELINE config 1, bounded samples
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
