@@ -206,6 +206,7 @@ struct GemmF32ExParams {
   float alpha; int alpha_cols; int act; int accumulate; int rows_per_sample;
   int aux_row_mod;  // > 0: aux is a [aux_row_mod, ldaux] table shared by all batches, row m % aux_row_mod (position embeddings)
   const float* rowbias;  // nullable: + rowbias[m] (a Dense bias when the product is computed transposed: MLP-Mixer token mixing)
+  int ksplit;            // K ranges per output tile (chosen by the launcher)
 };
 
 __device__ __forceinline__ float gelu_tanh_exact(float v) {
@@ -224,38 +225,56 @@ __global__ __launch_bounds__(256) void gemm_f32_ex_kernel(const GemmF32ExParams 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int row0 = blockIdx.y * GB, col0 = blockIdx.x * GB;
-  const int zo = blockIdx.z / p.inner, zi = blockIdx.z - zo * p.inner;
+  // grid.z = batch x K-splits (splits > 1 only for plain accumulating products: each split adds its partial with an atomic)
+  const int zb = blockIdx.z / p.ksplit, ks = blockIdx.z - zb * p.ksplit;
+  const int zo = zb / p.inner, zi = zb - zo * p.inner;
   const float* A = p.A + zo * p.sAo + zi * p.sAi;
   const float* W = p.W + zo * p.sWo + zi * p.sWi;
   const long coff = zo * p.sCo + zi * p.sCi;
+  const int kchunk = ((p.K + p.ksplit - 1) / p.ksplit + GK - 1) / GK * GK;
+  const int kbeg = ks * kchunk, kend = min(p.K, kbeg + kchunk);
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (kbeg >= kend) return;
   const int li = lane & 31, lk = lane >> 5;
-  for (int k0 = 0; k0 < p.K; k0 += GK) {
-    // A tile 64 (m) x 32 (k): 8 elements per thread, walking the operand's contiguous index fastest
+  // the next K-step's operand elements are fetched into registers under this K-step's MFMAs (the launches of the fp32 engines are
+  // small: a workgroup's loop is a chain of global-memory latencies otherwise)
+  float ra[8], rw[8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {  // A tile 64 (m) x 32 (k), walking the operand's contiguous index fastest
+      const int e = tid + 256 * r;
+      int row, kc;
+      if (p.transA) { row = e & 63; kc = e >> 6; } else { kc = e & 31; row = e >> 5; }
+      const int m = row0 + row, k = k0 + kc;
+      ra[r] = 0.f;
+      if (m < p.M && k < kend) ra[r] = p.transA ? A[(size_t)k * p.lda + m] : A[(size_t)m * p.lda + k];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {  // W tile 32 (k) x 64 (n)
+      const int e = tid + 256 * r;
+      int kr, nc;
+      if (p.transW) { kr = e & 31; nc = e >> 5; } else { nc = e & 63; kr = e >> 6; }
+      const int k = k0 + kr, n = col0 + nc;
+      rw[r] = 0.f;
+      if (k < kend && n < p.N) rw[r] = p.transW ? W[(size_t)n * p.ldw + k] : W[(size_t)k * p.ldw + n];
+    }
+  };
+  fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int e = tid + 256 * r;
       int row, kc;
       if (p.transA) { row = e & 63; kc = e >> 6; } else { kc = e & 31; row = e >> 5; }
-      const int m = row0 + row, k = k0 + kc;
-      float v = 0.f;
-      if (m < p.M && k < p.K) v = p.transA ? A[(size_t)k * p.lda + m] : A[(size_t)m * p.lda + k];
-      As[row * A_LD + kc] = v;
-    }
-    // W tile 32 (k) x 64 (n)
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int e = tid + 256 * r;
+      As[row * A_LD + kc] = ra[r];
       int kr, nc;
       if (p.transW) { kr = e & 31; nc = e >> 5; } else { nc = e & 63; kr = e >> 6; }
-      const int k = k0 + kr, n = col0 + nc;
-      float v = 0.f;
-      if (k < p.K && n < p.N) v = p.transW ? W[(size_t)n * p.ldw + k] : W[(size_t)k * p.ldw + n];
-      Bs[kr * B_LD + nc] = v;
+      Bs[kr * B_LD + nc] = rw[r];
     }
     __syncthreads();
+    if (k0 + GK < kend) fetch(k0 + GK);
 #pragma unroll
     for (int s = 0; s < GK / 2; ++s) {
       const float a = As[(wm * 32 + li) * A_LD + 2 * s + lk];
@@ -266,6 +285,14 @@ __global__ __launch_bounds__(256) void gemm_f32_ex_kernel(const GemmF32ExParams 
   }
   const int n = col0 + wn * 32 + li;
   if (n >= p.N) return;
+  if (p.ksplit > 1) {  // C += partial (plain accumulating product: the launcher allows no other epilogue term with a split)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (m < p.M) atomicAdd(p.C + (size_t)coff + (size_t)m * p.ldc + n, acc[r]);
+    }
+    return;
+  }
   const float bn = p.bias ? p.bias[n] : 0.f;
   const float sc = n < p.alpha_cols ? p.alpha : 1.0f;
   const float cs = p.colscale ? p.colscale[n] : 1.0f;
@@ -503,10 +530,22 @@ extern "C" int savit_gemm_f32_ex(const savit_gemm_f32_args* g, void* stream) {
   SAVIT_CHECK_ARG(g->lda >= (g->transA ? g->M : g->K) && g->ldw >= (g->transW ? g->K : g->N) && g->ldc >= g->N && (g->aux == nullptr || g->ldaux >= g->N));
   SAVIT_CHECK_ARG((g->act != 2 || g->U != nullptr) && (g->rowscale == nullptr || g->rows_per_sample >= 1) && g->act >= 0 && g->act <= 2 && g->aux_row_mod >= 0);
   if (g->M == 0) return SAVIT_OK;
+  // A long reduction into few output tiles (weight gradients: K = tokens) is split over K ranges that add their partials with fp32
+  // atomics - only for the plain accumulating form, where the order of the additions is the only thing a split changes.
+  int ksplit = 1;
+  const long tiles = (long)((g->N + GB - 1) / GB) * ((g->M + GB - 1) / GB) * g->batch;
+  const bool plain_acc = g->accumulate && !g->bias && !g->aux && !g->colscale && !g->rowscale && !g->C2 && !g->rowbias && g->act == 0 &&
+                         g->alpha_cols == 0;
+  if (plain_acc && g->K >= 8 * GK && tiles < 1024) {
+    ksplit = (int)((1024 + tiles - 1) / tiles);
+    if (ksplit > g->K / (2 * GK)) ksplit = g->K / (2 * GK);
+    if (ksplit < 1) ksplit = 1;
+    if ((long)g->batch * ksplit > 65535) ksplit = 1;
+  }
   GemmF32ExParams p{g->A, g->W, g->C, g->bias, g->aux, g->colscale, g->rowscale, g->C2, g->U, g->M, g->N, g->K, g->lda, g->ldw, g->ldc, g->ldaux,
                     g->transA, g->transW, g->inner, g->sAo, g->sAi, g->sWo, g->sWi, g->sCo, g->sCi, g->alpha, g->alpha_cols, g->act, g->accumulate,
-                    g->rows_per_sample > 0 ? g->rows_per_sample : 1, g->aux_row_mod, g->rowbias};
-  hipLaunchKernelGGL(gemm_f32_ex_kernel, dim3((g->N + GB - 1) / GB, (g->M + GB - 1) / GB, g->batch), dim3(256), 0, (hipStream_t)stream, p);
+                    g->rows_per_sample > 0 ? g->rows_per_sample : 1, g->aux_row_mod, g->rowbias, ksplit};
+  hipLaunchKernelGGL(gemm_f32_ex_kernel, dim3((g->N + GB - 1) / GB, (g->M + GB - 1) / GB, g->batch * ksplit), dim3(256), 0, (hipStream_t)stream, p);
   SAVIT_LAUNCH_RET();
 }
 
