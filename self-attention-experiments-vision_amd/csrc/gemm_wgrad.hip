@@ -466,6 +466,195 @@ __global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_ring_kernel(cons
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Ping-pong form of the ring tile for the grouped launches (one tile per workgroup over ALL tokens: no split, dW += tile).  In
+// wgrad_ring_tile the eight waves move in lock step: the two waves of a SIMD want the matrix pipe at the same time and wait for
+// their LDS fragments at the same time.  Here the waves of row half 0 (wi = 0: one per SIMD) and of row half 1 run ONE BARRIER
+// APART through four phases per 32-token stage,
+//     L0: request the fragments of k-step 0        | C0: wait for them, 8 MFMAs
+//     L1: request k-step 1, refill a ring slot     | C1: wait, 8 MFMAs
+// so that between two barriers one group issues MFMAs while its SIMD partners request fragments / issue LDS-DMA (the structure of
+// gemm_tn_pp_kernel).  Same K order per accumulator as the ring tile: the results are bitwise the same.
+//   WAR: the slot of stage st-1 is refilled (stage st-1+S) in L1(st): both groups have waited for their last fragments of stage
+//        st-1 by then (group 1's C1(st-1) ended one barrier before group 0's L1(st) began, and vice versa).
+//   RAW: every wave waits for ITS share of stage st+1 at the end of L1(st) (vmcnt(G (S-2)): all but the S-2 newest stages) and at
+//        least one barrier follows before any wave requests fragments of stage st+1 (L0(st+1)).
+template <int BI, int BJ, int WGI, int WGJ, int S>
+__device__ __forceinline__ void wgrad_pp_tile(const WgradParams& p, const int ti, const int tj, char* smem) {
+  static_assert(WGI == 2, "two row halves = the two ping-pong groups");
+  constexpr int NW = WGI * WGJ;
+  constexpr int TS = 32;
+  constexpr int WTI = BI / WGI, WTJ = BJ / WGJ;
+  constexpr int II = WTI / 32, JJ = WTJ / 32;
+  constexpr int XROW = BI * 2, YROW = BJ * 2;
+  constexpr int X_BYTES = TS * XROW, Y_BYTES = TS * YROW, STAGE = X_BYTES + Y_BYTES;
+  constexpr int X_INSTR = X_BYTES / 1024 / NW, Y_INSTR = Y_BYTES / 1024 / NW, G = X_INSTR + Y_INSTR;
+  static_assert(X_BYTES % (1024 * NW) == 0 && Y_BYTES % (1024 * NW) == 0, "tile/wave mismatch");
+  static_assert(S >= 3 && G * (S - 1) <= 63, "ring depth / vmcnt immediate");
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wi = wave / WGJ, wj = wave % WGJ;
+  const int i0 = ti * BI, j0 = tj * BJ;
+  const int NS = (p.M + TS - 1) / TS;
+  if (NS <= 0) return;
+
+  size_t xbytes = (size_t)p.M * p.ldx * 2, ybytes = (size_t)p.M * p.lddy * 2;
+  if (xbytes > 0xffffffe0ull) xbytes = 0xffffffe0ull;
+  if (ybytes > 0xffffffe0ull) ybytes = 0xffffffe0ull;
+  const auto srdX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X), 0, (uint32_t)xbytes, 0x00020000);
+  const auto srdY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dY), 0, (uint32_t)ybytes, 0x00020000);
+
+  auto stage = [&](int st, int slot) {  // as in wgrad_ring_tile (no patch gather on this path)
+    char* sX = smem + slot * STAGE;
+    char* sY = sX + X_BYTES;
+    const int m0 = st * TS;
+    {
+      constexpr int LPR = XROW / 16, RPI = 64 / LPR;
+#pragma unroll
+      for (int i = 0; i < X_INSTR; ++i) {
+        const int inst = wave * X_INSTR + i;
+        const int r = inst * RPI + lane / LPR;
+        const int c = (lane % LPR) ^ ((r & 3) << 2);
+        const int m = m0 + r;
+        uint32_t voff = 0xfffffff0u;
+        if (m < p.M) voff = (uint32_t)((size_t)m * p.ldx * 2 + (size_t)(i0 + c * 8) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdX, (__attribute__((address_space(3))) void*)(sX + inst * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+    {
+      constexpr int LPR = YROW / 16, RPI = 64 / LPR;
+#pragma unroll
+      for (int i = 0; i < Y_INSTR; ++i) {
+        const int inst = wave * Y_INSTR + i;
+        const int r = inst * RPI + lane / LPR;
+        const int c = (lane % LPR) ^ ((r & 3) << 2);
+        const int m = m0 + r;
+        uint32_t voff = 0xfffffff0u;
+        if (m < p.M) voff = (uint32_t)((size_t)m * p.lddy * 2 + (size_t)(j0 + c * 8) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdY, (__attribute__((address_space(3))) void*)(sY + inst * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+  };
+
+  const int g = lane >> 4, t = lane & 15;
+  const int q = t >> 2, h = g >> 1;
+  const int colx = wi * WTI + 16 * (g & 1) + 4 * (t & 3);
+  const int coly = wj * WTJ + 16 * (g & 1) + 4 * (t & 3);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  uint32_t offx[II], offy[JJ];
+#pragma unroll
+  for (int a = 0; a < II; ++a) {
+    const int col = colx + 32 * a;
+    offx[a] = lds0 + (8 * h + q) * XROW + (((col >> 3) ^ (q << 2)) << 4) + ((col & 7) << 1);
+  }
+#pragma unroll
+  for (int b = 0; b < JJ; ++b) {
+    const int col = coly + 32 * b;
+    offy[b] = lds0 + X_BYTES + (8 * h + q) * YROW + (((col >> 3) ^ (q << 2)) << 4) + ((col & 7) << 1);
+  }
+
+  f32x16 acc[II][JJ];
+#pragma unroll
+  for (int a = 0; a < II; ++a)
+#pragma unroll
+    for (int b = 0; b < JJ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  bf16x4 xl[II], xh[II], yl[JJ], yh[JJ];
+#define SAVIT_TR_READ(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+#define SAVIT_PP_REQUEST(slot_off, KS)                                                  \
+  do {                                                                                  \
+    _Pragma("unroll") for (int a_ = 0; a_ < II; ++a_) {                                 \
+      SAVIT_TR_READ(xl[a_], offx[a_] + (slot_off), (KS) * 16 * XROW);                   \
+      SAVIT_TR_READ(xh[a_], offx[a_] + (slot_off), (KS) * 16 * XROW + 4 * XROW);        \
+    }                                                                                   \
+    _Pragma("unroll") for (int b_ = 0; b_ < JJ; ++b_) {                                 \
+      SAVIT_TR_READ(yl[b_], offy[b_] + (slot_off), (KS) * 16 * YROW);                   \
+      SAVIT_TR_READ(yh[b_], offy[b_] + (slot_off), (KS) * 16 * YROW + 4 * YROW);        \
+    }                                                                                   \
+  } while (0)
+  auto compute = [&]() {  // between two barriers: wait for this wave's fragments, then its 8 MFMAs at raised priority
+#pragma unroll
+    for (int a = 0; a < II; ++a) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xl[a]), "+v"(xh[a]));
+#pragma unroll
+    for (int b = 0; b < JJ; ++b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yl[b]), "+v"(yh[b]));
+    bf16x8 xa[II], yb[JJ];
+#pragma unroll
+    for (int a = 0; a < II; ++a) xa[a] = __builtin_shufflevector(xl[a], xh[a], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+    for (int b = 0; b < JJ; ++b) yb[b] = __builtin_shufflevector(yl[b], yh[b], 0, 1, 2, 3, 4, 5, 6, 7);
+#ifndef ABL_NO_PRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int a = 0; a < II; ++a)
+#pragma unroll
+      for (int b = 0; b < JJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[a], yb[b], acc[a][b], 0, 0, 0);
+#ifndef ABL_NO_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  };
+
+  const int pre = NS < S ? NS : S;
+  for (int st = 0; st < pre; ++st) stage(st, st);
+  if (pre == S) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (S - 1)) : "memory");  // stage 0
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wi == 1) __builtin_amdgcn_s_barrier();  // row half 1 runs one barrier behind row half 0
+
+  int slot = 0;
+  for (int st = 0; st < NS; ++st) {
+    const uint32_t cur_off = (uint32_t)(slot * STAGE);
+    // ---- L0: fragments of k-step 0
+    SAVIT_PP_REQUEST(cur_off, 0);
+    __builtin_amdgcn_s_barrier();
+    // ---- C0
+    compute();
+    __builtin_amdgcn_s_barrier();
+    // ---- L1: fragments of k-step 1; refill the slot of stage st-1; this wave's share of stage st+1 must have landed
+    SAVIT_PP_REQUEST(cur_off, 1);
+    if (st >= 1 && st - 1 + S < NS) stage(st - 1 + S, slot == 0 ? S - 1 : slot - 1);
+    if (st - 1 + S < NS) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (S - 2)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    // ---- C1
+    compute();
+    __builtin_amdgcn_s_barrier();
+    slot = (slot + 1 == S) ? 0 : slot + 1;
+  }
+  if (wi == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count
+#undef SAVIT_PP_REQUEST
+#undef SAVIT_TR_READ
+
+  // dW += tile (the tile IS the whole sum over the tokens): plain read-modify-write, whole 128-B row segments per instruction
+  const int jl = lane & 31, hi5 = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < II; ++a)
+#pragma unroll
+    for (int b = 0; b < JJ; ++b) {
+      const int j = j0 + wj * WTJ + 32 * b + jl;
+      float old[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wi * WTI + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi5;
+        old[r] = (i < p.Kin && j < p.Nout) ? p.dW[(size_t)i * p.lddw + j] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wi * WTI + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi5;
+        if (i < p.Kin && j < p.Nout) p.dW[(size_t)i * p.lddw + j] = old[r] + acc[a][b][r];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Grouped launch: the weight gradients of SEVERAL Dense kernels (the four of an encoder layer, of one or more layers) in ONE grid,
 // one workgroup per 256 x 256 (or 128 x 128) output tile, each reducing over ALL tokens.  A single weight gradient has too few
 // output tiles for the chip (DeiT-B's W1: 36 tiles of 256 x 256 on 256 CUs), which is why the single-problem launch splits the
@@ -506,7 +695,10 @@ __global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_group_kernel(con
   p.tiles_per_split = (p.M + 31) / 32;
   p.rmw = 1;
   const int ti = t / p.tiles_j;
-  wgrad_ring_tile<BI, BJ, WGI, WGJ, S, false>(p, 0, ti, t - ti * p.tiles_j, smem);
+  if constexpr (BI == 256)
+    wgrad_pp_tile<BI, BJ, WGI, WGJ, S>(p, ti, t - ti * p.tiles_j, smem);
+  else
+    wgrad_ring_tile<BI, BJ, WGI, WGJ, S, false>(p, 0, ti, t - ti * p.tiles_j, smem);
 }
 
 // dW[i, j] += sum over splits of slab[s][i][j], splits added in index order (fixed order: the result is bitwise reproducible).
@@ -768,9 +960,12 @@ extern "C" int savit_gemm_bf16_wgrad_grouped(const savit_wgrad_problem* problems
   g.n = n;
   for (int i = n; i < WGRAD_GROUP_MAX; ++i) g.tile_end[i] = tiles;
   if (tile == 256) {
-    auto kfn = gemm_wgrad_group_kernel<256, 256, 2, 4, 4>;
+#ifndef WGRAD_GROUP_S
+#define WGRAD_GROUP_S 4  // ring slots of the 256 x 256 grouped tile (32 KB each)
+#endif
+    auto kfn = gemm_wgrad_group_kernel<256, 256, 2, 4, WGRAD_GROUP_S>;
     SAVIT_LDS_ONCE(kfn);
-    hipLaunchKernelGGL(kfn, dim3(tiles), dim3(512), (size_t)4 * 32 * (256 + 256) * 2, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(kfn, dim3(tiles), dim3(512), (size_t)WGRAD_GROUP_S * 32 * (256 + 256) * 2, (hipStream_t)stream, g);
   } else {
     auto kfn = gemm_wgrad_group_kernel<128, 128, 2, 2, 4>;
     SAVIT_LDS_ONCE(kfn);

@@ -8,7 +8,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import savit_amd  # noqa: F401
-from savit_amd import ops
+from savit_amd import lib as _l, ops
+
+if os.environ.get("SAVIT_EXP_LIB"):
+    _l.LIB_PATH = os.path.join(os.path.dirname(_l.LIB_PATH), "exp", "libsavit_%s.so" % os.environ["SAVIT_EXP_LIB"])
 
 bf16 = torch.bfloat16
 d, F, M, layers = (int(a) for a in (sys.argv[1:5] if len(sys.argv) >= 5 else (768, 3072, 25216, 2)))
