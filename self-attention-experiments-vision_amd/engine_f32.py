@@ -224,8 +224,11 @@ class ViTEngineF32(_F32Base):
 
     def set_images(self, images: torch.Tensor):
         S = self.cfg.img_size
+        if images.is_cuda and tuple(images.shape) == (S, S, 3, self.B):  # the loader's [H, W, C, N] (train.py:80): a permuted device copy
+            self.images.copy_(images.permute(3, 0, 1, 2).to(f32))
+            return
         if not images.is_cuda or tuple(images.shape) != (self.B, S, S, 3):
-            raise ValueError(f"images must be a GPU tensor [B={self.B},{S},{S},3] (NHWC)")
+            raise ValueError(f"images must be a GPU tensor [B={self.B},{S},{S},3] (NHWC) or [{S},{S},3,B={self.B}]")
         self.images.copy_(images.to(f32))
 
     def forward(self, images: Optional[torch.Tensor] = None) -> torch.Tensor:

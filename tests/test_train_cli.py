@@ -133,3 +133,25 @@ def test_cait_masks_differ_across_ranks_and_resume_consistently():
     keep = 1.0 - mc.stoch_depth_rate
     assert set(torch.unique(a).tolist()) <= {0.0, 1.0 / keep} or torch.allclose(torch.unique(a), torch.tensor([0.0, 1.0 / keep], device=a.device))
     assert abs(float((a > 0).float().mean()) - keep) < 0.08  # floor(keep + U) keeps with probability `keep` (stochastic_depth.py:21-23)
+
+
+@pytest.mark.gpu
+def test_short_run_float32_simple_train_mode(tmp_path, capsys):
+    """--dtype float32: create_model's default dtype, the arithmetic simple_train.py:72-90 trains config 1 (ViT-Ti/16, batch 8) in -
+    through the same loop: train, eval, Flax-format checkpoint, resume; other families / ranks / mixup say why not."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ck = str(tmp_path / "ck")
+    common = ["--model_name", "vit_ti_patch16", "--dtype", "float32", "--batch_size", "8", "--steps_per_epoch", "3", "--checkpoint_dir", ck,
+              "--clip_grad", "1.0", "--eval_every_epochs", "1", "--save_every_epochs", "1", "--log_every", "1", "--lr", "1e-3"]
+    assert train_cli.main(common + ["--num_epochs", "1"]) == 3
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    train = [l for l in lines if "train/loss" in l]
+    assert len(train) == 3 and abs(train[0]["train/loss"] - 6.9078) < 1e-4  # zero-init head: ln(1000), to fp32 accuracy
+    assert all(np.isfinite(t["train/loss"]) for t in train) and any("eval/loss" in l for l in lines)
+    assert os.path.exists(os.path.join(ck, "checkpoint_3"))
+    assert train_cli.main(common + ["--num_epochs", "2"]) == 6  # resumes
+    with pytest.raises(SystemExit, match="bfloat16"):
+        train_cli.main(["--model_name", "cait_xxs_24", "--dtype", "float32", "--batch_size", "2", "--max_steps", "1"])

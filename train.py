@@ -130,6 +130,9 @@ def main(argv=None):
     ap.add_argument("--mixup_alpha", type=float, default=0.0, help="batch mixup Beta parameter (reference pipeline: 0.8); 0 = off")
     ap.add_argument("--cutmix_alpha", type=float, default=0.0, help="batch cutmix Beta parameter (reference pipeline: 1.0); 0 = off")
     ap.add_argument("--mix_prob", type=float, default=1.0, help="probability of applying the drawn mix augmentation to a batch")
+    ap.add_argument("--dtype", default="bfloat16", choices=("bfloat16", "float32"),
+                    help="bfloat16 = what train.py:222-224 passes to create_model; float32 = create_model's default, the arithmetic of "
+                         "simple_train.py:72-90 (ViT family, one GPU: the exact-fp32 engine)")
     args = ap.parse_args(argv)
 
     import torch
@@ -152,7 +155,11 @@ def main(argv=None):
     from savit_amd import ddp
     from savit_amd.model import create_model
 
-    model = create_model(args.model_name, num_classes=1000, dtype=torch.bfloat16, img_size=args.img_size)  # train.py:222-224
+    fp32 = args.dtype == "float32"
+    model = create_model(args.model_name, num_classes=1000, dtype=torch.float32 if fp32 else torch.bfloat16, img_size=args.img_size)  # train.py:222-224
+    if fp32 and (model.cfg.kind != "vit" or world > 1 or args.mixup_alpha > 0 or args.cutmix_alpha > 0):
+        raise SystemExit("--dtype float32 trains the ViT family on one GPU without mix augmentation (simple_train.py); "
+                         "the other families and the data-parallel / mixup paths train in bfloat16")
     model.init(args.seed, torch.ones(1, args.img_size, args.img_size, 3, device="cuda"), is_training=False)  # train.py:29-31
     eng = model.engine(bs)
     start = restore_checkpoint(eng, args.checkpoint_dir) if args.checkpoint_dir else 0
@@ -219,7 +226,10 @@ def main(argv=None):
                 eng.forward(images, is_training=True, sd_seed=stochastic_depth_seed(args.seed, rank, step))
             else:
                 eng.forward(images)
-            eng.loss_backward(batch["labels"], args.label_smoothing, batch.get("mix_labels"), batch.get("ratio"))
+            if fp32:
+                eng.loss_backward(batch["labels"], args.label_smoothing)
+            else:
+                eng.loss_backward(batch["labels"], args.label_smoothing, batch.get("mix_labels"), batch.get("ratio"))
             if sync is not None:
                 sync.wait()
             eng.optimizer_step(lr=lr, weight_decay=args.weight_decay, max_norm=args.clip_grad or 0.0,
