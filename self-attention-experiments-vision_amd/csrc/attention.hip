@@ -1214,13 +1214,125 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
   }
 }
 
+// Packed form of the forward row (H = 8 and 4): a lane's four keys are two key PAIRS, the H x H head mixes run as v_pk_fma_f32 with
+// the coefficient pair (T[h][2j], T[h][2j+1]) as ONE 64-bit SGPR operand whose low / high half is broadcast to both halves of the
+// packed instruction through op_sel.  hipcc does not form this by itself (it splats the scalar through v_mov), and as C++ loads
+// the 2 x 64 coefficients either spill SGPRs (scalar loads hoisted out of the row loop: 240 v_readlane / v_writelane per row) or
+// become per-lane vector loads (32 flat loads per row: measured slower).  So one matrix at a time is fetched by inline-asm
+// s_load_dwordx16 inside the row and its register pairs feed the FMAs directly: 2 x 128 packed FMAs per row instead of 2 x 256
+// scalar ones, no spill traffic.  Same FMA order per accumulator: bitwise the scalar form's results (H = 2, 6, 16 keep that form).
+typedef __attribute__((ext_vector_type(16))) uint32_t th_u32x16;
+typedef __attribute__((ext_vector_type(8))) uint64_t th_u64x8;
+template <int H>
+struct ThCoef {  // the H x H matrix as H * H / 2 SGPR pairs
+  th_u64x8 q[(H * H / 2 + 7) / 8];
+  th_u32x16 r0, r1, r2, r3;
+  // issue() requests the matrix, wait() must run before the first use.  Between the two the registers are in flight: the uses are
+  // tied to wait()'s outputs, and the ISA of every kernel using this was checked for copies of r0..r3 in between (there are none).
+  __device__ __forceinline__ void issue(const float* T) {
+    static_assert(H == 8 || H == 4, "whole 64-byte quads");
+    if constexpr (H == 8) {
+      asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx16 %2, %4, 0x80\n\ts_load_dwordx16 %3, %4, 0xc0"
+                   : "=s"(r0), "=s"(r1), "=s"(r2), "=s"(r3)
+                   : "s"(T)
+                   : "memory");
+    } else {
+      asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(r0) : "s"(T) : "memory");
+    }
+  }
+  __device__ __forceinline__ void wait() {
+    if constexpr (H == 8) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r0), "+s"(r1), "+s"(r2), "+s"(r3)::"memory");
+      q[0] = __builtin_bit_cast(th_u64x8, r0); q[1] = __builtin_bit_cast(th_u64x8, r1);
+      q[2] = __builtin_bit_cast(th_u64x8, r2); q[3] = __builtin_bit_cast(th_u64x8, r3);
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r0)::"memory");
+      q[0] = __builtin_bit_cast(th_u64x8, r0);
+    }
+  }
+  __device__ __forceinline__ void load(const float* T) {
+    issue(T);
+    wait();
+  }
+};
+// lo / hi[kp] = sum_h T[h][2j] / T[h][2j+1] * x[h][kp]  (kp = key pair)
+#define TH_COEF(C, H_, J_) ((C).q[((H_) * (H / 2) + (J_)) / 8][((H_) * (H / 2) + (J_)) % 8])
+#define TH_MIX_PK(C, X, J, LO, HI)                                                                                             \
+  do {                                                                                                                          \
+    LO[0] = LO[1] = HI[0] = HI[1] = f32x2{0.f, 0.f};                                                                            \
+    _Pragma("unroll") for (int h_ = 0; h_ < H; ++h_) {                                                                          \
+      const uint64_t tp_ = (C).q[(h_ * (H / 2) + (J)) / 8][(h_ * (H / 2) + (J)) % 8];                                           \
+      _Pragma("unroll") for (int kp_ = 0; kp_ < 2; ++kp_) {                                                                      \
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(LO[kp_]) : "s"(tp_), "v"(X[h_][kp_]));                       \
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(HI[kp_]) : "s"(tp_), "v"(X[h_][kp_]));        \
+      }                                                                                                                         \
+    }                                                                                                                           \
+  } while (0)
+
 template <int H>
 __global__ __launch_bounds__(256) void th_softmax_fwd_kernel(const bf16_t* __restrict__ S, bf16_t* __restrict__ Pp, const float* __restrict__ T1g,
                                                               const float* __restrict__ T2g, int B, int N, int Np) {
-  const float* __restrict__ T1 = T1g;
-  const float* __restrict__ T2 = T2g;
   const int lane = threadIdx.x & 63;
   const long rows = (long)B * N;
+  if constexpr (H == 8 || H == 4) {
+    constexpr int HP = H / 2;
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+      const int b = (int)(row / N), q = (int)(row - (long)b * N);
+      f32x2 s2[H][2], p2[H][2];
+      const bool in_row = 4 * lane < Np;
+      ThCoef<H> c1, c2;
+      c1.issue(T1g);  // under the latency of the row loads
+#pragma unroll
+      for (int h = 0; h < H; ++h) {  // lane owns 4 CONSECUTIVE keys (one 8-byte load per head)
+        uint2 v = make_uint2(0u, 0u);
+        if (in_row) v = *reinterpret_cast<const uint2*>(S + (((size_t)b * H + h) * N + q) * Np + 4 * lane);
+        s2[h][0] = f32x2{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u)};
+        s2[h][1] = f32x2{__uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+      }
+      const bool k_ok[4] = {4 * lane < N, 4 * lane + 1 < N, 4 * lane + 2 < N, 4 * lane + 3 < N};
+      c1.wait();
+#pragma unroll
+      for (int j = 0; j < HP; ++j) {  // all mixes first: T1's registers are free for T2 before the softmax work starts
+        f32x2 lo[2], hi[2];
+        TH_MIX_PK(c1, s2, j, lo, hi);
+        p2[2 * j][0] = lo[0]; p2[2 * j][1] = lo[1];
+        p2[2 * j + 1][0] = hi[0]; p2[2 * j + 1][1] = hi[1];
+      }
+      c2.issue(T2g);  // under the softmax of the eight heads
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
+        float sp[4] = {k_ok[0] ? p2[i][0].x : -INFINITY, k_ok[1] ? p2[i][0].y : -INFINITY, k_ok[2] ? p2[i][1].x : -INFINITY,
+                       k_ok[3] ? p2[i][1].y : -INFINITY};
+        const float m = wave_max(fmaxf(fmaxf(sp[0], sp[1]), fmaxf(sp[2], sp[3])));
+        float l = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          sp[k] = __builtin_amdgcn_exp2f((sp[k] - m) * LOG2E);
+          l += sp[k];
+        }
+        const float inv = 1.0f / wave_sum(l);
+        p2[i][0] = f32x2{sp[0] * inv, sp[1] * inv};
+        p2[i][1] = f32x2{sp[2] * inv, sp[3] * inv};
+      }
+      c2.wait();
+#pragma unroll
+      for (int j = 0; j < HP; ++j) {
+        f32x2 lo[2], hi[2];
+        TH_MIX_PK(c2, p2, j, lo, hi);
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const f32x2* a = w ? hi : lo;
+          const float o4[4] = {k_ok[0] ? a[0].x : 0.f, k_ok[1] ? a[0].y : 0.f, k_ok[2] ? a[1].x : 0.f, k_ok[3] ? a[1].y : 0.f};
+          if (in_row)
+            *reinterpret_cast<uint2*>(Pp + (((size_t)b * H + 2 * j + w) * N + q) * Np + 4 * lane) =
+                make_uint2(pack_bf16x2(o4[0], o4[1]), pack_bf16x2(o4[2], o4[3]));
+        }
+      }
+    }
+    return;
+  }
+  const float* __restrict__ T1 = T1g;
+  const float* __restrict__ T2 = T2g;
   for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
     const int b = (int)(row / N), q = (int)(row - (long)b * N);
     float s[H][TH_KPL], pr[H][TH_KPL];
@@ -1260,6 +1372,7 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
                                                               float* __restrict__ slab, int B, int N, int Np) {
   static_assert(H <= 8 || H == 16, "dT partials are reduce-scattered as 8x8 tiles: up to 8 heads, or 16 as four tiles per matrix");
   constexpr int NB = (H + 7) / 8;  // 8x8 tiles per dimension of dT (H = 16: cait_m_*; that path spills registers - correct, not fast)
+  constexpr bool PK = (H == 8 || H == 4);  // packed head mixes (the three T-mixes of a row: 3 x 128 v_pk_fma_f32 instead of 3 x 256 FMAs)
   __shared__ float red[4][2 * NB * NB * 64];
   const float* __restrict__ T1 = T1g;
   const float* __restrict__ T2 = T2g;
@@ -1273,6 +1386,8 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
     uint32_t sp[H][TH_KPL / 2], dq[H][TH_KPL / 2];
     // lane owns keys 4*lane .. 4*lane+3: one 8-byte load per head and tensor; pair k2 = keys (2*k2, 2*k2+1)
     const bool in_row = 4 * lane < Np;
+    [[maybe_unused]] ThCoef<PK ? H : 4> c;
+    if constexpr (PK) c.issue(T1g);  // under the latency of the row loads
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       const size_t off = (((size_t)b * H + h) * N + q) * Np + 4 * lane;
@@ -1286,19 +1401,44 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
     }
     // ---- forward recompute: P_i = softmax_k(sum_h T1[h][i] S_h)
     float pr[H][TH_KPL];
+    if constexpr (PK) {  // packed head mixes: key pairs, coefficient pairs from SGPRs (see th_softmax_fwd_kernel)
+      c.wait();
 #pragma unroll
-    for (int k = 0; k < TH_KPL; ++k) {
-      float sv[H];
+      for (int kp = 0; kp < 2; ++kp) {
+        f32x2 sv2[H];
 #pragma unroll
-      for (int h = 0; h < H; ++h) sv[h] = th_unpack(sp[h][k >> 1], k & 1);
+        for (int h = 0; h < H; ++h) sv2[h] = unpack_bf16x2(sp[h][kp]);
 #pragma unroll
-      for (int i = 0; i < H; ++i) {
-        float a = 0.f;
+        for (int j = 0; j < H / 2; ++j) {
+          f32x2 lo = {0.f, 0.f}, hi = {0.f, 0.f};
 #pragma unroll
-        for (int h = 0; h < H; ++h) a += T1[h * H + i] * sv[h];
-        pr[i][k] = (4 * lane + k < N) ? a : -INFINITY;
+          for (int h = 0; h < H; ++h) {
+            const uint64_t tp = TH_COEF(c, h, j);
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(lo) : "s"(tp), "v"(sv2[h]));
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(hi) : "s"(tp), "v"(sv2[h]));
+          }
+          pr[2 * j][2 * kp] = (4 * lane + 2 * kp < N) ? lo.x : -INFINITY;
+          pr[2 * j][2 * kp + 1] = (4 * lane + 2 * kp + 1 < N) ? lo.y : -INFINITY;
+          pr[2 * j + 1][2 * kp] = (4 * lane + 2 * kp < N) ? hi.x : -INFINITY;
+          pr[2 * j + 1][2 * kp + 1] = (4 * lane + 2 * kp + 1 < N) ? hi.y : -INFINITY;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < TH_KPL; ++k) {
+        float sv[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) sv[h] = th_unpack(sp[h][k >> 1], k & 1);
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+          float a = 0.f;
+#pragma unroll
+          for (int h = 0; h < H; ++h) a += T1[h * H + i] * sv[h];
+          pr[i][k] = (4 * lane + k < N) ? a : -INFINITY;
+        }
       }
     }
+    if constexpr (PK) c.issue(T2g);  // T1's registers are free: T2 arrives under the softmax
 #pragma unroll
     for (int i = 0; i < H; ++i) {
       float m = fmaxf(fmaxf(pr[i][0], pr[i][1]), fmaxf(pr[i][2], pr[i][3]));
@@ -1321,23 +1461,53 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
       for (int j = 0; j < 64; ++j) g[j] = 0.f;
 #pragma unroll
       for (int h = 0; h < H; ++h) del[h] = 0.f;
+      if constexpr (PK) {
+        c.wait();
 #pragma unroll
-      for (int k = 0; k < TH_KPL; ++k) {
-        float dv[H];
+        for (int kp = 0; kp < 2; ++kp) {
+          f32x2 dv2[H];
 #pragma unroll
-        for (int i = 0; i < H; ++i) dv[i] = th_unpack(dq[i][k >> 1], k & 1);
+          for (int i = 0; i < H; ++i) dv2[i] = unpack_bf16x2(dq[i][kp]);
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-          float a = 0.f;
+          for (int h = 0; h < H; ++h) {
+            f32x2 a = {0.f, 0.f};
 #pragma unroll
-          for (int i = 0; i < H; ++i) {
-            a += T2[h * H + i] * dv[i];
-            g[h * 8 + i] += pr[h][k] * dv[i];
+            for (int j = 0; j < H / 2; ++j) {  // a += T2[h][2j] dv[2j] + T2[h][2j+1] dv[2j+1]
+              const uint64_t tp = TH_COEF(c, h, j);
+              asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a) : "s"(tp), "v"(dv2[2 * j]));
+              asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a) : "s"(tp), "v"(dv2[2 * j + 1]));
+            }
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+              g[h * 8 + i] += pr[h][2 * kp] * dv2[i].x;
+              g[h * 8 + i] += pr[h][2 * kp + 1] * dv2[i].y;
+            }
+            dp[h][2 * kp] = a.x;
+            dp[h][2 * kp + 1] = a.y;
+            del[h] += pr[h][2 * kp] * a.x;
+            del[h] += pr[h][2 * kp + 1] * a.y;
           }
-          dp[h][k] = a;
-          del[h] += pr[h][k] * a;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < TH_KPL; ++k) {
+          float dv[H];
+#pragma unroll
+          for (int i = 0; i < H; ++i) dv[i] = th_unpack(dq[i][k >> 1], k & 1);
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+              a += T2[h * H + i] * dv[i];
+              g[h * 8 + i] += pr[h][k] * dv[i];
+            }
+            dp[h][k] = a;
+            del[h] += pr[h][k] * a;
+          }
         }
       }
+      if constexpr (PK) c.issue(T1g);  // for the third mix, under the reduce-scatter and the delta reductions
       acc2[0] += reduce_scatter64(g, lane);
     } else {
 #pragma unroll
@@ -1410,23 +1580,53 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
 #pragma unroll
       for (int j = 0; j < 64; ++j) g[j] = 0.f;
       float dsv[H][TH_KPL];
+      if constexpr (PK) {
+        c.wait();
 #pragma unroll
-      for (int k = 0; k < TH_KPL; ++k) {
-        float dsp[H], sv[H];
-#pragma unroll
-        for (int i = 0; i < H; ++i) {
-          dsp[i] = pr[i][k] * (dp[i][k] - del[i]);
-          sv[i] = th_unpack(sp[i][k >> 1], k & 1);
-        }
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-          float a = 0.f;
+        for (int kp = 0; kp < 2; ++kp) {
+          f32x2 dsp2[H], sv2[H];
 #pragma unroll
           for (int i = 0; i < H; ++i) {
-            a += T1[h * H + i] * dsp[i];
-            g[h * 8 + i] += sv[h] * dsp[i];
+            dsp2[i] = f32x2{pr[i][2 * kp] * (dp[i][2 * kp] - del[i]), pr[i][2 * kp + 1] * (dp[i][2 * kp + 1] - del[i])};
+            sv2[i] = unpack_bf16x2(sp[i][kp]);
           }
-          dsv[h][k] = (4 * lane + k < N) ? a : 0.f;
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            f32x2 a = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < H / 2; ++j) {
+              const uint64_t tp = TH_COEF(c, h, j);
+              asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a) : "s"(tp), "v"(dsp2[2 * j]));
+              asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a) : "s"(tp), "v"(dsp2[2 * j + 1]));
+            }
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+              g[h * 8 + i] += sv2[h].x * dsp2[i].x;
+              g[h * 8 + i] += sv2[h].y * dsp2[i].y;
+            }
+            dsv[h][2 * kp] = (4 * lane + 2 * kp < N) ? a.x : 0.f;
+            dsv[h][2 * kp + 1] = (4 * lane + 2 * kp + 1 < N) ? a.y : 0.f;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < TH_KPL; ++k) {
+          float dsp[H], sv[H];
+#pragma unroll
+          for (int i = 0; i < H; ++i) {
+            dsp[i] = pr[i][k] * (dp[i][k] - del[i]);
+            sv[i] = th_unpack(sp[i][k >> 1], k & 1);
+          }
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+              a += T1[h * H + i] * dsp[i];
+              g[h * 8 + i] += sv[h] * dsp[i];
+            }
+            dsv[h][k] = (4 * lane + k < N) ? a : 0.f;
+          }
         }
       }
       if (in_row) {

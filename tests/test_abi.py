@@ -149,3 +149,24 @@ def test_no_hand_timed_permlane_swaps(built, tmp_path):
         if f.endswith((".hip", ".h")):
             s = open(os.path.join(csrc, f)).read()
             assert not re.search(r'"[^"\n]*v_permlane(16|32)_swap', s), f"inline-asm permlane swap in {f}"
+
+
+def test_talking_heads_coefficient_loads_are_not_touched_in_flight(built, tmp_path):
+    """The packed head mixes of the talking-heads row kernels fetch a coefficient matrix with inline-asm s_load_dwordx16 and wait for
+    it later (ThCoef::issue / wait, csrc/attention.hip).  hipcc does not know the destination SGPRs are in flight in between: the
+    built object must not read or copy them before the wait (tools/check_inflight_sgprs.py)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("check_inflight_sgprs", os.path.join(ROOT, "tools", "check_inflight_sgprs.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    isa = _device_isa("attention.o", tmp_path)
+    kernels = re.split(r"\n(?=[0-9a-f]+ <)", isa)
+    seen = 0
+    for k in kernels:
+        head = k.split("\n", 1)[0]
+        if "th_softmax_fwd_kernel" in head or "th_softmax_bwd_kernel" in head:
+            n, bad = chk.violations(k)
+            seen += n
+            assert not bad, (head, bad[:3])
+    assert seen >= 4 * 2 + 4 * 3  # H = 8: 4 quads x (2 matrices forward, 3 backward); H = 4 adds one quad per matrix use

@@ -10,6 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import savit_amd  # noqa: E402,F401
 from savit_amd import lib  # noqa: E402
 
+if os.environ.get("SAVIT_EXP_LIB"):
+    lib.LIB_PATH = os.path.join(os.path.dirname(lib.LIB_PATH), "exp", "libsavit_%s.so" % os.environ["SAVIT_EXP_LIB"])
+
 L = lib.load()
 B, N, H, hd = [int(a) for a in sys.argv[1:5]] if len(sys.argv) > 4 else (256, 196, 8, 48)
 d = H * hd
