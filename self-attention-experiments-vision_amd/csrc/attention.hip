@@ -1299,20 +1299,46 @@ __global__ __launch_bounds__(256) void th_softmax_fwd_kernel(const bf16_t* __res
         p2[2 * j + 1][0] = hi[0]; p2[2 * j + 1][1] = hi[1];
       }
       c2.issue(T2g);  // under the softmax of the eight heads
+      if constexpr (H == 8) {  // the eight row maxima / row sums as ONE transposing reduction each (th_rows.h)
+        float lm[8], m[8], ls[8], l[8];
 #pragma unroll
-      for (int i = 0; i < H; ++i) {
-        float sp[4] = {k_ok[0] ? p2[i][0].x : -INFINITY, k_ok[1] ? p2[i][0].y : -INFINITY, k_ok[2] ? p2[i][1].x : -INFINITY,
-                       k_ok[3] ? p2[i][1].y : -INFINITY};
-        const float m = wave_max(fmaxf(fmaxf(sp[0], sp[1]), fmaxf(sp[2], sp[3])));
-        float l = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          sp[k] = __builtin_amdgcn_exp2f((sp[k] - m) * LOG2E);
-          l += sp[k];
+        for (int i = 0; i < 8; ++i) {
+          p2[i][0] = f32x2{k_ok[0] ? p2[i][0].x : -INFINITY, k_ok[1] ? p2[i][0].y : -INFINITY};
+          p2[i][1] = f32x2{k_ok[2] ? p2[i][1].x : -INFINITY, k_ok[3] ? p2[i][1].y : -INFINITY};
+          lm[i] = fmaxf(fmaxf(p2[i][0].x, p2[i][0].y), fmaxf(p2[i][1].x, p2[i][1].y));
         }
-        const float inv = 1.0f / wave_sum(l);
-        p2[i][0] = f32x2{sp[0] * inv, sp[1] * inv};
-        p2[i][1] = f32x2{sp[2] * inv, sp[3] * inv};
+        wave_reduce8<true>(lm, m, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float e0 = __builtin_amdgcn_exp2f((p2[i][0].x - m[i]) * LOG2E), e1 = __builtin_amdgcn_exp2f((p2[i][0].y - m[i]) * LOG2E);
+          const float e2 = __builtin_amdgcn_exp2f((p2[i][1].x - m[i]) * LOG2E), e3 = __builtin_amdgcn_exp2f((p2[i][1].y - m[i]) * LOG2E);
+          p2[i][0] = f32x2{e0, e1};
+          p2[i][1] = f32x2{e2, e3};
+          ls[i] = (e0 + e1) + (e2 + e3);
+        }
+        wave_reduce8<false>(ls, l, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float inv = 1.0f / l[i];
+          p2[i][0] = p2[i][0] * inv;
+          p2[i][1] = p2[i][1] * inv;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+          float sp[4] = {k_ok[0] ? p2[i][0].x : -INFINITY, k_ok[1] ? p2[i][0].y : -INFINITY, k_ok[2] ? p2[i][1].x : -INFINITY,
+                         k_ok[3] ? p2[i][1].y : -INFINITY};
+          const float m = wave_max(fmaxf(fmaxf(sp[0], sp[1]), fmaxf(sp[2], sp[3])));
+          float l = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            sp[k] = __builtin_amdgcn_exp2f((sp[k] - m) * LOG2E);
+            l += sp[k];
+          }
+          const float inv = 1.0f / wave_sum(l);
+          p2[i][0] = f32x2{sp[0] * inv, sp[1] * inv};
+          p2[i][1] = f32x2{sp[2] * inv, sp[3] * inv};
+        }
       }
       c2.wait();
 #pragma unroll
@@ -1439,19 +1465,39 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
       }
     }
     if constexpr (PK) c.issue(T2g);  // T1's registers are free: T2 arrives under the softmax
+    if constexpr (H == 8) {  // eight maxima / sums as one transposing reduction each (th_rows.h)
+      float lm[8], m[8], ls[8], l[8];
 #pragma unroll
-    for (int i = 0; i < H; ++i) {
-      float m = fmaxf(fmaxf(pr[i][0], pr[i][1]), fmaxf(pr[i][2], pr[i][3]));
-      m = wave_max(m);
-      float l = 0.f;
+      for (int i = 0; i < 8; ++i) lm[i] = fmaxf(fmaxf(pr[i][0], pr[i][1]), fmaxf(pr[i][2], pr[i][3]));
+      wave_reduce8<true>(lm, m, lane);
 #pragma unroll
-      for (int k = 0; k < TH_KPL; ++k) {
-        pr[i][k] = __builtin_amdgcn_exp2f((pr[i][k] - m) * LOG2E);
-        l += pr[i][k];
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int k = 0; k < TH_KPL; ++k) pr[i][k] = __builtin_amdgcn_exp2f((pr[i][k] - m[i]) * LOG2E);
+        ls[i] = (pr[i][0] + pr[i][1]) + (pr[i][2] + pr[i][3]);
       }
-      const float inv = 1.0f / wave_sum(l);
+      wave_reduce8<false>(ls, l, lane);
 #pragma unroll
-      for (int k = 0; k < TH_KPL; ++k) pr[i][k] *= inv;
+      for (int i = 0; i < 8; ++i) {
+        const float inv = 1.0f / l[i];
+#pragma unroll
+        for (int k = 0; k < TH_KPL; ++k) pr[i][k] *= inv;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
+        float m = fmaxf(fmaxf(pr[i][0], pr[i][1]), fmaxf(pr[i][2], pr[i][3]));
+        m = wave_max(m);
+        float l = 0.f;
+#pragma unroll
+        for (int k = 0; k < TH_KPL; ++k) {
+          pr[i][k] = __builtin_amdgcn_exp2f((pr[i][k] - m) * LOG2E);
+          l += pr[i][k];
+        }
+        const float inv = 1.0f / wave_sum(l);
+#pragma unroll
+        for (int k = 0; k < TH_KPL; ++k) pr[i][k] *= inv;
+      }
     }
     // ---- dT2[h][i] += sum_k P_h dP'_i ; dP_h = sum_i T2[h][i] dP'_i ; delta_h = sum_k P_h dP_h
     float dp[H][TH_KPL], del[H];
@@ -1541,8 +1587,15 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
           acc2[hb * NB + ib] += reduce_scatter64(g, lane);
         }
     }
+    if constexpr (H == 8) {
+      float dl[8];
 #pragma unroll
-    for (int h = 0; h < H; ++h) del[h] = wave_sum(del[h]);
+      for (int h = 0; h < 8; ++h) dl[h] = del[h];
+      wave_reduce8<false>(dl, del, lane);
+    } else {
+#pragma unroll
+      for (int h = 0; h < H; ++h) del[h] = wave_sum(del[h]);
+    }
     // ---- dS'_i = P_i (dP_i - delta_i) ; dS_h = sum_i T1[h][i] dS'_i ; dT1[h][i] += sum_k S_h dS'_i
     if constexpr (H > 8) {
 #pragma unroll
