@@ -1399,6 +1399,7 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
   static_assert(H <= 8 || H == 16, "dT partials are reduce-scattered as 8x8 tiles: up to 8 heads, or 16 as four tiles per matrix");
   constexpr int NB = (H + 7) / 8;  // 8x8 tiles per dimension of dT (H = 16: cait_m_*; that path spills registers - correct, not fast)
   constexpr bool PK = (H == 8 || H == 4);  // packed head mixes (the three T-mixes of a row: 3 x 128 v_pk_fma_f32 instead of 3 x 256 FMAs)
+  constexpr bool PKO = PK;  // the two 8 x 8 outer products (dT2, dT1 partials) packed over key pairs as well, four heads at a time
   __shared__ float red[4][2 * NB * NB * 64];
   const float* __restrict__ T1 = T1g;
   const float* __restrict__ T2 = T2g;
@@ -1523,15 +1524,39 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
               asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a) : "s"(tp), "v"(dv2[2 * j]));
               asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a) : "s"(tp), "v"(dv2[2 * j + 1]));
             }
+            if constexpr (!PKO) {
 #pragma unroll
-            for (int i = 0; i < H; ++i) {
-              g[h * 8 + i] += pr[h][2 * kp] * dv2[i].x;
-              g[h * 8 + i] += pr[h][2 * kp + 1] * dv2[i].y;
+              for (int i = 0; i < H; ++i) {
+                g[h * 8 + i] += pr[h][2 * kp] * dv2[i].x;
+                g[h * 8 + i] += pr[h][2 * kp + 1] * dv2[i].y;
+              }
             }
             dp[h][2 * kp] = a.x;
             dp[h][2 * kp + 1] = a.y;
             del[h] += pr[h][2 * kp] * a.x;
             del[h] += pr[h][2 * kp + 1] * a.y;
+          }
+        }
+        if constexpr (PKO) {  // dT2 partials g[h][i] = sum over this lane's keys of P_h dP'_i: key pairs packed, four heads at a time
+#pragma unroll
+          for (int hh = 0; hh < H; hh += 4) {
+            f32x2 g2[4][H];
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+#pragma unroll
+              for (int i = 0; i < H; ++i) {
+                const f32x2 dvi = unpack_bf16x2(dq[i][kp]);
+#pragma unroll
+                for (int h4 = 0; h4 < 4; ++h4) {
+                  const f32x2 ph = f32x2{pr[hh + h4][2 * kp], pr[hh + h4][2 * kp + 1]};
+                  g2[h4][i] = kp == 0 ? ph * dvi : g2[h4][i] + ph * dvi;
+                }
+              }
+            }
+#pragma unroll
+            for (int h4 = 0; h4 < 4; ++h4)
+#pragma unroll
+              for (int i = 0; i < H; ++i) g[(hh + h4) * 8 + i] = g2[h4][i].x + g2[h4][i].y;
           }
         }
       } else {
@@ -1652,13 +1677,37 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
               asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a) : "s"(tp), "v"(dsp2[2 * j]));
               asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a) : "s"(tp), "v"(dsp2[2 * j + 1]));
             }
+            if constexpr (!PKO) {
 #pragma unroll
-            for (int i = 0; i < H; ++i) {
-              g[h * 8 + i] += sv2[h].x * dsp2[i].x;
-              g[h * 8 + i] += sv2[h].y * dsp2[i].y;
+              for (int i = 0; i < H; ++i) {
+                g[h * 8 + i] += sv2[h].x * dsp2[i].x;
+                g[h * 8 + i] += sv2[h].y * dsp2[i].y;
+              }
             }
             dsv[h][2 * kp] = (4 * lane + 2 * kp < N) ? a.x : 0.f;
             dsv[h][2 * kp + 1] = (4 * lane + 2 * kp + 1 < N) ? a.y : 0.f;
+          }
+        }
+        if constexpr (PKO) {  // dT1 partials g[h][i] = sum over this lane's keys of S_h dS'_i, packed as above
+#pragma unroll
+          for (int hh = 0; hh < H; hh += 4) {
+            f32x2 g2[4][H];
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+#pragma unroll
+              for (int i = 0; i < H; ++i) {
+                const f32x2 dsi = f32x2{pr[i][2 * kp] * (dp[i][2 * kp] - del[i]), pr[i][2 * kp + 1] * (dp[i][2 * kp + 1] - del[i])};
+#pragma unroll
+                for (int h4 = 0; h4 < 4; ++h4) {
+                  const f32x2 sh = unpack_bf16x2(sp[hh + h4][kp]);
+                  g2[h4][i] = kp == 0 ? sh * dsi : g2[h4][i] + sh * dsi;
+                }
+              }
+            }
+#pragma unroll
+            for (int h4 = 0; h4 < 4; ++h4)
+#pragma unroll
+              for (int i = 0; i < H; ++i) g[(hh + h4) * 8 + i] = g2[h4][i].x + g2[h4][i].y;
           }
         }
       } else {
