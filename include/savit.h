@@ -325,6 +325,8 @@ int savit_attention_fwd_f32(const float* qkv, float* o, int B, int N, int H, int
  *   A is [M, K] (transA: stored [K, M]), W is [K, N] (transW: stored [N, K]).  Serves Dense forward (attention.py:29-37,60-63,
  *   ff.py:26-31), its input-gradient (transW) and weight-gradient (transA, accumulate) products, Q K^T / P V and their VJPs per
  *   (image, head), LayerScale (layerscale.py:23) and stochastic depth (stochastic_depth.py:16-27) as colscale / rowscale.
+ *   A plain accumulating product (accumulate with no other epilogue term: the weight gradients) with a long K and few output tiles
+ *   is split over K ranges that add their partials with fp32 atomics: such results differ from run to run by summation order (1e-7).
  * savit_softmax_rows_f32 / _bwd_f32: nn.softmax over the last axis (attention.py:48) and dS = P (dP - sum_k dP P).
  * savit_head_mix_f32: TalkingHeadsBlock (talking_heads.py:13) y[b,i,e] = sum_h T[h,i] x[b,h,e], e over the N x N score positions.
  * savit_layernorm_bwd_f32: VJP of nn.LayerNorm(dtype=float32); dx (+ add, the residual cotangent), dgamma / dbeta accumulated.
