@@ -9,16 +9,22 @@ One "step" = one pass of the hot path over one synthetic batch already resident 
   (RCCL, bucketed, overlapped with backward; N > 1) + fused AdamW + bf16 operand refresh.
 Per-GPU batch is fixed at 128 images (BASELINE config 3: 1024 on 8 GPUs), i.e. weak scaling; `value` is the
 whole-job images/s.  Rank 0 prints ONE JSON line.  Extra objects on that line:
-  roofline      dominant kernel class (the MFMA GEMMs), achieved = algorithmic FLOPs per launch / mean launch duration,
-                measured live with HIP events on the launch stream (one instrumented step after the timed region);
-                peak = dense bf16 MFMA peak of MI355X.  `traffic` is null here (PMC passes are separate rocprofv3 runs;
-                see profiles/ and DESIGN.md).
+  roofline      the dominant GEMM kernel (by total time per step; picked from an instrumented forward+backward after warm-up):
+                achieved = algorithmic FLOPs per launch / mean launch duration, measured live INSIDE the timed region with HIP
+                timing events (hipEventDisableSystemFence) around every launch of that kernel on its launch stream;
+                peak = dense bf16 MFMA peak of MI355X.  `traffic` comes from the committed PMC passes (separate rocprofv3 runs;
+                profiles/ and DESIGN.md).
+  kernel_breakdown_ms / roofline_valid   three instrumented whole steps after the timed region (every launch bracketed, each step
+                enqueued behind a gate kernel so that no event pair contains host time, per-label minimum), and the checks
+                that the accounting adds up: launches x avg of the dominant kernel <= ms_per_step, sum of all launches <= 1.05 x
+                ms_per_step, live and instrumented averages of the dominant kernel within 10 %.  A failed check sets
+                "roofline_valid": false and dumps the per-label table to stderr.
   step_roofline whole-step figure of SURVEY.md 8d: images/s/GPU x 105.152 GFLOP per image / peak.
   cpu_baseline  the CPU restatement (oracle/torch_ref.py, JAX absent: SURVEY 8c) of BASELINE config 1 (ViT-Ti/16, batch 8,
                 fp32: forward+loss+backward = `value`, forward+loss alone = `forward_loss_value`) on this host's cores, bounded
                 sample, rank 0 at N=1 only; `headline_model_value` is the same restatement of the headline model.
-  other_configs (N=1, headline workload only) a short timing (>= 5 steps after 2 warm-up steps) of BASELINE configs 2, 4 and 5 on
-                the same GPU, each with images_per_gpu, ms_per_step and step_roofline.frac.
+  other_configs (N=1, headline workload only) a short timing (10 steps after 3 warm-up steps) of BASELINE configs 2, 4 and 5 on
+                the same GPU, each with images_per_gpu, ms_per_step, step_roofline.frac and its own dominant-kernel roofline.
 
 `python bench.py --gpus N` with N > 1 and no launcher around it starts the N ranks itself: the parent makes no GPU call (it does
 not even import torch), runs `python -m torch.distributed.run --nproc-per-node N ... bench.py <same flags>` as a child process and
@@ -72,6 +78,11 @@ def kernel_symbol(label: str, lib, M: int, d: int, F: int) -> str:
 
 
 def kernel_class(label: str) -> str:
+    label = label.split("#")[0]
+    if label.startswith("zero."):
+        return "memset"
+    if label in ("sumsq", "adamw") or label.startswith("cast "):
+        return "optimizer"
     if label.startswith("wgrad.group"):
         return "gemm_wgrad"
     if label.endswith(".wgrad.reduce"):
@@ -212,8 +223,169 @@ def init_bench_params(eng, cfg):
     eng.layout.view(eng.params, "Wh").copy_(torch.randn(cfg.embed_dim, cfg.num_classes, generator=g) * cfg.embed_dim ** -0.5)
 
 
-def time_other_config(model, B, img_size, steps=5, warmup=2):
-    """Short single-GPU timing of another BASELINE config (same step definition as the headline)."""
+def symbol_tables(times, cfg, eng, B):
+    """{launch label: ms} -> per kernel symbol (what rocprofv3 --kernel-trace --stats lists): total ms, launches, algorithmic flops,
+    the labels behind it; and the same per kernel class."""
+    d, F, M = cfg.embed_dim, cfg.hidden, eng.M
+    gemm_flops = {"qkv": 2.0 * M * d * 3 * d, "proj": 2.0 * M * d * d, "fc1": 2.0 * M * d * F, "fc2": 2.0 * M * d * F,
+                  "tok": 2.0 * B * d * cfg.n_patches * cfg.tokens_hidden}  # MLP-Mixer token-mixing GEMMs (unpadded, algorithmic)
+    names = {"Wqkv": "qkv", "Wo": "proj", "W1": "fc1", "W2": "fc2", "tW1": "tok", "tW2": "tok"}
+    sym, cls = {}, {}
+    for key, t_ms in times.items():
+        label = key.split("#")[0]
+        c = kernel_class(label)
+        parts = label.split(".")
+        fl = 0.0
+        if c in ("gemm_tn", "gemm_wgrad") and len(parts) >= 2 and parts[0].startswith("l") and parts[0][1:].isdigit():
+            fl = gemm_flops.get(names.get(parts[1], parts[1]), 0.0)
+        elif label.startswith("wgrad.group"):
+            fl = getattr(eng, "group_flops", {}).get(label, 0.0)
+        elif label in ("patch_embed", "Wpe.wgrad"):
+            fl = 2.0 * B * cfg.n_patches * cfg.patch_dim * d
+        elif label.startswith("head"):
+            fl = 2.0 * B * d * cfg.num_classes
+        sname = kernel_symbol(label, eng.L, M, d, F) if cfg.kind == "vit" else c
+        for table, k in ((sym, sname), (cls, c)):
+            e = table.setdefault(k, {"ms": 0.0, "n": 0, "flops": 0.0, "labels": []})
+            e["ms"] += t_ms
+            e["n"] += 1
+            e["flops"] += fl
+            e["labels"].append(label)
+    return sym, cls
+
+
+def pick_dominant(sym):
+    """The GEMM kernel symbol with the largest total time; totals within 5 % of the largest (run-to-run noise: the grouped
+    weight-gradient kernel and the plain-epilogue 320x256 kernel are both ~20 % of the DeiT-B step) are broken towards the kernel with
+    more flops per launch, so that the reported kernel does not flip between runs."""
+    gemm = [k for k in sym if k.startswith("gemm") and sym[k]["flops"] > 0]
+    top = max(sym[k]["ms"] for k in gemm)
+    return max((k for k in gemm if sym[k]["ms"] >= 0.95 * top), key=lambda k: sym[k]["flops"] / sym[k]["n"])
+
+
+def measure(eng, cfg, B, world, rank, sync, steps, warmup, dist=None, breakdown=True):
+    """warm-up, [instrumented forward+backward: which kernel dominates], the TIMED region with that kernel's launches bracketed by
+    timing events on the launch stream, [instrumented whole steps: per-class breakdown + consistency checks].
+    -> (elapsed seconds of the timed region (max over ranks), step fn, dict for the JSON line)"""
+    import torch
+
+    from savit_amd.timing import LaunchTimer, instrumented_steps
+
+    step, batches = make_step(eng, cfg, B, world, rank, sync)
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+
+    # ---- which GEMM kernel dominates this step?  (every rank, no collective, no parameter update: forward + loss + backward only)
+    saved_hooks, eng.bwd_hooks = eng.bwd_hooks, {}
+    lab0 = batches[0][1]
+
+    def fwd_bwd():
+        if cfg.kind == "cait":
+            eng.forward(is_training=True)
+        else:
+            eng.forward()
+        eng.loss_backward(lab0, label_smoothing=0.1)
+
+    pre = instrumented_steps(eng, fwd_bwd, reps=2)
+    eng.bwd_hooks = saved_hooks
+    sym0, _ = symbol_tables(pre["labels"], cfg, eng, B)
+    dom = pick_dominant(sym0)
+    dom_labels = sorted(set(sym0[dom]["labels"]))
+    live = LaunchTimer(steps * len(dom_labels) + 8, only=dom_labels)
+
+    # ---- the timed region
+    del step.exposed[:]
+    eng.launch_timer = live
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    eng.launch_timer = None
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_step = elapsed / steps * 1e3
+    info = {}
+    if rank != 0:
+        live.close()
+        return elapsed, step, info
+
+    # ---- roofline of the dominant kernel: algorithmic flops per launch / mean launch duration over the timed region
+    lt = live.results()
+    live.close()
+    n_l = len(lt)
+    tot_ms = sum(ms for _, ms in lt)
+    per_label_fl = {}
+    for lbl in dom_labels:
+        per_label_fl[lbl] = symbol_tables({lbl: 0.0}, cfg, eng, B)[0][dom]["flops"]
+    fl_tot = sum(per_label_fl[lbl] for lbl, _ in lt)
+    avg_ms = tot_ms / max(1, n_l)
+    ach = fl_tot / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    launches_per_step = n_l / steps
+    roof = {"bound": "mfma", "kernel": dom, "launches_per_step": round(launches_per_step, 2), "launches_timed": n_l,
+            "avg_launch_ms": round(avg_ms, 4), "min_launch_ms": round(min(ms for _, ms in lt), 4), "max_launch_ms": round(max(ms for _, ms in lt), 4),
+            "share_of_step": round(launches_per_step * avg_ms / ms_step, 3), "flops_per_launch": fl_tot / max(1, n_l),
+            "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+            "traffic": None,
+            "how": "HIP timing events (hipEventDisableSystemFence) around every launch of this kernel on its launch stream, over all timed steps"}
+    checks = {"dominant_fits_in_step": launches_per_step * avg_ms <= ms_step, "no_events_dropped": live.dropped == 0}
+    info["roofline"] = roof
+
+    # ---- per-class breakdown: whole steps (incl. optimizer + operand refresh), every launch bracketed, behind a gate kernel
+    if breakdown:
+        saved_hooks, eng.bwd_hooks = eng.bwd_hooks, {}
+        lr, wd = 5e-4 * (B * world) / 512.0, 1e-4
+
+        def whole():
+            fwd_bwd()
+            eng.optimizer_step(lr=lr, weight_decay=wd, max_norm=1.0)
+
+        post = instrumented_steps(eng, whole, reps=3)
+        eng.bwd_hooks = saved_hooks
+        sym1, cls1 = symbol_tables(post["labels"], cfg, eng, B)
+        total = sum(v["ms"] for v in cls1.values())
+        serial = not getattr(eng, "overlap_wgrad", False)  # engines with side streams run their serial plan when instrumented
+        best_span = min(r["span_ms"] for r in post["reps"])
+        checks["sum_le_1p05_step"] = (total <= 1.05 * ms_step) if serial else (total <= 1.05 * best_span)
+        checks["gate_reached"] = all(r["gate_reached"] for r in post["reps"])
+        if dom in sym1:
+            inst_avg = sym1[dom]["ms"] / sym1[dom]["n"]
+            roof["instrumented_avg_launch_ms"] = round(inst_avg, 4)
+            checks["live_vs_instrumented_within_10pct"] = abs(inst_avg - avg_ms) <= 0.10 * avg_ms
+        kb = {c: round(v["ms"], 3) for c, v in sorted(cls1.items(), key=lambda kv: -kv[1]["ms"])}
+        opt_ms = cls1.get("optimizer", {"ms": 0.0})["ms"] + sum(ms for k, ms in post["labels"].items() if k.split("#")[0] == "zero.gnorm")
+        kb["sum_fwd_bwd"] = round(total - opt_ms, 3)
+        kb["sum_step"] = round(total, 3)
+        info["kernel_breakdown_ms"] = kb
+        info["kernel_breakdown_how"] = (f"{len(post['reps'])} instrumented steps, every launch bracketed, each step enqueued behind a "
+                                        f"{post['gate_us']} us gate kernel, per-label minimum; span of one instrumented step {best_span:.3f} ms")
+        info["gemm_class_tflops"] = {c: round(cls1[c]["flops"] / (cls1[c]["ms"] * 1e-3) / 1e12, 2) for c in ("gemm_tn", "gemm_wgrad") if c in cls1 and cls1[c]["ms"] > 0}
+        info["top_kernels_ms"] = {k: {"total_ms": round(v["ms"], 3), "launches": v["n"], "avg_us": round(v["ms"] / v["n"] * 1e3, 1)}
+                                  for k, v in sorted(sym1.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+        info["_post_labels"] = post["labels"]
+    info["roofline_valid"] = all(bool(v) for v in checks.values())
+    info["roofline_checks"] = checks
+    if not info["roofline_valid"]:
+        print("bench.py: the per-kernel accounting failed its consistency checks:", checks, file=sys.stderr)
+        for k, ms in info.get("_post_labels", {}).items():
+            print(f"  {k:28s} {ms * 1e3:9.1f} us", file=sys.stderr)
+        for lbl, ms in lt[:200]:
+            print(f"  live {lbl:24s} {ms * 1e3:9.1f} us", file=sys.stderr)
+    info.pop("_post_labels", None)
+    return elapsed, step, info
+
+
+def time_other_config(model, B, img_size, steps=10, warmup=3):
+    """Short single-GPU timing of another BASELINE config (same step definition and the same per-kernel roofline as the headline)."""
     import torch
 
     from savit_amd.config import get_config, train_flops_per_image
@@ -222,27 +394,20 @@ def time_other_config(model, B, img_size, steps=5, warmup=2):
     eng = build_engine(cfg, B)
     init_bench_params(eng, cfg)
     eng.refresh_weights()
-    step, _ = make_step(eng, cfg, B, 1, 0, None)
-    for i in range(warmup):
-        step(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(i)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    el, step, info = measure(eng, cfg, B, 1, 0, None, steps, warmup, breakdown=False)
     ips, fpi = B * steps / el, train_flops_per_image(cfg)
     res = {"model": model, "img_size": img_size, "images_per_gpu": B, "steps": steps, "warmup": warmup, "value": round(ips, 1),
            "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 3),
            "step_roofline": {"bound": "mfma", "achieved": round(ips * fpi / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(ips * fpi / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "flops_per_image": fpi},
-           "final_loss": round(float(eng.loss.item()), 4)}
+           "roofline": {k: info["roofline"][k] for k in ("kernel", "launches_per_step", "avg_launch_ms", "achieved", "frac")},
+           "roofline_valid": info["roofline_valid"], "final_loss": round(float(eng.loss.item()), 4)}
     del step, eng
     torch.cuda.empty_cache()
     return res
 
 
-def time_config1_fp32(steps=20, warmup=3):
+def time_config1_fp32(steps=100, warmup=10):
     """BASELINE config 1 on the GPU: ViT-Ti/16, batch 8, fp32 arithmetic, forward + loss (what simple_train.py's plumbing run computes
     before its backward; the CPU restatement of the same thing is cpu_baseline.forward_loss_value)."""
     import torch
@@ -344,27 +509,8 @@ def main():
         sync = ddp.GradSync(eng.grads, buckets)
         eng.bwd_hooks = sync.hooks()
     eng.refresh_weights()
-    step, batches = make_step(eng, cfg, B, world, rank, sync)
     S = cfg.img_size
-
-    for i in range(args.warmup):
-        step(i)
-    del step.exposed[:]
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, step, info = measure(eng, cfg, B, world, rank, sync, args.steps, args.warmup, dist)
     loss = float(eng.loss.item())
     dist_info = None
     if dist is not None:
@@ -377,7 +523,7 @@ def main():
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ids,
                      "distinct_devices": len({(d.get("pci_bus_id"), d.get("uuid"), d.get("device")) for d in ids}),
                      "gradient_bytes_per_step": int(eng.grads.numel() * 4), "buckets": len(sync.buckets),
-                     "allreduce_exposed_ms": round(float(ex.item()), 4)}
+                     "allreduce_exposed_ms": round(float(ex.item()), 4), "reserved_cus": int(getattr(eng, "reserved_cus", 0))}
 
     out = None
     if rank == 0:
@@ -398,62 +544,16 @@ def main():
             "step_roofline": {"bound": "mfma", "achieved": round(per_gpu * fpi / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(per_gpu * fpi / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "flops_per_image": fpi},
         }
-
-    # ---- per-kernel accounting: one instrumented step (HIP events around every launch, on the launch stream)
-    if rank == 0:
-        saved_hooks, eng.bwd_hooks = eng.bwd_hooks, {}
-        times = eng.profile_step(batches[0][1])
-        eng.bwd_hooks = saved_hooks
+        out.update(info)
+        dom = out["roofline"]["kernel"]
         d, F, M = cfg.embed_dim, cfg.hidden, eng.M
-        gemm_flops = {"qkv": 2.0 * M * d * 3 * d, "proj": 2.0 * M * d * d, "fc1": 2.0 * M * d * F, "fc2": 2.0 * M * d * F,
-                      "tok": 2.0 * B * d * cfg.n_patches * cfg.tokens_hidden}  # MLP-Mixer token-mixing GEMMs (unpadded, algorithmic)
-        cls_ms, cls_n, cls_fl = {}, {}, {}
-        for label, t_ms in times.items():
-            c = kernel_class(label)
-            cls_ms[c] = cls_ms.get(c, 0.0) + t_ms
-            cls_n[c] = cls_n.get(c, 0) + 1
-            fl = 0.0
-            parts = label.split(".")
-            if c in ("gemm_tn", "gemm_wgrad") and len(parts) >= 2 and parts[0].startswith("l"):
-                key = {"Wqkv": "qkv", "Wo": "proj", "W1": "fc1", "W2": "fc2", "tW1": "tok", "tW2": "tok"}.get(parts[1], parts[1])
-                fl = gemm_flops.get(key, 0.0)
-            elif label.startswith("wgrad.group"):
-                fl = getattr(eng, "group_flops", {}).get(label, 0.0)
-            elif label in ("patch_embed", "Wpe.wgrad"):
-                fl = 2.0 * B * cfg.n_patches * cfg.patch_dim * d
-            elif label.startswith("head"):
-                fl = 2.0 * B * d * cfg.num_classes
-            cls_fl[c] = cls_fl.get(c, 0.0) + fl
-        total_ms = sum(cls_ms.values())
-        # dominant KERNEL SYMBOL (what rocprofv3 --kernel-trace --stats lists): total time, launches, algorithmic flops
-        sym_ms, sym_n, sym_fl = {}, {}, {}
-        for label, t_ms in times.items():
-            sym = kernel_symbol(label, eng.L, M, d, F) if cfg.kind == "vit" else kernel_class(label)
-            parts = label.split(".")
-            key = {"Wqkv": "qkv", "Wo": "proj", "W1": "fc1", "W2": "fc2", "tW1": "tok", "tW2": "tok"}.get(parts[1], parts[1]) if len(parts) >= 2 else ""
-            fl = gemm_flops.get(key, 0.0) if sym.startswith("gemm") and parts[0].startswith("l") else 0.0
-            if label.startswith("wgrad.group"):
-                fl = getattr(eng, "group_flops", {}).get(label, 0.0)
-            sym_ms[sym] = sym_ms.get(sym, 0.0) + t_ms
-            sym_n[sym] = sym_n.get(sym, 0) + 1
-            sym_fl[sym] = sym_fl.get(sym, 0.0) + fl
-        # dominant = the GEMM kernel symbol with the largest total time; totals within 5 % of the largest (run-to-run noise: the grouped
-        # weight-gradient kernel and the plain-epilogue 320x256 kernel are both ~20 % of this step) are broken towards the kernel with
-        # more flops per launch, so that the reported kernel does not flip between runs
-        gemm_syms = [k for k in sym_ms if k.startswith("gemm")]
-        top = max(sym_ms[k] for k in gemm_syms)
-        dom = max((k for k in gemm_syms if sym_ms[k] >= 0.95 * top), key=lambda k: sym_fl[k] / sym_n[k])
-        ach = sym_fl[dom] / (sym_ms[dom] * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "launches_per_step": sym_n[dom],
-                           "avg_launch_ms": round(sym_ms[dom] / sym_n[dom], 4), "share_of_step": round(sym_ms[dom] / total_ms, 3),
-                           "flops_per_launch": sym_fl[dom] / sym_n[dom], "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
         # HBM-side traffic of that kernel: PMC passes cannot run inside this process, so the figure is the committed
         # rocprofv3 --pmc measurement of the same workload (tools/pmc_summary.py -> profiles/*_pmc_traffic.json), when it
         # covers this kernel and this is the headline workload; null otherwise.
         try:
             if args.model == "vit_b_patch16" and B == 128:
-                src = next(f for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                src = next(f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+                           if os.path.exists(os.path.join(ROOT, "profiles", f)))
                 pm = json.load(open(os.path.join(ROOT, "profiles", src)))["kernels"].get(dom)
                 if pm:
                     out["roofline"]["traffic"] = pm["traffic_bytes"]
@@ -463,21 +563,14 @@ def main():
                         # (every weight gradient of the model, spread over the grouped launches: each takes one tile per CU)
                         n_div = len(getattr(eng, "wgrad_divert", ()))
                         per_layer = sum(2 * M * (a + b_) + 8 * a * b_ for a, b_ in ((d, 3 * d), (d, d), (d, F), (F, d)))
-                        out["roofline"]["algorithmic_bytes_per_launch"] = int((cfg.num_layers * per_layer - n_div * (4 * M * d + 8 * d * d)) / sym_n[dom])
-                    elif dom.startswith("gemm_wgrad_ring_kernel<256"):
-                        # operands read once + the split partials written once (slab form; the reduce kernel is its own row of the profile)
-                        sp = max(1, eng.L.savit_gemm_wgrad_workspace_bytes(M, d, F, 0, 0) // (d * F * 4))
-                        out["roofline"]["algorithmic_bytes_per_launch"] = int(sum(2 * M * (a + b_) + 4 * a * b_ * sp for a, b_ in ((d, 3 * d), (d, F), (F, d))) / 3)
-        except (OSError, ValueError, KeyError, StopIteration):
+                        out["roofline"]["algorithmic_bytes_per_launch"] = int((cfg.num_layers * per_layer - n_div * (4 * M * d + 8 * d * d)) / out["roofline"]["launches_per_step"])
+        except (OSError, ValueError, KeyError, StopIteration, ZeroDivisionError):
             pass
-        out["kernel_breakdown_ms"] = {c: round(v, 3) for c, v in sorted(cls_ms.items(), key=lambda kv: -kv[1])}
-        out["kernel_breakdown_ms"]["sum_fwd_bwd"] = round(total_ms, 3)
-        out["gemm_class_tflops"] = {c: round(cls_fl[c] / (cls_ms[c] * 1e-3) / 1e12, 2) for c in ("gemm_tn", "gemm_wgrad") if cls_ms.get(c)}
 
     # ---- other BASELINE configs on this GPU (rank 0, N=1, headline workload only): short timings, after the headline engine is freed
     headline = args.model == "vit_b_patch16" and B == 128 and args.img_size == 224
     if rank == 0 and world == 1 and headline and not args.no_other_configs:
-        del step, batches, eng
+        del step, eng
         torch.cuda.empty_cache()
         out["other_configs"] = {}
         for model, ob, osz, name in OTHER_CONFIGS:

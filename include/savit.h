@@ -354,6 +354,23 @@ int savit_softmax_xent_grad_f32(const float* logits, const int* labels, float la
 int savit_patchify_f32(const float* images, float* patches, int B, int img_size, int patch, void* stream);
 int savit_assemble_tokens_f32(const float* tok, const float* cls, const float* pos, float* x0, int B, int N, int d, void* stream);
 
+/* ---- measurement (bench.py, timing.py).  Not part of the training path: brackets for it.
+ * savit_timer_*: a pool of HIP timing events created with hipEventDisableSystemFence - a default-flag event performs a system-scope
+ *   release (cache writeback + invalidate) when recorded, which perturbs the launch being timed (round 3's bench line).  record() is
+ *   asynchronous on `stream`; elapsed_ms() needs both events completed (synchronise the stream first).
+ * savit_spin: one wave that waits `microseconds` on the 100 MHz constant clock (<= 200 000): the gate in front of an instrumented
+ *   step, so the host enqueues the whole step behind it and no event pair contains host time.
+ * savit_hold_cus: `cus` one-wave workgroups holding 96 KB of LDS each for `microseconds` - stands in for the CUs a resident RCCL
+ *   all-reduce occupies during backward (row a16 / e: tools/cu_thief_probe.py).
+ * savit_zero_bytes: hipMemsetAsync(dst, 0, bytes) as a plan entry (gradient / loss accumulators). */
+int savit_timer_create(int n_events, void** handle);
+int savit_timer_record(void* handle, int idx, void* stream);
+int savit_timer_elapsed_ms(void* handle, int first, int second, float* ms);
+int savit_timer_destroy(void* handle);
+int savit_spin(long microseconds, void* stream);
+int savit_hold_cus(int cus, long microseconds, void* stream);
+int savit_zero_bytes(void* dst, long bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

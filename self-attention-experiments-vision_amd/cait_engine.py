@@ -28,6 +28,7 @@ import torch
 from . import lib as _lib
 from .config import ModelConfig
 from .engine import WgradQueue, _Plan, _align, _copy_tree, add_wgrad, add_wgrad_group, finalize_wgrad_ws
+from .timing import timed_call
 
 bf16 = torch.bfloat16
 f32 = torch.float32
@@ -223,6 +224,7 @@ class CaiTEngine:
         self._img_buf = e(B, cfg.img_size, cfg.img_size, 3, dt=bf16)
         self._fwd_plan = self._bwd_plan = self._cast_plan = None
         self.bwd_hooks: Dict[str, object] = {}
+        self.launch_timer = None  # timing.LaunchTimer (bench.py, profile_step)
         self.weights_stale = True
         self.overlap_wgrad = _os.environ.get("SAVIT_OVERLAP_WGRAD", "1") != "0"
         self.n_side_streams = int(_os.environ.get("SAVIT_SIDE_STREAMS", "1"))
@@ -532,7 +534,7 @@ class CaiTEngine:
     def refresh_weights(self):
         if self._cast_plan is None:
             self._cast_plan = self._build_cast_plan()
-        self._cast_plan.run(self._stream())
+        self._cast_plan.run(self._stream(), self.launch_timer)
         self.weights_stale = False
 
     def set_images(self, images: torch.Tensor):
@@ -575,42 +577,37 @@ class CaiTEngine:
             self.refresh_weights()
         if self._fwd_plan is None:
             self._fwd_plan = self._build_fwd_plan()
-        self._fwd_plan.run(self._stream())
+        self._fwd_plan.run(self._stream(), self.launch_timer)
         return self.logits
 
     def loss_backward(self, labels, label_smoothing: float = 0.1, mix_labels=None, ratio=None, zero_grads: bool = True):
         s = self._stream()
         self.labels.copy_(labels.to(torch.int32))
         if zero_grads:
-            self.grads.zero_()
-        self.loss.zero_()
+            self._zero("zero.grads", self.grads)
+        self._zero("zero.loss", self.loss)
         ml = mr = None
         if mix_labels is not None:
             self._mix_labels = mix_labels.to(device=self.dev, dtype=torch.int32).contiguous()
             self._mix_ratio = ratio.to(device=self.dev, dtype=f32).contiguous()
             ml, mr = self._mix_labels.data_ptr(), self._mix_ratio.data_ptr()
-        _lib.check(self.L.savit_softmax_xent(self.logits.data_ptr(), self.cfg.num_classes, self.labels.data_ptr(), ml, mr, float(label_smoothing),
-                                             1.0 / self.B, self.loss_rows.data_ptr(), self.loss.data_ptr(), self.dlogits.data_ptr(), self.Cp,
-                                             self._off_ptr(self.grads, "bh"), self.top1.data_ptr(), self.top5.data_ptr(), self.B,
-                                             self.cfg.num_classes, s), "savit_softmax_xent")
-        self.dres.zero_()
+        timed_call(self.launch_timer, "xent", self.L.savit_softmax_xent, self.logits.data_ptr(), self.cfg.num_classes, self.labels.data_ptr(), ml, mr,
+                   float(label_smoothing), 1.0 / self.B, self.loss_rows.data_ptr(), self.loss.data_ptr(), self.dlogits.data_ptr(), self.Cp,
+                   self._off_ptr(self.grads, "bh"), self.top1.data_ptr(), self.top5.data_ptr(), self.B, self.cfg.num_classes, s)
+        self._zero("zero.dres", self.dres)
         if self.overlap_wgrad:
             if self._bwd_plan is None:
                 self._bwd_plan = self._build_bwd_plan()
             n = max(1, self.n_side_streams)
             while len(self._side_streams) < n:
                 self._side_streams.append(torch.cuda.Stream(device=self.dev))
-            self._bwd_plan.run_overlapped(torch.cuda.current_stream(), self._side_streams[:n], self.bwd_hooks)
+            self._bwd_plan.run_overlapped(torch.cuda.current_stream(), self._side_streams[:n], self.bwd_hooks, self.launch_timer)
             return self.loss
-        plan = self._serial_bwd_plan()
-        for fn, args, label in plan.calls:
-            rc = fn(*args, s)
-            if rc != 0:
-                _lib.check(rc, label)
-            cb = plan.hook_for(self.bwd_hooks, label)
-            if cb is not None:
-                cb()
+        self._serial_bwd_plan().run(s, self.launch_timer, self.bwd_hooks)
         return self.loss
+
+    def _zero(self, label: str, t: torch.Tensor):
+        timed_call(self.launch_timer, label, self.L.savit_zero_bytes, t.data_ptr(), t.numel() * t.element_size(), self._stream())
 
     def _serial_bwd_plan(self):
         if self._bwd_plan_serial is None:
@@ -628,43 +625,22 @@ class CaiTEngine:
         s = self._stream()
         self.step_count += 1
         ss = None
+        tm = self.launch_timer
         if max_norm and max_norm > 0:
-            self.gnorm_sq.zero_()
-            _lib.check(self.L.savit_sumsq(self.grads.data_ptr(), self.grads.numel(), self.gnorm_sq.data_ptr(), s), "savit_sumsq")
+            self._zero("zero.gnorm", self.gnorm_sq)
+            timed_call(tm, "sumsq", self.L.savit_sumsq, self.grads.data_ptr(), self.grads.numel(), self.gnorm_sq.data_ptr(), s)
             ss = self.gnorm_sq.data_ptr()
-        _lib.check(self.L.savit_adamw_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
-                                           self.params.numel(), float(lr), float(b1), float(b2), float(eps), float(weight_decay), self.step_count, ss,
-                                           float(max_norm or 0.0), float(grad_scale), s), "savit_adamw_step")
+        timed_call(tm, "adamw", self.L.savit_adamw_step, self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
+                   self.params.numel(), float(lr), float(b1), float(b2), float(eps), float(weight_decay), self.step_count, ss,
+                   float(max_norm or 0.0), float(grad_scale), s)
         self.refresh_weights()
 
-    def profile_step(self, labels, label_smoothing: float = 0.1):
-        if self.weights_stale:
-            self.refresh_weights()
-        if self._fwd_plan is None:
-            self._fwd_plan = self._build_fwd_plan()
-        bwd_plan = self._serial_bwd_plan()
-        s = self._stream()
-        self.labels.copy_(labels.to(torch.int32))
-        evs = []
+    def profile_step(self, labels, label_smoothing: float = 0.1, reps: int = 3, is_training: bool = False):
+        """Forward + loss + backward with every launch bracketed (timing.instrumented_steps) -> {launch label: ms, min over reps}."""
+        from .timing import instrumented_steps
 
-        def run(plan):
-            for fn, args, label in plan.calls:
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                rc = fn(*args, s)
-                b.record()
-                if rc != 0:
-                    _lib.check(rc, label)
-                evs.append((label, a, b))
+        def one():
+            self.forward(is_training=is_training)
+            self.loss_backward(labels, label_smoothing)
 
-        run(self._fwd_plan)
-        self.grads.zero_()
-        self.loss.zero_()
-        _lib.check(self.L.savit_softmax_xent(self.logits.data_ptr(), self.cfg.num_classes, self.labels.data_ptr(), None, None, float(label_smoothing),
-                                             1.0 / self.B, self.loss_rows.data_ptr(), self.loss.data_ptr(), self.dlogits.data_ptr(), self.Cp,
-                                             self._off_ptr(self.grads, "bh"), self.top1.data_ptr(), self.top5.data_ptr(), self.B,
-                                             self.cfg.num_classes, s), "savit_softmax_xent")
-        self.dres.zero_()
-        run(bwd_plan)
-        torch.cuda.synchronize()
-        return {label: a.elapsed_time(b) for label, a, b in evs}
+        return instrumented_steps(self, one, reps=reps)["labels"]

@@ -29,6 +29,7 @@ import torch
 
 from . import lib as _lib
 from .config import ModelConfig
+from .timing import timed_call
 
 bf16 = torch.bfloat16
 f32 = torch.float32
@@ -193,16 +194,31 @@ class _Plan:
                 cb()
         return fire
 
-    def run(self, stream: int):
+    def run(self, stream: int, timer=None, hooks: Optional[Dict[str, Callable[[], None]]] = None):
+        """Issue every launch on `stream`.  timer (timing.LaunchTimer): bracket the launches it tracks; hooks: run the callback of a
+        label (DDP bucket trigger) right behind its launch."""
+        if timer is None and not hooks:
+            for fn, args, label in self.calls:
+                rc = fn(*args, stream)
+                if rc != 0:
+                    _lib.check(rc, label)
+            return
         for fn, args, label in self.calls:
+            k = timer.begin(label, stream) if timer is not None else -1
             rc = fn(*args, stream)
+            if k >= 0:
+                timer.end(k, stream)
             if rc != 0:
                 _lib.check(rc, label)
+            cb = self.hook_for(hooks, label)
+            if cb is not None:
+                cb()
 
     def run_overlapped(self, main: "torch.cuda.Stream", sides: List["torch.cuda.Stream"],
-                       hooks: Optional[Dict[str, Callable[[], None]]] = None):
+                       hooks: Optional[Dict[str, Callable[[], None]]] = None, timer=None):
         """Main-chain launches on `main`, side launches round-robin on `sides`, ordered by events; every stream is joined
-        before each hook (the DDP bucket all-reduce reads gradients written on any of them) and at the end."""
+        before each hook (the DDP bucket all-reduce reads gradients written on any of them) and at the end.  timer: as in run()
+        (a side launch is bracketed on ITS stream: beside the main chain its wall time includes the time it shares the CUs)."""
         mh = main.cuda_stream
         ns = len(sides)
         last = [None] * ns  # last side call issued per side stream
@@ -216,13 +232,19 @@ class _Plan:
                     self._ev_done[i] = torch.cuda.Event()
                 ev.record(main)
                 st.wait_event(ev)
+                tk = timer.begin(label, st.cuda_stream) if timer is not None else -1
                 rc = fn(*args, st.cuda_stream)
+                if tk >= 0:
+                    timer.end(tk, st.cuda_stream)
                 self._ev_done[i].record(st)
                 last[k % ns] = i
             else:
                 for j in self.guard.get(i, ()):
                     main.wait_event(self._ev_done[j])
+                tk = timer.begin(label, mh) if timer is not None else -1
                 rc = fn(*args, mh)
+                if tk >= 0:
+                    timer.end(tk, mh)
             if rc != 0:
                 _lib.check(rc, label)
             cb = self.hook_for(hooks, label)
@@ -439,6 +461,7 @@ class ViTEngine:
         self._bwd_plan: Optional[_Plan] = None
         self._cast_plan: Optional[_Plan] = None
         self.bwd_hooks: Dict[str, Callable[[], None]] = {}  # label -> callback run right after that launch (DDP buckets)
+        self.launch_timer = None  # timing.LaunchTimer: brackets the launches it tracks (bench.py, profile_step)
         self.weights_stale = True
         # weight-gradient GEMMs on a second stream (SAVIT_OVERLAP_WGRAD=1 / 0 overrides the engine's default).  Round 2: with the
         # atomic-free weight gradients and the tail-split tiles the ViT family runs as fast or faster on ONE stream (DeiT-B 6 715 vs
@@ -701,7 +724,7 @@ class ViTEngine:
         """fp32 master -> bf16 MFMA operands (both layouts).  Call after the parameters change."""
         if self._cast_plan is None:
             self._cast_plan = self._build_cast_plan()
-        self._cast_plan.run(self._stream())
+        self._cast_plan.run(self._stream(), self.launch_timer)
         self.weights_stale = False
 
     def set_images(self, images: torch.Tensor):
@@ -733,7 +756,7 @@ class ViTEngine:
             self.refresh_weights()
         if self._fwd_plan is None:
             self._fwd_plan = self._build_fwd_plan()
-        self._fwd_plan.run(self._stream())
+        self._fwd_plan.run(self._stream(), self.launch_timer)
         return self.logits
 
     def loss_backward(self, labels: torch.Tensor, label_smoothing: float = 0.1, mix_labels: Optional[torch.Tensor] = None,
@@ -742,44 +765,37 @@ class ViTEngine:
         s = self._stream()
         self.labels.copy_(labels.to(torch.int32))
         if zero_grads:
-            self.grads.zero_()
-        self.loss.zero_()
+            self._zero("zero.grads", self.grads)
+        self._zero("zero.loss", self.loss)
         ml = mr = None
         if mix_labels is not None:
             self._mix_labels = mix_labels.to(device=self.dev, dtype=torch.int32).contiguous()
             self._mix_ratio = ratio.to(device=self.dev, dtype=f32).contiguous()
             ml, mr = self._mix_labels.data_ptr(), self._mix_ratio.data_ptr()
-        _lib.check(self.L.savit_softmax_xent(self.logits.data_ptr(), self.cfg.num_classes, self.labels.data_ptr(), ml, mr,
-                                             float(label_smoothing), 1.0 / self.B, self.loss_rows.data_ptr(), self.loss.data_ptr(),
-                                             self.dlogits.data_ptr(), self.Cp, self._off_ptr(self.grads, "bh"), self.top1.data_ptr(),
-                                             self.top5.data_ptr(), self.B, self.cfg.num_classes, s), "savit_softmax_xent")
+        timed_call(self.launch_timer, "xent", self.L.savit_softmax_xent, self.logits.data_ptr(), self.cfg.num_classes, self.labels.data_ptr(), ml, mr,
+                   float(label_smoothing), 1.0 / self.B, self.loss_rows.data_ptr(), self.loss.data_ptr(),
+                   self.dlogits.data_ptr(), self.Cp, self._off_ptr(self.grads, "bh"), self.top1.data_ptr(),
+                   self.top5.data_ptr(), self.B, self.cfg.num_classes, s)
         self.backward_from_dlogits()
         return self.loss
 
+    def _zero(self, label: str, t: torch.Tensor):
+        """hipMemsetAsync of an accumulator on the launch stream, as a labelled (timeable) launch."""
+        timed_call(self.launch_timer, label, self.L.savit_zero_bytes, t.data_ptr(), t.numel() * t.element_size(), self._stream())
+
     def backward_from_dlogits(self):
         """Backward from self.dlogits (bf16 [B, Cp], pad columns zero) into self.grads (accumulating)."""
-        self.dres.zero_()
-        self.dres_b.zero_()  # ring slot 0: lnf.bwd fills only the cls rows
+        self._zero("zero.dres", self.dres)
+        self._zero("zero.dres_b", self.dres_b)  # ring slot 0: lnf.bwd fills only the cls rows
         if self.overlap_wgrad:
             if self._bwd_plan is None:
                 self._bwd_plan = self._build_bwd_plan()
             n = max(1, self.n_side_streams)
             while len(self._side_streams) < n:
                 self._side_streams.append(torch.cuda.Stream(device=self.dev))
-            self._bwd_plan.run_overlapped(torch.cuda.current_stream(), self._side_streams[:n], self.bwd_hooks)
+            self._bwd_plan.run_overlapped(torch.cuda.current_stream(), self._side_streams[:n], self.bwd_hooks, self.launch_timer)
             return
-        s = self._stream()
-        plan = self._serial_bwd_plan()
-        if not self.bwd_hooks:
-            plan.run(s)
-            return
-        for fn, args, label in plan.calls:
-            rc = fn(*args, s)
-            if rc != 0:
-                _lib.check(rc, label)
-            cb = plan.hook_for(self.bwd_hooks, label)
-            if cb is not None:
-                cb()
+        self._serial_bwd_plan().run(self._stream(), self.launch_timer, self.bwd_hooks)
 
     def optimizer_step(self, lr: float, weight_decay: float = 0.0, max_norm: float = 0.0, b1: float = 0.9, b2: float = 0.999,
                        eps: float = 1e-8, grad_scale: float = 1.0):
@@ -790,50 +806,26 @@ class ViTEngine:
         s = self._stream()
         self.step_count += 1
         ss = None
+        tm = self.launch_timer
         if max_norm and max_norm > 0:
-            self.gnorm_sq.zero_()
-            _lib.check(self.L.savit_sumsq(self.grads.data_ptr(), self.grads.numel(), self.gnorm_sq.data_ptr(), s), "savit_sumsq")
+            self._zero("zero.gnorm", self.gnorm_sq)
+            timed_call(tm, "sumsq", self.L.savit_sumsq, self.grads.data_ptr(), self.grads.numel(), self.gnorm_sq.data_ptr(), s)
             ss = self.gnorm_sq.data_ptr()
-        _lib.check(self.L.savit_adamw_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
-                                           self.params.numel(), float(lr), float(b1), float(b2), float(eps), float(weight_decay),
-                                           self.step_count, ss, float(max_norm or 0.0), float(grad_scale), s), "savit_adamw_step")
+        timed_call(tm, "adamw", self.L.savit_adamw_step, self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
+                   self.params.numel(), float(lr), float(b1), float(b2), float(eps), float(weight_decay),
+                   self.step_count, ss, float(max_norm or 0.0), float(grad_scale), s)
         self.refresh_weights()
 
-    def profile_step(self, labels: torch.Tensor, label_smoothing: float = 0.1) -> Dict[str, float]:
-        """One forward + loss + backward with a HIP event pair around EVERY launch (on the launch stream).
-        Returns {launch label: milliseconds}.  Diagnostic: the events serialise nothing but add host overhead, so
-        use the sum of kernel times, not wall time."""
-        if self.weights_stale:
-            self.refresh_weights()
-        if self._fwd_plan is None:
-            self._fwd_plan = self._build_fwd_plan()
-        bwd_plan = self._serial_bwd_plan()
-        s = self._stream()
-        self.labels.copy_(labels.to(torch.int32))
-        evs: List[Tuple[str, torch.cuda.Event, torch.cuda.Event]] = []
+    def profile_step(self, labels: torch.Tensor, label_smoothing: float = 0.1, reps: int = 3) -> Dict[str, float]:
+        """Forward + loss + backward with EVERY launch bracketed by timing events on the launch stream, each repetition enqueued
+        behind a gate kernel (timing.instrumented_steps).  Returns {launch label: milliseconds, minimum over `reps`}."""
+        from .timing import instrumented_steps
 
-        def run(plan):
-            for fn, args, label in plan.calls:
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                rc = fn(*args, s)
-                b.record()
-                if rc != 0:
-                    _lib.check(rc, label)
-                evs.append((label, a, b))
+        def one():
+            self.forward()
+            self.loss_backward(labels, label_smoothing)
 
-        run(self._fwd_plan)
-        self.grads.zero_()
-        self.loss.zero_()
-        _lib.check(self.L.savit_softmax_xent(self.logits.data_ptr(), self.cfg.num_classes, self.labels.data_ptr(), None, None,
-                                             float(label_smoothing), 1.0 / self.B, self.loss_rows.data_ptr(), self.loss.data_ptr(),
-                                             self.dlogits.data_ptr(), self.Cp, self._off_ptr(self.grads, "bh"), self.top1.data_ptr(),
-                                             self.top5.data_ptr(), self.B, self.cfg.num_classes, s), "savit_softmax_xent")
-        self.dres.zero_()
-        self.dres_b.zero_()
-        run(bwd_plan)
-        torch.cuda.synchronize()
-        return {label: a.elapsed_time(b) for label, a, b in evs}
+        return instrumented_steps(self, one, reps=reps)["labels"]
 
     def activation_bytes(self) -> int:
         tot = 0

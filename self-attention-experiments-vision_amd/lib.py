@@ -131,6 +131,13 @@ _SIGNATURES = {
     "savit_softmax_xent_grad_f32": (c_int, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int, c_int, c_void_p]),
     "savit_patchify_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "savit_assemble_tokens_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "savit_timer_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "savit_timer_record": (c_int, [c_void_p, c_int, c_void_p]),
+    "savit_timer_elapsed_ms": (c_int, [c_void_p, c_int, c_int, POINTER(c_float)]),
+    "savit_timer_destroy": (c_int, [c_void_p]),
+    "savit_spin": (c_int, [c_long, c_void_p]),
+    "savit_hold_cus": (c_int, [c_int, c_long, c_void_p]),
+    "savit_zero_bytes": (c_int, [c_void_p, c_long, c_void_p]),
 }
 
 _lib = None

@@ -478,12 +478,8 @@ class TNTEngine(ViTEngine):
         return P
 
     def backward_from_dlogits(self):
-        self.dresi.zero_()  # the last layer's pixel output feeds Inner2Outer only: its cotangent starts from zero
+        self._zero("zero.dresi", self.dresi)  # the last layer's pixel output feeds Inner2Outer only: its cotangent starts from zero
         super().backward_from_dlogits()
-
-    def profile_step(self, labels, label_smoothing: float = 0.1):
-        self.dresi.zero_()
-        return super().profile_step(labels, label_smoothing)
 
     def activation_bytes(self) -> int:
         tot = 0
