@@ -57,7 +57,8 @@ def kernel_symbol(label: str, lib, M: int, d: int, F: int) -> str:
     """Launch label of the engine's plan -> the kernel symbol rocprofv3 reports (template arguments as in csrc/)."""
     parts = label.split(".")
     if label.startswith("wgrad.group"):
-        return "gemm_wgrad_group_kernel<256,256,2,4,3>"  # every width: edge tiles hang over the matrix (engine._wgrad_group_plan)
+        # engine.wgrad_group_tile: 128 x 384 tiles for the d = 384 models, else 256 x 256 (edge tiles hang over the matrix)
+        return "gemm_wgrad_group_kernel<128,384,2,4,3,32>" if (d % 256 or F % 256) and d % 384 == 0 and F % 384 == 0 else "gemm_wgrad_group_kernel<256,256,2,4,3,32>"
     op = ".".join(parts[1:]) if parts[0].startswith("l") and parts[0][1:].isdigit() else label
     shapes = {"qkv": (3 * d, d), "proj": (d, d), "fc1": (F, d), "fc2": (d, F), "fc2.dgrad": (F, d), "fc1.dgrad": (d, F),
               "proj.dgrad": (d, d), "qkv.dgrad": (d, 3 * d)}
@@ -141,22 +142,22 @@ def rank_probe():
     dist.destroy_process_group()
 
 
-def build_engine(cfg, B):
+def build_engine(cfg, B, reserved_cus=None):
     from savit_amd.engine import ViTEngine
 
     if cfg.kind == "cait":
         from savit_amd.cait_engine import CaiTEngine
 
-        return CaiTEngine(cfg, B)
+        return CaiTEngine(cfg, B, reserved_cus=reserved_cus)
     if cfg.kind == "mixer":
         from savit_amd.mixer_engine import MixerEngine
 
-        return MixerEngine(cfg, B)
+        return MixerEngine(cfg, B, reserved_cus=reserved_cus)
     if cfg.kind == "tnt":
         from savit_amd.tnt_engine import TNTEngine
 
-        return TNTEngine(cfg, B)
-    return ViTEngine(cfg, B)
+        return TNTEngine(cfg, B, reserved_cus=reserved_cus)
+    return ViTEngine(cfg, B, reserved_cus=reserved_cus)
 
 
 def make_step(eng, cfg, B, world, rank, sync):
@@ -496,11 +497,14 @@ def main():
 
     import savit_amd  # noqa: F401
     from savit_amd import ddp
+    if os.environ.get("SAVIT_EXP_LIB"):  # A/B runs against an experiment build of the library (tools/build_variant.sh)
+        from savit_amd import lib as _l
+        _l.LIB_PATH = os.path.join(os.path.dirname(_l.LIB_PATH), "exp", "libsavit_%s.so" % os.environ["SAVIT_EXP_LIB"])
     from savit_amd.config import get_config, train_flops_per_image
 
     cfg = get_config(args.model, img_size=args.img_size)
     B = args.batch
-    eng = build_engine(cfg, B)
+    eng = build_engine(cfg, B, reserved_cus=ddp.default_reserved_cus(world))  # backward is planned for the CUs the all-reduce leaves
     init_bench_params(eng, cfg)
     sync = None
     if world > 1:

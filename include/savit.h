@@ -112,6 +112,9 @@ typedef struct savit_gemm_args {
   int img_size, patch, tokens, token_offset;
   int tile;               /* 0 = auto; explicit ids select a kernel variant (benchmarks / tests, see gemm_tn.hip) */
   int colsum_rows;        /* 0, or the slab height savit_gemm_colsum_rows() gives for this shape and tile */
+  int cu_budget;          /* 0 = the whole device; else the CUs the auto heuristic (tile == 0) may count on: a data-parallel rank leaves
+                             some to the resident RCCL all-reduce (train.py:96), and a grid sized for ALL CUs would then run a second,
+                             nearly empty round */
 } savit_gemm_args;
 
 int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream);
@@ -120,12 +123,14 @@ int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream);
  * (M, N, K, tile) - one per (row tile, wave row); savit_colsum_finalize: out[n] (+)= sum_r slab[r][n] (fixed summation order
  * below 512 rows; taller slabs in accumulate mode are reduced in row chunks that add with fp32 atomics). */
 int savit_gemm_colsum_rows(int M, int N, int K, int tile);
+int savit_gemm_colsum_rows_cus(int M, int N, int K, int tile, int cu_budget); /* tile == 0: the auto choice for cu_budget CUs */
 int savit_colsum_finalize(const float* slab, int rows, int N, float* out, int accumulate, void* stream);
 /* Tile the auto heuristic (tile == 0) picks for a shape and epilogue.  K % 64 == 0: paired-stage kernels 17 = 192x128 (4 waves, two
  * workgroups per CU; the default), 13 = 256x256 (8 waves; GELU-forward on large grids), 12 = 128x128 (small / ragged problems);
  * otherwise 6 / 7 = 128x128 / 256x256 on the 32-deep ring.  savit_gemm_tn_auto_tile = the SAVIT_EPI_BF16 choice. */
 int savit_gemm_tn_auto_tile(int M, int N, int K);
 int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue);
+int savit_gemm_tn_auto_tile_cus(int M, int N, int K, int epilogue, int cu_budget); /* the same for cu_budget CUs (0 = all) */
 
 /* Weight-gradient GEMM: dW[Kin, Nout] += X[M, Kin]^T . dY[M, Nout]  (fp32 atomics into dW; caller zeroes).
  * X, dY bf16 row-major; reduction over M is split over `splits` workgroup groups (0 = auto).

@@ -27,7 +27,7 @@ import torch
 
 from . import lib as _lib
 from .config import ModelConfig
-from .engine import WgradQueue, _Plan, _align, _copy_tree, add_wgrad, add_wgrad_group, finalize_wgrad_ws
+from .engine import ViTEngine, WgradQueue, _Plan, _align, _copy_tree, add_wgrad, add_wgrad_group, finalize_wgrad_ws, wgrad_group_tile
 from .timing import timed_call
 
 bf16 = torch.bfloat16
@@ -128,7 +128,7 @@ def stochastic_depth_seed(seed: int, rank: int, step: int) -> int:
 
 class CaiTEngine:
     def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True,
-                 th_fused: "bool | None" = None):
+                 th_fused: "bool | None" = None, reserved_cus=None, wgrad_max_lag=None):
         if cfg.kind != "cait":
             raise ValueError("CaiTEngine needs a CaiT config")
         if cfg.head_dim not in (48, 64) or cfg.num_heads not in (2, 4, 6, 8, 16):
@@ -201,7 +201,7 @@ class CaiTEngine:
         self.d_h, self.d_o = e(M, d, dt=bf16), e(M, d, dt=bf16)
         # The SA layers' weight gradients wait in a FIFO of 256 x 256 output tiles and leave in grouped launches of one tile per CU
         # (engine.WgradQueue; a launch reaches back `wgrad_lag` layers), so the cotangents they read rotate through rings that deep.
-        self.n_cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        ViTEngine._init_cu_budget(self, reserved_cus, wgrad_max_lag)  # n_cus, reserved_cus, cu_budget, wgrad_max_lag
         self.wgrad_tile, self.wgrad_lag = self._wgrad_group_plan()
         depth = max(2, self.wgrad_lag + 1)
         self.dbr_ring = [e(M, d, dt=bf16) for _ in range(2 * depth)]
@@ -209,7 +209,7 @@ class CaiTEngine:
         self.dqkv_ring = [e(M, 3 * d, dt=bf16) for _ in range(depth)]
         self.dbr, self.d_u, self.dqkv = self.dbr_ring[0], self.d_u_ring[0], self.dqkv_ring[0]
         self.dsbuf = e(B, H, N, self.Np, dt=bf16)
-        self.colsum_slab = e(max(1, self.L.savit_gemm_colsum_rows(M, F, d, 0)), F)
+        self.colsum_slab = e(max(1, self.L.savit_gemm_colsum_rows_cus(M, F, d, 0, self.cu_budget if self.reserved_cus else 0)), F)
         self.dcls, self.dcls_b = e(B, d), e(B, d, dt=bf16)
         self.dbr_c, self.d_hc2, self.d_oc = e(B, d, dt=bf16), e(B, d, dt=bf16), e(B, d, dt=bf16)
         self.d_uc = e(B, F, dt=bf16)
@@ -288,6 +288,7 @@ class CaiTEngine:
         if not a.rows_per_sample:
             a.rows_per_sample = 1
         a.round_bias_bf16 = self.rp
+        a.cu_budget = self.cu_budget if (self.reserved_cus and self._building_bwd) else 0  # the all-reduce is resident during backward only
         plan.keep.append(a)
         plan.add(self.L.savit_gemm_bf16_tn, (ctypes.byref(a),), label, writes=writes)
 
@@ -300,13 +301,13 @@ class CaiTEngine:
         reasoning; CaiT-S24: 38 tiles per layer, a launch of 256 every ~7 layers); tile 0 (SAVIT_WGRAD_GROUP=0) = one launch per weight."""
         if _os.environ.get("SAVIT_WGRAD_GROUP", "auto") == "0":
             return 0, 0
-        tile = 256
+        tile = wgrad_group_tile(self.cfg.embed_dim, self.cfg.hidden)
         sizes = self._layer_wgrad_tiles(tile)
-        q, lag = WgradQueue(self.n_cus), 0
+        q, lag = WgradQueue(self.cu_budget, self.wgrad_max_lag), 0
         for l in range(self.cfg.num_layers - 1, -1, -1):
             for t in sizes:
                 q.push(None, l, t)
-            while q.pending() > 0 and (q.due() or l == 0):
+            while q.pending() > 0 and (q.due(l) or l == 0):
                 _, _, oldest = q.take(q.cap)
                 lag = max(lag, oldest - l)
         return tile, lag
@@ -408,6 +409,13 @@ class CaiTEngine:
         return P
 
     def _build_bwd_plan(self):
+        self._building_bwd = True
+        try:
+            return self._record_bwd_plan()
+        finally:
+            self._building_bwd = False
+
+    def _record_bwd_plan(self):
         P, L, cfg = _Plan(), self.L, self.cfg
         d, F, C, N, NL, NC, H, B, M, Mc = (cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.n_patches, cfg.num_layers, cfg.num_layers_token_only,
                                            cfg.num_heads, self.B, self.M, self.Mc)
@@ -459,7 +467,7 @@ class CaiTEngine:
         P.add(L.savit_pos_cls_grad, (self.dcls.data_ptr(), gp("cls"), None, B, 1, d, 0), "cls.grad")
         # ---- SA layers (reverse).  Their weight gradients wait in the tile FIFO (grouped launches of one tile per CU) or, ungrouped, go
         # to the side stream; dbr / d_u / dqkv rotate through rings as deep as a launch reaches back.
-        queue = WgradQueue(self.n_cus) if self.wgrad_tile else None
+        queue = WgradQueue(self.cu_budget, self.wgrad_max_lag) if self.wgrad_tile else None
         n_launch = [0]
 
         def wgrad_l(label, layer, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw):
@@ -470,7 +478,7 @@ class CaiTEngine:
         def flush_group(layer: int, last: bool):
             # after a layer's last input-gradient GEMM, before anything overwrites the oldest ring slots; the DDP trigger of an EARLIER
             # layer ('l{j}.ln1.bwd') whose last tile is in a launch fires behind that launch
-            while queue is not None and queue.pending() > 0 and (queue.due() or last):
+            while queue is not None and queue.pending() > 0 and (queue.due(layer) or last):
                 entries, done, oldest = queue.take(queue.cap)
                 assert oldest - layer <= self.wgrad_lag, "weight-gradient queue reaches back further than the cotangent rings"
                 add_wgrad_group(self, P, f"wgrad.group.{n_launch[0]}.l{oldest}-l{layer}", entries, self.wgrad_tile,

@@ -18,6 +18,9 @@
 #include "savit.h"
 #include <type_traits>
 
+static int device_cus();
+extern "C" int savit_gemm_tn_auto_tile_cus(int M, int N, int K, int epilogue, int cu_budget);
+
 namespace {
 
 constexpr int BK = 64;           // bf16 elements per K-tile  (128 B per LDS row)
@@ -1404,16 +1407,13 @@ __global__ __launch_bounds__(512) void gemm_tn_stream_kernel(const GemmParams p)
   }
 }
 
+#ifdef SAVIT_EXPERIMENTS  // tile 30 is never selected (round 3: built, bitwise-correct, slower): experiment builds only
 int launch_stream(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
   p.tiles_m = (p.a.M + 255) / 256;
   p.tiles_n = p.a.N / 128;
   p.row_group = p.tiles_m < 4 ? p.tiles_m : 4;  // 32 concurrent tiles per XCD = 4 A-panels x 8 W-panels (K = 768: 1.5 MB + 1.5 MB of L2)
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    return n;
-  }();
+  const int cus = device_cus();
   const int ntiles = p.tiles_m * p.tiles_n;
   int per = (cus + 7) / 8;  // workgroups per XCD: one per CU
   if (per > (ntiles + 7) / 8) per = (ntiles + 7) / 8;
@@ -1446,6 +1446,7 @@ inline bool stream_ok(const savit_gemm_args& a) {
                                             (a.colsum == nullptr || a.colsum_rows > 0);
   return false;
 }
+#endif  // SAVIT_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------------------
 // Ping-pong variant with 320-row tiles (tile 21: 320 x 256 x 64, 8 waves = 2 (M) x 4 (N), wave tile 160 x 64).  Why 320: the N = 768
@@ -1757,7 +1758,8 @@ template <int BM, int BM2, int BN, int WGM, int WGN, int ND>
 int launch_pair_tail(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
   int bp = 0, sp = 0;
-  if (!tail_split_plan(p.a.M, p.a.N, BM, BM2, BN, 512, &bp, &sp)) return launch_pair<BM, BN, WGM, WGN, ND>(p0, s);
+  const int slots = 2 * ((p.a.cu_budget > 0 && p.a.cu_budget < device_cus()) ? p.a.cu_budget : device_cus());
+  if (!tail_split_plan(p.a.M, p.a.N, BM, BM2, BN, slots, &bp, &sp)) return launch_pair<BM, BN, WGM, WGN, ND>(p0, s);
   p.tiles_n = (p.a.N + BN - 1) / BN;
   p.tiles_m = bp;
   p.big_tiles = bp * p.tiles_n;
@@ -1836,7 +1838,21 @@ int launch_tile(const GemmParams& p0, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue) {
+static int device_cus() {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  return cus;
+}
+
+extern "C" int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue) { return savit_gemm_tn_auto_tile_cus(M, N, K, epilogue, 0); }
+
+// cu_budget: the CUs this launch may count on (0 = all of the device's).  A data-parallel rank passes less than the device has while an
+// all-reduce is resident (engine.reserved_cus): the round model below then prices the tiles for THAT many CUs - a 237-tile grid that is one
+// round on 256 CUs is two rounds, the second nearly empty, on 224.
+extern "C" int savit_gemm_tn_auto_tile_cus(int M, int N, int K, int epilogue, int cu_budget) {
   // measured on MI355X in the training pipeline (tools/profile_step.py, tools/gemm_probe.py; DeiT-B, DeiT-S, ViT-L/16-384 shapes).
   // K % 64 == 0 selects the paired-stage kernels (whole-cache-line LDS-DMA), other K the 64-B-row ring.
   //  * 192x128, two 4-wave workgroups per CU (80 KB of LDS each): the default.  Against 128x128 it needs 19 % fewer L2->LDS bytes per
@@ -1850,7 +1866,7 @@ extern "C" int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue) {
   if (force > 0) return force;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
   const bool big = (t256 >= 512 && N % 128 == 0);
-  if (K % 64 != 0) return big ? 7 : 6;
+  if (K % 64 != 0) return 6;  // TNT's pixel stream (K = 32 / 96 / 160): narrow outputs, the 128x128 ring (a 256x256 ring tile existed through round 3; no shape of a supported model reached it)
   //  * 256x256 ping-pong (tile 20: the two M-halves of the 8-wave workgroup run one barrier apart, one in its MFMA segment while
   //    the other reads fragments and issues LDS-DMA): wide outputs on large grids with K >= 768 - measured against the next best
   //    tile with cold operands (tools/gemm_epi_bench.py): fc1+GELU 172 -> 155 us, fc2 input-gradient+GELU' 179 -> 171 us, qkv 117 -> 111 us,
@@ -1858,7 +1874,8 @@ extern "C" int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue) {
   //    K = 384 (DeiT-S, CaiT-S at 256 images) stays with the pair kernels: with cold operands the ping-pong tile is 7-11 % faster on
   //    those shapes too (SAVIT_EPI_SHAPE=50432,384,1536 tools/gemm_epi_bench.py), inside the training step - warm operands, same box,
   //    alternating runs - DeiT-S lost 1.4 % (17.63 -> 17.38 k img/s) and CaiT-S24, TNT, Mixer did not move.
-  if (K >= 768 && N % 256 == 0 && M >= 4096 && epilogue != SAVIT_EPI_PATCH) {
+  static const int pp_min_k = SAVIT_EXP_ENV_INT("SAVIT_PP_MIN_K", 768);  // SAVIT_EXPERIMENTS builds only (A/B runs)
+  if (K >= pp_min_k && N % 256 == 0 && M >= 4096 && epilogue != SAVIT_EPI_PATCH) {
     //  * 320x256 ping-pong (tile 21, round 3) against 256x256 (tile 20) and 192x128 (17 / 18): what a launch costs is (rounds of
     //    workgroups over the CUs) x (rows of a tile), weighted by what the tile's operand feed costs - the L2 -> LDS path of a CU, not
     //    the matrix pipe, bounds these kernels, and a 192x128 tile moves 1.7x the bytes per flop of a 256-wide one (measured: the same
@@ -1866,11 +1883,7 @@ extern "C" int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue) {
     //    rows = two; 792 + tail of 192x128): fc1 input gradient 142 -> 98 us, fc2 + residual 166 -> 121, qkv input gradient 112 -> 80,
     //    proj + residual 69 -> 58; N = 2304: 3 rounds of 320 rows against 4 of 256: qkv 108 -> 96 us; N = 3072: 4 x 320 = 5 x 256, the
     //    320-row tile moves 10 % fewer bytes: fc1 + GELU 147 -> 143, GELU' 167 -> 162 (tools/gemm_epi_bench.py, cold operands).
-    static const int cus = [] {
-      int dev = 0, n = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-      return n;
-    }();
+    const int cus = (cu_budget > 0 && cu_budget < device_cus()) ? cu_budget : device_cus();
     const long tn = N / 256;
     const long r256 = (((long)(M + 255) / 256 * tn + cus - 1) / cus) * 256;
     const long r320 = (((long)(M + 319) / 320 * tn + cus - 1) / cus) * 320;
@@ -1887,7 +1900,8 @@ extern "C" int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue) {
     //    DeiT-B's N = 768 products are 792 tiles on 512 slots (2 rounds, the second at 55 %) -> 510 tall + 420 short tiles.
     int bp, sp;
     static const bool no_tail = SAVIT_EXP_ENV_INT("SAVIT_NO_TAIL_SPLIT", 0) != 0;  // SAVIT_EXPERIMENTS builds only (A/B runs)
-    if (!no_tail && epilogue != SAVIT_EPI_DGELU && tail_split_plan(M, N, 192, 128, 128, 512, &bp, &sp)) return 18;
+    const int slots = 2 * ((cu_budget > 0 && cu_budget < device_cus()) ? cu_budget : device_cus());
+    if (!no_tail && epilogue != SAVIT_EPI_DGELU && tail_split_plan(M, N, 192, 128, 128, slots, &bp, &sp)) return 18;
     return 17;
   }
   return big ? 13 : 12;
@@ -1955,8 +1969,10 @@ inline bool tile_geometry(int tile, int* bm, int* wgm) {
 }
 }  // namespace
 
-extern "C" int savit_gemm_colsum_rows(int M, int N, int K, int tile) {
-  if (tile == 0) tile = savit_gemm_tn_auto_tile_epi(M, N, K, SAVIT_EPI_DGELU);  // the only epilogue with column sums
+extern "C" int savit_gemm_colsum_rows(int M, int N, int K, int tile) { return savit_gemm_colsum_rows_cus(M, N, K, tile, 0); }
+
+extern "C" int savit_gemm_colsum_rows_cus(int M, int N, int K, int tile, int cu_budget) {
+  if (tile == 0) tile = savit_gemm_tn_auto_tile_cus(M, N, K, SAVIT_EPI_DGELU, cu_budget);  // the only epilogue with column sums
   int bm = 0, wgm = 0;
   if (!tile_geometry(tile, &bm, &wgm) || M < 0) return -1;
   return ((M + bm - 1) / bm) * wgm;
@@ -1996,32 +2012,38 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   int tile = a.tile;
   if (tile == 0) {
-    tile = savit_gemm_tn_auto_tile_epi(a.M, a.N, a.K, a.epilogue);
+    tile = savit_gemm_tn_auto_tile_cus(a.M, a.N, a.K, a.epilogue, a.cu_budget);
     if ((tile == 20 || tile == 21) && a.lda < a.K) tile = 13;  // the ping-pong kernels do not take the aliased-row operand form
   }
-  if (a.colsum != nullptr && a.colsum_rows != 0) SAVIT_CHECK_ARG(a.colsum_rows == savit_gemm_colsum_rows(a.M, a.N, a.K, tile));
+  if (a.colsum != nullptr && a.colsum_rows != 0) {
+    int bm_ = 0, wgm_ = 0;
+    SAVIT_CHECK_ARG(tile_geometry(tile, &bm_, &wgm_) && a.colsum_rows == ((a.M + bm_ - 1) / bm_) * wgm_);
+  }
+  // The product library holds exactly the tiles savit_gemm_tn_auto_tile_cus can return (tests/test_abi.py checks that every one of
+  // them is reached by a shape of a supported model); the tiles it never picks - earlier rounds' forms, kept for A/B runs - exist
+  // in SAVIT_EXPERIMENTS builds only (tools/build_variant.sh).
   switch (tile) {
+    case 6: return launch_ring<128, 128, 2, 2, 4>(p, s);
+    case 12: return a.K % 64 ? SAVIT_EINVAL : launch_pair<128, 128, 2, 2, 2>(p, s);
+    case 13: return a.K % 64 ? SAVIT_EINVAL : launch_pair<256, 256, 2, 4, 2>(p, s);
+    case 17: return a.K % 64 ? SAVIT_EINVAL : launch_pair<192, 128, 2, 2, 2>(p, s);
+    case 18: return a.K % 64 ? SAVIT_EINVAL : launch_pair_tail<192, 128, 128, 2, 2, 2>(p, s);  // 17 with 128-row tiles for the last partial round
+    case 20: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp(p, s);
+    case 21: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp320(p, s);
+#ifdef SAVIT_EXPERIMENTS
+    case 7: return launch_ring<256, 256, 2, 4, 4>(p, s);
     case 1: return launch_tile<128, 128, 2, 2>(p, s);
     case 2: return launch_tile<256, 256, 2, 4>(p, s);
     case 3: return launch_tile<256, 128, 4, 2>(p, s);
     case 4: return launch_ring<128, 256, 2, 2, 3>(p, s);
     case 5: return launch_ring<256, 128, 2, 2, 3>(p, s);
-    case 6: return launch_ring<128, 128, 2, 2, 4>(p, s);
-    case 7: return launch_ring<256, 256, 2, 4, 4>(p, s);
     case 8: return launch_ring<128, 128, 2, 2, 2>(p, s);
     case 9: return launch_ring<128, 128, 2, 2, 3>(p, s);
     case 10: return launch_ring<256, 256, 2, 4, 4, true>(p, s);
     case 11: return launch_ring<128, 128, 2, 2, 4, true>(p, s);
-    case 12: return a.K % 64 ? SAVIT_EINVAL : launch_pair<128, 128, 2, 2, 2>(p, s);
-    case 13: return a.K % 64 ? SAVIT_EINVAL : launch_pair<256, 256, 2, 4, 2>(p, s);
     case 14: return a.K % 64 ? SAVIT_EINVAL : launch_pair<128, 256, 2, 2, 2>(p, s);
     case 15: return a.K % 64 ? SAVIT_EINVAL : launch_pair<256, 128, 2, 2, 2>(p, s);
-    case 17: return a.K % 64 ? SAVIT_EINVAL : launch_pair<192, 128, 2, 2, 2>(p, s);
-    case 18: return a.K % 64 ? SAVIT_EINVAL : launch_pair_tail<192, 128, 128, 2, 2, 2>(p, s);  // 17 with 128-row tiles for the last partial round
-    case 20: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp(p, s);
-    case 21: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp320(p, s);
-    case 30: return stream_ok(a) ? launch_stream(p, s) : SAVIT_EINVAL;
-#ifdef SAVIT_EXPERIMENTS
+    case 30: return stream_ok(a) ? launch_stream(p, s) : SAVIT_EINVAL;  // persistent streaming 256x128 (round 3: built, bitwise-correct, slower)
     // timing-only ablations of tile 20 (wrong results by construction; SAVIT_EPI_BF16 only) - never in the product library
     case 101: return launch_pp_ablation<1>(p, s);
     case 102: return launch_pp_ablation<2>(p, s);

@@ -490,6 +490,7 @@ __device__ __forceinline__ void wgrad_pp_tile(const WgradParams& p, const int ti
   constexpr int X_INSTR = X_BYTES / 1024 / NW, Y_INSTR = Y_BYTES / 1024 / NW, G = X_INSTR + Y_INSTR;
   static_assert(X_BYTES % (1024 * NW) == 0 && Y_BYTES % (1024 * NW) == 0, "tile/wave mismatch");
   static_assert(S >= 3 && G * (S - 1) <= 63, "ring depth / vmcnt immediate");
+  static_assert(XROW % 256 == 0 && YROW % 256 == 0 && WTI % 32 == 0 && WTJ % 32 == 0, "rows are whole 256-B swizzle segments");
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -509,12 +510,13 @@ __device__ __forceinline__ void wgrad_pp_tile(const WgradParams& p, const int ti
     char* sY = sX + X_BYTES;
     const int m0 = st * TS;
     {
-      constexpr int LPR = XROW / 16, RPI = 64 / LPR;
+      constexpr int LPR = XROW / 16;  // 16-B chunks per row; a 1-KB piece of the linear image may span two rows (768-B rows: BI = 384)
 #pragma unroll
       for (int i = 0; i < X_INSTR; ++i) {
         const int inst = wave * X_INSTR + i;
-        const int r = inst * RPI + lane / LPR;
-        const int c = (lane % LPR) ^ ((r & 3) << 2);
+        const int L = inst * 64 + lane;
+        const int r = L / LPR;
+        const int c = (L - r * LPR) ^ ((r & 3) << 2);
         const int m = m0 + r;
         uint32_t voff = 0xfffffff0u;
         if (m < p.M) voff = (uint32_t)((size_t)m * p.ldx * 2 + (size_t)(i0 + c * 8) * 2);
@@ -522,12 +524,13 @@ __device__ __forceinline__ void wgrad_pp_tile(const WgradParams& p, const int ti
       }
     }
     {
-      constexpr int LPR = YROW / 16, RPI = 64 / LPR;
+      constexpr int LPR = YROW / 16;
 #pragma unroll
       for (int i = 0; i < Y_INSTR; ++i) {
         const int inst = wave * Y_INSTR + i;
-        const int r = inst * RPI + lane / LPR;
-        const int c = (lane % LPR) ^ ((r & 3) << 2);
+        const int L = inst * 64 + lane;
+        const int r = L / LPR;
+        const int c = (L - r * LPR) ^ ((r & 3) << 2);
         const int m = m0 + r;
         uint32_t voff = 0xfffffff0u;
         if (m < p.M) voff = (uint32_t)((size_t)m * p.lddy * 2 + (size_t)(j0 + c * 8) * 2);
@@ -584,16 +587,12 @@ __device__ __forceinline__ void wgrad_pp_tile(const WgradParams& p, const int ti
     for (int a = 0; a < II; ++a) xa[a] = __builtin_shufflevector(xl[a], xh[a], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
     for (int b = 0; b < JJ; ++b) yb[b] = __builtin_shufflevector(yl[b], yh[b], 0, 1, 2, 3, 4, 5, 6, 7);
-#ifndef ABL_NO_PRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
+    __builtin_amdgcn_s_setprio(1);  // without it the same kernel is 13 % slower: the partner wave's requests interleave with the MFMA issue
 #pragma unroll
     for (int a = 0; a < II; ++a)
 #pragma unroll
       for (int b = 0; b < JJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[a], yb[b], acc[a][b], 0, 0, 0);
-#ifndef ABL_NO_PRIO
     __builtin_amdgcn_s_setprio(0);
-#endif
   };
 
   const int pre = NS < S ? NS : S;
@@ -655,6 +654,203 @@ __device__ __forceinline__ void wgrad_pp_tile(const WgradParams& p, const int ti
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The same ping-pong tile on v_mfma_f32_16x16x32_bf16 (round 4).  Under this kernel the chip holds its clock down (1.95 GHz: DESIGN
+// 6.3), and on MI355X a bf16 MFMA loop on the 16x16x32 shape holds a higher clock than the same flops on 32x32x16
+// (MI355X_MICROARCH.md, DVFS give-back item 7) at the same LDS bytes per flop: one MFMA spans a whole 32-token stage, a fragment is
+// 16 columns x 32 tokens (lane = (column, token block of 8): the four 16-lane groups of a transposing read take four token blocks of
+// the SAME 16 columns), two ds_read_b64_tr_b16 per fragment as before.  The swizzle of the stage image therefore separates rows
+// 8 apart as well: chunk ^= (row & 3) << 2 ^ ((row >> 3) & 1) << 1 (the 8 rows x 32 B a half-wave reads cover all 64 banks once).
+// Phases per stage as in wgrad_pp_tile:  L0: request the dY fragments + the first half of the X fragments | C0: II/2 x JJ MFMAs |
+// L1: request the second half of the X fragments, refill a ring slot | C1: II/2 x JJ MFMAs (the dY fragments stay in registers).
+// Rows of the stage image may be 768 B (BJ = 384: the d = 384 models, whose matrices are multiples of 128 and 384, not of 256):
+// the LDS-DMA pieces are cut from the linear image, a piece may span two rows.
+template <int BI, int BJ, int WGI, int WGJ, int S>
+__device__ __forceinline__ void wgrad_pp16_tile(const WgradParams& p, const int ti, const int tj, char* smem) {
+  static_assert(WGI == 2, "two row halves = the two ping-pong groups");
+  constexpr int NW = WGI * WGJ;
+  constexpr int TS = 32;
+  constexpr int WTI = BI / WGI, WTJ = BJ / WGJ;
+  constexpr int II = WTI / 16, JJ = WTJ / 16, IH = II / 2;
+  static_assert(II % 2 == 0 && WTI % 16 == 0 && WTJ % 16 == 0, "wave tile");
+  constexpr int XROW = BI * 2, YROW = BJ * 2;
+  constexpr int X_BYTES = TS * XROW, Y_BYTES = TS * YROW, STAGE = X_BYTES + Y_BYTES;
+  constexpr int X_INSTR = X_BYTES / 1024 / NW, Y_INSTR = Y_BYTES / 1024 / NW, G = X_INSTR + Y_INSTR;
+  static_assert(X_BYTES % (1024 * NW) == 0 && Y_BYTES % (1024 * NW) == 0, "tile/wave mismatch");
+  static_assert(XROW % 256 == 0 && YROW % 256 == 0, "rows are whole 256-B swizzle segments");
+  static_assert(S >= 3 && G * (S - 1) <= 63, "ring depth / vmcnt immediate");
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wi = wave / WGJ, wj = wave % WGJ;
+  const int i0 = ti * BI, j0 = tj * BJ;
+  const int NS = (p.M + TS - 1) / TS;
+  if (NS <= 0) return;
+
+  size_t xbytes = (size_t)p.M * p.ldx * 2, ybytes = (size_t)p.M * p.lddy * 2;
+  if (xbytes > 0xffffffe0ull) xbytes = 0xffffffe0ull;
+  if (ybytes > 0xffffffe0ull) ybytes = 0xffffffe0ull;
+  const auto srdX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.X), 0, (uint32_t)xbytes, 0x00020000);
+  const auto srdY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dY), 0, (uint32_t)ybytes, 0x00020000);
+
+  auto swz = [](int r) { return ((r & 3) << 2) ^ (((r >> 3) & 1) << 1); };
+  auto stage = [&](int st, int slot) {
+    char* sX = smem + slot * STAGE;
+    char* sY = sX + X_BYTES;
+    const int m0 = st * TS;
+    {
+      constexpr int LPR = XROW / 16;  // 16-B chunks per row
+#pragma unroll
+      for (int i = 0; i < X_INSTR; ++i) {
+        const int inst = wave * X_INSTR + i;
+        const int L = inst * 64 + lane;
+        const int r = L / LPR;
+        const int c = (L - r * LPR) ^ swz(r);
+        const int m = m0 + r;
+        uint32_t voff = 0xfffffff0u;
+        if (m < p.M) voff = (uint32_t)((size_t)m * p.ldx * 2 + (size_t)(i0 + c * 8) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdX, (__attribute__((address_space(3))) void*)(sX + inst * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+    {
+      constexpr int LPR = YROW / 16;
+#pragma unroll
+      for (int i = 0; i < Y_INSTR; ++i) {
+        const int inst = wave * Y_INSTR + i;
+        const int L = inst * 64 + lane;
+        const int r = L / LPR;
+        const int c = (L - r * LPR) ^ swz(r);
+        const int m = m0 + r;
+        uint32_t voff = 0xfffffff0u;
+        if (m < p.M) voff = (uint32_t)((size_t)m * p.lddy * 2 + (size_t)(j0 + c * 8) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdY, (__attribute__((address_space(3))) void*)(sY + inst * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+  };
+
+  // transposing reads: lane (g = lane >> 4, t = lane & 15) addresses token row 8 g + (t >> 2) (+ 4 for the second read) and the
+  // 8-byte piece t & 3 of the fragment's 16 columns; it receives column t, tokens 8 g .. 8 g + 7
+  const int g = lane >> 4, t = lane & 15;
+  const int row = 8 * g + (t >> 2);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  uint32_t offx[II], offy[JJ], offx4[II], offy4[JJ];
+#pragma unroll
+  for (int a = 0; a < II; ++a) {
+    const int col = wi * WTI + 16 * a + 4 * (t & 3);
+    offx[a] = lds0 + row * XROW + (((col >> 3) ^ swz(row)) << 4) + ((col & 7) << 1);
+    offx4[a] = lds0 + (row + 4) * XROW + (((col >> 3) ^ swz(row + 4)) << 4) + ((col & 7) << 1);
+  }
+#pragma unroll
+  for (int b = 0; b < JJ; ++b) {
+    const int col = wj * WTJ + 16 * b + 4 * (t & 3);
+    offy[b] = lds0 + X_BYTES + row * YROW + (((col >> 3) ^ swz(row)) << 4) + ((col & 7) << 1);
+    offy4[b] = lds0 + X_BYTES + (row + 4) * YROW + (((col >> 3) ^ swz(row + 4)) << 4) + ((col & 7) << 1);
+  }
+
+  f32x4 acc[II][JJ];
+#pragma unroll
+  for (int a = 0; a < II; ++a)
+#pragma unroll
+    for (int b = 0; b < JJ; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bf16x4 xl[IH], xh[IH], yl[JJ], yh[JJ];
+#define SAVIT_TR_READ(dst, addr) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr))
+  auto compute = [&](auto half_c) {  // between two barriers: wait for this wave's fragments, then its IH x JJ MFMAs at raised priority
+    constexpr int HALF = decltype(half_c)::value;
+#pragma unroll
+    for (int a = 0; a < IH; ++a) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xl[a]), "+v"(xh[a]));
+#pragma unroll
+    for (int b = 0; b < JJ; ++b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yl[b]), "+v"(yh[b]));
+    bf16x8 xa[IH], yb[JJ];
+#pragma unroll
+    for (int a = 0; a < IH; ++a) xa[a] = __builtin_shufflevector(xl[a], xh[a], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+    for (int b = 0; b < JJ; ++b) yb[b] = __builtin_shufflevector(yl[b], yh[b], 0, 1, 2, 3, 4, 5, 6, 7);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int a = 0; a < IH; ++a)
+#pragma unroll
+      for (int b = 0; b < JJ; ++b)
+        acc[HALF * IH + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[a], yb[b], acc[HALF * IH + a][b], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  const int pre = NS < S ? NS : S;
+  for (int st = 0; st < pre; ++st) stage(st, st);
+  if (pre == S) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (S - 1)) : "memory");  // stage 0
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wi == 1) __builtin_amdgcn_s_barrier();  // row half 1 runs one barrier behind row half 0
+
+  int slot = 0;
+  for (int st = 0; st < NS; ++st) {
+    const uint32_t cur_off = (uint32_t)(slot * STAGE);
+    // ---- L0: the dY fragments and the first half of the X fragments
+#pragma unroll
+    for (int b = 0; b < JJ; ++b) {
+      SAVIT_TR_READ(yl[b], offy[b] + cur_off);
+      SAVIT_TR_READ(yh[b], offy4[b] + cur_off);
+    }
+#pragma unroll
+    for (int a = 0; a < IH; ++a) {
+      SAVIT_TR_READ(xl[a], offx[a] + cur_off);
+      SAVIT_TR_READ(xh[a], offx4[a] + cur_off);
+    }
+    __builtin_amdgcn_s_barrier();
+    // ---- C0
+    compute(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_s_barrier();
+    // ---- L1: the second half of the X fragments; refill the slot of stage st-1; this wave's share of stage st+1 must have landed
+#pragma unroll
+    for (int a = 0; a < IH; ++a) {
+      SAVIT_TR_READ(xl[a], offx[IH + a] + cur_off);
+      SAVIT_TR_READ(xh[a], offx4[IH + a] + cur_off);
+    }
+    if (st >= 1 && st - 1 + S < NS) stage(st - 1 + S, slot == 0 ? S - 1 : slot - 1);
+    if (st - 1 + S < NS) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (S - 2)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    // ---- C1
+    compute(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_s_barrier();
+    slot = (slot + 1 == S) ? 0 : slot + 1;
+  }
+  if (wi == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count
+#undef SAVIT_TR_READ
+
+  // dW += tile (the tile IS the whole sum over the tokens).  Accumulator (a, b): lane = (column j = lane & 15, rows 4 (lane >> 4) ..
+  // + 3): one register = 16 lanes x 4 B = a 64-B row segment; once per tile over hundreds of stages
+  const int jl = lane & 15, i4 = 4 * (lane >> 4);
+#pragma unroll
+  for (int a = 0; a < II; ++a) {
+    float old[JJ][4];
+#pragma unroll
+    for (int b = 0; b < JJ; ++b) {
+      const int j = j0 + wj * WTJ + 16 * b + jl;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wi * WTI + 16 * a + i4 + r;
+        old[b][r] = (i < p.Kin && j < p.Nout) ? p.dW[(size_t)i * p.lddw + j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < JJ; ++b) {
+      const int j = j0 + wj * WTJ + 16 * b + jl;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wi * WTI + 16 * a + i4 + r;
+        if (i < p.Kin && j < p.Nout) p.dW[(size_t)i * p.lddw + j] = old[b][r] + acc[a][b][r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Grouped launch: the weight gradients of SEVERAL Dense kernels (the four of an encoder layer, of one or more layers) in ONE grid,
 // one workgroup per 256 x 256 (or 128 x 128) output tile, each reducing over ALL tokens.  A single weight gradient has too few
 // output tiles for the chip (DeiT-B's W1: 36 tiles of 256 x 256 on 256 CUs), which is why the single-problem launch splits the
@@ -676,7 +872,7 @@ struct WgradGroupParams {
   } pr[WGRAD_GROUP_MAX];
 };
 
-template <int BI, int BJ, int WGI, int WGJ, int S>
+template <int BI, int BJ, int WGI, int WGJ, int S, int MF = 32>  // MF: MFMA shape of the tile (16 = 16x16x32 ping-pong, 32 = 32x32x16)
 __global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_group_kernel(const WgradGroupParams g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware: each XCD takes a contiguous run of the tile list (problem-major, then row tile, then column tile), i.e. tiles that
@@ -695,7 +891,9 @@ __global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_group_kernel(con
   p.tiles_per_split = (p.M + 31) / 32;
   p.rmw = 1;
   const int ti = t / p.tiles_j;
-  if constexpr (BI == 256)
+  if constexpr (MF == 16)
+    wgrad_pp16_tile<BI, BJ, WGI, WGJ, S>(p, ti, t - ti * p.tiles_j, smem);
+  else if constexpr (BI == 256 || BJ == 384)
     wgrad_pp_tile<BI, BJ, WGI, WGJ, S>(p, ti, t - ti * p.tiles_j, smem);
   else
     wgrad_ring_tile<BI, BJ, WGI, WGJ, S, false>(p, 0, ti, t - ti * p.tiles_j, smem);
@@ -930,13 +1128,26 @@ static int wgrad_dispatch(const void* X, const void* dY, float* dW, int M, int K
 }
 
 // ---- grouped weight gradients (see gemm_wgrad_group_kernel)
+// tile codes of the grouped launch: 256 = 256 x 256, 128 = 128 x 128, 384 = 128 (Kin) x 384 (Nout) - the d = 384 models, whose matrices
+// (384 x 1152, 384 x 384, 384 x 1536, 1536 x 384) it covers exactly (256 x 256 tiles: 71 % of a launch inside a matrix)
+static bool group_tile_shape(int tile, int* bi, int* bj) {
+  switch (tile) {
+    case 128: *bi = 128; *bj = 128; return true;
+    case 256: *bi = 256; *bj = 256; return true;
+    case 384: *bi = 128; *bj = 384; return true;
+    default: return false;
+  }
+}
+
 extern "C" int savit_gemm_wgrad_group_tiles(int Kin, int Nout, int tile) {
-  if (Kin <= 0 || Nout <= 0 || (tile != 128 && tile != 256)) return 0;
-  return ((Kin + tile - 1) / tile) * ((Nout + tile - 1) / tile);
+  int bi, bj;
+  if (Kin <= 0 || Nout <= 0 || !group_tile_shape(tile, &bi, &bj)) return 0;
+  return ((Kin + bi - 1) / bi) * ((Nout + bj - 1) / bj);
 }
 
 extern "C" int savit_gemm_bf16_wgrad_grouped(const savit_wgrad_problem* problems, int count, int tile, void* stream) {
-  SAVIT_CHECK_ARG(problems != nullptr && count >= 1 && count <= WGRAD_GROUP_MAX && (tile == 128 || tile == 256));
+  int tile_bi, tile_bj;
+  SAVIT_CHECK_ARG(problems != nullptr && count >= 1 && count <= WGRAD_GROUP_MAX && group_tile_shape(tile, &tile_bi, &tile_bj));
   WgradGroupParams g{};
   int tiles = 0, n = 0;
   for (int i = 0; i < count; ++i) {
@@ -965,9 +1176,16 @@ extern "C" int savit_gemm_bf16_wgrad_grouped(const savit_wgrad_problem* problems
                          // fill its 4 MB L2 (4 x 32 KB x 32 = 4 MB), and panels shared between workgroups are evicted before their second
                          // reader arrives: FETCH_SIZE 1.96 -> 1.71 GB per 216-tile launch, 0.787 -> 0.764 ms per launch in the step
 #endif
-    auto kfn = gemm_wgrad_group_kernel<256, 256, 2, 4, WGRAD_GROUP_S>;
+#ifndef WGRAD_GROUP_MF
+#define WGRAD_GROUP_MF 32  // MFMA shape of the grouped tiles (16: the 16x16x32 form, measured 11 % slower - A/B builds: tools/build_variant.sh)
+#endif
+    auto kfn = gemm_wgrad_group_kernel<256, 256, 2, 4, WGRAD_GROUP_S, WGRAD_GROUP_MF>;
     SAVIT_LDS_ONCE(kfn);
     hipLaunchKernelGGL(kfn, dim3(tiles), dim3(512), (size_t)WGRAD_GROUP_S * 32 * (256 + 256) * 2, (hipStream_t)stream, g);
+  } else if (tile == 384) {
+    auto kfn = gemm_wgrad_group_kernel<128, 384, 2, 4, 3, WGRAD_GROUP_MF>;
+    SAVIT_LDS_ONCE(kfn);
+    hipLaunchKernelGGL(kfn, dim3(tiles), dim3(512), (size_t)3 * 32 * (128 + 384) * 2, (hipStream_t)stream, g);
   } else {
     auto kfn = gemm_wgrad_group_kernel<128, 128, 2, 2, 4>;
     SAVIT_LDS_ONCE(kfn);

@@ -16,6 +16,21 @@ import torch
 import torch.distributed as dist
 
 
+def default_reserved_cus(world: int) -> int:
+    """CUs a rank plans to leave to the resident RCCL all-reduce during backward (engine `reserved_cus`): 0 alone, 16 of the 256
+    in a data-parallel job unless SAVIT_RESERVED_CUS says otherwise.  Why plan at all (tools/cu_thief_probe.py, profiles/r04_cu_thief.log:
+    a stand-in that holds n CUs for the length of the step, DeiT-B/16 at 128 images): with 16 CUs taken the step is 16 % slower when
+    the launch plan assumes the whole chip (a grid of one tile per CU runs a second, nearly empty round) and 8 % slower when it was
+    planned for 240 CUs; with 32 taken 24 % against 16 % - about the share of the chip that is gone.  How many CUs RCCL's channels
+    really hold on an 8 x MI355X node is unmeasured (no such node was available): the driver's scaling run is where this default
+    gets checked."""
+    import os
+
+    if os.environ.get("SAVIT_RESERVED_CUS"):
+        return int(os.environ["SAVIT_RESERVED_CUS"])
+    return 16 if world > 1 else 0
+
+
 def plan_buckets(layer_starts: List[int], final_start: int, total: int, min_bucket_elems: int) -> List[Tuple[int, int, str]]:
     """Buckets in the order backward completes them: [(start, end, trigger_label)].  trigger_label names the
     backward launch after which the slice is final: 'l{i}.ln1.bwd' closes layer i, 'Wpe.wgrad' closes the

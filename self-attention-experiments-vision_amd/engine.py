@@ -293,7 +293,7 @@ def add_wgrad_group(eng, plan: _Plan, label: str, entries: list, tile: int, defe
     flops = 0.0
     for q, ((X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw), t0, tc) in zip(arr, entries):
         q.X, q.dY, q.dW, q.M, q.Kin, q.Nout, q.ldx, q.lddy, q.lddw, q.tile_begin, q.tile_count = X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, t0, tc
-        flops += 2.0 * Mr * Kin * Nout * tc / (-(-Kin // tile) * -(-Nout // tile))  # the weight's flops, by its share of tiles in this launch
+        flops += 2.0 * Mr * Kin * Nout * tc / int(eng.L.savit_gemm_wgrad_group_tiles(Kin, Nout, tile))  # the weight's flops, by its share of tiles in this launch
     plan.keep.append(arr)
     plan.add(eng.L.savit_gemm_bf16_wgrad_grouped, (arr, len(entries), tile), label, side=side,
              reads=tuple(sorted({e[0][1] for e in entries})) if side else ())
@@ -304,14 +304,29 @@ def add_wgrad_group(eng, plan: _Plan, label: str, entries: list, tile: int, defe
     eng.group_flops[label] = flops
 
 
+def wgrad_group_tile(d: int, F: int) -> int:
+    """Tile code of the grouped weight-gradient launches for a model of width d / hidden width F: 256 x 256 where the matrices are
+    multiples of it (DeiT-B, ViT-L), 128 x 384 for the d = 384 models (DeiT-S, CaiT-S: every matrix is a whole number of those tiles;
+    with 256 x 256 tiles 29 % of a launch hung over the matrix edges), else 256 x 256 with edge tiles."""
+    if d % 256 == 0 and F % 256 == 0:
+        return 256
+    if d % 384 == 0 and F % 384 == 0:
+        return 384
+    return 256
+
+
 class WgradQueue:
-    """FIFO of weight-gradient output tiles waiting for a grouped launch.  A launch takes exactly `cap` tiles (one per CU: a full
-    round of workgroups), cutting a weight between two launches where it must; what is left at the end goes out as the last launch."""
+    """FIFO of weight-gradient output tiles waiting for a grouped launch.  A launch takes exactly `cap` tiles (one per CU the rank
+    may count on: a full round of workgroups), cutting a weight between two launches where it must; what is left at the end goes out
+    as the last launch.  max_lag (layers, None = unbounded): a launch also goes out, as a partial round, once the oldest waiting
+    gradient is that many layers behind - it bounds how far a data-parallel bucket trigger is deferred and how deep the cotangent rings
+    must be (narrow models fill a round only every 6-15 layers)."""
 
     MAX_ENTRIES = 64  # savit_gemm_bf16_wgrad_grouped takes at most this many (weight, tile range) entries per launch
 
-    def __init__(self, cap: int):
+    def __init__(self, cap: int, max_lag: Optional[int] = None):
         self.cap = cap
+        self.max_lag = max_lag
         self.items: List[list] = []  # [problem, layer, tiles, next tile]
 
     def push(self, problem, layer: int, tiles: int):
@@ -320,9 +335,12 @@ class WgradQueue:
     def pending(self) -> int:
         return sum(it[2] - it[3] for it in self.items)
 
-    def due(self) -> bool:
-        """A launch's worth is waiting: a full round of tiles, or as many entries as one launch takes (narrow models)."""
-        return self.pending() >= self.cap or len(self.items) >= self.MAX_ENTRIES
+    def due(self, layer: Optional[int] = None) -> bool:
+        """A launch's worth is waiting: a full round of tiles, as many entries as one launch takes (narrow models), or - with
+        max_lag - a gradient that has waited max_lag layers (backward is at `layer`, counting down)."""
+        if self.pending() >= self.cap or len(self.items) >= self.MAX_ENTRIES:
+            return True
+        return self.max_lag is not None and layer is not None and bool(self.items) and self.items[0][1] - layer >= self.max_lag
 
     def take(self, n: int):
         """-> (entries [(problem, tile_begin, tile_count)], layers whose LAST pending tile is in this launch, oldest layer touched)"""
@@ -366,7 +384,11 @@ def finalize_wgrad_ws(eng, plan: _Plan):
 class ViTEngine:
     DEFAULT_OVERLAP = False  # weight gradients on a side stream? (see _init_step_state)
 
-    def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True):
+    def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True,
+                 reserved_cus: Optional[int] = None, wgrad_max_lag: Optional[int] = None):
+        """reserved_cus: CUs this rank leaves to a resident RCCL all-reduce (train.py:96) - grids are then planned for the remaining
+        ones (default: SAVIT_RESERVED_CUS, else 0; ddp.default_reserved_cus(world) is what bench.py / train.py pass at world > 1).
+        wgrad_max_lag: bound, in layers, on how long a weight gradient waits for a full grouped launch (WgradQueue)."""
         if cfg.kind != "vit":
             raise NotImplementedError("ViTEngine handles the ViT family; CaiT uses CaiTEngine")
         if cfg.head_dim not in (48, 64):
@@ -382,6 +404,7 @@ class ViTEngine:
         self.B = int(batch)
         self.dev = torch.device(device)
         self.rp = int(round_like_reference)
+        self._init_cu_budget(reserved_cus, wgrad_max_lag)
         self.layout = ParamLayout(cfg)
         d, F, C, N, NL = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers
         self.M = self.B * N
@@ -428,13 +451,28 @@ class ViTEngine:
         self.d_o = e(M, d, dt=bf16)
         self.dqkv_ring = [e(M, 3 * d, dt=bf16) for _ in range(depth)]
         self.dqkv = self.dqkv_ring[0]
-        self.colsum_slab = e(max(1, self.L.savit_gemm_colsum_rows(M, F, d, 0)), F)
+        self.colsum_slab = e(max(1, self.L.savit_gemm_colsum_rows_cus(M, F, d, 0, self.cu_budget if self.reserved_cus else 0)), F)
         self.d_z = e(self.B, d, dt=bf16)
         ws = self.L.savit_layernorm_bwd_workspace_bytes(M, d)
         self.ln_ws = torch.empty(max(int(ws), 16), dtype=torch.uint8, device=self.dev)
         self._init_step_state()
 
     # ---- state every engine of this package shares (the Mixer / TNT engines subclass this one and lay out their own activations)
+    def _init_cu_budget(self, reserved_cus: Optional[int], wgrad_max_lag: Optional[int]):
+        """CUs the launch plans may count on.  Everything that sizes a grid for "one round of workgroups" reads cu_budget: the grouped
+        weight-gradient launches (WgradQueue cap) and the TN GEMM tile choice (savit_gemm_args.cu_budget)."""
+        self.n_cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        if reserved_cus is None:
+            reserved_cus = int(os.environ.get("SAVIT_RESERVED_CUS", "0"))
+        if not 0 <= int(reserved_cus) < self.n_cus:
+            raise ValueError(f"reserved_cus must be in [0, {self.n_cus})")
+        self.reserved_cus = int(reserved_cus)
+        self.cu_budget = self.n_cus - self.reserved_cus
+        self._building_bwd = False  # set while a backward plan is recorded: only its launches run beside the all-reduce
+        if wgrad_max_lag is None and os.environ.get("SAVIT_WGRAD_MAX_LAG"):
+            wgrad_max_lag = int(os.environ["SAVIT_WGRAD_MAX_LAG"])
+        self.wgrad_max_lag = wgrad_max_lag
+
     def _init_flat_buffers(self):
         """Parameters, gradients, optimizer state: flat fp32 buffers in the layout's order (Adam moments allocated on first use)."""
         self.params = torch.zeros(self.layout.total, dtype=f32, device=self.dev)
@@ -470,7 +508,6 @@ class ViTEngine:
         self.overlap_wgrad = os.environ.get("SAVIT_OVERLAP_WGRAD", "1" if self.DEFAULT_OVERLAP else "0") != "0"
         self.n_side_streams = int(os.environ.get("SAVIT_SIDE_STREAMS", "1"))
         self.wgrad_cu_share = float(os.environ.get("SAVIT_WGRAD_CU_SHARE", "0.56"))
-        self.n_cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
         self._side_streams: List[torch.cuda.Stream] = []
         self._building_serial = False
         self._bwd_plan_serial: Optional[_Plan] = None  # every launch sized for the whole chip: profile_step / one-stream runs
@@ -526,6 +563,7 @@ class ViTEngine:
         if not a.rows_per_sample:
             a.rows_per_sample = 1
         a.round_bias_bf16 = self.rp
+        a.cu_budget = self.cu_budget if (self.reserved_cus and self._building_bwd) else 0  # the all-reduce is resident during backward only
         plan.keep.append(a)
         plan.add(self.L.savit_gemm_bf16_tn, (ctypes.byref(a),), label, writes=writes)
 
@@ -578,13 +616,20 @@ class ViTEngine:
         return P
 
     def _build_bwd_plan(self) -> _Plan:
+        self._building_bwd = True
+        try:
+            return self._record_bwd_plan()
+        finally:
+            self._building_bwd = False
+
+    def _record_bwd_plan(self) -> _Plan:
         P, L, cfg = _Plan(), self.L, self.cfg
         d, F, C, N, NL, H, B, M = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers, cfg.num_heads, self.B, self.M
         pp = lambda n: self._off_ptr(self.params, n)  # noqa: E731
         gp = lambda n: self._off_ptr(self.grads, n)  # noqa: E731
         ws, wsb = self.ln_ws.data_ptr(), self.ln_ws.numel()
 
-        queue = WgradQueue(self.wgrad_cap) if self.wgrad_tile else None
+        queue = WgradQueue(self.wgrad_cap, self.wgrad_max_lag) if self.wgrad_tile else None
         n_launch = [0]
 
         def wgrad(label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0), layer=None):
@@ -598,7 +643,7 @@ class ViTEngine:
             # called between a layer's last input-gradient GEMM and its ln1.bwd (which overwrites the oldest ring slot): every
             # cotangent of the last `wgrad_lag` + 1 layers is still intact.  A launch takes one tile per CU; the DDP trigger
             # ('l{j}.ln1.bwd') of an EARLIER layer whose last tile is in it fires behind it, the current layer's own follows naturally.
-            while queue is not None and queue.pending() > 0 and (queue.due() or last):
+            while queue is not None and queue.pending() > 0 and (queue.due(layer) or last):
                 entries, done, oldest = queue.take(queue.cap)
                 assert oldest - layer <= self.wgrad_lag, "weight-gradient queue reaches back further than the cotangent rings"
                 add_wgrad_group(self, P, f"wgrad.group.{n_launch[0]}.l{oldest}-l{layer}", entries, self.wgrad_tile,
@@ -673,10 +718,10 @@ class ViTEngine:
         env = os.environ.get("SAVIT_WGRAD_GROUP", "auto")
         if env == "0" or d % 8 or F % 8:
             return 0, 0, frozenset(), 0
-        tile = 256
+        tile = wgrad_group_tile(d, F)
         sizes = [(n, int(self.L.savit_gemm_wgrad_group_tiles(a, b, tile))) for n, a, b in (("W2", F, d), ("W1", d, F), ("Wo", d, d), ("Wqkv", d, 3 * d))]
         per_layer = sum(t for _, t in sizes)
-        cap = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        cap = self.cu_budget
         total = NL * per_layer
         rounds = -(-total // cap)
         need = total - (rounds - 1) * cap  # tiles in the last, partial round
@@ -685,12 +730,12 @@ class ViTEngine:
         if rounds >= 2 and need <= 0.12 * cap and -(-need // wo) <= NL:
             divert = frozenset(range(-(-need // wo)))  # the layers processed LAST (0, 1, ...): their d x d gradients run per weight
         # dry run of the queue: how many layers does a launch reach back?
-        q, lag = WgradQueue(cap), 0
+        q, lag = WgradQueue(cap, self.wgrad_max_lag), 0
         for l in range(NL - 1, -1, -1):
             for n, t in sizes:
                 if not (n == "Wo" and l in divert):
                     q.push(None, l, t)
-            while q.pending() > 0 and (q.due() or l == 0):
+            while q.pending() > 0 and (q.due(l) or l == 0):
                 _, _, oldest = q.take(cap)
                 lag = max(lag, oldest - l)
         return tile, cap, divert, lag

@@ -25,7 +25,7 @@ class GemmArgs(Structure):
         ("epilogue", c_int), ("alpha", c_float), ("alpha_cols", c_int), ("rows_per_sample", c_int),
         ("round_out_bf16", c_int), ("round_bias_bf16", c_int),
         ("img_size", c_int), ("patch", c_int), ("tokens", c_int), ("token_offset", c_int),
-        ("tile", c_int), ("colsum_rows", c_int),
+        ("tile", c_int), ("colsum_rows", c_int), ("cu_budget", c_int),
     ]
 
 
@@ -62,7 +62,9 @@ _SIGNATURES = {
     "savit_gemm_bf16_tn": (c_int, [POINTER(GemmArgs), c_void_p]),
     "savit_gemm_tn_auto_tile": (c_int, [c_int, c_int, c_int]),
     "savit_gemm_tn_auto_tile_epi": (c_int, [c_int, c_int, c_int, c_int]),
+    "savit_gemm_tn_auto_tile_cus": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "savit_gemm_colsum_rows": (c_int, [c_int, c_int, c_int, c_int]),
+    "savit_gemm_colsum_rows_cus": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "savit_colsum_finalize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "savit_gemm_wgrad_auto_variant": (c_int, [c_int, c_int, c_int]),
     "savit_gemm_bf16_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

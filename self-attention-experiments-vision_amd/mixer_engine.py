@@ -113,7 +113,8 @@ class MixerEngine(ViTEngine):
 
     DEFAULT_OVERLAP = True  # many small launches: the side stream still pays (engine.ViTEngine._init_step_state)
 
-    def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True):
+    def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True,
+                 reserved_cus=None, wgrad_max_lag=None):
         if cfg.kind != "mixer":
             raise NotImplementedError("MixerEngine handles the MLP-Mixer family")
         if cfg.embed_dim % 64 != 0 or cfg.patch % 8 != 0 or cfg.num_classes % 8 != 0:
@@ -125,6 +126,7 @@ class MixerEngine(ViTEngine):
         self.B = int(batch)
         self.dev = torch.device(device)
         self.rp = int(round_like_reference)
+        self._init_cu_budget(reserved_cus, wgrad_max_lag)
         self.layout = MixerLayout(cfg)
         d, F, C, n, NL = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.n_patches, cfg.num_layers
         Lp, Fp = self.layout.Lp, self.layout.Fp
@@ -167,8 +169,8 @@ class MixerEngine(ViTEngine):
         self.d_tu_ring = [e(Md, Fp, dt=bf16) for _ in range(depth)]
         self.dhT = e(Md, Lp, dt=bf16)
         self.d_h = e(M, d, dt=bf16)
-        self.colsum_slab = e(max(1, self.L.savit_gemm_colsum_rows(M, F, d, 0)), F)
-        self.tcolsum_slab = e(max(1, self.L.savit_gemm_colsum_rows(Md, Fp, Lp, 0)), Fp)
+        self.colsum_slab = e(max(1, self.L.savit_gemm_colsum_rows_cus(M, F, d, 0, self.cu_budget if self.reserved_cus else 0)), F)
+        self.tcolsum_slab = e(max(1, self.L.savit_gemm_colsum_rows_cus(Md, Fp, Lp, 0, self.cu_budget if self.reserved_cus else 0)), Fp)
         self.trowsum_slab = z(max(1, self.L.savit_transpose_rowsum_rows(self.B, d)), Lp)  # pad columns stay zero
         self.d_z = e(self.B, d, dt=bf16)
         ws = self.L.savit_layernorm_bwd_workspace_bytes(M, d)
@@ -260,7 +262,7 @@ class MixerEngine(ViTEngine):
                    lda=d, ldb=d, ldc=C, epilogue=_lib.EPI_F32, round_out_bf16=self.rp)
         return P
 
-    def _build_bwd_plan(self) -> _Plan:
+    def _record_bwd_plan(self) -> _Plan:
         P, L, cfg, lay = _Plan(), self.L, self.cfg, self.layout
         d, F, C, n, NL, B, M, Md = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.n_patches, cfg.num_layers, self.B, self.M, self.Md
         Lp, Fp = lay.Lp, lay.Fp

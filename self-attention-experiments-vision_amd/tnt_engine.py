@@ -138,7 +138,8 @@ class TNTEngine(ViTEngine):
 
     DEFAULT_OVERLAP = True  # many small launches: the side stream still pays (engine.ViTEngine._init_step_state)
 
-    def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True):
+    def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True,
+                 reserved_cus=None, wgrad_max_lag=None):
         if cfg.kind != "tnt":
             raise NotImplementedError("TNTEngine handles the TNT family")
         if cfg.head_dim != 64 or cfg.embed_dim % 64 or cfg.num_classes % 8 or cfg.patch % 8:
@@ -153,6 +154,7 @@ class TNTEngine(ViTEngine):
         self.B = int(batch)
         self.dev = torch.device(device)
         self.rp = int(round_like_reference)
+        self._init_cu_budget(reserved_cus, wgrad_max_lag)
         self.layout = lay = TNTLayout(cfg)
         do, Fo, C, N, NL, n, npx = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers, cfg.n_patches, cfg.n_pixels
         Fi, dap = lay.Fi, lay.dap
@@ -226,8 +228,8 @@ class TNTEngine(ViTEngine):
         self.idqkv_ring = [e(Mi, 3 * dap, dt=bf16) for _ in range(depth)]
         self.id_h = e(Mi, di, dt=bf16)
         self.id_o = e(Mi, dap, dt=bf16)
-        self.colsum_slab = e(max(1, self.L.savit_gemm_colsum_rows(Mo, Fo, do, 0)), Fo)
-        self.icolsum_slab = e(max(1, self.L.savit_gemm_colsum_rows(Mi, Fi, Kpi, 0)), Fi)
+        self.colsum_slab = e(max(1, self.L.savit_gemm_colsum_rows_cus(Mo, Fo, do, 0, self.cu_budget if self.reserved_cus else 0)), Fo)
+        self.icolsum_slab = e(max(1, self.L.savit_gemm_colsum_rows_cus(Mi, Fi, Kpi, 0, self.cu_budget if self.reserved_cus else 0)), Fi)
         self.d_z = e(self.B, do, dt=bf16)
         ws = max(self.L.savit_layernorm_bwd_workspace_bytes(Mo, do), self.L.savit_layernorm_bwd_workspace_bytes(Mi, di))
         self.ln_ws = torch.empty(max(int(ws), 16), dtype=torch.uint8, device=self.dev)
@@ -368,7 +370,7 @@ class TNTEngine(ViTEngine):
                    lda=do, ldb=do, ldc=C, epilogue=_lib.EPI_F32, round_out_bf16=self.rp)
         return P
 
-    def _build_bwd_plan(self) -> _Plan:
+    def _record_bwd_plan(self) -> _Plan:
         P, L, cfg, lay = _Plan(), self.L, self.cfg, self.layout
         do, Fo, C, N, NL, Ho, B = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers, cfg.num_heads, self.B
         di, Hi, npx, n = cfg.inner_embed_dim, cfg.inner_num_heads, cfg.n_pixels, cfg.n_patches

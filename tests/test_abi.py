@@ -116,6 +116,56 @@ def test_product_library_has_no_experiment_switches(built):
             assert "getenv" not in s, f"{f}: getenv in the library"
 
 
+def test_every_compiled_tn_tile_is_reachable_from_the_auto_heuristic(built):
+    """libsavit.so holds no GEMM tile nobody selects.  tests/golden/gemm_shapes.json lists every TN GEMM the engines
+    of the four families launch (tools/dump_gemm_shapes.py, run on the GPU box: ViT-Ti/S/B/L, CaiT-S24/XXS24, Mixer-B/16, S/32, TNT-S/B at
+    the bench batch sizes); the kernel families compiled into gemm_tn.o must be exactly the tiles savit_gemm_tn_auto_tile_cus returns for
+    them (whole device and with 32 CUs reserved for a resident all-reduce), and every other tile id is rejected."""
+    import json
+    import shutil
+    import subprocess
+    import tempfile
+
+    L = built.lib.load()
+    shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "gemm_shapes.json")))
+    reach = set()
+    for v in shapes.values():
+        for M, N, K, epi, alias in v["shapes"]:
+            for cus in (0, 224):
+                t = L.savit_gemm_tn_auto_tile_cus(M, N, K, epi, cus)
+                reach.add(13 if (t in (20, 21) and alias) else t)  # the ping-pong kernels do not take aliased rows: savit_gemm_bf16_tn falls back
+    family = {"gemm_tn_ring_kernel<128, 128, 2, 2, 4,": 6, "gemm_tn_pair_kernel<128, 128, 2, 2, 2,": 12, "gemm_tn_pair_kernel<256, 256, 2, 4, 2,": 13,
+              "gemm_tn_pair_kernel<192, 128, 2, 2, 2,": 17, "gemm_tn_pair_tail_kernel<192, 128, 128, 2, 2, 2,": 18, "gemm_tn_pp_kernel<": 20,
+              "gemm_tn_pp320_kernel<": 21}
+    assert reach == set(family.values()), sorted(reach)
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(readelf) and os.path.exists(objdump) and shutil.which("c++filt")):
+        pytest.skip("llvm-readelf / c++filt not available")
+    with tempfile.TemporaryDirectory() as d:
+        dst = os.path.join(d, "gemm_tn.o")
+        shutil.copy(os.path.join(ROOT, "self-attention-experiments-vision_amd", "csrc", "gemm_tn.o"), dst)
+        subprocess.run([objdump, "--offloading", dst], check=True, capture_output=True)
+        co = [f for f in os.listdir(d) if "gfx950" in f][0]
+        notes = subprocess.run([readelf, "--notes", os.path.join(d, co)], check=True, capture_output=True, text=True).stdout
+    mangled = re.findall(r"\.name:\s+(\S+)", notes)
+    names = subprocess.run(["c++filt"] + mangled, check=True, capture_output=True, text=True).stdout.splitlines()
+    kernels = sorted({re.sub(r"^void \(anonymous namespace\)::", "", n).split("(")[0] for n in names if "gemm_tn_" in n})
+    assert kernels, "no TN GEMM kernel found in gemm_tn.o"
+    compiled = set()
+    for k in kernels:
+        hit = [t for pre, t in family.items() if k.startswith(pre)]
+        assert len(hit) == 1, f"{k}: a kernel family no tile of the auto heuristic maps to"
+        compiled.add(hit[0])
+    assert compiled == reach, (sorted(compiled), sorted(reach))
+    P = 0x1000
+    a = built.lib.GemmArgs()
+    a.A, a.Bt, a.C, a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.epilogue, a.rows_per_sample = P, P, P, 4096, 4096, 4096, 4096, 4096, 4096, 0, 1
+    for tile in sorted(set(range(1, 40)) - reach):
+        a.tile = tile
+        assert L.savit_gemm_bf16_tn(ctypes.byref(a), None) == 1001, tile
+
+
 def _device_isa(obj_name, tmp_path):
     """Disassemble the gfx950 code object embedded in csrc/<obj_name> (llvm-objdump --offloading extracts next to its input)."""
     import shutil

@@ -42,7 +42,7 @@ def test_symbol_tables_and_dominant_kernel():
     assert sym[plain]["n"] == 48 and abs(sym[plain]["ms"] - 12 * (0.085 + 0.089 + 0.033 + 0.078)) < 1e-9
     assert abs(sym[plain]["flops"] - 12 * 2.0 * M * d * (3 * d + F + d + 3 * d)) < 1.0
     assert sym["gemm_tn_pp320_kernel<1>"]["flops"] == 12 * 2.0 * M * d * F
-    assert sym["gemm_wgrad_group_kernel<256,256,2,4,3>"]["flops"] == 8.0e11
+    assert sym["gemm_wgrad_group_kernel<256,256,2,4,3,32>"]["flops"] == 8.0e11
     assert cls["gemm_tn"]["n"] == 96 and cls["attention_fwd"]["n"] == 12
     assert bench.pick_dominant(sym) == plain  # 3.42 ms against 0.70
     # within 5 % of each other: the kernel with more flops per launch wins, whatever the order

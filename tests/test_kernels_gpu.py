@@ -109,7 +109,12 @@ def _mk(rng, M, K, scale=1.0):
     return rb(rng.standard_normal((M, K)) * scale)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 13, 14, 15, 17, 18, 20, 21])
+# every tile the product library holds (= every tile the auto heuristic can pick: tests/test_abi.py); the earlier rounds' other forms
+# exist in SAVIT_EXPERIMENTS builds only
+PRODUCT_TILES = [6, 12, 13, 17, 18, 20, 21]
+
+
+@pytest.mark.parametrize("tile", PRODUCT_TILES)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 256, 128), (197 * 2, 192 * 3, 192), (591, 768, 768), (1000, 384, 1536),
                                    (37, 1000, 192), (300, 64, 128)])
 def test_gemm_bf16_plain(ops, tile, M, N, K):
@@ -151,7 +156,7 @@ def test_gemm_qkv_alpha_and_strided_views(ops):
     assert float(Cw[:, :d].abs().max()) == 0 and float(Cw[:, 2 * d:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("tile", [1, 2, 4, 7, 10, 11, 12, 13, 17, 18, 20, 21])
+@pytest.mark.parametrize("tile", PRODUCT_TILES)
 def test_gemm_bias_gelu(ops, tile):
     rng = np.random.default_rng(6)
     M, d, F = 197 * 3, 192, 768
@@ -168,7 +173,7 @@ def test_gemm_bias_gelu(ops, tile):
     assert np.abs(host(Aact) - a_ref).max() <= 2 ** -7 * max(1.0, np.abs(a_ref).max())
 
 
-@pytest.mark.parametrize("tile", [1, 2, 4, 7, 10, 11, 12, 13, 17, 18, 20, 21])
+@pytest.mark.parametrize("tile", PRODUCT_TILES)
 def test_gemm_residual_layerscale_stochdepth(ops, tile):
     rng = np.random.default_rng(7)
     B, N, d, F = 3, 197, 192, 768
@@ -208,7 +213,7 @@ def test_gemm_dgelu_and_colsum(ops):
     assert rel(host(cs), host(dU).astype(np.float64).sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("tile", [0, 12, 13, 17, 3, 20, 21])
+@pytest.mark.parametrize("tile", [0, 6, 12, 13, 17, 20, 21])
 def test_gemm_dgelu_colsum_slab_is_deterministic(ops, tile):
     """colsum as a [rows, N] slab of per-row-tile partials + savit_colsum_finalize: same sums as the atomic form, and bitwise
     reproducible (no atomics)."""
@@ -309,33 +314,6 @@ def test_gemm_large_grid_tiles_vs_oracle_and_each_other(ops, epi, M, N, K):
         assert torch.equal(got[17][0], got[13][0])  # 192x128 and 256x256 tiles also agree bit for bit (same K order)
 
 
-@pytest.mark.parametrize("epi", [0, 1, 3])
-@pytest.mark.parametrize("M,N,K", [(19700, 1536, 768), (3001, 1024, 576), (300, 128, 1024), (25216, 2304, 768), (6000, 768, 2304),
-                                   (777, 3072, 640)])
-def test_gemm_stream_tile(ops, epi, M, N, K):
-    """Tile 30 - the persistent 256 x 128 kernel that drains tile t's epilogue between the MFMAs of tile t + 1 - on its three
-    epilogues (qkv: scaled columns, no bias; fc1: bias + GELU, two outputs; fc2 input gradient: GELU' x cotangent + column-sum
-    slab): against exact fp64 math on the same bf16 operands and BITWISE against the 256 x 256 pair kernel (tile 13, same K order).
-    Shapes: K-loops of 9, 10, 12, 16 and 36 K-tiles (every pattern of chunk pairs next to / apart from each other), a ragged last row
-    tile, fewer tiles than CUs, one column tile, and seven tiles per workgroup (the continuous pipeline across tile boundaries)."""
-    got = {}
-    for tile in (13, 30):
-        outs, want = _epi_case(ops, 77 * epi + K, M, N, K, epi, tile, plain_bias=False)
-        assert all(torch.isfinite(o.float()).all() for o in outs), (tile, "an output element was not written")
-        e = rel(host(outs[0]), want)
-        assert e < 1e-3, (tile, e)
-        got[tile] = outs
-    for i, (x, y) in enumerate(zip(got[13], got[30])):
-        if epi == 3 and i == 1:
-            assert rel(host(x).sum(0), host(y).sum(0)) < 1e-6  # slabs of different heights: compare the column sums
-        else:
-            assert torch.equal(x, y), (i, int((x != y).sum()))
-    # the same launch again: bitwise repeatable
-    outs2, _ = _epi_case(ops, 77 * epi + K, M, N, K, epi, 30, plain_bias=False)
-    for x, y in zip(got[30], outs2):
-        assert torch.equal(x, y)
-
-
 def test_gemm_f32_head(ops):
     rng = np.random.default_rng(9)
     B, d, C = 37, 192, 1000
@@ -407,7 +385,7 @@ def test_wgrad_slab_reduction(ops, M, Kin, Nout, splits):
     assert rel(host(dW2) - host(base), ref) < 2e-5
 
 
-@pytest.mark.parametrize("tile", [256, 128])
+@pytest.mark.parametrize("tile", [256, 128, 384])
 def test_wgrad_grouped_matches_fp64_and_is_reproducible(ops, tile):
     """savit_gemm_bf16_wgrad_grouped: several weight gradients in one launch, one workgroup per output tile over ALL tokens.  Each
     dW: the fp64 product within fp32 summation error, accumulated onto its old value, bitwise repeatable; ragged Kin / Nout (tiles

@@ -327,3 +327,46 @@ def test_flax_checkpoint_roundtrip(tmp_path, name):
         la, lb = leaves(eng.layout.flax_tree(a_flat)), leaves(eng2.layout.flax_tree(b_flat))
         assert len(la) == len(lb) and all(torch.equal(x, y) for x, y in zip(la, lb))
     assert torch.equal(eng2.forward(img), ref_logits)
+
+
+@pytest.mark.parametrize("name,B", [("vit_s_patch16", 6), ("vit_b_patch16", 4)])
+def test_grouped_and_per_weight_weight_gradients_agree(name, B, monkeypatch):
+    """Engine level: the tile FIFO of grouped launches (128 x 384 tiles for d = 384, 256 x 256 for d = 768; with and without a
+    bound on the reach-back, with CUs reserved for a resident all-reduce) against one launch per weight - same gradients up to fp32
+    summation order, same loss."""
+    from savit_amd.config import get_config
+    from savit_amd.engine import ViTEngine
+
+    cfg = get_config(name)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    img = torch.randn(B, 224, 224, 3, device="cuda", generator=g).to(torch.bfloat16)
+    lab = torch.randint(0, 1000, (B,), device="cuda", generator=g, dtype=torch.int32)
+
+    def grads(**kw):
+        eng = ViTEngine(cfg, B, **kw)
+        eng.init_params(5)
+        eng.layout.view(eng.params, "Wh").copy_(torch.randn(cfg.embed_dim, cfg.num_classes, generator=torch.Generator().manual_seed(1)) * 0.03)
+        eng.forward(img)
+        eng.loss_backward(lab)
+        torch.cuda.synchronize()
+        return eng, eng.grads.clone(), float(eng.loss.item())
+
+    monkeypatch.setenv("SAVIT_WGRAD_GROUP", "0")
+    e0, g0, l0 = grads()
+    assert e0.wgrad_tile == 0
+    monkeypatch.delenv("SAVIT_WGRAD_GROUP")
+    e1, g1, l1 = grads()
+    assert e1.wgrad_tile == (384 if cfg.embed_dim == 384 else 256)
+    e2, g2, l2 = grads(wgrad_max_lag=2, reserved_cus=32)
+    assert e2.wgrad_lag <= 2 and e2.wgrad_cap == e2.n_cus - 32
+    assert l0 == l1 == l2
+    for gg in (g1, g2):
+        for nm in ("l0.Wqkv", "l3.W1", f"l{cfg.num_layers - 1}.W2", "l5.Wo", "Wpe", "pos"):
+            a, b = e0.layout.view(g0, nm), e0.layout.view(gg, nm)
+            assert float((a - b).norm() / a.norm()) < 2e-6, nm
+        assert float((g0 - gg).norm() / g0.norm()) < 2e-6
+    g1b = grads()[1]  # and the grouped form is bitwise repeatable (the per-weight launches of this small batch use fp32 atomics)
+    for l in range(cfg.num_layers):
+        for w in ("Wqkv", "Wo", "W1", "W2"):
+            if not (w == "Wo" and l in e1.wgrad_divert):
+                assert torch.equal(e0.layout.view(g1, f"l{l}.{w}"), e0.layout.view(g1b, f"l{l}.{w}")), (l, w)

@@ -5,13 +5,13 @@ import savit_amd  # noqa: F401
 from savit_amd.engine import WgradQueue, _Plan
 
 
-def _drain(tiles_per_layer, layers, cap):
+def _drain(tiles_per_layer, layers, cap, max_lag=None):
     """The engines' loop: push a layer's weights (processed last layer first), launch while a launch's worth is waiting."""
-    q, launches = WgradQueue(cap), []
+    q, launches = WgradQueue(cap, max_lag), []
     for l in range(layers - 1, -1, -1):
         for w, t in enumerate(tiles_per_layer):
             q.push((l, w), l, t)
-        while q.pending() > 0 and (q.due() or l == 0):
+        while q.pending() > 0 and (q.due(l) or l == 0):
             entries, done, oldest = q.take(q.cap)
             launches.append((l, entries, done, oldest))
     assert q.pending() == 0
@@ -50,6 +50,28 @@ def test_entry_cap_for_narrow_models():
     launches = _drain([3, 3, 1, 3], 24, 256)
     assert all(len(e) <= WgradQueue.MAX_ENTRIES for _, e, _, _ in launches)
     assert sum(sum(c for _, _, c in e) for _, e, _, _ in launches) == 24 * 10
+
+
+def test_max_lag_bounds_the_reach_back_with_partial_rounds():
+    """Narrow models fill a round of 256 tiles only every 6-15 layers: with max_lag a launch goes out, as a partial round,
+    once its oldest gradient has waited that many layers - the bound on deferred data-parallel triggers and on the ring depth."""
+    for sizes, layers in (([3, 3, 1, 3], 24), ([12, 12, 3, 9], 12), ([6, 6, 2, 6], 12)):  # CaiT-XXS, DeiT-S (128 x 384 tiles), ViT-Ti
+        free = _drain(sizes, layers, 256)
+        capped = _drain(sizes, layers, 256, max_lag=3)
+        assert max(o - at for at, _, _, o in free) > 3
+        assert max(o - at for at, _, _, o in capped) <= 3
+        assert sum(sum(c for _, _, c in e) for _, e, _, _ in capped) == layers * sum(sizes)
+        finished = [l for _, _, done, _ in capped for l in done]
+        assert sorted(finished) == list(range(layers))
+    # where full rounds come often enough nothing changes (DeiT-B: lag 3 either way)
+    assert _drain([36, 36, 9, 27], 12, 256, max_lag=3) == _drain([36, 36, 9, 27], 12, 256)
+
+
+def test_reserved_cus_shrink_the_round():
+    """A data-parallel rank leaves CUs to the resident all-reduce: a launch is then one tile per REMAINING CU."""
+    launches = _drain([36, 36, 9, 27], 12, 224)
+    counts = [sum(c for _, _, c in e) for _, e, _, _ in launches]
+    assert counts[:-1] == [224] * (len(counts) - 1) and 0 < counts[-1] <= 224 and sum(counts) == 12 * 108
 
 
 def test_hook_alias_defers_triggers_behind_the_group_launch():

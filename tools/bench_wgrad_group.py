@@ -15,7 +15,7 @@ if os.environ.get("SAVIT_EXP_LIB"):
 
 bf16 = torch.bfloat16
 d, F, M, layers = (int(a) for a in (sys.argv[1:5] if len(sys.argv) >= 5 else (768, 3072, 25216, 2)))
-tile = 256 if d % 256 == 0 and F % 256 == 0 else 128
+tile = int(os.environ.get("SAVIT_GROUP_TILE", "0")) or (256 if d % 256 == 0 and F % 256 == 0 else (384 if d % 384 == 0 and F % 384 == 0 else 128))
 g = torch.Generator(device="cuda").manual_seed(0)
 probs = []
 for _ in range(layers):

@@ -155,6 +155,9 @@ def main(argv=None):
     from savit_amd import ddp
     from savit_amd.model import create_model
 
+    # a data-parallel rank plans its backward launches for the CUs the resident all-reduce leaves (engine reserved_cus, ddp.py)
+    os.environ.setdefault("SAVIT_RESERVED_CUS", str(ddp.default_reserved_cus(world)))
+
     fp32 = args.dtype == "float32"
     model = create_model(args.model_name, num_classes=1000, dtype=torch.float32 if fp32 else torch.bfloat16, img_size=args.img_size)  # train.py:222-224
     if fp32 and (model.cfg.kind != "vit" or world > 1 or args.mixup_alpha > 0 or args.cutmix_alpha > 0):
