@@ -283,6 +283,11 @@ int savit_softmax_xent(const float* logits, int ld_logits, const int* labels, co
 int savit_sumsq(const float* g, long n, float* out, void* stream);
 int savit_adamw_step(float* params, const float* grads, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                      float weight_decay, int step, const float* grad_sumsq, float max_norm, float grad_scale, void* stream);
+/* The same update; params_bf16 (nullable) additionally receives the updated parameters rounded to bf16 in the same flat layout: the
+ * [in, out] bf16 operands of the input-gradient GEMMs are views into it (no cast pass over the fp32 parameters). */
+int savit_adamw_step_mirror(float* params, const float* grads, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                            float weight_decay, int step, const float* grad_sumsq, float max_norm, float grad_scale, void* params_bf16,
+                            void* stream);
 
 /* ---- operand preparation: fp32 master weights [batch][R][C] -> bf16 [batch][R][C] (dst_n) and/or transposed
  * [batch][C][R] (dst_t); fp32 -> bf16 elementwise; input batches [H,W,C,N] fp32 -> [N,H,W,C] bf16 (train.py:80-81). */

@@ -124,21 +124,53 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 // ---- fused AdamW over the flat parameter buffer  (optax.chain(clip_by_global_norm, scale_by_adam,
 // additive_weight_decay, scale(-lr)) + apply_updates: train.py:25-27,100 with the descent sign of
 // simple_train.py:27).  28 B/param of HBM traffic, one launch for the whole model.
+// mirror (nullable): the updated parameters are also stored rounded to bf16, in the same flat layout - the [in, out] MFMA operands
+// of the input-gradient GEMMs are views into that mirror, so no separate cast pass re-reads the fp32 parameters (30 B/param).
+template <bool MIRROR>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                      float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
                                                      float wd, float bc1, float bc2, const float* __restrict__ sumsq, float max_norm,
-                                                     float grad_scale) {
+                                                     float grad_scale, bf16_t* __restrict__ mirror) {
   float gs = grad_scale;
   if (sumsq != nullptr && max_norm > 0.f) {
     const float norm = sqrtf(*sumsq) * grad_scale;
     if (!(norm < max_norm)) gs *= max_norm / norm;
   }
-  const long n4 = n >> 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    float4 pv = reinterpret_cast<float4*>(p)[i];
-    const float4 gv = reinterpret_cast<const float4*>(g)[i];
-    float4 mv = reinterpret_cast<float4*>(m)[i];
-    float4 vv = reinterpret_cast<float4*>(v)[i];
+  // a thread owns 8 consecutive parameters (two float4 of each stream), so the bf16 mirror is written as one 16-byte piece
+  const long n8 = n >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float4 pv[2], mv[2], vv[2], gv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      pv[h] = reinterpret_cast<float4*>(p)[2 * i + h];
+      gv[h] = reinterpret_cast<const float4*>(g)[2 * i + h];
+      mv[h] = reinterpret_cast<float4*>(m)[2 * i + h];
+      vv[h] = reinterpret_cast<float4*>(v)[2 * i + h];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float* pp = &pv[h].x; const float* gp = &gv[h].x; float* mp = &mv[h].x; float* vp = &vv[h].x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gg = gp[k] * gs;
+        mp[k] = b1 * mp[k] + (1.0f - b1) * gg;
+        vp[k] = b2 * vp[k] + (1.0f - b2) * gg * gg;
+        const float u = (mp[k] / bc1) / (sqrtf(vp[k] / bc2) + eps) + wd * pp[k];
+        pp[k] -= lr * u;
+      }
+      reinterpret_cast<float4*>(p)[2 * i + h] = pv[h];
+      reinterpret_cast<float4*>(m)[2 * i + h] = mv[h];
+      reinterpret_cast<float4*>(v)[2 * i + h] = vv[h];
+    }
+    if (MIRROR)
+      reinterpret_cast<uint4*>(mirror)[i] = make_uint4(pack_bf16x2(pv[0].x, pv[0].y), pack_bf16x2(pv[0].z, pv[0].w),
+                                                       pack_bf16x2(pv[1].x, pv[1].y), pack_bf16x2(pv[1].z, pv[1].w));
+  }
+  // n % 8 == 4: the last float4 (n % 4 == 0 is the entry point's contract)
+  if ((n & 4) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const long i4 = (n >> 2) - 1;
+    float4 pv = reinterpret_cast<float4*>(p)[i4], mv = reinterpret_cast<float4*>(m)[i4], vv = reinterpret_cast<float4*>(v)[i4];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i4];
     float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -148,9 +180,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       const float u = (mp[k] / bc1) / (sqrtf(vp[k] / bc2) + eps) + wd * pp[k];
       pp[k] -= lr * u;
     }
-    reinterpret_cast<float4*>(p)[i] = pv;
-    reinterpret_cast<float4*>(m)[i] = mv;
-    reinterpret_cast<float4*>(v)[i] = vv;
+    reinterpret_cast<float4*>(p)[i4] = pv;
+    reinterpret_cast<float4*>(m)[i4] = mv;
+    reinterpret_cast<float4*>(v)[i4] = vv;
+    if (MIRROR) reinterpret_cast<uint2*>(mirror)[i4] = make_uint2(pack_bf16x2(pv.x, pv.y), pack_bf16x2(pv.z, pv.w));
   }
 }
 
@@ -254,14 +287,27 @@ extern "C" int savit_sumsq(const float* g, long n, float* out, void* stream) {
 extern "C" int savit_adamw_step(float* params, const float* grads, float* m, float* v, long n, float lr, float b1, float b2,
                                 float eps, float weight_decay, int step, const float* grad_sumsq, float max_norm, float grad_scale,
                                 void* stream) {
-  SAVIT_CHECK_ARG(params && grads && m && v && n >= 0 && n % 4 == 0 && step >= 1);
+  return savit_adamw_step_mirror(params, grads, m, v, n, lr, b1, b2, eps, weight_decay, step, grad_sumsq, max_norm, grad_scale, nullptr, stream);
+}
+
+extern "C" int savit_adamw_step_mirror(float* params, const float* grads, float* m, float* v, long n, float lr, float b1, float b2,
+                                       float eps, float weight_decay, int step, const float* grad_sumsq, float max_norm, float grad_scale,
+                                       void* params_bf16, void* stream) {
+  SAVIT_CHECK_ARG(params && grads && m && v && n >= 0 && n % 4 == 0 && step >= 1 && ((uintptr_t)params_bf16 % 8) == 0);
   SAVIT_CHECK_ARG(((uintptr_t)params % 16) == 0 && ((uintptr_t)grads % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0);
   if (n == 0) return SAVIT_OK;
   const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
-  long blocks = (n / 4 + 255) / 256;
+  long blocks = (n / 8 + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n, lr, b1, b2, eps,
-                     weight_decay, bc1, bc2, grad_sumsq, max_norm, grad_scale);
+  if (blocks < 1) blocks = 1;
+  if (params_bf16 != nullptr) {
+    SAVIT_CHECK_ARG(((uintptr_t)params_bf16 % 16) == 0);
+    hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n, lr, b1, b2, eps,
+                       weight_decay, bc1, bc2, grad_sumsq, max_norm, grad_scale, (bf16_t*)params_bf16);
+  } else {
+    hipLaunchKernelGGL(adamw_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n, lr, b1, b2, eps,
+                       weight_decay, bc1, bc2, grad_sumsq, max_norm, grad_scale, (bf16_t*)nullptr);
+  }
   SAVIT_LAUNCH_RET();
 }
 

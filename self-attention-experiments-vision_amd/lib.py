@@ -112,6 +112,8 @@ _SIGNATURES = {
     "savit_sumsq": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
     "savit_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float, c_int,
                                  c_void_p, c_float, c_float, c_void_p]),
+    "savit_adamw_step_mirror": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float, c_int,
+                                        c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "savit_cast_transpose_bf16": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_long, c_int, c_void_p, c_long, c_int,
                                           c_void_p]),
     "savit_cast_bf16": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),

@@ -359,7 +359,7 @@ def test_grouped_and_per_weight_weight_gradients_agree(name, B, monkeypatch):
     assert e1.wgrad_tile == (384 if cfg.embed_dim == 384 else 256)
     e2, g2, l2 = grads(wgrad_max_lag=2, reserved_cus=32)
     assert e2.wgrad_lag <= 2 and e2.wgrad_cap == e2.n_cus - 32
-    assert l0 == l1 == l2
+    assert abs(l0 - l1) < 2e-6 * l0 and abs(l0 - l2) < 2e-6 * l0  # same forward; the scalar loss is an fp32 atomic sum over the rows
     for gg in (g1, g2):
         for nm in ("l0.Wqkv", "l3.W1", f"l{cfg.num_layers - 1}.W2", "l5.Wo", "Wpe", "pos"):
             a, b = e0.layout.view(g0, nm), e0.layout.view(gg, nm)
