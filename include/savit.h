@@ -43,6 +43,13 @@ int savit_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma,
                         const float* dres_in, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* dcolsum,
                         int rows, int d, long x_stride, long out_stride, int round_params_bf16, void* workspace,
                         long workspace_bytes, void* stream);
+/* The same (wide rows: d > 64), and its finalize launch ALSO adds the column sums of an extra slab to extra_out[extra_n]
+ * (extra_out[c] += sum_r extra_slab[r][c], r < extra_rows, one adder per column, fixed order): the bias-gradient partials the GELU'
+ * GEMM wrote (savit_gemm_colsum_rows) ride along instead of their own savit_colsum_finalize launch. */
+int savit_layernorm_bwd_ex(const void* dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
+                           const float* dres_in, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* dcolsum,
+                           int rows, int d, long x_stride, long out_stride, int round_params_bf16, void* workspace,
+                           long workspace_bytes, const float* extra_slab, int extra_rows, int extra_n, float* extra_out, void* stream);
 /* Scratch the call above needs (per-block partial column sums; 16-B aligned, contents undefined afterwards). */
 long savit_layernorm_bwd_workspace_bytes(int rows, int d);
 

@@ -204,9 +204,42 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_narrow_kernel(const bf16_t*
 // its share of slab rows with 4 row-lanes per column, reduces in LDS and issues one atomic per column
 // (FIN_SPLIT adders per address).
 constexpr int FIN_SPLIT = 8;
+// Blocks behind the first ceil(3d/64) columns of the grid (y = 0 only) reduce an EXTRA slab [xrows][xn] into xout += column sums, in a
+// fixed order (one adder per column): the bias-gradient partials of the GELU' GEMM ride along with a LayerNorm finalize of the same
+// layer instead of paying for a launch of their own (12 per DeiT-B step).
 __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int d,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               float* __restrict__ dcolsum) {
+                                                               float* __restrict__ dcolsum, const float* __restrict__ xslab = nullptr,
+                                                               int xrows = 0, int xn = 0, float* __restrict__ xout = nullptr) {
+  const int nb0 = (3 * d + 63) / 64;
+  if ((int)blockIdx.x >= nb0) {
+    if (blockIdx.y != 0) return;
+    // 64 columns = 16 lanes x float4, the rows over 16 groups (independent loads, ~rows/16 deep), then an LDS tree: fixed order
+    __shared__ float4 xpart[16][16];
+    const int cx = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int c = ((int)blockIdx.x - nb0) * 64 + cx * 4;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < xn) {  // xn % 4 == 0
+      for (int r = grp; r < xrows; r += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(xslab + (size_t)r * xn + c);
+        s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+      }
+    }
+    xpart[grp][cx] = s4;
+    __syncthreads();
+    if (grp == 0 && c < xn) {
+      float4 t4 = xpart[0][cx];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) {
+        const float4 v = xpart[k][cx];
+        t4.x += v.x; t4.y += v.y; t4.z += v.z; t4.w += v.w;
+      }
+      float4* o = reinterpret_cast<float4*>(xout + c);
+      const float4 old = *o;
+      *o = make_float4(old.x + t4.x, old.y + t4.y, old.z + t4.z, old.w + t4.w);
+    }
+    return;
+  }
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);  // in [0, 3d)
   const int rl = threadIdx.x >> 6;                        // row lane 0..3
   const int per = (nblk + FIN_SPLIT - 1) / FIN_SPLIT;
@@ -336,6 +369,28 @@ extern "C" int savit_layernorm_bwd(const void* dy, const float* x, const float* 
                                    long workspace_bytes, void* stream) {
   return savit_layernorm_bwd_mapped(dy, x, gamma, mean, rstd, dres_in, dx, dx_bf16, dgamma, dbeta, dcolsum, rows, d, x_stride, out_stride,
                                     round_params_bf16, 0, 0, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int savit_layernorm_bwd_ex(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                      const float* dres_in, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* dcolsum,
+                                      int rows, int d, long x_stride, long out_stride, int round_params_bf16, void* workspace,
+                                      long workspace_bytes, const float* extra_slab, int extra_rows, int extra_n, float* extra_out,
+                                      void* stream) {
+  SAVIT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && x_stride >= d && out_stride >= d && (x_stride % 4) == 0 &&
+                  (out_stride % 4) == 0 && rows > 0 && d > 64 && (d % 4) == 0 && d <= 64 * 4 * LN_MAX_CHUNKS);
+  SAVIT_CHECK_ARG(extra_slab && extra_out && extra_rows >= 0 && extra_n > 0 && extra_n % 4 == 0 && (dgamma || dbeta || dcolsum) &&
+                  ((uintptr_t)extra_slab % 16) == 0 && ((uintptr_t)extra_out % 16) == 0);
+  SAVIT_CHECK_ARG(workspace != nullptr && ((uintptr_t)workspace % 16) == 0 &&
+                  workspace_bytes >= savit_layernorm_bwd_workspace_bytes(rows, d));
+  hipStream_t s = (hipStream_t)stream;
+  const int ch = (d / 4 + 63) / 64;
+  float* partial = (float*)workspace;
+  const int grid = ln_bwd_grid(rows);
+  LN_DISPATCH(ch, ln_bwd_kernel, grid, (const bf16_t*)dy, x, gamma, mean, rstd, dres_in, dx, (bf16_t*)dx_bf16, partial, rows, d,
+              x_stride, out_stride, round_params_bf16, 0, 0, 0);
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * d + 63) / 64 + (extra_n + 63) / 64, FIN_SPLIT), dim3(256), 0, s, partial, grid, d,
+                     dgamma, dbeta, dcolsum, extra_slab, extra_rows, extra_n, extra_out);
+  SAVIT_LAUNCH_RET();
 }
 
 extern "C" int savit_layernorm_bwd_mapped(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,

@@ -679,14 +679,20 @@ class ViTEngine:
             self._gemm(P, f"l{l}.fc2.dgrad", writes=(d_u,), A=ring[ri], Bt=w("W2_n"), C=d_u, aux=self.u[l].data_ptr(),
                        colsum=self.colsum_slab.data_ptr(), colsum_rows=self.colsum_slab.shape[0], M=M, N=F, K=d, lda=d, ldb=d, ldc=F,
                        ldaux=F, epilogue=_lib.EPI_DGELU)
-            P.add(L.savit_colsum_finalize, (self.colsum_slab.data_ptr(), self.colsum_slab.shape[0], F, gp(f"l{l}.b1"), 1), f"l{l}.b1.grad")
+            # the slab is reduced into db1 by the finalize launch of this layer's ln2.bwd below (savit_layernorm_bwd_ex: wide rows only)
+            if d <= 64:
+                P.add(L.savit_colsum_finalize, (self.colsum_slab.data_ptr(), self.colsum_slab.shape[0], F, gp(f"l{l}.b1"), 1), f"l{l}.b1.grad")
             wgrad(f"l{l}.W1.wgrad", self.h2[l].data_ptr(), d_u, gp(f"l{l}.W1"), M, d, F, d, F, F, layer=l)
             self._gemm(P, f"l{l}.fc1.dgrad", A=d_u, Bt=w("W1_n"), C=self.d_h.data_ptr(), M=M, N=d, K=F, lda=F, ldb=F,
                        ldc=d, epilogue=_lib.EPI_BF16)
             ri = (ri + 1) % len(ring)
-            P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(),
-                                          self.dres.data_ptr(), self.dres.data_ptr(), ring[ri], gp(f"l{l}.ln2_g"),
-                                          gp(f"l{l}.ln2_b"), None, M, d, d, d, self.rp, ws, wsb), f"l{l}.ln2.bwd", writes=(ring[ri],))
+            ln2_args = (self.d_h.data_ptr(), self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(),
+                        self.dres.data_ptr(), self.dres.data_ptr(), ring[ri], gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b"), None, M, d, d, d, self.rp, ws, wsb)
+            if d > 64:
+                P.add(L.savit_layernorm_bwd_ex, ln2_args + (self.colsum_slab.data_ptr(), self.colsum_slab.shape[0], F, gp(f"l{l}.b1")),
+                      f"l{l}.ln2.bwd", writes=(ring[ri],))
+            else:
+                P.add(L.savit_layernorm_bwd, ln2_args, f"l{l}.ln2.bwd", writes=(ring[ri],))
             # attention branch: x_mid = x_l + attn(LN1(x_l)) Wo     (attention.py:21-67, vit.py:19-24)
             wgrad(f"l{l}.Wo.wgrad", self.o[l].data_ptr(), ring[ri], gp(f"l{l}.Wo"), M, d, d, d, d, d, layer=l)
             self._gemm(P, f"l{l}.proj.dgrad", A=ring[ri], Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=M, N=d, K=d, lda=d, ldb=d,

@@ -52,6 +52,8 @@ _SIGNATURES = {
     "savit_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_float,
                                     c_int, c_void_p]),
     "savit_layernorm_bwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_long, c_long, c_int, c_void_p, c_long, c_void_p]),
+    "savit_layernorm_bwd_ex": (c_int, [c_void_p] * 11 + [c_int, c_int, c_long, c_long, c_int, c_void_p, c_long, c_void_p, c_int, c_int, c_void_p,
+                                       c_void_p]),
     "savit_layernorm_bwd_workspace_bytes": (c_long, [c_int, c_int]),
     "savit_layernorm_fwd_mapped": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_float, c_int, c_int, c_int, c_int, c_void_p]),
     "savit_layernorm_bwd_mapped": (c_int, [c_void_p] * 11 + [c_int, c_int, c_long, c_long, c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p]),

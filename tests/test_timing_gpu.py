@@ -33,8 +33,8 @@ def test_timer_measures_a_gate_kernel():
     torch.cuda.synchronize()
     (l0, ms0), (l1, ms1) = t.results()
     assert (l0, l1) == ("spin2000", "spin500")
-    assert 2.0 <= ms0 <= 2.5, ms0
-    assert 0.5 <= ms1 <= 0.8, ms1
+    assert 2.0 <= ms0 <= 3.0, ms0  # the spin sleeps between clock reads: it overshoots, it never undershoots
+    assert 0.5 <= ms1 <= 1.0, ms1
     assert L.savit_spin(10 ** 7, s) == _lib.SAVIT_EINVAL  # bounded: a gate can never be a hang
     t.close()
 
