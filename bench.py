@@ -57,8 +57,8 @@ def kernel_symbol(label: str, lib, M: int, d: int, F: int) -> str:
     """Launch label of the engine's plan -> the kernel symbol rocprofv3 reports (template arguments as in csrc/)."""
     parts = label.split(".")
     if label.startswith("wgrad.group"):
-        # engine.wgrad_group_tile: 128 x 384 tiles for the d = 384 models, else 256 x 256 (edge tiles hang over the matrix)
-        return "gemm_wgrad_group_kernel<128,384,2,4,3,32>" if (d % 256 or F % 256) and d % 384 == 0 and F % 384 == 0 else "gemm_wgrad_group_kernel<256,256,2,4,3,32>"
+        # engine.wgrad_group_tile: 256 x 384 / 384 x 256 tiles for the d = 384 models, else 256 x 256 (edge tiles hang over the matrix)
+        return "gemm_wgrad_group_mixed_kernel<3>" if (d % 256 or F % 256) and d % 384 == 0 and F % 384 == 0 else "gemm_wgrad_group_kernel<256,256,2,4,3,32>"
     op = ".".join(parts[1:]) if parts[0].startswith("l") and parts[0][1:].isdigit() else label
     shapes = {"qkv": (3 * d, d), "proj": (d, d), "fc1": (F, d), "fc2": (d, F), "fc2.dgrad": (F, d), "fc1.dgrad": (d, F),
               "proj.dgrad": (d, d), "qkv.dgrad": (d, 3 * d)}

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
@@ -52,10 +53,18 @@ inline hipError_t savit_raise_lds_limit(const void* kfn) {
   // the limit covers dynamic LDS only: a kernel's static __shared__ arrays come out of the same 160 KB
   return hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)at.sharedSizeBytes);
 }
+// The attribute applies to the CURRENT device: the once-flag is per (kernel symbol, device) - a process that later launches on another
+// GPU raises the limit there too (first launch per device; at most 16 devices per process, beyond that the call is made every time).
 #define SAVIT_LDS_ONCE(kfn)                                                                  \
   do {                                                                                       \
-    static const hipError_t lds_once_ = savit_raise_lds_limit((const void*)(kfn));           \
-    if (lds_once_ != hipSuccess) return (int)lds_once_;                                      \
+    static std::atomic<int> lds_done_[16];                                                   \
+    int dev_ = 0;                                                                            \
+    (void)hipGetDevice(&dev_);                                                               \
+    if (dev_ < 0 || dev_ >= 16 || lds_done_[dev_].load(std::memory_order_acquire) == 0) {    \
+      const hipError_t e_ = savit_raise_lds_limit((const void*)(kfn));                       \
+      if (e_ != hipSuccess) return (int)e_;                                                  \
+      if (dev_ >= 0 && dev_ < 16) lds_done_[dev_].store(1, std::memory_order_release);       \
+    }                                                                                        \
   } while (0)
 
 // Development switches (ablation tiles that compute wrong results on purpose, SAVIT_* environment overrides of the tile / split

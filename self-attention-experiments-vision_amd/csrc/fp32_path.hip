@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256) void gemm_f32_ex_kernel(const GemmF32ExParams 
 }
 
 // softmax over the last axis (attention.py:48) of `rows` rows of N values, and its VJP dS = P (dP - sum_k dP P); one wave per row
-__global__ __launch_bounds__(256) void softmax_rows_f32_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int N, int ld) {
+// x and y may be the same buffer (the engines normalise in place: each lane reads its elements before it writes them) - no __restrict__
+__global__ __launch_bounds__(256) void softmax_rows_f32_kernel(const float* x, float* y, long rows, int N, int ld) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -329,7 +330,8 @@ __global__ __launch_bounds__(256) void softmax_rows_f32_kernel(const float* __re
   const float inv = 1.0f / l;
   for (int c = lane; c < N; c += 64) yr[c] = expf(xr[c] - m) * inv;
 }
-__global__ __launch_bounds__(256) void softmax_rows_bwd_f32_kernel(const float* __restrict__ pr, const float* __restrict__ dp, float* __restrict__ ds, long rows,
+// dp and ds may be the same buffer (in-place use by the engines) - no __restrict__ on that pair
+__global__ __launch_bounds__(256) void softmax_rows_bwd_f32_kernel(const float* __restrict__ pr, const float* dp, float* ds, long rows,
                                                                     int N, int ld) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);

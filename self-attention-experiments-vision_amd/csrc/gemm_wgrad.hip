@@ -872,6 +872,41 @@ struct WgradGroupParams {
   } pr[WGRAD_GROUP_MAX];
 };
 
+// Tile 640: 256 x 384 or 384 x 256, whichever covers the weight with fewer tiles (d = 384 models: Wqkv 384 x 1152 and W1 384 x 1536 take
+// 384 x 256 - 5 and 6 tiles -, Wo 384 x 384 and W2 1536 x 384 take 256 x 384 - 2 and 6: 19 tiles per layer, 95 % of a launch inside a
+// matrix, 12 MFMAs per 14 transposing reads per wave and k-step instead of 6 per 10 of the 128 x 384 tile).
+__host__ __device__ inline bool wgrad_mixed_tall(int Kin, int Nout) {  // true: 384 (Kin) x 256 (Nout)
+  const int a = ((Kin + 255) / 256) * ((Nout + 383) / 384), b = ((Kin + 383) / 384) * ((Nout + 255) / 256);
+  return b < a;
+}
+
+template <int S>
+__global__ __launch_bounds__(512, 2) void gemm_wgrad_group_mixed_kernel(const WgradGroupParams g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wid = xcd_remap(blockIdx.x, g.tile_end[g.n - 1]);
+  int pi = 0;
+  while (wid >= g.tile_end[pi]) ++pi;
+  const int t = wid - (pi ? g.tile_end[pi - 1] : 0) + g.pr[pi].tile_begin;
+  WgradParams p{};
+  p.X = g.pr[pi].X; p.dY = g.pr[pi].dY; p.dW = g.pr[pi].dW;
+  p.M = g.pr[pi].M; p.Kin = g.pr[pi].Kin; p.Nout = g.pr[pi].Nout;
+  p.ldx = g.pr[pi].ldx; p.lddy = g.pr[pi].lddy; p.lddw = g.pr[pi].lddw;
+  p.splits = 1;
+  p.tiles_per_split = (p.M + 31) / 32;
+  p.rmw = 1;
+  if (wgrad_mixed_tall(p.Kin, p.Nout)) {
+    p.tiles_i = (p.Kin + 383) / 384;
+    p.tiles_j = (p.Nout + 255) / 256;
+    const int ti = t / p.tiles_j;
+    wgrad_pp_tile<384, 256, 2, 4, S>(p, ti, t - ti * p.tiles_j, smem);
+  } else {
+    p.tiles_i = (p.Kin + 255) / 256;
+    p.tiles_j = (p.Nout + 383) / 384;
+    const int ti = t / p.tiles_j;
+    wgrad_pp_tile<256, 384, 2, 4, S>(p, ti, t - ti * p.tiles_j, smem);
+  }
+}
+
 template <int BI, int BJ, int WGI, int WGJ, int S, int MF = 32>  // MF: MFMA shape of the tile (16 = 16x16x32 ping-pong, 32 = 32x32x16)
 __global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_group_kernel(const WgradGroupParams g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1135,6 +1170,7 @@ static bool group_tile_shape(int tile, int* bi, int* bj) {
     case 128: *bi = 128; *bj = 128; return true;
     case 256: *bi = 256; *bj = 256; return true;
     case 384: *bi = 128; *bj = 384; return true;
+    case 640: *bi = 256; *bj = 384; return true;  // or 384 x 256 per weight: wgrad_mixed_tall
     default: return false;
   }
 }
@@ -1142,6 +1178,7 @@ static bool group_tile_shape(int tile, int* bi, int* bj) {
 extern "C" int savit_gemm_wgrad_group_tiles(int Kin, int Nout, int tile) {
   int bi, bj;
   if (Kin <= 0 || Nout <= 0 || !group_tile_shape(tile, &bi, &bj)) return 0;
+  if (tile == 640 && wgrad_mixed_tall(Kin, Nout)) return ((Kin + 383) / 384) * ((Nout + 255) / 256);
   return ((Kin + bi - 1) / bi) * ((Nout + bj - 1) / bj);
 }
 
@@ -1182,6 +1219,10 @@ extern "C" int savit_gemm_bf16_wgrad_grouped(const savit_wgrad_problem* problems
     auto kfn = gemm_wgrad_group_kernel<256, 256, 2, 4, WGRAD_GROUP_S, WGRAD_GROUP_MF>;
     SAVIT_LDS_ONCE(kfn);
     hipLaunchKernelGGL(kfn, dim3(tiles), dim3(512), (size_t)WGRAD_GROUP_S * 32 * (256 + 256) * 2, (hipStream_t)stream, g);
+  } else if (tile == 640) {
+    auto kfn = gemm_wgrad_group_mixed_kernel<3>;
+    SAVIT_LDS_ONCE(kfn);
+    hipLaunchKernelGGL(kfn, dim3(tiles), dim3(512), (size_t)3 * 32 * (256 + 384) * 2, (hipStream_t)stream, g);
   } else if (tile == 384) {
     auto kfn = gemm_wgrad_group_kernel<128, 384, 2, 4, 3, WGRAD_GROUP_MF>;
     SAVIT_LDS_ONCE(kfn);

@@ -306,12 +306,14 @@ def add_wgrad_group(eng, plan: _Plan, label: str, entries: list, tile: int, defe
 
 def wgrad_group_tile(d: int, F: int) -> int:
     """Tile code of the grouped weight-gradient launches for a model of width d / hidden width F: 256 x 256 where the matrices are
-    multiples of it (DeiT-B, ViT-L), 128 x 384 for the d = 384 models (DeiT-S, CaiT-S: every matrix is a whole number of those tiles;
-    with 256 x 256 tiles 29 % of a launch hung over the matrix edges), else 256 x 256 with edge tiles."""
+    multiples of it (DeiT-B, ViT-L); for the d = 384 models (DeiT-S, CaiT-S) 256 x 384 or 384 x 256 per weight, whichever covers it with
+    fewer tiles (95 % of a launch inside a matrix; with 256 x 256 tiles 29 % hung over the matrix edges); else 256 x 256 with edge tiles."""
+    if os.environ.get("SAVIT_WGRAD_TILE"):  # A/B runs
+        return int(os.environ["SAVIT_WGRAD_TILE"])
     if d % 256 == 0 and F % 256 == 0:
         return 256
     if d % 384 == 0 and F % 384 == 0:
-        return 384
+        return 640  # 256 x 384 or 384 x 256 per weight (19 tiles per layer at d = 384; 128 x 384 tiles: code 384, 36 per layer)
     return 256
 
 

@@ -215,7 +215,8 @@ def test_talking_heads_coefficient_loads_are_not_touched_in_flight(built, tmp_pa
     seen = 0
     for k in kernels:
         head = k.split("\n", 1)[0]
-        if "th_softmax_fwd_kernel" in head or "th_softmax_bwd_kernel" in head:
+        if "s_load_dwordx16" in k:  # EVERY kernel that uses the in-flight scalar loads, whatever its name
+            assert "th_softmax_fwd_kernel" in head or "th_softmax_bwd_kernel" in head, f"{head}: a new user of ThCoef - add it here knowingly"
             n, bad = chk.violations(k)
             seen += n
             assert not bad, (head, bad[:3])

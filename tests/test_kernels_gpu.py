@@ -385,7 +385,7 @@ def test_wgrad_slab_reduction(ops, M, Kin, Nout, splits):
     assert rel(host(dW2) - host(base), ref) < 2e-5
 
 
-@pytest.mark.parametrize("tile", [256, 128, 384])
+@pytest.mark.parametrize("tile", [256, 128, 384, 640])
 def test_wgrad_grouped_matches_fp64_and_is_reproducible(ops, tile):
     """savit_gemm_bf16_wgrad_grouped: several weight gradients in one launch, one workgroup per output tile over ALL tokens.  Each
     dW: the fp64 product within fp32 summation error, accumulated onto its old value, bitwise repeatable; ragged Kin / Nout (tiles
