@@ -17,7 +17,7 @@ whole-job images/s.  Rank 0 prints ONE JSON line.  Extra objects on that line:
   kernel_breakdown_ms / roofline_valid   three instrumented whole steps after the timed region (every launch bracketed, each step
                 enqueued behind a gate kernel so that no event pair contains host time, per-label minimum), and the checks
                 that the accounting adds up: launches x avg of the dominant kernel <= ms_per_step, sum of all launches <= 1.05 x
-                ms_per_step, live and instrumented averages of the dominant kernel within 10 %.  A failed check sets
+                ms_per_step (net of what an empty bracket costs, measured), live and instrumented averages of the dominant kernel within 10 %.  A failed check sets
                 "roofline_valid": false and dumps the per-label table to stderr.
   step_roofline whole-step figure of SURVEY.md 8d: images/s/GPU x 105.152 GFLOP per image / peak.
   cpu_baseline  the CPU restatement (oracle/torch_ref.py, JAX absent: SURVEY 8c) of BASELINE config 1 (ViT-Ti/16, batch 8,
@@ -356,7 +356,15 @@ def measure(eng, cfg, B, world, rank, sync, steps, warmup, dist=None, breakdown=
         total = sum(v["ms"] for v in cls1.values())
         serial = not getattr(eng, "overlap_wgrad", False)  # engines with side streams run their serial plan when instrumented
         best_span = min(r["span_ms"] for r in post["reps"])
-        checks["sum_le_1p05_step"] = (total <= 1.05 * ms_step) if serial else (total <= 1.05 * best_span)
+        # every bracket contains its own marker packets on top of its kernel (measured with empty brackets: ~1 us, several under
+        # rocprofv3): the sum is checked net of that
+        net = total - post["launches"] * post["pair_overhead_ms"]
+        # under rocprofv3 (its tool library is preloaded) every dispatch carries the profiler's own packets: 1.10 there
+        profiled = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES"))
+        lim = 1.10 if profiled else 1.05
+        checks["sum_le_1p05_step"] = (net <= lim * ms_step) if serial else (net <= lim * best_span)
+        if profiled:
+            info["profiler_attached"] = True
         checks["gate_reached"] = all(r["gate_reached"] for r in post["reps"])
         if dom in sym1:
             inst_avg = sym1[dom]["ms"] / sym1[dom]["n"]
@@ -366,6 +374,8 @@ def measure(eng, cfg, B, world, rank, sync, steps, warmup, dist=None, breakdown=
         opt_ms = cls1.get("optimizer", {"ms": 0.0})["ms"] + sum(ms for k, ms in post["labels"].items() if k.split("#")[0] == "zero.gnorm")
         kb["sum_fwd_bwd"] = round(total - opt_ms, 3)
         kb["sum_step"] = round(total, 3)
+        kb["sum_step_net_of_brackets"] = round(net, 3)
+        info["bracket_overhead_us"] = round(post["pair_overhead_ms"] * 1e3, 2)
         info["kernel_breakdown_ms"] = kb
         info["kernel_breakdown_how"] = (f"{len(post['reps'])} instrumented steps, every launch bracketed, each step enqueued behind a "
                                         f"{post['gate_us']} us gate kernel, per-label minimum; span of one instrumented step {best_span:.3f} ms")

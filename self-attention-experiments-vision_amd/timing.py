@@ -98,7 +98,8 @@ def instrumented_steps(eng, run_step: Callable[[], None], reps: int = 3, gate_us
     bracketed, each repetition enqueued behind a gate kernel.  One stream: engines that normally put weight gradients on side
     streams run their serial plan here (per-kernel figures are taken serially: DESIGN.md 6).
 
-    -> {"labels": {label: min ms over the repetitions}, "reps": [{"sum_ms", "span_ms", "host_issue_ms"}], "gate_us"}"""
+    -> {"labels": {label: min ms over the repetitions}, "reps": [{"sum_ms", "span_ms", "host_issue_ms"}], "gate_us", "launches",
+        "pair_overhead_ms": median duration of an EMPTY bracket (what every figure above contains on top of its kernel)}"""
     import time
 
     L = _lib.load()
@@ -122,7 +123,7 @@ def instrumented_steps(eng, run_step: Callable[[], None], reps: int = 3, gate_us
         issue_ms = (time.perf_counter() - t0) * 1e3
         torch.cuda.synchronize()
         if gate_us <= 0:
-            gate_us = int(min(150000, max(3000, 2.0 * issue_ms * 1e3)))
+            gate_us = int(min(150000, max(2000, 1.5 * issue_ms * 1e3)))
         best: Dict[str, float] = {}
         order: List[str] = []
         rep_info = []
@@ -150,7 +151,17 @@ def instrumented_steps(eng, run_step: Callable[[], None], reps: int = 3, gate_us
                     best[key] = min(best[key], ms)
                 tot += ms
             rep_info.append({"sum_ms": tot, "span_ms": timer.span_ms(), "host_issue_ms": host, "gate_reached": host * 1e3 < gate_us})
-        return {"labels": {k: best[k] for k in order}, "reps": rep_info, "gate_us": gate_us, "launches": n}
+        # what a bracket costs by itself: pairs with nothing between them (a marker is a packet of its own on the queue; under
+        # rocprofv3 every dispatch carries more)
+        timer.reset()
+        torch.cuda.synchronize()
+        for _ in range(min(32, timer.n)):
+            k = timer.begin("empty", s)
+            timer.end(k, s)
+        torch.cuda.synchronize()
+        empties = sorted(ms for _, ms in timer.results())
+        return {"labels": {k: best[k] for k in order}, "reps": rep_info, "gate_us": gate_us, "launches": n,
+                "pair_overhead_ms": empties[len(empties) // 2]}
     finally:
         eng.launch_timer, eng.overlap_wgrad = saved_timer, saved_overlap
         if timer is not None:

@@ -7,7 +7,7 @@ TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="$GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs"
+B="$GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs"
 SAVIT_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial -o s -- python3 $B > $OUT/serial_bench.json 2> $OUT/serial.err
 echo serial done
 SAVIT_OVERLAP_WGRAD=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/overlap -o o -- python3 $B > $OUT/overlap_bench.json 2> $OUT/overlap.err
@@ -26,15 +26,18 @@ cp $(find $OUT/serial -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_serial_ke
 cp $(find $OUT/overlap -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_overlap_kernel_stats.csv
 tail -1 $OUT/serial_bench.json > $OUT/${TAG}_serial_bench.json
 tail -1 $OUT/overlap_bench.json > $OUT/${TAG}_overlap_bench.json
-# BASELINE config 4 (CaiT-S24, 256 images): kernel stats of the same bench harness
-C="$GRAFT_REPO_ROOT/bench.py --model cait_s_24 --batch 256 --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs"
+# the other BASELINE configs (2: DeiT-S 256 img, 4: CaiT-S24 256 img, 5: ViT-L/16-384 256 img): kernel stats of the same bench harness
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cait -o c -- python3 $C > $OUT/cait_bench.json 2> $OUT/cait.err
-echo cait done
+for cfgname in "deit_s --model vit_s_patch16 --batch 256 --steps 10 --warmup 3" "cait_s24 --model cait_s_24 --batch 256 --steps 5 --warmup 2" "vit_l384 --model vit_l_patch16 --img-size 384 --batch 256 --steps 4 --warmup 2"; do
+  set -- $cfgname
+  nm=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$nm -o c -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu-baseline --no-other-configs > $OUT/${nm}_bench.json 2> $OUT/$nm.err
+  echo $nm done
+  cp $(find $OUT/$nm -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${nm}_kernel_stats.csv
+  tail -1 $OUT/${nm}_bench.json > $OUT/${TAG}_${nm}_bench.json
+  rm -rf $OUT/$nm
+done
 cd $GRAFT_REPO_ROOT
-cp $(find $OUT/cait -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_cait_s24_kernel_stats.csv
-tail -1 $OUT/cait_bench.json > $OUT/${TAG}_cait_s24_bench.json
-rm -rf $OUT/cait
 # the raw traces are large: keep only the summaries
 rm -rf $OUT/serial $OUT/overlap $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma
 cat $OUT/pmc_summary.txt; cat $OUT/mfma_summary.txt; head -12 $OUT/${TAG}_serial_kernel_stats.csv
