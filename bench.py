@@ -369,7 +369,8 @@ def measure(eng, cfg, B, world, rank, sync, steps, warmup, dist=None, breakdown=
         if dom in sym1:
             inst_avg = sym1[dom]["ms"] / sym1[dom]["n"]
             roof["instrumented_avg_launch_ms"] = round(inst_avg, 4)
-            checks["live_vs_instrumented_within_10pct"] = abs(inst_avg - avg_ms) <= 0.10 * avg_ms
+            if world == 1:  # (with an all-reduce resident in the timed region the live figure is SUPPOSED to differ from the instrumented, exchange-free one)
+                checks["live_vs_instrumented_within_10pct"] = abs(inst_avg - avg_ms) <= 0.10 * avg_ms
         kb = {c: round(v["ms"], 3) for c, v in sorted(cls1.items(), key=lambda kv: -kv[1]["ms"])}
         opt_ms = cls1.get("optimizer", {"ms": 0.0})["ms"] + sum(ms for k, ms in post["labels"].items() if k.split("#")[0] == "zero.gnorm")
         kb["sum_fwd_bwd"] = round(total - opt_ms, 3)

@@ -66,9 +66,12 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
                   dgamma: torch.Tensor, dbeta: torch.Tensor, dres_in: Optional[torch.Tensor] = None,
                   dx: Optional[torch.Tensor] = None, dx_bf16: Optional[torch.Tensor] = None,
-                  dcolsum: Optional[torch.Tensor] = None, round_params: bool = True, workspace: Optional[torch.Tensor] = None):
+                  dcolsum: Optional[torch.Tensor] = None, round_params: bool = True, workspace: Optional[torch.Tensor] = None,
+                  extra_slab: Optional[torch.Tensor] = None, extra_out: Optional[torch.Tensor] = None):
     """Backward of layernorm_fwd; dgamma/dbeta/dcolsum are accumulated (caller zeroes).  workspace: optional
-    uint8/any CUDA tensor of >= savit_layernorm_bwd_workspace_bytes(rows, d) bytes (allocated here if None)."""
+    uint8/any CUDA tensor of >= savit_layernorm_bwd_workspace_bytes(rows, d) bytes (allocated here if None).
+    extra_slab [rows_x, n_x] fp32 + extra_out [n_x] fp32: the finalize launch also adds the slab's column sums to extra_out
+    (savit_layernorm_bwd_ex: the bias-gradient partials of the GELU' GEMM; rows wider than 64 columns only)."""
     _chk(dy, bf16, "dy", 2)
     _chk(x, f32, "x", 2)
     rows, d, xs = _rows2d(x, "x")
@@ -99,6 +102,16 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
     wbytes = workspace.numel() * workspace.element_size()
     if not workspace.is_cuda or wbytes < need:
         raise ValueError("layernorm_bwd: workspace too small")
+    if extra_slab is not None or extra_out is not None:
+        _chk(extra_slab, f32, "extra_slab", 2)
+        _chk(extra_out, f32, "extra_out", 1)
+        if not extra_slab.is_contiguous() or extra_out.numel() != extra_slab.shape[1]:
+            raise ValueError("extra_slab must be contiguous [rows, n] and extra_out [n]")
+        _lib.check(L.savit_layernorm_bwd_ex(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres_in), _p(dx), _p(dx_bf16), _p(dgamma),
+                                            _p(dbeta), _p(dcolsum), rows, d, xs, os_, int(round_params), _p(workspace), wbytes,
+                                            _p(extra_slab), extra_slab.shape[0], extra_slab.shape[1], _p(extra_out), _stream()),
+                   "savit_layernorm_bwd_ex")
+        return dx
     _lib.check(L.savit_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres_in), _p(dx), _p(dx_bf16), _p(dgamma),
                                      _p(dbeta), _p(dcolsum), rows, d, xs, os_, int(round_params), _p(workspace), wbytes, _stream()),
                "savit_layernorm_bwd")
@@ -392,17 +405,22 @@ def sumsq(g: torch.Tensor, out: torch.Tensor):
 
 def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float, b1: float = 0.9,
                b2: float = 0.999, eps: float = 1e-8, weight_decay: float = 0.0, grad_sumsq: Optional[torch.Tensor] = None,
-               max_norm: float = 0.0, grad_scale: float = 1.0):
+               max_norm: float = 0.0, grad_scale: float = 1.0, mirror: Optional[torch.Tensor] = None):
+    """mirror: optional bf16 tensor of p's size that receives bf16(updated p) (savit_adamw_step_mirror)."""
     for name, t in (("p", p), ("g", g), ("m", m), ("v", v)):
         _chk(t, f32, name, 1)
         if t.numel() != p.numel() or not t.is_contiguous():
             raise ValueError("adamw_step: size mismatch")
     if grad_sumsq is not None:
         _chk(grad_sumsq, f32, "grad_sumsq")
+    if mirror is not None:
+        _chk(mirror, bf16, "mirror", 1)
+        if mirror.numel() != p.numel() or not mirror.is_contiguous():
+            raise ValueError("adamw_step: mirror size mismatch")
     L = _lib.load()
-    _lib.check(L.savit_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(b1), float(b2), float(eps),
-                                  float(weight_decay), int(step), _p(grad_sumsq), float(max_norm), float(grad_scale), _stream()),
-               "savit_adamw_step")
+    _lib.check(L.savit_adamw_step_mirror(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(b1), float(b2), float(eps),
+                                         float(weight_decay), int(step), _p(grad_sumsq), float(max_norm), float(grad_scale), _p(mirror),
+                                         _stream()), "savit_adamw_step_mirror")
 
 
 def cast_transpose_bf16(src: torch.Tensor, batch: int, R: int, C: int, src_bs: int, dst_n: Optional[torch.Tensor], dn_bs: int,

@@ -166,6 +166,26 @@ def test_every_compiled_tn_tile_is_reachable_from_the_auto_heuristic(built):
         assert L.savit_gemm_bf16_tn(ctypes.byref(a), None) == 1001, tile
 
 
+def test_tile_choice_follows_the_cu_budget(built):
+    """A data-parallel rank that leaves CUs to the resident all-reduce (train.py:96) gets grids priced for the CUs that remain: DeiT-B's
+    N = 768 products are ONE round of 237 tiles of 320 rows on 256 (or 240) CUs and two rounds on 224 - the heuristic must move off that tile - and
+    the column-sum slab height follows the tile."""
+    L = built.lib.load()
+    M = 128 * 197
+    assert L.savit_gemm_tn_auto_tile_cus(M, 768, 768, 0, 0) == 21 == L.savit_gemm_tn_auto_tile_epi(M, 768, 768, 0)
+    assert L.savit_gemm_tn_auto_tile_cus(M, 768, 768, 0, 256) == 21 and L.savit_gemm_tn_auto_tile_cus(M, 768, 768, 0, 1000) == 21
+    assert L.savit_gemm_tn_auto_tile_cus(M, 768, 768, 0, 240) == 21  # 237 tiles still fit one round of 240 CUs
+    t = L.savit_gemm_tn_auto_tile_cus(M, 768, 768, 0, 224)            # ... not one of 224
+    assert t in (17, 18, 20)
+    for cus in (0, 240, 224):
+        tile = L.savit_gemm_tn_auto_tile_cus(M, 3072, 768, 3, cus)
+        assert L.savit_gemm_colsum_rows_cus(M, 3072, 768, 0, cus) == L.savit_gemm_colsum_rows(M, 3072, 768, tile)
+    assert L.savit_gemm_wgrad_group_tiles(384, 1152, 640) == 5 and L.savit_gemm_wgrad_group_tiles(384, 384, 640) == 2
+    assert L.savit_gemm_wgrad_group_tiles(384, 1536, 640) == 6 and L.savit_gemm_wgrad_group_tiles(1536, 384, 640) == 6
+    assert L.savit_gemm_wgrad_group_tiles(384, 1152, 384) == 9 and L.savit_gemm_wgrad_group_tiles(768, 768, 256) == 9
+    assert L.savit_gemm_wgrad_group_tiles(768, 768, 192) == 0
+
+
 def _device_isa(obj_name, tmp_path):
     """Disassemble the gfx950 code object embedded in csrc/<obj_name> (llvm-objdump --offloading extracts next to its input)."""
     import shutil

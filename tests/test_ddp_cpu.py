@@ -151,3 +151,14 @@ def test_bench_rejects_mismatched_world(repo_root):
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "!= WORLD_SIZE" in r.stderr
+
+
+def test_default_reserved_cus(monkeypatch):
+    """A data-parallel rank plans its backward launches for the CUs the resident all-reduce leaves (engine reserved_cus): 0 alone, 16 of
+    256 at world > 1, SAVIT_RESERVED_CUS overrides (train.py:96 / :228-230 have no counterpart: XLA plans its own collectives)."""
+    from savit_amd import ddp
+
+    monkeypatch.delenv("SAVIT_RESERVED_CUS", raising=False)
+    assert ddp.default_reserved_cus(1) == 0 and ddp.default_reserved_cus(2) == 16 and ddp.default_reserved_cus(8) == 16
+    monkeypatch.setenv("SAVIT_RESERVED_CUS", "24")
+    assert ddp.default_reserved_cus(1) == 24 and ddp.default_reserved_cus(8) == 24

@@ -686,6 +686,57 @@ def test_adamw_and_clip(ops):
     assert rel(host(pt), p) < 1e-6 and rel(host(mt), m) < 1e-5 and rel(host(vt), v) < 1e-4  # fp32 moments vs fp64 oracle
 
 
+@pytest.mark.parametrize("n", [8 * 4096, 8 * 4096 + 4, 4])
+def test_adamw_mirror_is_bf16_of_the_updated_parameters(ops, n):
+    """savit_adamw_step_mirror: the same update as savit_adamw_step (bitwise) plus bf16(params) in the same flat layout - the [in, out]
+    MFMA operands of the input-gradient GEMMs are views into that mirror (train.py:25-27,100 + the bf16 cast of train.py:81's graph)."""
+    g0 = torch.Generator(device="cuda").manual_seed(n)
+    p = torch.randn(n, device="cuda", generator=g0)
+    g = torch.randn(n, device="cuda", generator=g0) * 2
+    a = [p.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")]
+    b = [p.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")]
+    mirror = torch.full((n,), float("nan"), dtype=bf16, device="cuda")
+    ss = torch.zeros(1, device="cuda")
+    ops.sumsq(g, ss)
+    for step in (1, 2):
+        ops.adamw_step(a[0], g, a[1], a[2], step, 1e-2, weight_decay=1e-3, grad_sumsq=ss, max_norm=1.0)
+        ops.adamw_step(b[0], g, b[1], b[2], step, 1e-2, weight_decay=1e-3, grad_sumsq=ss, max_norm=1.0, mirror=mirror)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(mirror, b[0].to(bf16))
+    assert not torch.equal(b[0], p)
+
+
+def test_layernorm_bwd_with_the_bias_gradient_slab_riding_along(ops):
+    """savit_layernorm_bwd_ex = savit_layernorm_bwd + savit_colsum_finalize(accumulate) in its finalize launch: same dx, same LN
+    gradients, and the slab's column sums added to extra_out in a fixed order (bitwise repeatable)."""
+    rng = np.random.default_rng(21)
+    rows, d, nx, rx = 1000, 192, 768, 158
+    x = dev(rng.standard_normal((rows, d)).astype(np.float32) * 2 + 0.5)
+    gam = dev((1 + 0.1 * rng.standard_normal(d)).astype(np.float32))
+    bet = dev((0.1 * rng.standard_normal(d)).astype(np.float32))
+    y, mean, rstd = ops.layernorm_fwd(x, gam, bet)
+    dy = dev(rng.standard_normal((rows, d)).astype(np.float32), bf16)
+    slab = dev(rng.standard_normal((rx, nx)).astype(np.float32))
+    base = dev(rng.standard_normal(nx).astype(np.float32))
+
+    def run(extra):
+        dg, db = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+        out = base.clone()
+        dx = ops.layernorm_bwd(dy, x, gam, mean, rstd, dg, db, **(dict(extra_slab=slab, extra_out=out) if extra else {}))
+        return dx, dg, db, out
+
+    dx0, dg0, db0, _ = run(False)
+    dx1, dg1, db1, out1 = run(True)
+    assert torch.equal(dx0, dx1)
+    assert rel(host(dg1), host(dg0)) < 1e-6 and rel(host(db1), host(db0)) < 1e-6  # (a few fp32 atomic adders finish these)
+    ref = host(base).astype(np.float64) + host(slab).astype(np.float64).sum(0)
+    assert rel(host(out1), ref) < 1e-6
+    assert torch.equal(out1, run(True)[3])
+    with pytest.raises(ValueError):
+        ops.layernorm_bwd(dy, x, gam, mean, rstd, dg0, db0, extra_slab=slab, extra_out=base[:-4])
+
+
 def test_cast_transpose_and_layout(ops):
     rng = np.random.default_rng(3)
     L, R, C, bs = 3, 100, 72, 100 * 72 + 40
