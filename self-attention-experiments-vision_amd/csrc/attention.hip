@@ -476,6 +476,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const AttnParams2 pp) {
   const int trow = 4 * (g >> 1) + (t >> 2);
   const int tcol = 16 * (g & 1) + 4 * (t & 3);
   constexpr int KC = 4;
+  const f32x16 zero16f = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int qb = wave; qb < NT; qb += nwv) {
     const int q = qb * 32 + ql;
     bf16x8 qf[4];
@@ -493,12 +494,11 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const AttnParams2 pp) {
       float cmax = -INFINITY;
 #pragma unroll
       for (int j = 0; j < KC; ++j) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[j][r] = -INFINITY;
         const int kt = c0 + j;
         if (kt < NT) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) s[j][r] = 0.f;
+          // the accumulator starts from the MFMA's inline-constant zero C operand; only the LAST key tile can hold keys >= N
+          // (round 4: this kernel is VALU-issue-bound at N = 577 - 2 x the MFMA time per tile - so every instruction per score counts)
+          s[j] = zero16f;
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
             if (16 * ks < hd) {
@@ -506,12 +506,15 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const AttnParams2 pp) {
               s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[j], 0, 0, 0);
             }
           }
+          if (kt == NT - 1) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (key >= p.N) s[j][r] = -INFINITY;
-            cmax = fmaxf(cmax, s[j][r]);
+            for (int r = 0; r < 16; ++r) {
+              const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              if (key >= p.N) s[j][r] = -INFINITY;
+            }
           }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cmax = fmaxf(cmax, s[j][r]);
         }
       }
       cmax = half_max(cmax);
@@ -578,8 +581,9 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
   const auto srdD = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.d_o), 0, (uint32_t)bytes_o, 0x00020000);
   stage_image_rt<0>(img0, srd, row_base, p.N, p.ld, p.d + hh * hd, wave, nwv, lane, NT, hd);
   stage_image_rt<0>(img1, srd, row_base, p.N, p.ld, 2 * p.d + hh * hd, wave, nwv, lane, NT, hd);
+  // lse_s holds -LSE * log2(e), so P = exp2(fma(S, log2 e, lse_s)); rows q >= N hold -inf (P = 0)
   for (int i = threadIdx.x; i < NT * 32; i += blockDim.x)
-    lse_s[i] = (i < p.N) ? p.lse[((size_t)b * p.H + hh) * p.N + i] : INFINITY;
+    lse_s[i] = (i < p.N) ? -LOG2E * p.lse[((size_t)b * p.H + hh) * p.N + i] : -INFINITY;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -587,8 +591,11 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
   const int g = lane >> 4, t = lane & 15;
   const int trow = 4 * (g >> 1) + (t >> 2);
   const int tcol = 16 * (g & 1) + 4 * (t & 3);
+  const f32x16 zero16f = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  // ---- pass A: queries on the lane; K, V resident
+  // ---- pass A: queries on the lane; K, V resident.  (Round 4: both passes are VALU-issue-bound at N = 577, so they take the lean
+  // per-score arithmetic of the resident kernel: zero-C accumulators, LSE / delta folded into the exp argument and the dS product,
+  // the key mask on the last tile only, vector reads of the statistics.)
   for (int qb = wave; qb < NT; qb += nwv) {
     const int q = qb * 32 + ql;
     bf16x8 qf[4], df[4];
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
     }
     delta = half_sum(delta);
     if (half == 0) del_s[q] = delta;
-    const float nlse = -lse_s[q];
+    const float nlse2 = lse_s[q];  // -LSE * log2 e; -inf for rows q >= N
     f32x16 dq[2];
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb)
@@ -612,12 +619,8 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
       for (int r = 0; r < 16; ++r) dq[eb][r] = 0.f;
 #pragma unroll 1
     for (int kt = 0; kt < NT; ++kt) {
-      f32x16 sa, da;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        sa[r] = nlse;
-        da[r] = -delta;
-      }
+      f32x16 sa = zero16f, da = zero16f;
+      ATTN_PRIO(1);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (16 * ks < hd) {
@@ -627,13 +630,20 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
           da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[ks], da, 0, 0, 0);
         }
       }
+      ATTN_PRIO(0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float pr = __builtin_amdgcn_exp2f(sa[r] * LOG2E);
-        if (key >= p.N) pr = 0.f;
-        sa[r] = pr * da[r];
+        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], LOG2E, nlse2));
+        sa[r] = pr * (da[r] - delta);  // dS^T
       }
+      if (kt == NT - 1) {  // only the last key tile can hold keys >= N
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (key >= p.N) sa[r] = 0.f;
+        }
+      }
+      ATTN_PRIO(1);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 dsf = acc_to_frag(sa, s2);
@@ -643,6 +653,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
           dq[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq[eb], 0, 0, 0);
         }
       }
+      ATTN_PRIO(0);
     }
     if (q < p.N) {
       bf16_t* drow = p.dqkv + (size_t)(row_base + q) * p.ld + hh * hd;
@@ -675,13 +686,15 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
       }
 #pragma unroll 1
     for (int qt = 0; qt < NT; ++qt) {
-      f32x16 sa, da;
+      f32x16 sa = zero16f, da = zero16f;
+      // -LSE*log2e and delta of this tile's queries: register r holds query qt*32 + 8*(r>>2) + 4*half + (r&3): four 16-byte reads each
+      float4 nl4[4], dl4[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        sa[r] = -lse_s[qq];
-        da[r] = -del_s[qq];
+      for (int g4 = 0; g4 < 4; ++g4) {
+        nl4[g4] = *reinterpret_cast<const float4*>(lse_s + qt * 32 + 8 * g4 + 4 * half);
+        dl4[g4] = *reinterpret_cast<const float4*>(del_s + qt * 32 + 8 * g4 + 4 * half);
       }
+      ATTN_PRIO(1);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (16 * ks < hd) {
@@ -691,12 +704,20 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
           da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr, vf[ks], da, 0, 0, 0);
         }
       }
+      ATTN_PRIO(0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pr = __builtin_amdgcn_exp2f(sa[r] * LOG2E);
-        sa[r] = pr;
-        da[r] = pr * da[r];
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float nl[4] = {nl4[g4].x, nl4[g4].y, nl4[g4].z, nl4[g4].w};
+        const float dl[4] = {dl4[g4].x, dl4[g4].y, dl4[g4].z, dl4[g4].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g4 + j;
+          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], LOG2E, nl[j]));  // rows q >= N: -inf -> 0
+          sa[r] = pr;
+          da[r] = pr * (da[r] - dl[j]);
+        }
       }
+      ATTN_PRIO(1);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 pf = acc_to_frag(sa, s2);
@@ -709,6 +730,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
           dk[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dk[eb], 0, 0, 0);
         }
       }
+      ATTN_PRIO(0);
     }
     if (key < p.N) {
       bf16_t* krow = p.dqkv + (size_t)(row_base + key) * p.ld + p.d + hh * hd;
