@@ -53,6 +53,47 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const char* img, int row0, int col
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// The same transposed fragment for kernels that keep an LDS-DMA in flight across their passes: hipcc (ROCm 7.2) puts
+// `s_waitcnt vmcnt(0)` in front of the ds_read_tr16 BUILTIN whenever an LDS-DMA may be outstanding (it cannot prove that the two do not
+// alias), which makes the prefetch of the next item land before the pass starts - no overlap (the persistent backward of round 2 and
+// the first one of round 4 both ran at the one-item kernel's speed for this reason).  The asm form is invisible to that pass;
+// completion is waited for by lds_tr_wait (an `s_waitcnt lgkmcnt(0)` that names every destination "+v", so no consumer or copy can be
+// scheduled above it; the compiler's own counted lgkmcnt waits stay correct because LDS returns in order - they can only over-wait).
+struct TrFrag {
+  bf16x4 lo, hi;
+};
+__device__ __forceinline__ uint32_t lds_addr32(const char* p) { return (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)p); }
+// a_lo / a_hi: LDS byte addresses of rows row0 / row0 + 8 (tr_lane_off below + image + 32-row tile); OFF: compile-time byte offset
+// on top (another image, the second k-step), so that one pair of address registers serves every fragment of a tile column
+template <int OFF>
+__device__ __forceinline__ void lds_tr_issue(TrFrag& f, uint32_t a_lo, uint32_t a_hi) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(a_lo), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(a_hi), "n"(OFF));
+}
+// byte offset inside an image of this lane's piece of the transposed fragment at rows trow (+ 8 if hi), columns col..col+3; adding
+// multiples of 16 rows does not change the swizzle (rot3 looks at row bits 1..3)
+__device__ __forceinline__ uint32_t tr_lane_off(int trow, int col, bool hi) {
+  const int r = trow + (hi ? 8 : 0);
+  return (uint32_t)(r * ROWB + (((col >> 3) ^ rot3(r)) << 4) + ((col & 7) << 1));
+}
+__device__ __forceinline__ void lds_tr_wait(TrFrag& a, TrFrag& b, TrFrag& c, TrFrag& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi));
+}
+// 16-byte LDS reads in the same style (OFF: compile-time byte offset)
+__device__ __forceinline__ void lds_read_f4(f32x4& v, uint32_t addr, int off) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
+}
+__device__ __forceinline__ void lds_f4_wait(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void lds_read_u4(uint4& v, uint32_t addr) {
+  u32x4 t;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(t) : "v"(addr));
+  v = make_uint4(t[0], t[1], t[2], t[3]);
+}
+__device__ __forceinline__ bf16x8 tr_join(const TrFrag& f) { return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+
 // registers 8s..8s+7 of a 32x32 fp32 accumulator -> bf16 B-operand fragment of k-step s
 __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int s) {
   union { uint32_t u[4]; bf16x8 v; } r;
@@ -78,6 +119,32 @@ __device__ __forceinline__ void store_row_tile(bf16_t* row, const f32x16 (&acc)[
     }
 }
 
+// The same tile through a 4 KB LDS image private to the wave (128-byte rows, the images' swizzle), read back as WHOLE rows - lane =
+// (row 8j + lane/8, 16-byte chunk lane%8) - and stored 8 rows x 128 B per instruction.  store_row_tile's instructions touch 32 cache
+// lines each (32 B per row); the L1's tag pipe takes a few cycles per line, and in the persistent backward - which issues its
+// stores while the partner waves compute - that was 4.3 us per pass for the second wave of every SIMD (round 4, s_memrealtime stamps).
+// rows_valid: rows of the tile inside the matrix.  The reads are inline asm (see TrFrag); LDS serves a wave's operations in order.
+__device__ __forceinline__ void store_tile_rows(char* scr, bf16_t* tile0, size_t ld, int rows_valid, const f32x16 (&acc)[2], int ql, int half,
+                                                int lane, float sc) {
+#pragma unroll
+  for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4 += 2)
+      *reinterpret_cast<uint4*>(scr + img_off(ql, 4 * eb + g4 + half)) = merge_row_halves(
+          make_uint2(pack_bf16x2(acc[eb][4 * g4] * sc, acc[eb][4 * g4 + 1] * sc), pack_bf16x2(acc[eb][4 * g4 + 2] * sc, acc[eb][4 * g4 + 3] * sc)),
+          make_uint2(pack_bf16x2(acc[eb][4 * g4 + 4] * sc, acc[eb][4 * g4 + 5] * sc), pack_bf16x2(acc[eb][4 * g4 + 6] * sc, acc[eb][4 * g4 + 7] * sc)));
+  uint4 v[4];
+  const uint32_t a = lds_addr32(scr);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) lds_read_u4(v[j], a + (uint32_t)img_off(8 * j + (lane >> 3), lane & 7));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 8 * j + (lane >> 3);
+    if (row < rows_valid) *reinterpret_cast<uint4*>(tile0 + (size_t)row * ld + 8 * (lane & 7)) = v[j];
+  }
+}
+
 // Stage `rows` (multiple of 8*NW... handled by caller loop) token rows of one [token][64] slice into an LDS image.
 // src column offset `col0` (elements) inside rows of length ld; token t maps to global row row_base + t; t >= N -> zeros.
 template <int NW, int NT>
@@ -86,6 +153,26 @@ __device__ __forceinline__ void stage_image(char* img, __amdgpu_buffer_rsrc_t sr
   constexpr int INSTR = NT * 32 / 8;  // wave-instructions for the whole image (8 rows each)
   const int lrow = lane >> 3, pc = lane & 7;
   for (int inst = wave; inst < INSTR; inst += NW) {
+    const int t = inst * 8 + lrow;
+    const int c = pc ^ rot3(t);
+    uint32_t voff = 0xfffffff0u;
+    if (t < N) voff = (uint32_t)(((size_t)(row_base + t) * ld + col0 + c * 8) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(img + inst * 1024), 16, voff, 0, 0, 0);
+  }
+}
+
+// The same with a compile-time instruction count per wave (NW waves, NT * 4 instructions, NW divides them): straight-line code, so
+// hipcc can COUNT the LDS-DMA instructions behind an earlier global load and wait for that load alone (after a loop of unknown
+// trip count its vmcnt waits drain the LDS-DMA as well)
+template <int NW, int NT>
+__device__ __forceinline__ void stage_image_u(char* img, __amdgpu_buffer_rsrc_t srd, long row_base, int N, int ld, int col0, int wave,
+                                              int lane) {
+  constexpr int INSTR = NT * 32 / 8;
+  static_assert(INSTR % NW == 0, "whole instructions per wave");
+  const int lrow = lane >> 3, pc = lane & 7;
+#pragma unroll
+  for (int k = 0; k < INSTR / NW; ++k) {
+    const int inst = wave * (INSTR / NW) + k;  // a wave stages its OWN 32-row block: after its own vmcnt(0) it may read those rows
     const int t = inst * 8 + lrow;
     const int c = pc ^ rot3(t);
     uint32_t voff = 0xfffffff0u;
@@ -421,7 +508,331 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
 }
 
 
+// Persistent form of the backward (round 4; N <= 224): a workgroup walks over (batch, head) items with the SAME four images, but only
+// two are live per pass, so the other two are refilled under it.  Pass B (dK, dV) needs Q, dO whole and this wave's 32 rows of K, V;
+// pass A (dQ) needs K, V whole and this wave's rows of Q, dO plus delta = rowsum(dO * O).  Per item, pass B first:
+//   [barrier a]  LDS-DMA K,V(i) | pass B(i) | this wave's Q,dO rows out of the images -> registers
+//   [barrier b]  dK,dV stores | requests for item i+1: LDS-DMA of this wave's O rows, its K,V rows, LDS-DMA Q,dO | pass A(i) |
+//                own vmcnt(0) | delta, LSE of item i+1 -> LDS; K,V rows -> pass-B fragments | dQ stores
+// What it took (each item measured with s_memrealtime stamps, tools/attn_stamps.py; profiles/r04_attn_bwd_pers.log):
+//  * every LDS read that hipcc can attribute to the LDS address space gets `s_waitcnt vmcnt(0)` in front while an LDS-DMA is in
+//    flight (the ds_read_tr16 builtin, plain float4 reads of the statistics): the transposed fragments and the statistics are read
+//    by inline asm (TrFrag, lds_read_f4) - without that nothing overlaps (round 2's persistent form, and this one's first build);
+//  * a spilled register is reloaded by a VMEM operation that waits for everything issued before it, the LDS-DMA included: the rows
+//    requested from HBM are live only during pass A (the pass with registers to spare), the O rows go by LDS-DMA into a 4 KB image
+//    private to the wave, fragments and statistics are requested in halves; 251 VGPRs, no scratch;
+//  * the LDS-DMA is issued by straight-line code (stage_image_u) so that the waits hipcc places are COUNTED ones, and each wave
+//    stages its own 32-row block, so delta / the K, V fragments of the next item need only the wave's own vmcnt(0), before barrier a;
+//  * the CU accepts a vector-memory instruction every ~50 cycles, slower when it touches 32 cache lines: all row traffic is whole
+//    128-byte rows - stores through the wave's image (store_tile_rows: the second wave of every SIMD spent 4.3 us issuing its dK, dV
+//    stores as 32-byte pieces), K, V rows read whole and turned into fragments through the image, barrier a bare (not waiting for
+//    the dQ stores).
+// DeiT-B's layer: 138 -> 129 us per launch (117 in the step); a workgroup's item 20.7 -> 17 us with the passes at 10.7 us: what is
+// left between the passes is the issue of ~45 vector-memory instructions per wave and two barriers.
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void attn_bwd_pers_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int IMG = NT * 32 * ROWB;
+  char* imgK = smem;
+  char* imgV = smem + IMG;
+  char* imgQ = smem + 2 * IMG;
+  char* imgD = smem + 3 * IMG;  // dO
+  float* lse_s = reinterpret_cast<float*>(smem + 4 * IMG);
+  float* del_s = lse_s + NT * 32;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* scr = smem + 4 * IMG + 2 * NT * 32 * (int)sizeof(float) + wave * (32 * ROWB);  // this wave's 4 KB transposition image
+  const int nitems = p.B * p.H;
+  size_t bytes = (size_t)p.B * p.N * p.ld * 2;
+  if (bytes > 0xffffffe0ull) bytes = 0xffffffe0ull;
+  size_t bytes_o = (size_t)p.B * p.N * p.d * 2;
+  if (bytes_o > 0xffffffe0ull) bytes_o = 0xffffffe0ull;
+  const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.qkv), 0, (uint32_t)bytes, 0x00020000);
+  const auto srdD = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.d_o), 0, (uint32_t)bytes_o, 0x00020000);
+  const int ql = lane & 31, half = lane >> 5;
+  const int g = lane >> 4, t = lane & 15;
+  const int trow = 4 * (g >> 1) + (t >> 2);
+  const int tcol = 16 * (g & 1) + 4 * (t & 3);
+  const int q = wave * 32 + ql;  // this wave's row in both passes (key in B, query in A)
+  uint32_t trc[2][2];  // [eb][lo / hi]: transposed-fragment addresses of tile 0 in the first image
+#pragma unroll
+  for (int eb = 0; eb < 2; ++eb) {
+    trc[eb][0] = lds_addr32(smem) + tr_lane_off(trow, 32 * eb + tcol, false);
+    trc[eb][1] = lds_addr32(smem) + tr_lane_off(trow, 32 * eb + tcol, true);
+  }
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+  auto stage_kv = [&](int item) {
+    const int b = item / p.H, hh = item - b * p.H;
+    stage_image_u<NT, NT>(imgK, srd, (long)b * p.N, p.N, p.ld, p.d + hh * HD, wave, lane);
+    stage_image_u<NT, NT>(imgV, srd, (long)b * p.N, p.N, p.ld, 2 * p.d + hh * HD, wave, lane);
+  };
+  auto stage_qd = [&](int item) {
+    const int b = item / p.H, hh = item - b * p.H;
+    stage_image_u<NT, NT>(imgQ, srd, (long)b * p.N, p.N, p.ld, hh * HD, wave, lane);
+    stage_image_u<NT, NT>(imgD, srdD, (long)b * p.N, p.N, p.d, hh * HD, wave, lane);
+  };
+  // this wave's 32 rows of O (for delta = rowsum(dO * O); dO comes out of its LDS image) go by LDS-DMA into the wave's transposition
+  // image (no registers), its LSE values and its rows of K, V (B operands of pass B) into registers; all as whole 128-byte rows.
+  bf16x8 kf[4], vf[4];
+  float lse_q = 0.f;
+  const auto srdO = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.o), 0, (uint32_t)bytes_o, 0x00020000);
+  auto request_o = [&](int item) {
+    const int b = item / p.H, hh = item - b * p.H;
+    lse_q = INFINITY;  // rows q >= N: -LSE * log2 e = -inf, P = 0
+    if (q < p.N) lse_q = p.lse[((size_t)b * p.H + hh) * p.N + q];
+    const int lrow = lane >> 3, pc = lane & 7;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = 8 * j + lrow;
+      const int c = pc ^ rot3(t);
+      uint32_t voff = 0xfffffff0u;
+      if (wave * 32 + t < p.N) voff = (uint32_t)(((size_t)((long)b * p.N + wave * 32 + t) * p.d + hh * HD + c * 8) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdO, (__attribute__((address_space(3))) void*)(scr + j * 1024), 16, voff, 0, 0, 0);
+    }
+  };
+  auto request_rows = [&](int item, bf16x8 (&f)[4], int col0) {  // whole rows again (kf / vf hold them raw until rows_to_frags)
+    const int b = item / p.H, hh = item - b * p.H;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wave * 32 + 8 * j + (lane >> 3);
+      f[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (row < p.N) f[j] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)((long)b * p.N + row) * p.ld + col0 + hh * HD + 8 * (lane & 7));
+    }
+  };
+  auto request_kv = [&](int item) {
+    request_rows(item, kf, p.d);
+    request_rows(item, vf, 2 * p.d);
+  };
+  // raw rows -> B-operand fragments (lane = (row, half), 16-byte chunks 2 ks + half) through the transposition image
+  auto rows_to_frags = [&](bf16x8 (&f)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16x8*>(scr + img_off(8 * j + (lane >> 3), lane & 7)) = f[j];
+    uint4 v[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) lds_read_u4(v[ks], lds_addr32(scr) + (uint32_t)img_off(ql, 2 * ks + half));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f[ks] = __builtin_bit_cast(bf16x8, v[ks]);
+  };
+  // delta and -LSE * log2 e of this wave's queries, once ITS rows of the item's dO image and of O have landed (its own LDS-DMA: no
+  // barrier needed): LDS for everybody's pass B (published by barrier a), registers for this wave's pass A.
+  float delta = 0.f, nlse2 = 0.f;
+  auto finish_delta = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wave * 32 + 8 * j + (lane >> 3);
+      const bf16x8 dv = lds_row_frag(imgD, row, lane & 7);  // rows >= N are zero in both
+      const bf16x8 ov = lds_row_frag(scr, 8 * j + (lane >> 3), lane & 7);
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part += bf16_to_f32((bf16_t)ov[e]) * bf16_to_f32((bf16_t)dv[e]);
+      part += dpp_mov<0xB1>(part);   // quad_perm [1,0,3,2]
+      part += dpp_mov<0x4E>(part);   // quad_perm [2,3,0,1]
+      part += dpp_mov<0x141>(part);  // row_half_mirror: the other quad of the 8 lanes of this row
+      if ((lane & 7) == 0) del_s[row] = part;
+    }
+    nlse2 = -LOG2E * lse_q;
+    if (half == 0) lse_s[q] = nlse2;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(delta) : "v"(lds_addr32(smem) + 4 * IMG + (uint32_t)((NT * 32 + q) * 4)) : "memory");
+  };
+
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+  stage_qd(item);
+  request_o(item);
+  request_kv(item);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  finish_delta();
+  rows_to_frags(kf);
+  rows_to_frags(vf);
+  __syncthreads();  // barrier a of the first item
+#pragma unroll 1
+  for (;;) {
+    const int nxt = item + gridDim.x;
+    const bool has_next = nxt < nitems;
+    const int b = item / p.H, hh = item - b * p.H;
+    const long row_base = (long)b * p.N;
+    stage_kv(item);
+    // ---- pass B: this wave owns keys (lane = key).  S[q][key] non-swapped: rows = queries (registers).
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) {
+      dk[eb] = zero16;
+      dv[eb] = zero16;
+    }
+#pragma unroll 1
+    for (int qt = 0; qt < NT; ++qt) {
+      f32x16 sa = zero16, da = zero16;
+      // -LSE*log2e and delta of this tile's queries: register r holds query qt*32 + 8*(r>>2) + 4*half + (r&3): four 16-byte reads
+      // each, as inline asm in two halves (any LDS load the compiler knows the address space of gets `s_waitcnt vmcnt(0)` in front
+      // while an LDS-DMA is in flight - these did, and the K, V prefetch landed before the pass went on)
+      f32x4 nl4[4], dl4[4];
+      const uint32_t sta = lds_addr32(smem) + 4 * IMG + (uint32_t)((qt * 32 + 4 * half) * 4);
+#pragma unroll
+      for (int g4 = 0; g4 < 2; ++g4) {
+        lds_read_f4(nl4[g4], sta, 32 * g4);
+        lds_read_f4(dl4[g4], sta, NT * 32 * 4 + 32 * g4);
+      }
+      ATTN_PRIO(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 qfr = lds_row_frag(imgQ, qt * 32 + ql, 2 * ks + half);
+        const bf16x8 dfr = lds_row_frag(imgD, qt * 32 + ql, 2 * ks + half);
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[ks], sa, 0, 0, 0);
+        da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr, vf[ks], da, 0, 0, 0);
+        if (ks == 1) __builtin_amdgcn_sched_barrier(0);  // the second half's fragments are requested under these MFMAs: 16 registers less
+      }
+      ATTN_PRIO(0);
+      TrFrag dtf[2][2], qtf[2][2];  // k-step 1's are requested under k-step 0's MFMAs
+      const uint32_t tb = (uint32_t)(qt * 32 * ROWB);
+#ifdef ATTN_TR_EARLY
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) {
+        lds_tr_issue<3 * IMG - 2 * IMG>(dtf[0][eb], trc[eb][0] + tb + 2 * IMG, trc[eb][1] + tb + 2 * IMG);
+        lds_tr_issue<0>(qtf[0][eb], trc[eb][0] + tb + 2 * IMG, trc[eb][1] + tb + 2 * IMG);
+      }
+#endif
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        if (g4 == 0) {
+          lds_f4_wait(nl4[0], dl4[0], nl4[1], dl4[1]);
+#pragma unroll
+          for (int h4 = 2; h4 < 4; ++h4) {  // the second half arrives under the first half's arithmetic
+            lds_read_f4(nl4[h4], sta, 32 * h4);
+            lds_read_f4(dl4[h4], sta, NT * 32 * 4 + 32 * h4);
+          }
+        }
+        if (g4 == 2) lds_f4_wait(nl4[2], dl4[2], nl4[3], dl4[3]);
+        const float nl[4] = {nl4[g4][0], nl4[g4][1], nl4[g4][2], nl4[g4][3]};
+        const float dl[4] = {dl4[g4][0], dl4[g4][1], dl4[g4][2], dl4[g4][3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g4 + j;
+          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], LOG2E, nl[j]));  // rows q >= N: -inf -> 0
+          sa[r] = pr;
+          da[r] = pr * (da[r] - dl[j]);
+        }
+      }
+#ifndef ATTN_TR_EARLY
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) {
+        lds_tr_issue<3 * IMG - 2 * IMG>(dtf[0][eb], trc[eb][0] + tb + 2 * IMG, trc[eb][1] + tb + 2 * IMG);
+        lds_tr_issue<0>(qtf[0][eb], trc[eb][0] + tb + 2 * IMG, trc[eb][1] + tb + 2 * IMG);
+      }
+#endif
+      lds_tr_wait(dtf[0][0], dtf[0][1], qtf[0][0], qtf[0][1]);
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) {
+        lds_tr_issue<IMG + 16 * ROWB>(dtf[1][eb], trc[eb][0] + tb + 2 * IMG, trc[eb][1] + tb + 2 * IMG);
+        lds_tr_issue<16 * ROWB>(qtf[1][eb], trc[eb][0] + tb + 2 * IMG, trc[eb][1] + tb + 2 * IMG);
+      }
+      ATTN_PRIO(1);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_to_frag(sa, s2);
+        const bf16x8 dsf = acc_to_frag(da, s2);
+        if (s2 == 1) lds_tr_wait(dtf[1][0], dtf[1][1], qtf[1][0], qtf[1][1]);
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) {
+          dv[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(dtf[s2][eb]), pf, dv[eb], 0, 0, 0);
+          dk[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(qtf[s2][eb]), dsf, dk[eb], 0, 0, 0);
+        }
+      }
+      ATTN_PRIO(0);
+    }
+    // this wave's Q, dO rows for pass A, before the images are released
+    bf16x8 qf[4], df[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = lds_row_frag(imgQ, q, 2 * ks + half);
+      df[ks] = lds_row_frag(imgD, q, 2 * ks + half);
+    }
+    const float delta_a = delta, nlse2_a = nlse2;
+    __syncthreads();  // barrier b: K, V landed; Q, dO images and the statistics free
+    {
+      bf16_t* ktile = p.dqkv + (size_t)(row_base + wave * 32) * p.ld + p.d + hh * HD;
+      store_tile_rows(scr, ktile, p.ld, p.N - wave * 32, dk, ql, half, lane, 1.0f);
+      store_tile_rows(scr, ktile + p.d, p.ld, p.N - wave * 32, dv, ql, half, lane, 1.0f);
+    }
+    if (has_next) {
+      // (issued a few per key tile inside pass A instead - unrolled tile loop - these spill registers, and a spill reload is a VMEM
+      // operation that waits for everything before it: measured slower)
+      request_o(nxt);
+      request_kv(nxt);
+      stage_qd(nxt);
+    }
+    // ---- pass A: this wave owns queries (lane = query).  dQ^T[e][q] = sum_key K^T[e][key] dS^T[key][q]
+    f32x16 dq[2];
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) dq[eb] = zero16;
+#pragma unroll 1
+    for (int kt = 0; kt < NT; ++kt) {
+      // accumulators start from the MFMA's inline-constant zero C operand (no per-tile register initialisation); the LSE /
+      // delta offsets fold into the exp argument and the dS product: this loop is VALU-bound, every instruction per score counts
+      f32x16 sa = zero16, da = zero16;
+      ATTN_PRIO(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kfr = lds_row_frag(imgK, kt * 32 + ql, 2 * ks + half);
+        const bf16x8 vfr = lds_row_frag(imgV, kt * 32 + ql, 2 * ks + half);
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[ks], sa, 0, 0, 0);
+        da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, df[ks], da, 0, 0, 0);
+        if (ks == 1) __builtin_amdgcn_sched_barrier(0);
+      }
+      ATTN_PRIO(0);
+      TrFrag ktf[2][2];
+      const uint32_t tb = (uint32_t)(kt * 32 * ROWB);
+#ifdef ATTN_TR_EARLY
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) {
+        lds_tr_issue<0>(ktf[0][eb], trc[eb][0] + tb, trc[eb][1] + tb);
+        lds_tr_issue<16 * ROWB>(ktf[1][eb], trc[eb][0] + tb, trc[eb][1] + tb);
+      }
+#endif
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], LOG2E, nlse2_a));
+        sa[r] = pr * (da[r] - delta_a);  // dS^T
+      }
+      if (kt == NT - 1) {  // only the last key tile can hold keys >= N
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (key >= p.N) sa[r] = 0.f;
+        }
+      }
+#ifndef ATTN_TR_EARLY
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) {
+        lds_tr_issue<0>(ktf[0][eb], trc[eb][0] + tb, trc[eb][1] + tb);
+        lds_tr_issue<16 * ROWB>(ktf[1][eb], trc[eb][0] + tb, trc[eb][1] + tb);
+      }
+#endif
+      lds_tr_wait(ktf[0][0], ktf[0][1], ktf[1][0], ktf[1][1]);
+      ATTN_PRIO(1);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 dsf = acc_to_frag(sa, s2);
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) dq[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(ktf[s2][eb]), dsf, dq[eb], 0, 0, 0);
+      }
+      ATTN_PRIO(0);
+    }
+    if (has_next) {  // this wave's rows of the next item's dO, O, K, V are here after ITS vmcnt(0): statistics, B operands of pass B
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      finish_delta();
+      rows_to_frags(kf);
+      rows_to_frags(vf);
+    }
+    store_tile_rows(scr, p.dqkv + (size_t)(row_base + wave * 32) * p.ld + hh * HD, p.ld, p.N - wave * 32, dq, ql, half, lane, p.dq_scale);
+    // barrier a of the next item: its Q, dO landed (every wave waited for its share above), its statistics written; K, V images
+    // free.  Bare: a __syncthreads() would wait for the dQ stores as well.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (!has_next) break;
+    item = nxt;
+  }
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // General kernels: any N <= 608 (19 key tiles: ViT-L/16 at 384^2 has N = 577), head_dim 48 or 64 (48 = every CaiT size;
@@ -1652,12 +2063,28 @@ extern "C" int savit_attention_bwd(const void* qkv, const void* o, const void* d
     hipLaunchKernelGGL(attn_bwd2_kernel, dim3(B * H), dim3(64 * (nt < 8 ? nt : 8)), lds, (hipStream_t)stream, pp);
     SAVIT_LAUNCH_RET();
   }
-  // One (batch, head) item per workgroup.  A persistent variant that double-buffers the K,V / Q,dO image pairs across items (LDS-DMA
-  // of the next item under the current pass, counted vmcnt waits, buffer stores) was built and measured in round 2 and dropped: with
-  // the passes compiled out the data movement of this kernel is 45 us of loads + 47 us of stores, the two passes with the loads hidden
-  // take 123 us, and everything together ran 148 us against 139 us here - the passes, not the data movement, bound this backward
-  // (seven waves on four SIMDs run their LDS -> MFMA -> exp -> MFMA chains nearly serially).
+  // N <= 224: persistent workgroups (attn_bwd_pers_kernel).  Round 2 built a persistent form as well and dropped it (148 us against
+  // 139): its transposed-fragment reads were the ds_read_tr16 builtin, in front of which hipcc waits for vmcnt(0) while an LDS-DMA is
+  // in flight, so nothing overlapped - see TrFrag.  N = 225 .. 256 (four images + the transposition images exceed the LDS) and
+  // -DATTN_BWD_ONE_ITEM experiment builds: one (batch, head) item per workgroup.
+#ifndef ATTN_BWD_ONE_ITEM
+  if (nt <= 7) {  // persistent form: four images + statistics + one 4 KB transposition image per wave (N <= 224: 145 KB of LDS)
+#define ATTN_PERS_LDS ((size_t)4 * NT * 32 * ROWB + (size_t)2 * NT * 32 * sizeof(float) + (size_t)NT * 32 * ROWB)
+    switch (nt) {
+      case 1: ATTN_CASE(attn_bwd_pers_kernel, 1, ATTN_PERS_LDS, persistent_grid(B * H, lds, 64 * NT))
+      case 2: ATTN_CASE(attn_bwd_pers_kernel, 2, ATTN_PERS_LDS, persistent_grid(B * H, lds, 64 * NT))
+      case 3: ATTN_CASE(attn_bwd_pers_kernel, 3, ATTN_PERS_LDS, persistent_grid(B * H, lds, 64 * NT))
+      case 4: ATTN_CASE(attn_bwd_pers_kernel, 4, ATTN_PERS_LDS, persistent_grid(B * H, lds, 64 * NT))
+      case 5: ATTN_CASE(attn_bwd_pers_kernel, 5, ATTN_PERS_LDS, persistent_grid(B * H, lds, 64 * NT))
+      case 6: ATTN_CASE(attn_bwd_pers_kernel, 6, ATTN_PERS_LDS, persistent_grid(B * H, lds, 64 * NT))
+      default: ATTN_CASE(attn_bwd_pers_kernel, 7, ATTN_PERS_LDS, persistent_grid(B * H, lds, 64 * NT))
+    }
+    SAVIT_LAUNCH_RET();
+  }
+  switch (nt) { default: ATTN_CASE(attn_bwd_kernel, 8, (size_t)4 * NT * 32 * ROWB + (size_t)2 * NT * 32 * sizeof(float), B * H) }
+#else
   ATTN_DISPATCH(attn_bwd_kernel, (size_t)4 * NT * 32 * ROWB + (size_t)2 * NT * 32 * sizeof(float), B * H)
+#endif
   SAVIT_LAUNCH_RET();
 }
 

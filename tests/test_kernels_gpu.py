@@ -591,7 +591,10 @@ def test_attention_general_fwd_bwd(ops, B, N, H, hd):
         assert r < 1e-3, (name, "vs emulated", r)
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (2, 196, 2), (1, 50, 4), (1, 33, 1), (1, 256, 1), (3, 224, 2), (2, 225, 1), (37, 197, 12)])
+# (37, 197, 12), (64, 197, 12), (65, 64, 12): more (image, head) items than resident workgroups - the persistent kernel's item loop with
+# two and three items per workgroup; N = 225, 256: the one-item kernel (the persistent form's LDS does not fit above N = 224)
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (2, 196, 2), (1, 50, 4), (1, 33, 1), (1, 256, 1), (3, 224, 2), (2, 225, 1), (37, 197, 12),
+                                   (64, 197, 12), (65, 64, 12), (5, 97, 3), (3, 129, 2), (2, 161, 5), (1, 1, 1)])
 def test_attention_bwd(ops, B, N, H):
     rng = np.random.default_rng(B * 10 + N)
     d = H * 64
