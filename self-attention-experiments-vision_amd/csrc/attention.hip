@@ -201,7 +201,8 @@ struct AttnParams {
 // Persistent: each workgroup walks over (batch, head) items blockIdx.x, += gridDim.x with TWO K/V image pairs in LDS, so the
 // LDS-DMA of the next item runs under the MFMA/softmax work of the current one.  (Measured before: loads + stores alone 34 us,
 // compute alone 54 us, together 63 us per launch - every workgroup of a launch is in the same phase, so co-resident workgroups
-// do not cover each other; two 4-wave workgroups per CU ran in the same 63 us.)
+// do not cover each other; two 4-wave workgroups per CU ran in the same 63 us.)  Round 4: O leaves as whole 128-byte rows through a
+// fifth LDS image (store_tile_rows; 43.8 -> 41.7 us per launch at DeiT-B's layer - 32-byte row pieces cost the L1 32 lines per store).
 template <int NT>
 __global__ __launch_bounds__(64 * NT) void attn_fwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -310,11 +311,11 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_kernel(const AttnParams p) {
         }
       }
     }
-    if (q < p.N) {
-      const float inv = 1.0f / l;
-      bf16_t* orow = p.o + (size_t)(row_base + q) * p.d + hh * HD;
-      store_row_tile(orow, oacc, half, HD, inv);
-      if (half == 0 && p.lse != nullptr) p.lse[((size_t)b * p.H + hh) * p.N + q] = m + __logf(l);
+    {
+      const float inv = 1.0f / l;  // rows q >= N: finite (every key of the last tile masked alike), never stored
+      store_tile_rows(smem + 4 * IMG + wave * (32 * ROWB), p.o + (size_t)(row_base + wave * 32) * p.d + hh * HD, p.d, p.N - wave * 32, oacc, ql,
+                      half, lane, inv);
+      if (q < p.N && half == 0 && p.lse != nullptr) p.lse[((size_t)b * p.H + hh) * p.N + q] = m + __logf(l);
     }
     cur ^= 1;
   }
@@ -2041,7 +2042,7 @@ extern "C" int savit_attention_fwd(const void* qkv, void* o, float* lse, int B, 
     SAVIT_LAUNCH_RET();
   }
   // persistent workgroups: as many as fit the CUs' LDS at once (two K/V image pairs each), every one walking over items
-  ATTN_DISPATCH(attn_fwd_kernel, (size_t)4 * NT * 32 * ROWB, persistent_grid(B * H, (size_t)4 * NT * 32 * ROWB, 64 * NT))
+  ATTN_DISPATCH(attn_fwd_kernel, (size_t)5 * NT * 32 * ROWB, persistent_grid(B * H, (size_t)5 * NT * 32 * ROWB, 64 * NT))
   SAVIT_LAUNCH_RET();
 }
 
