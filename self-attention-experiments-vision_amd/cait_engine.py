@@ -486,14 +486,16 @@ class CaiTEngine:
                 n_launch[0] += 1
 
         ring, ri = [t.data_ptr() for t in self.dbr_ring], 0
+        fuse_ls = d > 64  # savit_layernorm_bwd_ls serves wide rows (every head_dim 48 / 64 geometry)
         for l in range(NL - 1, -1, -1):
             st = self.stats[l]
             w = lambda n, l=l: self.w[n][l].data_ptr()  # noqa: E731
             sd0, sd1 = self.sd[2 * l].data_ptr(), self.sd[2 * l + 1].data_ptr()
             d_u, dqkv = self.d_u_ring[l % len(self.d_u_ring)].data_ptr(), self.dqkv_ring[l % len(self.dqkv_ring)].data_ptr()
-            ri = (ri + 1) % len(ring)
-            P.add(L.savit_layerscale_bwd, (self.dres.data_ptr(), self.br2[l].data_ptr(), pp(f"l{l}.ls2"), sd1, N, ring[ri], gp(f"l{l}.ls2"),
-                                           gp(f"l{l}.b2"), M, d, d, ws, wsb), f"l{l}.ls2.bwd", writes=(ring[ri],))
+            if l == NL - 1 or not fuse_ls:  # below the first layer processed there is no LayerNorm backward to ride on
+                ri = (ri + 1) % len(ring)
+                P.add(L.savit_layerscale_bwd, (self.dres.data_ptr(), self.br2[l].data_ptr(), pp(f"l{l}.ls2"), sd1, N, ring[ri], gp(f"l{l}.ls2"),
+                                               gp(f"l{l}.b2"), M, d, d, ws, wsb), f"l{l}.ls2.bwd", writes=(ring[ri],))
             wgrad_l(f"l{l}.W2.wgrad", l, self.a[l].data_ptr(), ring[ri], gp(f"l{l}.W2"), M, F, d, F, d, d)
             # bias gradient: per-row-tile partial sums to a slab + finalize, as in the ViT engine (atomic column sums cost this launch
             # 160 instead of 117 us at CaiT-S24: 50 k rows adding into 1536 addresses)
@@ -504,12 +506,20 @@ class CaiTEngine:
             wgrad_l(f"l{l}.W1.wgrad", l, self.h2[l].data_ptr(), d_u, gp(f"l{l}.W1"), M, d, F, d, F, F)
             self._gemm(P, f"l{l}.fc1.dgrad", A=d_u, Bt=w("W1_n"), C=self.d_h.data_ptr(), M=M, N=d, K=F, lda=F, ldb=F, ldc=d,
                        epilogue=_lib.EPI_BF16)
-            P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(),
-                                          self.dres.data_ptr(), self.dres.data_ptr(), None, gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b"), None, M, d, d, d,
-                                          self.rp, ws, wsb), f"l{l}.ln2.bwd")
+            # LayerNorm backward + the LayerScale backward of the sub-block before it in ONE pass over the residual gradient
+            # (savit_layernorm_bwd_ls; two launches re-read it: 30 + 5 us per sub-block at CaiT-S24)
             ri = (ri + 1) % len(ring)
-            P.add(L.savit_layerscale_bwd, (self.dres.data_ptr(), self.br1[l].data_ptr(), pp(f"l{l}.ls1"), sd0, N, ring[ri], gp(f"l{l}.ls1"),
-                                           None, M, d, d, ws, wsb), f"l{l}.ls1.bwd", writes=(ring[ri],))
+            if not fuse_ls:
+                P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(),
+                                              self.dres.data_ptr(), self.dres.data_ptr(), None, gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b"), None, M, d, d,
+                                              d, self.rp, ws, wsb), f"l{l}.ln2.bwd")
+                P.add(L.savit_layerscale_bwd, (self.dres.data_ptr(), self.br1[l].data_ptr(), pp(f"l{l}.ls1"), sd0, N, ring[ri], gp(f"l{l}.ls1"),
+                                               None, M, d, d, ws, wsb), f"l{l}.ls1.bwd", writes=(ring[ri],))
+            else:
+                P.add(L.savit_layernorm_bwd_ls, (self.d_h.data_ptr(), self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(),
+                                                 self.dres.data_ptr(), self.dres.data_ptr(), gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b"), M, d, d, d,
+                                                 self.rp, self.br1[l].data_ptr(), pp(f"l{l}.ls1"), sd0, N, ring[ri], gp(f"l{l}.ls1"), None, ws, wsb),
+                      f"l{l}.ln2.bwd", writes=(ring[ri],))
             wgrad_l(f"l{l}.Wo.wgrad", l, self.o[l].data_ptr(), ring[ri], gp(f"l{l}.Wo"), M, d, d, d, d, d)
             self._gemm(P, f"l{l}.proj.dgrad", A=ring[ri], Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=M, N=d, K=d, lda=d, ldb=d, ldc=d,
                        epilogue=_lib.EPI_BF16)
@@ -525,9 +535,16 @@ class CaiTEngine:
             self._gemm(P, f"l{l}.qkv.dgrad", A=dqkv, Bt=w("Wqkv_n"), C=self.d_h.data_ptr(), M=M, N=d, K=3 * d, lda=3 * d, ldb=3 * d,
                        ldc=d, epilogue=_lib.EPI_BF16)
             flush_group(l, last=(l == 0))
-            P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
-                                          self.dres.data_ptr(), self.dres.data_ptr(), self.dres_b.data_ptr(), gp(f"l{l}.ln1_g"), gp(f"l{l}.ln1_b"),
-                                          None, M, d, d, d, self.rp, ws, wsb), f"l{l}.ln1.bwd")
+            if l > 0 and fuse_ls:  # ... and layer l-1's second sub-block behind this layer's first LayerNorm
+                ri = (ri + 1) % len(ring)
+                P.add(L.savit_layernorm_bwd_ls, (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
+                                                 self.dres.data_ptr(), self.dres.data_ptr(), gp(f"l{l}.ln1_g"), gp(f"l{l}.ln1_b"), M, d, d, d,
+                                                 self.rp, self.br2[l - 1].data_ptr(), pp(f"l{l - 1}.ls2"), self.sd[2 * l - 1].data_ptr(), N, ring[ri],
+                                                 gp(f"l{l - 1}.ls2"), gp(f"l{l - 1}.b2"), ws, wsb), f"l{l}.ln1.bwd", writes=(ring[ri],))
+            else:  # the bf16 copy feeds the patch-embed weight gradient
+                P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
+                                              self.dres.data_ptr(), self.dres.data_ptr(), self.dres_b.data_ptr(), gp(f"l{l}.ln1_g"),
+                                              gp(f"l{l}.ln1_b"), None, M, d, d, d, self.rp, ws, wsb), f"l{l}.ln1.bwd")
         P.add(L.savit_pos_cls_grad, (self.dres.data_ptr(), gp("pos"), None, B, N, d, 0), "pos.grad")
         self._wgrad(P, "Wpe.wgrad", self._img_buf.data_ptr(), self.dres_b.data_ptr(), gp("Wpe"), M, cfg.patch_dim, d, 0, d, d,
                     patch=(cfg.patch, cfg.img_size, N, 0))

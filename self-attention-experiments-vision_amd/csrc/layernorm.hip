@@ -210,8 +210,9 @@ constexpr int FIN_SPLIT = 8;
 __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int d,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                float* __restrict__ dcolsum, const float* __restrict__ xslab = nullptr,
-                                                               int xrows = 0, int xn = 0, float* __restrict__ xout = nullptr) {
-  const int nb0 = (3 * d + 63) / 64;
+                                                               int xrows = 0, int xn = 0, float* __restrict__ xout = nullptr, int nf = 3,
+                                                               float* __restrict__ out3 = nullptr) {
+  const int nb0 = (nf * d + 63) / 64;  // nf families of column sums in a slab row (3; 4 from ln_bwd_ls_kernel)
   if ((int)blockIdx.x >= nb0) {
     if (blockIdx.y != 0) return;
     // 64 columns = 16 lanes x float4, the rows over 16 groups (independent loads, ~rows/16 deep), then an LDS tree: fixed order
@@ -240,22 +241,22 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __res
     }
     return;
   }
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);  // in [0, 3d)
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);  // in [0, nf * d)
   const int rl = threadIdx.x >> 6;                        // row lane 0..3
   const int per = (nblk + FIN_SPLIT - 1) / FIN_SPLIT;
   const int r0 = blockIdx.y * per;
   const int r1 = min(nblk, r0 + per);
   float s = 0.f;
-  if (col < 3 * d) {
-    for (int r = r0 + rl; r < r1; r += 4) s += partial[(size_t)r * 3 * d + col];
+  if (col < nf * d) {
+    for (int r = r0 + rl; r < r1; r += 4) s += partial[(size_t)r * nf * d + col];
   }
   __shared__ float red[4][64];
   red[rl][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rl == 0 && col < 3 * d) {
+  if (rl == 0 && col < nf * d) {
     s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     const int which = col / d, c = col - which * d;
-    float* out = which == 0 ? dgamma : (which == 1 ? dbeta : dcolsum);
+    float* out = which == 0 ? dgamma : (which == 1 ? dbeta : (which == 2 ? dcolsum : out3));
     if (out != nullptr) atomicAdd(out + c, s);
   }
 }
@@ -350,6 +351,136 @@ __global__ __launch_bounds__(LN_THREADS) void layerscale_bwd_kernel(const float*
 }
 
 
+// LayerNorm backward with the LayerScale (+ stochastic depth) backward of the sub-block whose output cotangent it produces (CaiT: the
+// residual gradient this kernel writes is exactly what layerscale_bwd_kernel would read next, cait.py:28-60 in reverse):
+//   out = LN-VJP(dy) + dres_in  -> fp32 dx_out;   dbr = bf16(out * rs * ls);   d_ls += sum_rows out * rs * branch;   dbias += sum_rows dbr
+// One pass over the residual gradient instead of two (round 4: the separate launch re-read 4 + 2 B and wrote 2 B per element, 30 + 5 us
+// per sub-block at CaiT-S24).  Slab rows are [dgamma | dbeta | d_ls | dbias] (4 families); same arithmetic per element as the two kernels.
+template <int CH>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_ls_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                                const float* __restrict__ rstd_in, const float* __restrict__ dres_in,
+                                                                float* __restrict__ dx_out, float* __restrict__ partial, int rows, int d, long x_stride,
+                                                                long out_stride, int round_params, const bf16_t* __restrict__ branch,
+                                                                const float* __restrict__ ls, const float* __restrict__ rowscale,
+                                                                int rows_per_sample, bf16_t* __restrict__ dbr) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nchunk = d >> 2;
+  float4 g[CH], gl[CH], dg[CH], db[CH], dl[CH], dbl[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ci = lane + 64 * c;
+    g[c] = (ci < nchunk) ? reinterpret_cast<const float4*>(gamma)[ci] : make_float4(0, 0, 0, 0);
+    if (round_params) g[c] = make_float4(round_bf16(g[c].x), round_bf16(g[c].y), round_bf16(g[c].z), round_bf16(g[c].w));
+    gl[c] = (ci < nchunk) ? reinterpret_cast<const float4*>(ls)[ci] : make_float4(0, 0, 0, 0);
+    dg[c] = db[c] = dl[c] = dbl[c] = make_float4(0, 0, 0, 0);
+  }
+  const float inv_d = 1.0f / (float)d;
+  float4 xv_n[CH], rs_n[CH];
+  uint2 dv_n[CH], bv_n[CH];
+  float mean_n = 0.f, rstd_n = 0.f, rsc_n = 1.f;
+  auto load_row = [&](int row) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * x_stride);
+    const uint2* dyr = reinterpret_cast<const uint2*>(dy + (size_t)row * d);
+    const uint2* brr = reinterpret_cast<const uint2*>(branch + (size_t)row * d);
+    mean_n = mean_in[row];
+    rstd_n = rstd_in[row];
+    rsc_n = rowscale ? rowscale[row / rows_per_sample] : 1.0f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ci = lane + 64 * c;
+      xv_n[c] = make_float4(0, 0, 0, 0);
+      rs_n[c] = make_float4(0, 0, 0, 0);
+      dv_n[c] = make_uint2(0u, 0u);
+      bv_n[c] = make_uint2(0u, 0u);
+      if (ci < nchunk) {
+        xv_n[c] = xr[ci];
+        dv_n[c] = dyr[ci];
+        bv_n[c] = brr[ci];
+        if (dres_in) rs_n[c] = reinterpret_cast<const float4*>(dres_in + (size_t)row * out_stride)[ci];
+      }
+    }
+  };
+  const int row_step = gridDim.x * LN_WAVES;
+  int row = blockIdx.x * LN_WAVES + wave;
+  if (row < rows) load_row(row);
+  for (; row < rows; row += row_step) {
+    const float mean = mean_n, rstd = rstd_n, rsc = rsc_n;
+    float4 xh[CH], gy[CH], rs[CH];
+    uint2 dvc[CH], bvc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      xh[c] = xv_n[c];
+      rs[c] = rs_n[c];
+      dvc[c] = dv_n[c];
+      bvc[c] = bv_n[c];
+    }
+    if (row + row_step < rows) load_row(row + row_step);
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ci = lane + 64 * c;
+      if (ci < nchunk) {
+        const float4 xv = xh[c];
+        const uint2 dv = dvc[c];
+        const float d0 = __uint_as_float(dv.x << 16), d1 = __uint_as_float(dv.x & 0xffff0000u);
+        const float d2 = __uint_as_float(dv.y << 16), d3 = __uint_as_float(dv.y & 0xffff0000u);
+        xh[c] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        gy[c] = make_float4(d0 * g[c].x, d1 * g[c].y, d2 * g[c].z, d3 * g[c].w);
+        dg[c].x += d0 * xh[c].x; dg[c].y += d1 * xh[c].y; dg[c].z += d2 * xh[c].z; dg[c].w += d3 * xh[c].w;
+        db[c].x += d0; db[c].y += d1; db[c].z += d2; db[c].w += d3;
+        c1 += (gy[c].x + gy[c].y) + (gy[c].z + gy[c].w);
+        c2 += (gy[c].x * xh[c].x + gy[c].y * xh[c].y) + (gy[c].z * xh[c].z + gy[c].w * xh[c].w);
+      } else {
+        xh[c] = make_float4(0, 0, 0, 0);
+        gy[c] = make_float4(0, 0, 0, 0);
+      }
+    }
+    c1 = wave_sum(c1) * inv_d;
+    c2 = wave_sum(c2) * inv_d;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ci = lane + 64 * c;
+      if (ci < nchunk) {
+        float4 o = make_float4(rstd * (gy[c].x - c1 - xh[c].x * c2), rstd * (gy[c].y - c1 - xh[c].y * c2),
+                               rstd * (gy[c].z - c1 - xh[c].z * c2), rstd * (gy[c].w - c1 - xh[c].w * c2));
+        o.x += rs[c].x; o.y += rs[c].y; o.z += rs[c].z; o.w += rs[c].w;
+        reinterpret_cast<float4*>(dx_out + (size_t)row * out_stride)[ci] = o;
+        const uint2 bv = bvc[c];
+        const float b0 = __uint_as_float(bv.x << 16), b1 = __uint_as_float(bv.x & 0xffff0000u);
+        const float b2 = __uint_as_float(bv.y << 16), b3 = __uint_as_float(bv.y & 0xffff0000u);
+        const float o0 = round_bf16(o.x * rsc * gl[c].x), o1 = round_bf16(o.y * rsc * gl[c].y);
+        const float o2 = round_bf16(o.z * rsc * gl[c].z), o3 = round_bf16(o.w * rsc * gl[c].w);
+        reinterpret_cast<uint2*>(dbr + (size_t)row * d)[ci] = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+        dl[c].x += o.x * rsc * b0; dl[c].y += o.y * rsc * b1; dl[c].z += o.z * rsc * b2; dl[c].w += o.w * rsc * b3;
+        dbl[c].x += o0; dbl[c].y += o1; dbl[c].z += o2; dbl[c].w += o3;
+      }
+    }
+  }
+  __shared__ float4 red[LN_WAVES][64];
+#pragma unroll
+  for (int which = 0; which < 4; ++which) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float4 v = which == 0 ? dg[c] : (which == 1 ? db[c] : (which == 2 ? dl[c] : dbl[c]));
+      __syncthreads();
+      red[wave][lane] = v;
+      __syncthreads();
+      if (wave == 0) {
+        float4 t = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < LN_WAVES; ++w) {
+          t.x += red[w][lane].x; t.y += red[w][lane].y; t.z += red[w][lane].z; t.w += red[w][lane].w;
+        }
+        const int ci = lane + 64 * c;
+        if (ci < nchunk) reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 4 + which) * d)[ci] = t;
+      }
+    }
+  }
+}
+
+
 }  // namespace
 
 static int ln_bwd_grid(int rows) { return ln_grid(rows, 256 * 3); }
@@ -360,7 +491,7 @@ extern "C" int savit_layernorm_bwd_mapped(const void* dy, const float* x, const 
 
 extern "C" long savit_layernorm_bwd_workspace_bytes(int rows, int d) {
   if (rows <= 0 || d <= 0) return 0;
-  return (long)ln_bwd_grid(rows) * 3 * d * (long)sizeof(float);
+  return (long)ln_bwd_grid(rows) * 4 * d * (long)sizeof(float);  // 4 families of partial column sums (savit_layernorm_bwd_ls; 3 otherwise)
 }
 
 extern "C" int savit_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
@@ -440,5 +571,26 @@ extern "C" int savit_layerscale_bwd(const float* dres, const void* branch_bf16, 
               partial, rows, d, dres_stride);
   hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * d + 63) / 64, FIN_SPLIT), dim3(256), 0, s, partial, grid, d, d_layerscale, dbias,
                      (float*)nullptr);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_layernorm_bwd_ls(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                      const float* dres_in, float* dx, float* dgamma, float* dbeta, int rows, int d, long x_stride,
+                                      long out_stride, int round_params_bf16, const void* branch_bf16, const float* layerscale,
+                                      const float* rowscale, int rows_per_sample, void* dbranch_bf16, float* d_layerscale, float* dbias,
+                                      void* workspace, long workspace_bytes, void* stream) {
+  SAVIT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && x_stride >= d && out_stride >= d && (x_stride % 4) == 0 &&
+                  (out_stride % 4) == 0 && rows >= 0 && d > 64 && (d % 4) == 0 && d <= 64 * 4 * LN_MAX_CHUNKS);
+  SAVIT_CHECK_ARG(branch_bf16 && layerscale && dbranch_bf16 && d_layerscale && (rowscale == nullptr || rows_per_sample >= 1));
+  if (rows == 0) return SAVIT_OK;
+  SAVIT_CHECK_ARG(workspace != nullptr && ((uintptr_t)workspace % 16) == 0 && workspace_bytes >= savit_layernorm_bwd_workspace_bytes(rows, d));
+  hipStream_t s = (hipStream_t)stream;
+  const int ch = (d / 4 + 63) / 64;
+  const int grid = ln_bwd_grid(rows);
+  float* partial = (float*)workspace;
+  LN_DISPATCH(ch, ln_bwd_ls_kernel, grid, (const bf16_t*)dy, x, gamma, mean, rstd, dres_in, dx, partial, rows, d, x_stride, out_stride,
+              round_params_bf16, (const bf16_t*)branch_bf16, layerscale, rowscale, rows_per_sample, (bf16_t*)dbranch_bf16);
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((4 * d + 63) / 64, FIN_SPLIT), dim3(256), 0, s, partial, grid, d, dgamma, dbeta, d_layerscale,
+                     (const float*)nullptr, 0, 0, (float*)nullptr, 4, dbias);
   SAVIT_LAUNCH_RET();
 }

@@ -903,6 +903,70 @@ def test_fused_talking_heads_geometry_gate(ops):
                                    torch.eye(16, device="cuda"), 2, 196, 16, head_dim=48)
 
 
+@pytest.mark.parametrize("rows,d,rps,with_bias,with_rs", [(2 * 196, 384, 196, True, True), (5 * 197, 192, 197, False, True), (7, 768, 1, True, False),
+                                                          (3 * 50, 128, 50, True, True), (64, 1024, 1, False, False)])
+def test_layernorm_bwd_ls_equals_the_two_launches(ops, rows, d, rps, with_bias, with_rs):
+    """savit_layernorm_bwd_ls = savit_layernorm_bwd followed by savit_layerscale_bwd on the residual gradient it wrote (the reverse of
+    cait.py:28-60: LayerNorm VJP, then layerscale.py:18-23 / stochastic_depth.py:16-27 of the sub-block before it) - element by element
+    the same arithmetic, so dx and dbranch must agree exactly and the column sums to summation order."""
+    from savit_amd import lib as _lib
+
+    L = _lib.load()
+    rng = np.random.default_rng(rows * 3 + d)
+    nsamp = rows // rps
+    x = (rng.standard_normal((rows, d)) * 2 + 0.3).astype(np.float32)
+    dy = rb(rng.standard_normal((rows, d)))
+    dres = rng.standard_normal((rows, d)).astype(np.float32)
+    gamma = (1 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    branch = rb(rng.standard_normal((rows, d)))
+    ls = (0.5 + rng.random(d)).astype(np.float32)
+    rs = np.where(rng.random(nsamp) < 0.7, 1.0 / 0.9, 0.0).astype(np.float32)
+    mean = x.mean(1).astype(np.float32)
+    rstd = (1.0 / np.sqrt(x.var(1) + 1e-6)).astype(np.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    ws = int(L.savit_layernorm_bwd_workspace_bytes(rows, d))
+    t_ws = torch.empty(max(ws, 16), dtype=torch.uint8, device="cuda")
+    t_x, t_dy, t_g, t_m, t_r = dev(x), dev(dy, bf16), dev(gamma), dev(mean), dev(rstd)
+    t_br, t_ls, t_rs = dev(branch, bf16), dev(ls), dev(rs)
+    init = {k: rng.standard_normal(d).astype(np.float32) for k in ("dg", "db", "dls", "dbias")}  # the column sums ACCUMULATE
+
+    def run(fused):
+        t_dres = dev(dres.copy())
+        o = {k: dev(v.copy()) for k, v in init.items()}
+        t_dbr = torch.full((rows, d), 7.0, dtype=bf16, device="cuda")
+        dbias = o["dbias"].data_ptr() if with_bias else None
+        rsp = t_rs.data_ptr() if with_rs else None
+        if fused:
+            rc = L.savit_layernorm_bwd_ls(t_dy.data_ptr(), t_x.data_ptr(), t_g.data_ptr(), t_m.data_ptr(), t_r.data_ptr(), t_dres.data_ptr(),
+                                          t_dres.data_ptr(), o["dg"].data_ptr(), o["db"].data_ptr(), rows, d, d, d, 1, t_br.data_ptr(), t_ls.data_ptr(),
+                                          rsp, rps, t_dbr.data_ptr(), o["dls"].data_ptr(), dbias, t_ws.data_ptr(), ws, st)
+            assert rc == 0
+        else:
+            rc = L.savit_layernorm_bwd(t_dy.data_ptr(), t_x.data_ptr(), t_g.data_ptr(), t_m.data_ptr(), t_r.data_ptr(), t_dres.data_ptr(),
+                                       t_dres.data_ptr(), None, o["dg"].data_ptr(), o["db"].data_ptr(), None, rows, d, d, d, 1, t_ws.data_ptr(), ws, st)
+            assert rc == 0
+            rc = L.savit_layerscale_bwd(t_dres.data_ptr(), t_br.data_ptr(), t_ls.data_ptr(), rsp, rps, t_dbr.data_ptr(), o["dls"].data_ptr(), dbias,
+                                        rows, d, d, t_ws.data_ptr(), ws, st)
+            assert rc == 0
+        torch.cuda.synchronize()
+        return host(t_dres), host(t_dbr), {k: host(v) for k, v in o.items()}
+
+    dx_f, dbr_f, o_f = run(True)
+    dx_u, dbr_u, o_u = run(False)
+    assert np.array_equal(dx_f, dx_u) and np.array_equal(dbr_f, dbr_u)
+    for k in ("dg", "db", "dls") + (("dbias",) if with_bias else ()):
+        assert rel(o_f[k] - init[k], o_u[k] - init[k]) < 1e-5, k
+    if not with_bias:
+        assert np.array_equal(o_f["dbias"], init["dbias"])
+    # and against the formulas in fp64
+    xh = (x.astype(np.float64) - mean[:, None]) * rstd[:, None]
+    gy = dy.astype(np.float64) * rb(gamma)
+    want_dx = rstd[:, None] * (gy - gy.mean(1, keepdims=True) - xh * (gy * xh).mean(1, keepdims=True)) + dres
+    assert rel(dx_f, want_dx) < 1e-5
+    rs_rows = (np.repeat(rs, rps)[:, None] if with_rs else np.ones((rows, 1))).astype(np.float64)
+    assert rel(o_f["dls"] - init["dls"], (want_dx * rs_rows * branch).sum(0)) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------ LayerScale backward (row a9)
 @pytest.mark.parametrize("rows,d,rps,with_bias", [(2 * 196, 384, 196, True), (5 * 197, 192, 197, False), (7, 768, 1, True), (64, 4096, 1, True)])
 def test_layerscale_bwd(ops, rows, d, rps, with_bias):
