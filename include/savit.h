@@ -72,12 +72,12 @@ int savit_layerscale_bwd(const float* dres, const void* branch_bf16, const float
 /* savit_layernorm_bwd (wide rows, d > 64; no bf16 copy, no column sums of dx) FOLLOWED BY savit_layerscale_bwd on the dx it produces, in
  * one pass over the residual gradient: dx = LN-VJP(dy) + dres_in; dbranch = bf16(dx * rs * ls); d_layerscale, dbias as above.  In the
  * reverse of CaiT's EncoderBlock (cait.py:28-60) every LayerNorm backward is followed by the LayerScale backward of the sub-block
- * before it; element by element the results are those of the two calls. */
+ * before it; element by element the results are those of the two calls.  extra_slab (nullable): as in savit_layernorm_bwd_ex. */
 int savit_layernorm_bwd_ls(const void* dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
                            const float* dres_in, float* dx, float* dgamma, float* dbeta, int rows, int d, long x_stride, long out_stride,
                            int round_params_bf16, const void* branch_bf16, const float* layerscale, const float* rowscale,
                            int rows_per_sample, void* dbranch_bf16, float* d_layerscale, float* dbias, void* workspace,
-                           long workspace_bytes, void* stream);
+                           long workspace_bytes, const float* extra_slab, int extra_rows, int extra_n, float* extra_out, void* stream);
 
 /* ---- Class attention (cait.py:10-15): one query per image (cls) against Nk keys.  q bf16 [B, ldq] pre-scaled; kv bf16 [B*Nk, ldkv]
  * with keys at column h*hd and values at column d + h*hd; o bf16 [B, d]; probs fp32 [B,H,Nk] (saved for backward). */

@@ -502,7 +502,8 @@ class CaiTEngine:
             self._gemm(P, f"l{l}.fc2.dgrad", writes=(d_u,), A=ring[ri], Bt=w("W2_n"), C=d_u, aux=self.u[l].data_ptr(),
                        colsum=self.colsum_slab.data_ptr(), colsum_rows=self.colsum_slab.shape[0], M=M, N=F, K=d, lda=d, ldb=d, ldc=F,
                        ldaux=F, epilogue=_lib.EPI_DGELU)
-            P.add(L.savit_colsum_finalize, (self.colsum_slab.data_ptr(), self.colsum_slab.shape[0], F, gp(f"l{l}.b1"), 1), f"l{l}.b1.grad")
+            if not fuse_ls:  # (fused: the slab's column sums ride along with this layer's ln2.bwd finalize)
+                P.add(L.savit_colsum_finalize, (self.colsum_slab.data_ptr(), self.colsum_slab.shape[0], F, gp(f"l{l}.b1"), 1), f"l{l}.b1.grad")
             wgrad_l(f"l{l}.W1.wgrad", l, self.h2[l].data_ptr(), d_u, gp(f"l{l}.W1"), M, d, F, d, F, F)
             self._gemm(P, f"l{l}.fc1.dgrad", A=d_u, Bt=w("W1_n"), C=self.d_h.data_ptr(), M=M, N=d, K=F, lda=F, ldb=F, ldc=d,
                        epilogue=_lib.EPI_BF16)
@@ -518,7 +519,8 @@ class CaiTEngine:
             else:
                 P.add(L.savit_layernorm_bwd_ls, (self.d_h.data_ptr(), self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(),
                                                  self.dres.data_ptr(), self.dres.data_ptr(), gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b"), M, d, d, d,
-                                                 self.rp, self.br1[l].data_ptr(), pp(f"l{l}.ls1"), sd0, N, ring[ri], gp(f"l{l}.ls1"), None, ws, wsb),
+                                                 self.rp, self.br1[l].data_ptr(), pp(f"l{l}.ls1"), sd0, N, ring[ri], gp(f"l{l}.ls1"), None, ws, wsb,
+                                                 self.colsum_slab.data_ptr(), self.colsum_slab.shape[0], F, gp(f"l{l}.b1")),
                       f"l{l}.ln2.bwd", writes=(ring[ri],))
             wgrad_l(f"l{l}.Wo.wgrad", l, self.o[l].data_ptr(), ring[ri], gp(f"l{l}.Wo"), M, d, d, d, d, d)
             self._gemm(P, f"l{l}.proj.dgrad", A=ring[ri], Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=M, N=d, K=d, lda=d, ldb=d, ldc=d,
@@ -540,7 +542,8 @@ class CaiTEngine:
                 P.add(L.savit_layernorm_bwd_ls, (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
                                                  self.dres.data_ptr(), self.dres.data_ptr(), gp(f"l{l}.ln1_g"), gp(f"l{l}.ln1_b"), M, d, d, d,
                                                  self.rp, self.br2[l - 1].data_ptr(), pp(f"l{l - 1}.ls2"), self.sd[2 * l - 1].data_ptr(), N, ring[ri],
-                                                 gp(f"l{l - 1}.ls2"), gp(f"l{l - 1}.b2"), ws, wsb), f"l{l}.ln1.bwd", writes=(ring[ri],))
+                                                 gp(f"l{l - 1}.ls2"), gp(f"l{l - 1}.b2"), ws, wsb, None, 0, 0, None), f"l{l}.ln1.bwd",
+                      writes=(ring[ri],))
             else:  # the bf16 copy feeds the patch-embed weight gradient
                 P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
                                               self.dres.data_ptr(), self.dres.data_ptr(), self.dres_b.data_ptr(), gp(f"l{l}.ln1_g"),

@@ -578,10 +578,13 @@ extern "C" int savit_layernorm_bwd_ls(const void* dy, const float* x, const floa
                                       const float* dres_in, float* dx, float* dgamma, float* dbeta, int rows, int d, long x_stride,
                                       long out_stride, int round_params_bf16, const void* branch_bf16, const float* layerscale,
                                       const float* rowscale, int rows_per_sample, void* dbranch_bf16, float* d_layerscale, float* dbias,
-                                      void* workspace, long workspace_bytes, void* stream) {
+                                      void* workspace, long workspace_bytes, const float* extra_slab, int extra_rows, int extra_n,
+                                      float* extra_out, void* stream) {
   SAVIT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && x_stride >= d && out_stride >= d && (x_stride % 4) == 0 &&
                   (out_stride % 4) == 0 && rows >= 0 && d > 64 && (d % 4) == 0 && d <= 64 * 4 * LN_MAX_CHUNKS);
   SAVIT_CHECK_ARG(branch_bf16 && layerscale && dbranch_bf16 && d_layerscale && (rowscale == nullptr || rows_per_sample >= 1));
+  SAVIT_CHECK_ARG(extra_slab == nullptr || (extra_out && extra_rows >= 0 && extra_n > 0 && extra_n % 4 == 0 && ((uintptr_t)extra_slab % 16) == 0 &&
+                                            ((uintptr_t)extra_out % 16) == 0));
   if (rows == 0) return SAVIT_OK;
   SAVIT_CHECK_ARG(workspace != nullptr && ((uintptr_t)workspace % 16) == 0 && workspace_bytes >= savit_layernorm_bwd_workspace_bytes(rows, d));
   hipStream_t s = (hipStream_t)stream;
@@ -590,7 +593,8 @@ extern "C" int savit_layernorm_bwd_ls(const void* dy, const float* x, const floa
   float* partial = (float*)workspace;
   LN_DISPATCH(ch, ln_bwd_ls_kernel, grid, (const bf16_t*)dy, x, gamma, mean, rstd, dres_in, dx, partial, rows, d, x_stride, out_stride,
               round_params_bf16, (const bf16_t*)branch_bf16, layerscale, rowscale, rows_per_sample, (bf16_t*)dbranch_bf16);
-  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((4 * d + 63) / 64, FIN_SPLIT), dim3(256), 0, s, partial, grid, d, dgamma, dbeta, d_layerscale,
-                     (const float*)nullptr, 0, 0, (float*)nullptr, 4, dbias);
+  const int xn = extra_slab ? extra_n : 0;  // the extra slab's column sums ride along as in savit_layernorm_bwd_ex
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((4 * d + 63) / 64 + (xn + 63) / 64, FIN_SPLIT), dim3(256), 0, s, partial, grid, d, dgamma, dbeta,
+                     d_layerscale, extra_slab, extra_rows, xn, extra_out, 4, dbias);
   SAVIT_LAUNCH_RET();
 }

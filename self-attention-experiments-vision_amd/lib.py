@@ -59,7 +59,7 @@ _SIGNATURES = {
     "savit_layernorm_bwd_mapped": (c_int, [c_void_p] * 11 + [c_int, c_int, c_long, c_long, c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p]),
     "savit_layerscale_bwd": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_long, c_void_p]),
     "savit_layernorm_bwd_ls": (c_int, [c_void_p] * 9 + [c_int, c_int, c_long, c_long, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                                        c_void_p, c_void_p, c_long, c_void_p]),
+                                        c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "savit_class_attention_fwd": (c_int, [c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "savit_class_attention_bwd": (c_int, [c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int,
                                           c_int, c_float, c_void_p]),

@@ -930,6 +930,9 @@ def test_layernorm_bwd_ls_equals_the_two_launches(ops, rows, d, rps, with_bias, 
     t_br, t_ls, t_rs = dev(branch, bf16), dev(ls), dev(rs)
     init = {k: rng.standard_normal(d).astype(np.float32) for k in ("dg", "db", "dls", "dbias")}  # the column sums ACCUMULATE
 
+    xs, xo0 = rng.standard_normal((37, 64)).astype(np.float32), rng.standard_normal(64).astype(np.float32)
+    t_xs, t_xo = dev(xs), dev(xo0.copy())
+
     def run(fused):
         t_dres = dev(dres.copy())
         o = {k: dev(v.copy()) for k, v in init.items()}
@@ -939,8 +942,11 @@ def test_layernorm_bwd_ls_equals_the_two_launches(ops, rows, d, rps, with_bias, 
         if fused:
             rc = L.savit_layernorm_bwd_ls(t_dy.data_ptr(), t_x.data_ptr(), t_g.data_ptr(), t_m.data_ptr(), t_r.data_ptr(), t_dres.data_ptr(),
                                           t_dres.data_ptr(), o["dg"].data_ptr(), o["db"].data_ptr(), rows, d, d, d, 1, t_br.data_ptr(), t_ls.data_ptr(),
-                                          rsp, rps, t_dbr.data_ptr(), o["dls"].data_ptr(), dbias, t_ws.data_ptr(), ws, st)
+                                          rsp, rps, t_dbr.data_ptr(), o["dls"].data_ptr(), dbias, t_ws.data_ptr(), ws, t_xs.data_ptr(), 37, 64,
+                                          t_xo.data_ptr(), st)
             assert rc == 0
+            torch.cuda.synchronize()
+            assert rel(host(t_xo), xo0 + xs.sum(0)) < 1e-6  # the extra slab's column sums ride along (savit_layernorm_bwd_ex's contract)
         else:
             rc = L.savit_layernorm_bwd(t_dy.data_ptr(), t_x.data_ptr(), t_g.data_ptr(), t_m.data_ptr(), t_r.data_ptr(), t_dres.data_ptr(),
                                        t_dres.data_ptr(), None, o["dg"].data_ptr(), o["db"].data_ptr(), None, rows, d, d, d, 1, t_ws.data_ptr(), ws, st)
