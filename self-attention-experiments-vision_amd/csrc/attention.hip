@@ -1617,6 +1617,8 @@ __global__ __launch_bounds__(256) void th_softmax_fwd_kernel(const bf16_t* __res
 // Register plan (H = 8): S and dP' stay PACKED as bf16 pairs (16 + 16 VGPRs), P / dP are fp32 [H][4] (32 + 32), the 2 x H x H
 // per-lane dT partials persist across the rows a wave processes (128); every mixing loop runs key-outer so only 8 + 8 unpacked
 // temporaries are live.  The first version kept everything in fp32 and spilled 580 B/lane to scratch (1.55 ms per layer).
+// Round 4 (H = 8): the two outer products run on the matrix pipe (MO below): 189 -> ~140 us per CaiT-S24 layer, the whole backward of the
+// layer's attention 430 -> 379 us (tools/th_bench.py).
 template <int H>
 __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __restrict__ S, const bf16_t* __restrict__ dPp, bf16_t* __restrict__ dS,
                                                               const float* __restrict__ T1g, const float* __restrict__ T2g,
@@ -1624,8 +1626,31 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
   static_assert(H <= 8 || H == 16, "dT partials are reduce-scattered as 8x8 tiles: up to 8 heads, or 16 as four tiles per matrix");
   constexpr int NB = (H + 7) / 8;  // 8x8 tiles per dimension of dT (H = 16: cait_m_*; that path spills registers - correct, not fast)
   constexpr bool PK = (H == 8 || H == 4);  // packed head mixes (the three T-mixes of a row: 3 x 128 v_pk_fma_f32 instead of 3 x 256 FMAs)
-  constexpr bool PKO = PK;  // the two 8 x 8 outer products (dT2, dT1 partials) packed over key pairs as well, four heads at a time
+  // H = 8: the two 8 x 8 outer products dT2 += P dP'^T, dT1 += S dS'^T (contraction over the row's keys) on the MATRIX pipe.  Per row
+  // they were 2 x (192 packed multiply-adds + 32 adds + a 64-value reduce-scatter of 156 instructions) = a third of this kernel's
+  // vector instructions (VALU-issue-bound: ~2 300 per row).  P and dS' (hi + lo bf16 halves: fp32-exact products against the bf16
+  // S, dP') go through an LDS image per wave - [16 rows = 8 heads hi | 8 heads lo][256 keys], rows 528 B apart so that the 16 rows
+  // of a fragment read hit 16 different bank groups - and v_mfma_f32_16x16x32_bf16 accumulates C[hi | lo head][head] over the rows a
+  // wave processes: 16 MFMAs + ~100 LDS operations + 128 conversions per row.  Other H keep the packed / scalar vector forms.
+  constexpr bool MO = (H == 8);
+  constexpr bool PKO = PK && !MO;  // vector form of the outer products, packed over key pairs, four heads at a time
+  constexpr int MO_PITCH = 528, MO_A = 16 * MO_PITCH, MO_WAVE = MO_A + 8 * MO_PITCH;
+  __shared__ __attribute__((aligned(16))) char mo_lds[MO ? 4 * MO_WAVE : 16];
   __shared__ float red[4][2 * NB * NB * 64];
+  f32x4 mo_c1 = {0.f, 0.f, 0.f, 0.f}, mo_c2 = {0.f, 0.f, 0.f, 0.f};  // C1[P hi | lo head][dP' head], C2[dS' hi | lo head][S head]
+  [[maybe_unused]] char* mo_a = mo_lds + (MO ? (threadIdx.x >> 6) * MO_WAVE : 0);
+  [[maybe_unused]] char* mo_b = mo_a + (MO ? MO_A : 0);
+  // 8 k-steps of 32 keys; lanes holding keys >= N wrote zeros
+  [[maybe_unused]] auto mo_mfma = [&](f32x4 c) {
+    const int lane_ = threadIdx.x & 63;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(mo_a + (lane_ & 15) * MO_PITCH + ks * 64 + (lane_ >> 4) * 16);
+      const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(mo_b + (lane_ & 7) * MO_PITCH + ks * 64 + (lane_ >> 4) * 16);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, c, 0, 0, 0);
+    }
+    return c;
+  };
   const float* __restrict__ T1 = T1g;
   const float* __restrict__ T2 = T2g;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1804,7 +1829,20 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
         }
       }
       if constexpr (PK) c.issue(T1g);  // for the third mix, under the reduce-scatter and the delta reductions
-      acc2[0] += reduce_scatter64(g, lane);
+      if constexpr (MO) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {  // P (hi, lo) -> rows h, 8 + h; dP' -> B row h; this lane's 4 keys = 8 bytes
+          const uint32_t h0 = pack_bf16x2(pr[h][0], pr[h][1]), h1 = pack_bf16x2(pr[h][2], pr[h][3]);
+          const f32x2 f0 = unpack_bf16x2(h0), f1 = unpack_bf16x2(h1);
+          *reinterpret_cast<uint2*>(mo_a + h * MO_PITCH + lane * 8) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(mo_a + (8 + h) * MO_PITCH + lane * 8) =
+              make_uint2(pack_bf16x2(pr[h][0] - f0.x, pr[h][1] - f0.y), pack_bf16x2(pr[h][2] - f1.x, pr[h][3] - f1.y));
+          *reinterpret_cast<uint2*>(mo_b + h * MO_PITCH + lane * 8) = make_uint2(dq[h][0], dq[h][1]);
+        }
+        mo_c1 = mo_mfma(mo_c1);
+      } else {
+        acc2[0] += reduce_scatter64(g, lane);
+      }
     } else {
 #pragma unroll
       for (int h = 0; h < H; ++h) del[h] = 0.f;
@@ -1892,6 +1930,13 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
           for (int i = 0; i < H; ++i) {
             dsp2[i] = f32x2{pr[i][2 * kp] * (dp[i][2 * kp] - del[i]), pr[i][2 * kp + 1] * (dp[i][2 * kp + 1] - del[i])};
             sv2[i] = unpack_bf16x2(sp[i][kp]);
+            if constexpr (MO) {  // dS' (hi, lo) -> rows i, 8 + i (this key pair = 4 bytes); S -> B row i
+              const uint32_t hi_ = pack_bf16x2(dsp2[i].x, dsp2[i].y);
+              const f32x2 f_ = unpack_bf16x2(hi_);
+              *reinterpret_cast<uint32_t*>(mo_a + i * MO_PITCH + lane * 8 + kp * 4) = hi_;
+              *reinterpret_cast<uint32_t*>(mo_a + (8 + i) * MO_PITCH + lane * 8 + kp * 4) = pack_bf16x2(dsp2[i].x - f_.x, dsp2[i].y - f_.y);
+              *reinterpret_cast<uint32_t*>(mo_b + i * MO_PITCH + lane * 8 + kp * 4) = sp[i][kp];
+            }
           }
 #pragma unroll
           for (int h = 0; h < H; ++h) {
@@ -1962,13 +2007,39 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
           *reinterpret_cast<uint2*>(dS + (((size_t)b * H + h) * N + q) * Np + 4 * lane) =
               make_uint2(pack_bf16x2(dsv[h][0], dsv[h][1]), pack_bf16x2(dsv[h][2], dsv[h][3]));
       }
-      acc1[0] += reduce_scatter64(g, lane);
+      if constexpr (MO) {
+        mo_c2 = mo_mfma(mo_c2);
+      } else {
+        acc1[0] += reduce_scatter64(g, lane);
+      }
     }
   }
+  if constexpr (MO) {
+    // lane (n, quad) holds C[4 quad + j][n]: rows 0-7 the hi halves, 8-15 the lo halves.  dT1[h][i] = C2[i][h] + C2[8+i][h] goes to
+    // red[wave][h*8 + i], dT2[h][i] = C1[h][i] + C1[8+h][i] to red[wave][64 + h*8 + i]: the lo quads add onto the hi quads' stores
+    const int n_ = lane & 15, quad = lane >> 4;
+    __syncthreads();  // (every wave is past its last fragment read)
+    if (n_ < 8 && quad < 2) {
 #pragma unroll
-  for (int t = 0; t < NB * NB; ++t) {
-    red[wave][t * 64 + lane] = acc1[t];
-    red[wave][(NB * NB + t) * 64 + lane] = acc2[t];
+      for (int j = 0; j < 4; ++j) {
+        red[wave][n_ * 8 + 4 * quad + j] = mo_c2[j];
+        red[wave][64 + (4 * quad + j) * 8 + n_] = mo_c1[j];
+      }
+    }
+    __syncthreads();
+    if (n_ < 8 && quad >= 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        red[wave][n_ * 8 + 4 * (quad - 2) + j] += mo_c2[j];
+        red[wave][64 + (4 * (quad - 2) + j) * 8 + n_] += mo_c1[j];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NB * NB; ++t) {
+      red[wave][t * 64 + lane] = acc1[t];
+      red[wave][(NB * NB + t) * 64 + lane] = acc2[t];
+    }
   }
   __syncthreads();
   // slab row: [dT1 (H*H) | dT2 (H*H)], entry (h, i) sits in tile (h/8, i/8), reduce-scatter lane (h%8)*8 + i%8
