@@ -863,10 +863,13 @@ struct AttnParams2 {
 };
 
 
+template <int KS>  // head_dim / 16: compile-time, so that the k-step loops are branch-free (round 4: with a run-time head_dim hipcc emitted
+                   // `read one fragment - wait - one MFMA - branch` per k-step, every LDS latency exposed: 870 cycles per score tile in this phase)
 __global__ __launch_bounds__(512) void attn_fwd2_kernel(const AttnParams2 pp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const AttnParams& p = pp.a;
-  const int NT = pp.nt, hd = pp.hd;
+  const int NT = pp.nt;
+  constexpr int hd = 16 * KS;
   const int IMG = NT * 32 * ROWB;
   char* imgK = smem;
   char* imgV = smem + IMG;
@@ -888,47 +891,50 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const AttnParams2 pp) {
   const int trow = 4 * (g >> 1) + (t >> 2);
   const int tcol = 16 * (g & 1) + 4 * (t & 3);
   constexpr int KC = 4;
+  uint32_t trv[2][2];  // [eb][rows r.. / r + 8..]: transposed-fragment addresses of V's tile 0 (TrFrag: requested under the exps)
+#pragma unroll
+  for (int eb = 0; eb < 2; ++eb) {
+    trv[eb][0] = lds_addr32(imgV) + tr_lane_off(trow, 32 * eb + tcol, false);
+    trv[eb][1] = lds_addr32(imgV) + tr_lane_off(trow, 32 * eb + tcol, true);
+  }
   const f32x16 zero16f = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int qb = wave; qb < NT; qb += nwv) {
     const int q = qb * 32 + ql;
     bf16x8 qf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      qf[ks] = load_row_frag_global(p.qkv, (size_t)(row_base + q), p.ld, hh * hd + 16 * ks + 8 * half, q < p.N && 16 * ks < hd);
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = load_row_frag_global(p.qkv, (size_t)(row_base + q), p.ld, hh * hd + 16 * ks + 8 * half, q < p.N);
     float m = -INFINITY, l = 0.f;
     f32x16 oacc[2];
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[eb][r] = 0.f;
-    for (int c0 = 0; c0 < NT; c0 += KC) {
-      f32x16 s[KC];
+    // one chunk of K (<= KC) key tiles, K a compile-time count: straight-line code (fragment reads hoisted, MFMAs back to back)
+    auto chunk = [&](int c0, auto kc) {
+      constexpr int K = decltype(kc)::value;
+      f32x16 s[K];
       float cmax = -INFINITY;
 #pragma unroll
-      for (int j = 0; j < KC; ++j) {
-        const int kt = c0 + j;
-        if (kt < NT) {
-          // the accumulator starts from the MFMA's inline-constant zero C operand; only the LAST key tile can hold keys >= N
-          // (round 4: this kernel is VALU-issue-bound at N = 577 - 2 x the MFMA time per tile - so every instruction per score counts)
-          s[j] = zero16f;
+      for (int j = 0; j < K; ++j) {
+        // the accumulator starts from the MFMA's inline-constant zero C operand; only the LAST key tile can hold keys >= N
+        s[j] = zero16f;
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            if (16 * ks < hd) {
-              const bf16x8 kf = lds_row_frag(imgK, kt * 32 + ql, 2 * ks + half);
-              s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[j], 0, 0, 0);
-            }
-          }
-          if (kt == NT - 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-              if (key >= p.N) s[j][r] = -INFINITY;
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) cmax = fmaxf(cmax, s[j][r]);
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 kf = lds_row_frag(imgK, (c0 + j) * 32 + ql, 2 * ks + half);
+          s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[j], 0, 0, 0);
         }
       }
+      if (c0 + K == NT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = (NT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (key >= p.N) s[K - 1][r] = -INFINITY;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cmax = fmaxf(cmax, s[j][r]);
       cmax = half_max(cmax);
       const float m_new = fmaxf(m, cmax);  // finite: every chunk holds at least one valid key
       const float alpha = __builtin_amdgcn_exp2f((m - m_new) * LOG2E);
@@ -939,27 +945,45 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const AttnParams2 pp) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[eb][r] *= alpha;
 #pragma unroll
-      for (int j = 0; j < KC; ++j) {
-        const int kt = c0 + j;
-        if (kt < NT) {
+      for (int j = 0; j < K; ++j) {
+        // this tile's V^T fragments are requested before its exps and waited for behind them (hipcc keeps the ds_read_tr16 builtin
+        // next to its MFMA: one exposed LDS round trip per MFMA)
+        TrFrag vf[2][2];
+        const uint32_t tb = (uint32_t)((c0 + j) * 32 * ROWB);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float e = __builtin_amdgcn_exp2f(s[j][r] * LOG2E - mb);
-            s[j][r] = e;
-            l += e;
-          }
+        for (int eb = 0; eb < 2; ++eb) {
+          if (32 * eb >= hd) continue;
+          lds_tr_issue<0>(vf[0][eb], trv[eb][0] + tb, trv[eb][1] + tb);
+          lds_tr_issue<16 * ROWB>(vf[1][eb], trv[eb][0] + tb, trv[eb][1] + tb);
+        }
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 pf = acc_to_frag(s[j], s2);
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(s[j][r] * LOG2E - mb);
+          s[j][r] = e;
+          l += e;
+        }
+        if constexpr (hd > 32) lds_tr_wait(vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0].lo), "+v"(vf[0][0].hi), "+v"(vf[1][0].lo), "+v"(vf[1][0].hi));
 #pragma unroll
-            for (int eb = 0; eb < 2; ++eb) {
-              const bf16x8 vf = lds_tr_frag(imgV, kt * 32 + 16 * s2 + trow, 32 * eb + tcol);
-              oacc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[eb], 0, 0, 0);
-            }
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = acc_to_frag(s[j], s2);
+#pragma unroll
+          for (int eb = 0; eb < 2; ++eb) {
+            if (32 * eb >= hd) continue;
+            oacc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vf[s2][eb]), pf, oacc[eb], 0, 0, 0);
           }
         }
       }
       m = m_new;
+    };
+    int c0 = 0;
+#pragma unroll 1
+    for (; c0 + KC <= NT; c0 += KC) chunk(c0, std::integral_constant<int, KC>{});
+    switch (NT - c0) {
+      case 1: chunk(c0, std::integral_constant<int, 1>{}); break;
+      case 2: chunk(c0, std::integral_constant<int, 2>{}); break;
+      case 3: chunk(c0, std::integral_constant<int, 3>{}); break;
+      default: break;
     }
     l = half_sum(l);
     if (q < p.N) {
@@ -971,10 +995,12 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const AttnParams2 pp) {
   }
 }
 
+template <int KS>  // head_dim / 16 (see attn_fwd2_kernel)
 __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const AttnParams& p = pp.a;
-  const int NT = pp.nt, hd = pp.hd;
+  const int NT = pp.nt;
+  constexpr int hd = 16 * KS;
   const int IMG = NT * 32 * ROWB;
   char* img0 = smem;        // pass A: K      pass B: Q
   char* img1 = smem + IMG;  // pass A: V      pass B: dO
@@ -1004,6 +1030,13 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
   const int trow = 4 * (g >> 1) + (t >> 2);
   const int tcol = 16 * (g & 1) + 4 * (t & 3);
   const f32x16 zero16f = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  uint32_t trc[2][2];  // [eb][rows r.. / r + 8..]: transposed-fragment addresses of tile 0 in image 0 (TrFrag: requested under the exps -
+                       // hipcc keeps the ds_read_tr16 builtin next to its MFMA, one exposed LDS round trip each)
+#pragma unroll
+  for (int eb = 0; eb < 2; ++eb) {
+    trc[eb][0] = lds_addr32(img0) + tr_lane_off(trow, 32 * eb + tcol, false);
+    trc[eb][1] = lds_addr32(img0) + tr_lane_off(trow, 32 * eb + tcol, true);
+  }
 
   // ---- pass A: queries on the lane; K, V resident.  (Round 4: both passes are VALU-issue-bound at N = 577, so they take the lean
   // per-score arithmetic of the resident kernel: zero-C accumulators, LSE / delta folded into the exp argument and the dS product,
@@ -1013,8 +1046,8 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
     bf16x8 qf[4], df[4];
     float delta = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const bool ok = q < p.N && 16 * ks < hd;
+    for (int ks = 0; ks < KS; ++ks) {
+      const bool ok = q < p.N;
       qf[ks] = load_row_frag_global(p.qkv, (size_t)(row_base + q), p.ld, hh * hd + 16 * ks + 8 * half, ok);
       df[ks] = load_row_frag_global(p.d_o, (size_t)(row_base + q), p.d, hh * hd + 16 * ks + 8 * half, ok);
       const bf16x8 ov = load_row_frag_global(p.o, (size_t)(row_base + q), p.d, hh * hd + 16 * ks + 8 * half, ok);
@@ -1034,15 +1067,21 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
       f32x16 sa = zero16f, da = zero16f;
       ATTN_PRIO(1);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (16 * ks < hd) {
-          const bf16x8 kf = lds_row_frag(img0, kt * 32 + ql, 2 * ks + half);
-          const bf16x8 vf = lds_row_frag(img1, kt * 32 + ql, 2 * ks + half);
-          sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sa, 0, 0, 0);
-          da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[ks], da, 0, 0, 0);
-        }
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = lds_row_frag(img0, kt * 32 + ql, 2 * ks + half);
+        const bf16x8 vf = lds_row_frag(img1, kt * 32 + ql, 2 * ks + half);
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sa, 0, 0, 0);
+        da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[ks], da, 0, 0, 0);
       }
       ATTN_PRIO(0);
+      TrFrag ktf[2][2];
+      const uint32_t tb = (uint32_t)(kt * 32 * ROWB);
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) {
+        if (32 * eb >= hd) continue;
+        lds_tr_issue<0>(ktf[0][eb], trc[eb][0] + tb, trc[eb][1] + tb);
+        lds_tr_issue<16 * ROWB>(ktf[1][eb], trc[eb][0] + tb, trc[eb][1] + tb);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], LOG2E, nlse2));
@@ -1055,14 +1094,16 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
           if (key >= p.N) sa[r] = 0.f;
         }
       }
+      if constexpr (hd > 32) lds_tr_wait(ktf[0][0], ktf[0][1], ktf[1][0], ktf[1][1]);
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ktf[0][0].lo), "+v"(ktf[0][0].hi), "+v"(ktf[1][0].lo), "+v"(ktf[1][0].hi));
       ATTN_PRIO(1);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 dsf = acc_to_frag(sa, s2);
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb) {
-          const bf16x8 ktf = lds_tr_frag(img0, kt * 32 + 16 * s2 + trow, 32 * eb + tcol);
-          dq[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq[eb], 0, 0, 0);
+          if (32 * eb >= hd) continue;
+          dq[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(ktf[s2][eb]), dsf, dq[eb], 0, 0, 0);
         }
       }
       ATTN_PRIO(0);
@@ -1083,8 +1124,8 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
     const int key = kb * 32 + ql;
     bf16x8 kf[4], vf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const bool ok = key < p.N && 16 * ks < hd;
+    for (int ks = 0; ks < KS; ++ks) {
+      const bool ok = key < p.N;
       kf[ks] = load_row_frag_global(p.qkv, (size_t)(row_base + key), p.ld, p.d + hh * hd + 16 * ks + 8 * half, ok);
       vf[ks] = load_row_frag_global(p.qkv, (size_t)(row_base + key), p.ld, 2 * p.d + hh * hd + 16 * ks + 8 * half, ok);
     }
@@ -1108,15 +1149,21 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
       }
       ATTN_PRIO(1);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (16 * ks < hd) {
-          const bf16x8 qfr = lds_row_frag(img0, qt * 32 + ql, 2 * ks + half);
-          const bf16x8 dfr = lds_row_frag(img1, qt * 32 + ql, 2 * ks + half);
-          sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[ks], sa, 0, 0, 0);
-          da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr, vf[ks], da, 0, 0, 0);
-        }
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 qfr = lds_row_frag(img0, qt * 32 + ql, 2 * ks + half);
+        const bf16x8 dfr = lds_row_frag(img1, qt * 32 + ql, 2 * ks + half);
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[ks], sa, 0, 0, 0);
+        da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr, vf[ks], da, 0, 0, 0);
       }
       ATTN_PRIO(0);
+      TrFrag dtf[2][2], qtf[2][2];  // k-step 0's requested under the exps, k-step 1's under k-step 0's MFMAs
+      const uint32_t tb = (uint32_t)(qt * 32 * ROWB), imgd = (uint32_t)IMG;
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) {
+        if (32 * eb >= hd) continue;
+        lds_tr_issue<0>(dtf[0][eb], trc[eb][0] + tb + imgd, trc[eb][1] + tb + imgd);
+        lds_tr_issue<0>(qtf[0][eb], trc[eb][0] + tb, trc[eb][1] + tb);
+      }
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const float nl[4] = {nl4[g4].x, nl4[g4].y, nl4[g4].z, nl4[g4].w};
@@ -1129,17 +1176,28 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
           da[r] = pr * (da[r] - dl[j]);
         }
       }
+      if constexpr (hd > 32) lds_tr_wait(dtf[0][0], dtf[0][1], qtf[0][0], qtf[0][1]);
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dtf[0][0].lo), "+v"(dtf[0][0].hi), "+v"(qtf[0][0].lo), "+v"(qtf[0][0].hi));
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) {
+        if (32 * eb >= hd) continue;
+        lds_tr_issue<16 * ROWB>(dtf[1][eb], trc[eb][0] + tb + imgd, trc[eb][1] + tb + imgd);
+        lds_tr_issue<16 * ROWB>(qtf[1][eb], trc[eb][0] + tb, trc[eb][1] + tb);
+      }
       ATTN_PRIO(1);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 pf = acc_to_frag(sa, s2);
         const bf16x8 dsf = acc_to_frag(da, s2);
+        if (s2 == 1) {
+          if constexpr (hd > 32) lds_tr_wait(dtf[1][0], dtf[1][1], qtf[1][0], qtf[1][1]);
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dtf[1][0].lo), "+v"(dtf[1][0].hi), "+v"(qtf[1][0].lo), "+v"(qtf[1][0].hi));
+        }
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb) {
-          const bf16x8 dtf = lds_tr_frag(img1, qt * 32 + 16 * s2 + trow, 32 * eb + tcol);
-          const bf16x8 qtf = lds_tr_frag(img0, qt * 32 + 16 * s2 + trow, 32 * eb + tcol);
-          dv[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dtf, pf, dv[eb], 0, 0, 0);
-          dk[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dk[eb], 0, 0, 0);
+          if (32 * eb >= hd) continue;
+          dv[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(dtf[s2][eb]), pf, dv[eb], 0, 0, 0);
+          dk[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(qtf[s2][eb]), dsf, dk[eb], 0, 0, 0);
         }
       }
       ATTN_PRIO(0);
@@ -2108,8 +2166,18 @@ extern "C" int savit_attention_fwd(const void* qkv, void* o, float* lse, int B, 
   if (head_dim != HD || nt > 8 || attn_force_general()) {
     AttnParams2 pp{p, nt, head_dim};
     const size_t lds = (size_t)2 * nt * 32 * ROWB;
-    SAVIT_LDS_ONCE(attn_fwd2_kernel);
-    hipLaunchKernelGGL(attn_fwd2_kernel, dim3(B * H), dim3(64 * (nt < 8 ? nt : 8)), lds, (hipStream_t)stream, pp);
+#define ATTN2_LAUNCH(KERNEL, KSV)                                                                                                  \
+  {                                                                                                                                \
+    auto kfn = KERNEL<KSV>;                                                                                                        \
+    SAVIT_LDS_ONCE(kfn);                                                                                                           \
+    hipLaunchKernelGGL(kfn, dim3(B * H), dim3(64 * (nt < 8 ? nt : 8)), lds, (hipStream_t)stream, pp);                              \
+  } break;
+    switch (head_dim / 16) {
+      case 1: ATTN2_LAUNCH(attn_fwd2_kernel, 1)
+      case 2: ATTN2_LAUNCH(attn_fwd2_kernel, 2)
+      case 3: ATTN2_LAUNCH(attn_fwd2_kernel, 3)
+      default: ATTN2_LAUNCH(attn_fwd2_kernel, 4)
+    }
     SAVIT_LAUNCH_RET();
   }
   // persistent workgroups: as many as fit the CUs' LDS at once (two K/V image pairs each), every one walking over items
@@ -2131,8 +2199,12 @@ extern "C" int savit_attention_bwd(const void* qkv, const void* o, const void* d
   if (head_dim != HD || nt > 8 || attn_force_general()) {
     AttnParams2 pp{p, nt, head_dim};
     const size_t lds = (size_t)2 * nt * 32 * ROWB + (size_t)2 * nt * 32 * sizeof(float);
-    SAVIT_LDS_ONCE(attn_bwd2_kernel);
-    hipLaunchKernelGGL(attn_bwd2_kernel, dim3(B * H), dim3(64 * (nt < 8 ? nt : 8)), lds, (hipStream_t)stream, pp);
+    switch (head_dim / 16) {
+      case 1: ATTN2_LAUNCH(attn_bwd2_kernel, 1)
+      case 2: ATTN2_LAUNCH(attn_bwd2_kernel, 2)
+      case 3: ATTN2_LAUNCH(attn_bwd2_kernel, 3)
+      default: ATTN2_LAUNCH(attn_bwd2_kernel, 4)
+    }
     SAVIT_LAUNCH_RET();
   }
   // N <= 224: persistent workgroups (attn_bwd_pers_kernel).  Round 2 built a persistent form as well and dropped it (148 us against
