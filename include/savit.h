@@ -395,6 +395,10 @@ int savit_timer_elapsed_ms(void* handle, int first, int second, float* ms);
 int savit_timer_destroy(void* handle);
 int savit_spin(long microseconds, void* stream);
 int savit_hold_cus(int cus, long microseconds, void* stream);
+/* CUs the persistent kernels (attention forward / backward: one workgroup per CU walking over (image, head) items) size their grids
+ * for; 0 (default) = every CU of the device.  A data-parallel rank sets its launch plan's budget (device CUs - reserved_cus) so that no
+ * persistent workgroup has to wait for a CU that RCCL's channels hold.  Process-wide; results do not depend on it. */
+int savit_set_cu_budget(int cus);
 int savit_zero_bytes(void* dst, long bytes, void* stream);
 
 #ifdef __cplusplus

@@ -2129,7 +2129,9 @@ static int persistent_grid(int items, size_t lds_bytes, int threads) {
   if (per_cu > by_threads) per_cu = by_threads;
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 2) per_cu = 2;  // the kernels hold 128-256 VGPRs
-  const long g = (long)cus * per_cu;
+  int use = savit_cu_budget_.load(std::memory_order_relaxed);  // savit_set_cu_budget: CUs not held by other kernels (0: all)
+  if (use <= 0 || use > cus) use = cus;
+  const long g = (long)use * per_cu;
   return (int)(items < g ? items : g);
 }
 #define ATTN_DISPATCH(KERNEL, LDS_EXPR, GRID)                                                                       \

@@ -43,6 +43,12 @@ __device__ __forceinline__ void nt_store_u4(void* p, uint4 v) {
 
 #define SAVIT_LAUNCH_RET() return (int)hipGetLastError()
 
+// CUs the persistent kernels (one workgroup per CU walking over work items: attention forward / backward) may count on; 0 = all.
+// Set through savit_set_cu_budget by a host that knows other kernels hold CUs beside its own (a data-parallel rank: RCCL's channels);
+// a persistent grid of one workgroup per CU of the WHOLE chip would leave the workgroups that find no free CU to start when the
+// first ones have finished all their items - twice the kernel's time.  One variable for the library (C++17 inline).
+inline std::atomic<int> savit_cu_budget_{0};
+
 // Kernels that use more than the default 64 KB of dynamic LDS need their limit raised.  That is done ONCE per kernel symbol (a
 // function-local static: initialised thread-safely, C++11) to the CU's whole 160 KB - a limit, not an allocation: each launch still
 // passes the bytes it uses - instead of a driver call in front of every launch.

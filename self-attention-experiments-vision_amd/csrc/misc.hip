@@ -87,3 +87,9 @@ extern "C" int savit_zero_bytes(void* dst, long bytes, void* stream) {
   if (bytes == 0) return SAVIT_OK;
   return (int)hipMemsetAsync(dst, 0, (size_t)bytes, (hipStream_t)stream);
 }
+
+extern "C" int savit_set_cu_budget(int cus) {
+  SAVIT_CHECK_ARG(cus >= 0);
+  savit_cu_budget_.store(cus, std::memory_order_relaxed);
+  return SAVIT_OK;
+}

@@ -471,7 +471,8 @@ class ViTEngine:
     # ---- state every engine of this package shares (the Mixer / TNT engines subclass this one and lay out their own activations)
     def _init_cu_budget(self, reserved_cus: Optional[int], wgrad_max_lag: Optional[int]):
         """CUs the launch plans may count on.  Everything that sizes a grid for "one round of workgroups" reads cu_budget: the grouped
-        weight-gradient launches (WgradQueue cap) and the TN GEMM tile choice (savit_gemm_args.cu_budget)."""
+        weight-gradient launches (WgradQueue cap), the TN GEMM tile choice (savit_gemm_args.cu_budget) and the persistent attention
+        kernels' grids (savit_set_cu_budget)."""
         self.n_cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
         if reserved_cus is None:
             reserved_cus = int(os.environ.get("SAVIT_RESERVED_CUS", "0"))
@@ -479,6 +480,8 @@ class ViTEngine:
             raise ValueError(f"reserved_cus must be in [0, {self.n_cus})")
         self.reserved_cus = int(reserved_cus)
         self.cu_budget = self.n_cus - self.reserved_cus
+        # the persistent attention kernels size their grids (one workgroup per CU) from the same budget; process-wide, 0 = every CU
+        _lib.check(self.L.savit_set_cu_budget(self.cu_budget if self.reserved_cus else 0), "savit_set_cu_budget")
         self._building_bwd = False  # set while a backward plan is recorded: only its launches run beside the all-reduce
         if wgrad_max_lag is None and os.environ.get("SAVIT_WGRAD_MAX_LAG"):
             wgrad_max_lag = int(os.environ["SAVIT_WGRAD_MAX_LAG"])

@@ -145,6 +145,7 @@ _SIGNATURES = {
     "savit_timer_destroy": (c_int, [c_void_p]),
     "savit_spin": (c_int, [c_long, c_void_p]),
     "savit_hold_cus": (c_int, [c_int, c_long, c_void_p]),
+    "savit_set_cu_budget": (c_int, [c_int]),
     "savit_zero_bytes": (c_int, [c_void_p, c_long, c_void_p]),
 }
 

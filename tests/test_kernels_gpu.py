@@ -1071,3 +1071,26 @@ def test_class_attention_fwd_bwd(ops, B, Nk, H, hd):
     print(f"[class attn emul {B},{Nk},{H},{hd}] " + " ".join(f"{k_} {v_:.1e}" for k_, v_ in ca.items()))
     for k_, v_ in ca.items():
         assert v_ < 1e-4, (k_, v_)  # measured <= 1.9e-5 (mostly bit-exact)
+
+
+def test_attention_cu_budget_changes_the_grid_not_the_result(ops):
+    """savit_set_cu_budget: the persistent attention kernels walk the same items with fewer workgroups - bit-identical outputs."""
+    from savit_amd import lib as _lib
+
+    L = _lib.load()
+    B, N, H = 40, 197, 12
+    d = H * 64
+    rng = np.random.default_rng(5)
+    qkv = dev(rb(rng.standard_normal((B * N, 3 * d)) * 0.5), bf16)
+    d_o = dev(rb(rng.standard_normal((B * N, d))), bf16)
+    outs = []
+    try:
+        for budget in (0, 240, 100, 7):
+            assert L.savit_set_cu_budget(budget) == 0
+            o, lse = ops.attention_fwd(qkv, B, N, H)
+            outs.append((o, lse, ops.attention_bwd(qkv, o, d_o, lse, B, N, H, dq_scale=0.125)))
+    finally:
+        L.savit_set_cu_budget(0)
+    assert L.savit_set_cu_budget(-1) != 0
+    for o, lse, dq in outs[1:]:
+        assert torch.equal(o, outs[0][0]) and torch.equal(lse, outs[0][1]) and torch.equal(dq, outs[0][2])
