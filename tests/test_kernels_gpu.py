@@ -553,7 +553,8 @@ def test_attention_fwd_spike(ops):
 
 
 @pytest.mark.parametrize("B,N,H,hd", [(2, 197, 3, 48), (1, 196, 8, 48), (1, 577, 2, 64), (1, 300, 1, 48), (2, 17, 2, 48), (1, 608, 1, 64),
-                                      (392, 16, 4, 16), (5, 16, 4, 32), (2, 50, 2, 16)])  # TNT's inner transformer: 16 pixel tokens, padded heads
+                                      (392, 16, 4, 16), (5, 16, 4, 32), (2, 50, 2, 16),  # TNT's inner transformer: 16 pixel tokens, padded heads
+                                      (1, 256, 2, 48), (2, 129, 2, 48), (1, 384, 1, 64), (1, 545, 1, 32)])  # key tiles: 8 = 2 chunks, 5 = 1 + 1, 12, 18 = 4 + 2
 def test_attention_general_fwd_bwd(ops, B, N, H, hd):
     """General kernels: head_dim 48 (every CaiT size) and N > 256 (ViT-L/16 at 384^2: N = 577), online softmax."""
     rng = np.random.default_rng(B * 7 + N + hd)
