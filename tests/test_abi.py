@@ -241,3 +241,43 @@ def test_talking_heads_coefficient_loads_are_not_touched_in_flight(built, tmp_pa
             seen += n
             assert not bad, (head, bad[:3])
     assert seen >= 4 * 2 + 4 * 3  # H = 8: 4 quads x (2 matrices forward, 3 backward); H = 4 adds one quad per matrix use
+
+
+def test_overlapped_kernels_hold_no_scratch_and_no_builtin_waits(built, tmp_path):
+    """The persistent attention backward keeps an LDS-DMA in flight across its passes.  Two things silently turn that into no overlap at
+    all: a spilled register (its reload is a VMEM operation that waits for everything issued before it) and a
+    `s_waitcnt vmcnt(0)` that hipcc puts in front of LDS reads it can attribute (the ds_read_tr16 builtin, typed float reads).  So: no
+    scratch in the instantiations the BASELINE geometries launch, no scratch_* instruction in them, and between the two barriers of a
+    pass no full vmcnt wait in the loop bodies (the only vmcnt(0) of the kernel are the ones in front of its barriers)."""
+    import re
+    import shutil
+    import subprocess
+
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(readelf) and shutil.which("c++filt")):
+        pytest.skip("llvm-readelf / c++filt not available")
+    isa = _device_isa("attention.o", tmp_path)
+    co = [f for f in os.listdir(str(tmp_path)) if "gfx950" in f][0]
+    notes = subprocess.run([readelf, "--notes", os.path.join(str(tmp_path), co)], check=True, capture_output=True, text=True).stdout
+    scratch = {}
+    for blk in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        scratch[name] = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+    checked = 0
+    for mangled, bytes_ in scratch.items():
+        if not re.search(r"attn_bwd_pers_kernelILi[567]E|attn_fwd_kernelILi7E|attn_[fb]wd2_kernelILi4E", mangled):
+            continue
+        checked += 1
+        assert bytes_ == 0, f"{mangled}: {bytes_} bytes of scratch"
+        body = isa.split("<" + mangled + ">:")[1].split("\n\n")[0]
+        assert "scratch_" not in body, mangled
+    assert checked >= 6, checked
+    # the persistent backward for DeiT's N = 197: every full vmcnt wait sits right in front of an s_barrier (its passes have none)
+    body = isa.split("<" + [m for m in scratch if "attn_bwd_pers_kernelILi7E" in m][0] + ">:")[1].split("\n\n")[0]
+    lines = [ln.split("//")[0].strip() for ln in body.splitlines() if ln.strip()]
+    ops = [ln for ln in lines if re.match(r"^(s_waitcnt|s_barrier|v_mfma|buffer_load|global_load|global_store|s_cbranch)", ln)]
+    for i, op in enumerate(ops):
+        if op.startswith("s_waitcnt") and re.search(r"vmcnt\(0\)", op):
+            window = ops[i + 1:i + 4]
+            assert any(w.startswith("s_barrier") or (w.startswith("s_waitcnt") and "vmcnt(0)" in w) for w in window) or \
+                not any(w.startswith("v_mfma") for w in ops[i + 1:i + 3]), ("a full vmcnt wait inside a pass", i, op, window)
