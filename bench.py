@@ -45,10 +45,10 @@ if ROOT not in sys.path:
 MFMA_BF16_PEAK_TFLOPS = 2516.6  # 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md chip table)
 
 
-TN_TILES = {6: "gemm_tn_ring_kernel<128,128,2,2,4,%d>", 7: "gemm_tn_ring_kernel<256,256,2,4,4,%d>",
+TN_TILES = {6: "gemm_tn_ring_kernel<128,128,2,2,4,%d,false>",
             12: "gemm_tn_pair_kernel<128,128,2,2,2,%d>", 13: "gemm_tn_pair_kernel<256,256,2,4,2,%d>",
             17: "gemm_tn_pair_kernel<192,128,2,2,2,%d>", 18: "gemm_tn_pair_tail_kernel<192,128,128,2,2,2,%d>",
-            20: "gemm_tn_pp_kernel<%d,0>", 21: "gemm_tn_pp320_kernel<%d>", 30: "gemm_tn_stream_kernel<%d>"}
+            20: "gemm_tn_pp_kernel<%d,0>", 21: "gemm_tn_pp320_kernel<%d>"}
 WG_VARIANTS = {1: "gemm_wgrad_ring_kernel<128,128,2,2,4,false>", 3: "gemm_wgrad_ring_kernel<256,256,2,4,4,false>"}
 EPI_OF = {"qkv": 0, "proj": 2, "fc1": 1, "fc2": 2, "fc2.dgrad": 3, "fc1.dgrad": 0, "proj.dgrad": 0, "qkv.dgrad": 0}
 
@@ -76,6 +76,36 @@ def kernel_symbol(label: str, lib, M: int, d: int, F: int) -> str:
     if op.startswith("ln"):
         return "ln_bwd_kernel(+finalize)" if op.endswith(".bwd") else "ln_fwd_kernel"
     return "other(" + op + ")"
+
+
+WG_GROUP_TILES = {256: "gemm_wgrad_group_kernel<256,256,2,4,3,32>", 640: "gemm_wgrad_group_mixed_kernel<3>",
+                  384: "gemm_wgrad_group_kernel<128,384,2,4,3,32>", 128: "gemm_wgrad_group_kernel<128,128,2,2,4,32>"}
+
+
+def tn_symbol(lib, M: int, N: int, K: int, epilogue: int, tile: int = 0, cu_budget: int = 0) -> str:
+    """The kernel symbol savit_gemm_bf16_tn launches for this problem (tile 0 = the library's own choice for cu_budget CUs)."""
+    if tile == 0:
+        tile = lib.savit_gemm_tn_auto_tile_cus(M, N, K, epilogue, cu_budget)
+    return TN_TILES.get(tile, "gemm_tn tile %d <%%d>" % tile) % epilogue
+
+
+def plan_symbols(eng) -> dict:
+    """{launch label: kernel symbol} read off the engine's recorded launch plans (any family): every TN GEMM from the argument
+    block it will be launched with, every grouped weight-gradient launch from its tile code.  Labels of other launches are absent
+    (kernel_symbol / kernel_class name them)."""
+    out = {}
+    lib = getattr(eng, "L", None)
+    flops = eng.__dict__.setdefault("plan_flops", {}) if hasattr(eng, "__dict__") else {}
+    for plan in (getattr(eng, "_fwd_plan", None), getattr(eng, "_bwd_plan", None), getattr(eng, "_bwd_plan_serial", None)):
+        for fn, args, label in (plan.calls if plan is not None else ()):
+            name = getattr(fn, "__name__", "")
+            if name == "savit_gemm_bf16_tn":
+                a = args[0]._obj
+                out[label] = tn_symbol(lib, a.M, a.N, a.K, a.epilogue, a.tile, a.cu_budget)
+                flops[label] = 2.0 * a.M * a.N * a.K  # algorithmic (operands padded with zeros - head, Mixer tokens - count as stored)
+            elif name == "savit_gemm_bf16_wgrad_grouped":
+                out[label] = WG_GROUP_TILES.get(int(args[2]), "gemm_wgrad_group tile %d" % int(args[2]))
+    return out
 
 
 def kernel_class(label: str) -> str:
@@ -120,9 +150,27 @@ def launch_ranks(n: int) -> int:
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"  # dmabuf IPC between the ranks' RCCL peers (the only mode this host driver supports)
     env.setdefault("OMP_NUM_THREADS", "4")   # torch.distributed.run would set 1; the CPU side of a rank only drives launches
+    env.update(rccl_env_for(n, env))         # RCCL's channels (= resident CUs) bounded by the CUs backward is planned to leave it
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
+
+
+def rccl_env_for(world: int, env) -> dict:
+    """NCCL_MAX/MIN_NCHANNELS for the rank processes of a `world`-rank job (ddp.rccl_channel_env; restated here without importing
+    torch: the launcher parent must stay GPU-free).  tests/test_ddp_cpu.py checks both against each other."""
+    if world <= 1:
+        return {}
+    if env.get("SAVIT_RESERVED_CUS"):
+        reserved = int(env["SAVIT_RESERVED_CUS"])
+    elif env.get("NCCL_MAX_NCHANNELS"):
+        reserved = int(env["NCCL_MAX_NCHANNELS"])
+    else:
+        reserved = 16
+    if reserved <= 0:
+        return {}
+    mx = env.get("NCCL_MAX_NCHANNELS") or str(reserved)
+    return {"NCCL_MAX_NCHANNELS": mx, "NCCL_MIN_NCHANNELS": env.get("NCCL_MIN_NCHANNELS") or str(min(int(mx), reserved))}
 
 
 def rank_probe():
@@ -136,8 +184,12 @@ def rank_probe():
     t = torch.tensor([float(dist.get_rank())])
     dist.all_reduce(t)
     if dist.get_rank() == 0:
+        from savit_amd import ddp
+
         print(json.dumps({"launcher_probe": True, "world": dist.get_world_size(), "rank_sum": t.item(),
-                          "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}))
+                          "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                          "rccl_channels": ddp.rccl_channels_in_effect(), "nccl_min_nchannels": os.environ.get("NCCL_MIN_NCHANNELS"),
+                          "reserved_cus": ddp.default_reserved_cus(dist.get_world_size())}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -232,6 +284,7 @@ def symbol_tables(times, cfg, eng, B):
                   "tok": 2.0 * B * d * cfg.n_patches * cfg.tokens_hidden}  # MLP-Mixer token-mixing GEMMs (unpadded, algorithmic)
     names = {"Wqkv": "qkv", "Wo": "proj", "W1": "fc1", "W2": "fc2", "tW1": "tok", "tW2": "tok"}
     sym, cls = {}, {}
+    psym = plan_symbols(eng)
     for key, t_ms in times.items():
         label = key.split("#")[0]
         c = kernel_class(label)
@@ -245,7 +298,9 @@ def symbol_tables(times, cfg, eng, B):
             fl = 2.0 * B * cfg.n_patches * cfg.patch_dim * d
         elif label.startswith("head"):
             fl = 2.0 * B * d * cfg.num_classes
-        sname = kernel_symbol(label, eng.L, M, d, F) if cfg.kind == "vit" else c
+        elif c == "gemm_tn" and cfg.kind != "vit":
+            fl = getattr(eng, "plan_flops", {}).get(label, 0.0)  # class-attention layers, TNT's inner stream, ...: 2 M N K of the launch
+        sname = psym.get(label) or (kernel_symbol(label, eng.L, M, d, F) if cfg.kind == "vit" else c)
         for table, k in ((sym, sname), (cls, c)):
             e = table.setdefault(k, {"ms": 0.0, "n": 0, "flops": 0.0, "labels": []})
             e["ms"] += t_ms
@@ -253,6 +308,37 @@ def symbol_tables(times, cfg, eng, B):
             e["flops"] += fl
             e["labels"].append(label)
     return sym, cls
+
+
+def traffic_lookup(kernel: str, headline: bool, profiles_dir: str = None, running: dict = None) -> dict:
+    """`roofline.traffic` for `kernel`: HBM-side bytes per launch from the newest committed rocprofv3 --pmc passes of the headline
+    workload (tools/pmc_summary.py -> profiles/rNN_pmc_traffic.json; a counter pass cannot run inside this process) - but only while
+    that file was measured on THIS code: it carries the SHA-256 of each kernel's machine code (fingerprint.py), compared here with the
+    library that is running.  A mismatch (kernel edited, renamed, or a file from before round 5) yields "traffic": null and
+    "traffic_stale": true with the reason, never another build's number."""
+    from savit_amd import fingerprint as fpr
+
+    res = {"traffic": None}
+    if not headline:
+        return res
+    pdir = profiles_dir or os.path.join(ROOT, "profiles")
+    try:
+        files = sorted((f for f in os.listdir(pdir) if f.startswith("r") and f.endswith("_pmc_traffic.json") and f[1:3].isdigit()), reverse=True)
+        if not files:
+            return res
+        src = files[0]
+        pj = json.load(open(os.path.join(pdir, src)))
+        pm = pj["kernels"].get(kernel)
+        stale, why = fpr.traffic_is_stale(pj, kernel, running)
+        res["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, FETCH doubled)"
+        res["traffic_stale"] = bool(stale or pm is None)
+        res["traffic_check"] = why
+        if pm and not stale:
+            res["traffic"] = pm["traffic_bytes"]
+    except (OSError, ValueError, KeyError) as e:
+        res["traffic_stale"] = True
+        res["traffic_check"] = f"could not read the PMC summary: {e}"
+    return res
 
 
 def pick_dominant(sym):
@@ -280,6 +366,7 @@ def measure(eng, cfg, B, world, rank, sync, steps, warmup, dist=None, breakdown=
     # ---- which GEMM kernel dominates this step?  (every rank, no collective, no parameter update: forward + loss + backward only)
     saved_hooks, eng.bwd_hooks = eng.bwd_hooks, {}
     lab0 = batches[0][1]
+    eng.set_images(batches[0][0])  # the instrumented passes run forward() on the resident image buffer: batch 0's images WITH batch 0's labels
 
     def fwd_bwd():
         if cfg.kind == "cait":
@@ -310,12 +397,13 @@ def measure(eng, cfg, B, world, rank, sync, steps, warmup, dist=None, breakdown=
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     eng.launch_timer = None
+    final_loss = float(eng.loss.item())  # the loss of the LAST TIMED step, read before any instrumented pass touches the engine
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_step = elapsed / steps * 1e3
-    info = {}
+    info = {"final_loss": round(final_loss, 4)}
     if rank != 0:
         live.close()
         return elapsed, step, info
@@ -350,7 +438,17 @@ def measure(eng, cfg, B, world, rank, sync, steps, warmup, dist=None, breakdown=
             fwd_bwd()
             eng.optimizer_step(lr=lr, weight_decay=wd, max_norm=1.0)
 
+        # the instrumented steps really update the parameters (5 optimizer steps on one batch): the training state is put back after
+        eng.set_images(batches[0][0])
+        snap = {k: getattr(eng, k).clone() for k in ("params", "adam_m", "adam_v", "params_bf16") if getattr(eng, k, None) is not None}
+        snap_step = eng.step_count
         post = instrumented_steps(eng, whole, reps=3)
+        for k, v in snap.items():
+            getattr(eng, k).copy_(v)
+        eng.step_count = snap_step
+        del snap
+        eng._mirror_fresh = False
+        eng.refresh_weights()
         eng.bwd_hooks = saved_hooks
         sym1, cls1 = symbol_tables(post["labels"], cfg, eng, B)
         total = sum(v["ms"] for v in cls1.values())
@@ -413,7 +511,7 @@ def time_other_config(model, B, img_size, steps=10, warmup=3):
            "step_roofline": {"bound": "mfma", "achieved": round(ips * fpi / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(ips * fpi / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "flops_per_image": fpi},
            "roofline": {k: info["roofline"][k] for k in ("kernel", "launches_per_step", "avg_launch_ms", "achieved", "frac")},
-           "roofline_valid": info["roofline_valid"], "final_loss": round(float(eng.loss.item()), 4)}
+           "roofline_valid": info["roofline_valid"], "final_loss": info["final_loss"]}
     del step, eng
     torch.cuda.empty_cache()
     return res
@@ -501,6 +599,7 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.update(rccl_env_for(world, os.environ))  # (a rank started by an external launcher: before the first communicator)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -526,7 +625,7 @@ def main():
     eng.refresh_weights()
     S = cfg.img_size
     elapsed, step, info = measure(eng, cfg, B, world, rank, sync, args.steps, args.warmup, dist)
-    loss = float(eng.loss.item())
+    loss = info.pop("final_loss")  # read right behind the timed loop (the instrumented passes used to overwrite it)
     dist_info = None
     if dist is not None:
         # self-evidence of the multi-GPU run: the backend torch.distributed reports, its world size, every rank's device identity
@@ -538,7 +637,8 @@ def main():
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ids,
                      "distinct_devices": len({(d.get("pci_bus_id"), d.get("uuid"), d.get("device")) for d in ids}),
                      "gradient_bytes_per_step": int(eng.grads.numel() * 4), "buckets": len(sync.buckets),
-                     "allreduce_exposed_ms": round(float(ex.item()), 4), "reserved_cus": int(getattr(eng, "reserved_cus", 0))}
+                     "allreduce_exposed_ms": round(float(ex.item()), 4), "reserved_cus": int(getattr(eng, "reserved_cus", 0)),
+                     "rccl_channels": ddp.rccl_channels_in_effect(), "rccl_min_channels": os.environ.get("NCCL_MIN_NCHANNELS")}
 
     out = None
     if rank == 0:
@@ -555,7 +655,8 @@ def main():
                                    "fwd + label-smoothed CE + bwd + grad all-reduce + AdamW",
                        "images_per_gpu": B, "global_batch": B * world, "seq_len": cfg.seq_len, "parallelism": f"dp{world}",
                        "final_loss": round(loss, 4), **({"distributed": dist_info} if dist_info else {})},
-            **({"allreduce_exposed_ms": dist_info["allreduce_exposed_ms"]} if dist_info else {}),
+            **({"allreduce_exposed_ms": dist_info["allreduce_exposed_ms"], "reserved_cus": dist_info["reserved_cus"],
+                "rccl_channels": dist_info["rccl_channels"]} if dist_info else {}),
             "step_roofline": {"bound": "mfma", "achieved": round(per_gpu * fpi / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(per_gpu * fpi / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "flops_per_image": fpi},
         }
@@ -565,22 +666,13 @@ def main():
         # HBM-side traffic of that kernel: PMC passes cannot run inside this process, so the figure is the committed
         # rocprofv3 --pmc measurement of the same workload (tools/pmc_summary.py -> profiles/*_pmc_traffic.json), when it
         # covers this kernel and this is the headline workload; null otherwise.
-        try:
-            if args.model == "vit_b_patch16" and B == 128:
-                src = next(f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
-                           if os.path.exists(os.path.join(ROOT, "profiles", f)))
-                pm = json.load(open(os.path.join(ROOT, "profiles", src)))["kernels"].get(dom)
-                if pm:
-                    out["roofline"]["traffic"] = pm["traffic_bytes"]
-                    out["roofline"]["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, FETCH doubled)"
-                    if dom.startswith("gemm_wgrad_group_kernel"):
-                        # operands read once (X and dY of every weight of the group) + dW read and written once (fp32)
-                        # (every weight gradient of the model, spread over the grouped launches: each takes one tile per CU)
-                        n_div = len(getattr(eng, "wgrad_divert", ()))
-                        per_layer = sum(2 * M * (a + b_) + 8 * a * b_ for a, b_ in ((d, 3 * d), (d, d), (d, F), (F, d)))
-                        out["roofline"]["algorithmic_bytes_per_launch"] = int((cfg.num_layers * per_layer - n_div * (4 * M * d + 8 * d * d)) / out["roofline"]["launches_per_step"])
-        except (OSError, ValueError, KeyError, StopIteration, ZeroDivisionError):
-            pass
+        out["roofline"].update(traffic_lookup(dom, headline=(args.model == "vit_b_patch16" and B == 128 and args.img_size == 224)))
+        if dom.startswith("gemm_wgrad_group_kernel"):
+            # operands read once (X and dY of every weight of the group) + dW written once (fp32; round 5: the first tile of a weight
+            # stores, nothing is read back)  (every weight gradient of the model, spread over the grouped launches: each takes one tile per CU)
+            n_div = len(getattr(eng, "wgrad_divert", ()))
+            per_layer = sum(2 * M * (a + b_) + 4 * a * b_ for a, b_ in ((d, 3 * d), (d, d), (d, F), (F, d)))
+            out["roofline"]["algorithmic_bytes_per_launch"] = int((cfg.num_layers * per_layer - n_div * (4 * M * d + 4 * d * d)) / max(1e-9, out["roofline"]["launches_per_step"]))
 
     # ---- other BASELINE configs on this GPU (rank 0, N=1, headline workload only): short timings, after the headline engine is freed
     headline = args.model == "vit_b_patch16" and B == 128 and args.img_size == 224

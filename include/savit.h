@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SAVIT_ABI_VERSION 1
+#define SAVIT_ABI_VERSION 2 /* 2 (round 5): savit_gemm_args gained the trailing cu_budget; TN tile ids 1-5, 7-11, 14, 15, 30 left the product library */
 int savit_abi_version(void);
 
 /* ---- LayerNorm: flax nn.LayerNorm(dtype), eps 1e-6 (models/vit.py:19,26,57; models/cait.py:30,42,99,111,176)

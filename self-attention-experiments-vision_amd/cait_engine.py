@@ -623,15 +623,7 @@ class CaiTEngine:
                    float(label_smoothing), 1.0 / self.B, self.loss_rows.data_ptr(), self.loss.data_ptr(), self.dlogits.data_ptr(), self.Cp,
                    self._off_ptr(self.grads, "bh"), self.top1.data_ptr(), self.top5.data_ptr(), self.B, self.cfg.num_classes, s)
         self._zero("zero.dres", self.dres)
-        if self.overlap_wgrad:
-            if self._bwd_plan is None:
-                self._bwd_plan = self._build_bwd_plan()
-            n = max(1, self.n_side_streams)
-            while len(self._side_streams) < n:
-                self._side_streams.append(torch.cuda.Stream(device=self.dev))
-            self._bwd_plan.run_overlapped(torch.cuda.current_stream(), self._side_streams[:n], self.bwd_hooks, self.launch_timer)
-            return self.loss
-        self._serial_bwd_plan().run(s, self.launch_timer, self.bwd_hooks)
+        ViTEngine._run_bwd(self)
         return self.loss
 
     def _zero(self, label: str, t: torch.Tensor):

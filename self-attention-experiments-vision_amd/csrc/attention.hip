@@ -750,6 +750,9 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_pers_kernel(const AttnParams
       df[ks] = lds_row_frag(imgD, q, 2 * ks + half);
     }
     const float delta_a = delta, nlse2_a = nlse2;
+    // barrier b must order every wave's K / V LDS-DMA (stage_kv) before pass A reads rows other waves staged: the wait is explicit
+    // (a workgroup-scope fence does not oblige the compiler to drain vmcnt on gfx9; tests/test_abi.py checks the ISA for it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // barrier b: K, V landed; Q, dO images and the statistics free
     {
       bf16_t* ktile = p.dqkv + (size_t)(row_base + wave * 32) * p.ld + p.d + hh * HD;

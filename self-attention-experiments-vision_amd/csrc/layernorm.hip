@@ -11,11 +11,13 @@ namespace {
 //   out  = dx (+ dres_in)           -> fp32 dx_out (gradient of the residual stream) and optional bf16 copy
 //   dgamma += sum_rows dy*xhat ; dbeta += sum_rows dy ; dcolsum += sum_rows out   (per-lane registers ->
 //   LDS cross-wave -> per-block partial slab -> finalize kernel)
+// dres_in and dx_out carry no __restrict__: the engines pass the SAME buffer for both (the residual gradient is updated in place; a
+// row is read - one pipeline stage ahead - before it is written, by the wave that owns it).
 template <int CH>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ gamma, const float* __restrict__ mean_in,
-                                                             const float* __restrict__ rstd_in, const float* __restrict__ dres_in,
-                                                             float* __restrict__ dx_out, bf16_t* __restrict__ dx_bf16,
+                                                             const float* __restrict__ rstd_in, const float* dres_in,
+                                                             float* dx_out, bf16_t* __restrict__ dx_bf16,
                                                              float* __restrict__ partial, int rows, int d, long x_stride,
                                                              long out_stride, int round_params, int grp, int grp_stride, int grp_off) {
   const int lane = threadIdx.x & 63;
@@ -135,8 +137,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
 
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_narrow_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                                     const float* __restrict__ gamma, const float* __restrict__ mean_in,
-                                                                    const float* __restrict__ rstd_in, const float* __restrict__ dres_in,
-                                                                    float* __restrict__ dx_out, bf16_t* __restrict__ dx_bf16,
+                                                                    const float* __restrict__ rstd_in, const float* dres_in,
+                                                                    float* dx_out, bf16_t* __restrict__ dx_bf16,
                                                                     float* __restrict__ partial, int rows, int d, long x_stride, long out_stride,
                                                                     int round_params) {
   const int sub = threadIdx.x >> 4, ci = threadIdx.x & 15;
@@ -359,8 +361,8 @@ __global__ __launch_bounds__(LN_THREADS) void layerscale_bwd_kernel(const float*
 template <int CH>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_ls_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                                 const float* __restrict__ gamma, const float* __restrict__ mean_in,
-                                                                const float* __restrict__ rstd_in, const float* __restrict__ dres_in,
-                                                                float* __restrict__ dx_out, float* __restrict__ partial, int rows, int d, long x_stride,
+                                                                const float* __restrict__ rstd_in, const float* dres_in,
+                                                                float* dx_out, float* __restrict__ partial, int rows, int d, long x_stride,
                                                                 long out_stride, int round_params, const bf16_t* __restrict__ branch,
                                                                 const float* __restrict__ ls, const float* __restrict__ rowscale,
                                                                 int rows_per_sample, bf16_t* __restrict__ dbr) {

@@ -16,19 +16,69 @@ import torch
 import torch.distributed as dist
 
 
-def default_reserved_cus(world: int) -> int:
-    """CUs a rank plans to leave to the resident RCCL all-reduce during backward (engine `reserved_cus`): 0 alone, 16 of the 256
-    in a data-parallel job unless SAVIT_RESERVED_CUS says otherwise.  Why plan at all (tools/cu_thief_probe.py, profiles/r04_cu_thief.log:
-    a stand-in that holds n CUs for the length of the step, DeiT-B/16 at 128 images): with 16 CUs taken the step is 16 % slower when
-    the launch plan assumes the whole chip (a grid of one tile per CU runs a second, nearly empty round) and 8 % slower when it was
-    planned for 240 CUs; with 32 taken 24 % against 16 % - about the share of the chip that is gone.  How many CUs RCCL's channels
-    really hold on an 8 x MI355X node is unmeasured (no such node was available): the driver's scaling run is where this default
-    gets checked."""
+def default_reserved_cus(world: int, env=None) -> int:
+    """CUs a rank plans to leave to the resident RCCL all-reduce during backward (engine `reserved_cus`): 0 alone; at world > 1
+    SAVIT_RESERVED_CUS, else the channel bound the user gave RCCL (NCCL_MAX_NCHANNELS: one channel = one workgroup = one CU), else 16.
+    Why plan at all (tools/cu_thief_probe.py, profiles/r04_cu_thief.log: a stand-in that holds n CUs for the length of the step,
+    DeiT-B/16 at 128 images): with 16 CUs taken the step is 18 % slower when the launch plan assumes the whole chip (a grid of one tile
+    per CU runs a second, nearly empty round) and 6 % slower when it was planned for 240 CUs; with 32 taken 27 % against 17 %.  The plan
+    only holds if RCCL really stays inside the reserve: `rccl_channel_env` is the other half (round 5)."""
     import os
 
-    if os.environ.get("SAVIT_RESERVED_CUS"):
-        return int(os.environ["SAVIT_RESERVED_CUS"])
+    env = os.environ if env is None else env
+    if env.get("SAVIT_RESERVED_CUS"):
+        return int(env["SAVIT_RESERVED_CUS"])
+    if world > 1 and env.get("NCCL_MAX_NCHANNELS"):
+        return int(env["NCCL_MAX_NCHANNELS"])  # the user bounded RCCL: plan for exactly that
     return 16 if world > 1 else 0
+
+
+def rccl_channel_env(reserved_cus: int, env=None) -> Dict[str, str]:
+    """The RCCL settings that keep its resident kernels inside `reserved_cus` CUs: an RCCL channel is one workgroup that owns a CU for
+    the length of the collective, so the bound on channels IS the bound on CUs.  NCCL_MAX_NCHANNELS = NCCL_MIN_NCHANNELS = reserved_cus
+    pins the footprint (RCCL's own choice on an 8-GPU xGMI node is 28-64 channels: 11-25 % of the chip, unplanned - profiles/r04_cu_thief.log
+    prices that at +18...27 % on the step).  Values the user already exported win (and `default_reserved_cus` then plans for THEIR bound).
+    Must be in the environment before the first RCCL communicator is created: bench.launch_ranks / train.py export it to the rank
+    processes, `apply_rccl_channel_env` sets it in a rank started by an external launcher."""
+    import os
+
+    env = os.environ if env is None else env
+    out: Dict[str, str] = {}
+    if reserved_cus <= 0:
+        return out
+    mx = env.get("NCCL_MAX_NCHANNELS") or str(int(reserved_cus))
+    out["NCCL_MAX_NCHANNELS"] = mx
+    out["NCCL_MIN_NCHANNELS"] = env.get("NCCL_MIN_NCHANNELS") or str(min(int(mx), int(reserved_cus)))
+    return out
+
+
+def apply_rccl_channel_env(reserved_cus: int) -> Dict[str, str]:
+    """Export `rccl_channel_env` into this process (call BEFORE dist.init_process_group).  -> what is now in effect."""
+    import os
+
+    e = rccl_channel_env(reserved_cus)
+    os.environ.update(e)
+    return e
+
+
+def rccl_channels_in_effect(env=None) -> Optional[int]:
+    """The channel bound RCCL runs under in this process (None: RCCL's own choice) - recorded in the N > 1 bench line."""
+    import os
+
+    env = os.environ if env is None else env
+    v = env.get("NCCL_MAX_NCHANNELS")
+    return int(v) if v else None
+
+
+def parse_rccl_channels(debug_text: str) -> Optional[int]:
+    """Number of collective channels RCCL reports under NCCL_DEBUG=INFO (max over communicators), or None when the log has no such
+    line.  RCCL prints e.g. 'NCCL INFO 16 coll channels, 0 collnet channels, 0 nvls channels, 16 p2p channels, ...' per communicator
+    and 'Channel 07/16 : 0' lines while it builds the rings."""
+    import re
+
+    n = [int(m.group(1)) for m in re.finditer(r"(\d+) coll channels", debug_text)]
+    n += [int(m.group(1)) for m in re.finditer(r"Channel \d+/(\d+)\s*:", debug_text)]
+    return max(n) if n else None
 
 
 def plan_buckets(layer_starts: List[int], final_start: int, total: int, min_bucket_elems: int) -> List[Tuple[int, int, str]]:

@@ -480,8 +480,9 @@ class ViTEngine:
             raise ValueError(f"reserved_cus must be in [0, {self.n_cus})")
         self.reserved_cus = int(reserved_cus)
         self.cu_budget = self.n_cus - self.reserved_cus
-        # the persistent attention kernels size their grids (one workgroup per CU) from the same budget; process-wide, 0 = every CU
-        _lib.check(self.L.savit_set_cu_budget(self.cu_budget if self.reserved_cus else 0), "savit_set_cu_budget")
+        # the persistent attention kernels size their grids (one workgroup per CU) from the same budget.  The library's setting is
+        # process-wide, so it is raised around THIS engine's backward launches only (`_run_bwd`): forward and optimizer have no
+        # all-reduce beside them, and another engine in the process is not affected.
         self._building_bwd = False  # set while a backward plan is recorded: only its launches run beside the all-reduce
         if wgrad_max_lag is None and os.environ.get("SAVIT_WGRAD_MAX_LAG"):
             wgrad_max_lag = int(os.environ["SAVIT_WGRAD_MAX_LAG"])
@@ -858,15 +859,26 @@ class ViTEngine:
         """Backward from self.dlogits (bf16 [B, Cp], pad columns zero) into self.grads (accumulating)."""
         self._zero("zero.dres", self.dres)
         self._zero("zero.dres_b", self.dres_b)  # ring slot 0: lnf.bwd fills only the cls rows
-        if self.overlap_wgrad:
-            if self._bwd_plan is None:
-                self._bwd_plan = self._build_bwd_plan()
-            n = max(1, self.n_side_streams)
-            while len(self._side_streams) < n:
-                self._side_streams.append(torch.cuda.Stream(device=self.dev))
-            self._bwd_plan.run_overlapped(torch.cuda.current_stream(), self._side_streams[:n], self.bwd_hooks, self.launch_timer)
-            return
-        self._serial_bwd_plan().run(self._stream(), self.launch_timer, self.bwd_hooks)
+        self._run_bwd()
+
+    def _run_bwd(self):
+        """Issue the backward plan; the launch-time CU budget of the library (grids of the persistent attention kernels) is this
+        engine's for the length of the issue and back to "every CU" afterwards."""
+        if self.reserved_cus:
+            _lib.check(self.L.savit_set_cu_budget(self.cu_budget), "savit_set_cu_budget")
+        try:
+            if self.overlap_wgrad:
+                if self._bwd_plan is None:
+                    self._bwd_plan = self._build_bwd_plan()
+                n = max(1, self.n_side_streams)
+                while len(self._side_streams) < n:
+                    self._side_streams.append(torch.cuda.Stream(device=self.dev))
+                self._bwd_plan.run_overlapped(torch.cuda.current_stream(), self._side_streams[:n], self.bwd_hooks, self.launch_timer)
+            else:
+                self._serial_bwd_plan().run(self._stream(), self.launch_timer, self.bwd_hooks)
+        finally:
+            if self.reserved_cus:
+                _lib.check(self.L.savit_set_cu_budget(0), "savit_set_cu_budget")
 
     def optimizer_step(self, lr: float, weight_decay: float = 0.0, max_norm: float = 0.0, b1: float = 0.9, b2: float = 0.999,
                        eps: float = 1e-8, grad_scale: float = 1.0):

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsavit.so")
 
 SAVIT_EINVAL = 1001
+ABI_VERSION = 2  # include/savit.h SAVIT_ABI_VERSION: the struct layouts below belong to this version
 
 EPI_BF16, EPI_BIAS_GELU, EPI_RESID, EPI_DGELU, EPI_F32, EPI_PATCH = range(6)
 
@@ -173,7 +174,7 @@ def load() -> ctypes.CDLL:
             raise RuntimeError(f"libsavit.so does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.savit_abi_version() != 1:
+    if lib.savit_abi_version() != ABI_VERSION:
         raise RuntimeError("libsavit.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

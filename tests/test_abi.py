@@ -32,7 +32,7 @@ def test_header_symbols_exported(built):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in savit.h but not exported"
     assert names == built.lib.exported_symbols(), "lib.py signature table and savit.h disagree"
-    assert lib.savit_abi_version() == 1
+    assert lib.savit_abi_version() == built.lib.ABI_VERSION == 2
 
 
 def test_gemm_args_struct_layout(built):
@@ -281,3 +281,130 @@ def test_overlapped_kernels_hold_no_scratch_and_no_builtin_waits(built, tmp_path
             window = ops[i + 1:i + 4]
             assert any(w.startswith("s_barrier") or (w.startswith("s_waitcnt") and "vmcnt(0)" in w) for w in window) or \
                 not any(w.startswith("v_mfma") for w in ops[i + 1:i + 3]), ("a full vmcnt wait inside a pass", i, op, window)
+
+
+def _load_tool(name):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+INFLIGHT_KERNELS = {  # object -> kernels whose LDS reads are inline asm with a hand-placed wait
+    "attention.o": r"attn_bwd_pers_kernelILi[1-7]E|attn_[fb]wd2_kernelILi[1-4]E|attn_fwd_kernelILi[1-8]E|th_softmax_(fwd|bwd)_kernel",
+    "gemm_wgrad.o": r"gemm_wgrad_group_kernel|gemm_wgrad_group_mixed_kernel|gemm_wgrad_ring_kernel",
+    "gemm_tn.o": r"gemm_tn_pp320_kernel|gemm_tn_pp_kernel|gemm_tn_pers_kernel",
+}
+
+
+@pytest.mark.parametrize("obj", sorted(INFLIGHT_KERNELS))
+def test_no_vgpr_is_touched_while_its_lds_read_is_in_flight(built, tmp_path, obj):
+    """The transposed / 16-byte LDS reads of the overlapped kernels are inline asm whose wait comes later by hand (TrFrag, lds_read_f4,
+    SAVIT_TR_READ, the park reads): hipcc believes the destination VGPRs are defined at the asm and may read, copy or re-use them
+    before the `s_waitcnt lgkmcnt` that retires the read.  tools/check_inflight_vgprs.py follows the LDS queue through the control
+    flow of the BUILT kernels and fails on any such instruction."""
+    chk = _load_tool("check_inflight_vgprs")
+    kernels = chk.split_kernels(_device_isa(obj, tmp_path))
+    pat = re.compile(INFLIGHT_KERNELS[obj])
+    seen = reads = 0
+    for name, body in kernels.items():
+        if not pat.search(name):
+            continue
+        n, bad = chk.violations(body)
+        assert not bad, (name, bad[:4])
+        assert chk.violations.last_unreached == 0, (name, "the control-flow walk missed instructions", chk.violations.last_unreached)
+        seen += 1
+        reads += n
+    assert seen >= 4 and reads >= 100, (seen, reads)
+    if obj == "gemm_wgrad.o":  # the kernels the verdict names must be among them
+        assert any("gemm_wgrad_group_kernel" in k for k in kernels) and any("gemm_wgrad_group_mixed_kernel" in k for k in kernels)
+    if obj == "attention.o":
+        for need in ("attn_bwd_pers_kernelILi7E", "attn_fwd2_kernelILi4E", "attn_bwd2_kernelILi4E"):
+            assert any(need in k for k in kernels), need
+
+
+def test_inflight_vgpr_guard_fails_on_a_copy_before_the_wait(built, tmp_path):
+    """The guard must FAIL on an object that has the defect: (a) a hand-made kernel, compiled here, with a `v_mov` of the destination
+    between the asm `ds_read_b64_tr_b16` and its `s_waitcnt`; (b) the real weight-gradient kernel's listing with such a copy spliced
+    in behind its first transposed read, and with the read's wait removed (a use behind the loop exit)."""
+    import shutil
+    import subprocess
+
+    chk = _load_tool("check_inflight_vgprs")
+    if shutil.which("hipcc"):
+        src = tmp_path / "bad.hip"
+        src.write_text(r'''
+#include <hip/hip_runtime.h>
+typedef __attribute__((ext_vector_type(2))) unsigned u2;
+__global__ void bad_copy_kernel(unsigned* out, int n) {
+  __shared__ unsigned buf[1024];
+  for (int i = threadIdx.x; i < 1024; i += blockDim.x) buf[i] = i * n;
+  __syncthreads();
+  unsigned addr = (unsigned)(threadIdx.x * 8);
+  u2 v; unsigned stale;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(stale) : "v"(v.x));   // the copy a live-range split would make: reads v in flight
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
+  out[threadIdx.x] = v.x + v.y + stale;
+}
+__global__ void good_kernel(unsigned* out, int n) {
+  __shared__ unsigned buf[1024];
+  for (int i = threadIdx.x; i < 1024; i += blockDim.x) buf[i] = i * n;
+  __syncthreads();
+  unsigned addr = (unsigned)(threadIdx.x * 8);
+  u2 v; unsigned later;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(later) : "v"(v.x));
+  out[threadIdx.x] = v.x + v.y + later;
+}
+''')
+        obj = tmp_path / "bad.o"
+        subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-c", str(src), "-o", str(obj)], check=True, capture_output=True)
+        sub = tmp_path / "x"
+        sub.mkdir()
+        shutil.copy(str(obj), str(sub / "bad.o"))
+        objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+        subprocess.run([objdump, "--offloading", str(sub / "bad.o")], check=True, capture_output=True)
+        co = [f for f in os.listdir(str(sub)) if "gfx950" in f][0]
+        isa = subprocess.run([objdump, "-d", str(sub / co)], check=True, capture_output=True, text=True).stdout
+        ks = chk.split_kernels(isa)
+        nb, bad = chk.violations([b for k, b in ks.items() if "bad_copy_kernel" in k][0])
+        assert nb >= 1 and bad and any("v_mov_b32" in c for _, c in bad), bad
+        ng, good = chk.violations([b for k, b in ks.items() if "good_kernel" in k][0])
+        assert ng >= 1 and not good, good
+    # (b) the real kernel, with the defect spliced into its listing
+    kernels = chk.split_kernels(_device_isa("gemm_wgrad.o", tmp_path))
+    body = [b for k, b in kernels.items() if "gemm_wgrad_group_kernelILi256ELi256" in k][0]
+    assert not chk.violations(body)[1]
+    lines = body.splitlines()
+    at = next(i for i, ln in enumerate(lines) if "ds_read_b64_tr_b16" in ln)
+    dst = re.search(r"v\[(\d+):\d+\]", lines[at]).group(1)
+    spliced = lines[:at + 1] + [f"\tv_mov_b32_e32 v255, v{dst}                // 00000FFFFFF0: 7E000000"] + lines[at + 1:]
+    assert any("v255" in c for _, c in chk.violations("\n".join(spliced))[1])
+    no_wait = [ln for ln in lines if not re.search(r"s_waitcnt\s+lgkmcnt", ln.split("//")[0])]
+    assert chk.violations("\n".join(no_wait))[1], "with every lgkmcnt wait removed the MFMAs read fragments in flight"
+
+
+def test_persistent_attention_backward_barrier_b_waits_for_the_lds_dma(built, tmp_path):
+    """ADVICE r4: barrier b of attn_bwd_pers_kernel orders every wave's K / V LDS-DMA before pass A reads rows other waves staged.  The
+    wait must not depend on what hipcc attaches to __syncthreads(): the source issues `s_waitcnt vmcnt(0)` itself, and the built kernel
+    must show that bare wait directly in front of an s_barrier (only further waits between them)."""
+    isa = _device_isa("attention.o", tmp_path)
+    found = 0
+    for n in (5, 6, 7):
+        body = isa.split("attn_bwd_pers_kernelILi%dE" % n, 1)[1].split("s_endpgm")[0]
+        ops = [ln.split("//")[0].strip() for ln in body.splitlines() if ln.strip()]
+        ops = [o for o in ops if re.match(r"^[sv]_|^ds_|^buffer_|^global_", o)]
+        ok = False
+        for i, o in enumerate(ops):
+            if o == "s_waitcnt vmcnt(0)":
+                j = i + 1
+                while j < len(ops) and ops[j].startswith("s_waitcnt"):
+                    j += 1
+                ok = ok or (j < len(ops) and ops[j] == "s_barrier")
+        assert ok, f"attn_bwd_pers_kernel<{n}>: no explicit vmcnt(0) in front of a barrier"
+        found += 1
+    assert found == 3

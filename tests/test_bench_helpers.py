@@ -52,3 +52,58 @@ def test_symbol_tables_and_dominant_kernel():
     assert bench.pick_dominant(bench.symbol_tables(times, cfg, eng, B)[0]).startswith("gemm_wgrad_group_kernel")
     times["wgrad.group.0.l11-l9"] = sym[plain]["ms"] * 0.90
     assert bench.pick_dominant(bench.symbol_tables(times, cfg, eng, B)[0]) == plain
+
+
+def test_library_fingerprint_and_traffic_staleness(tmp_path):
+    """`roofline.traffic` must be impossible to go stale: tools/pmc_summary.py stores the code hash of every kernel it
+    has figures for (fingerprint.py reads them out of libsavit.so); bench.traffic_lookup returns the figure only while the running
+    library's hash of that kernel is the same, and says "traffic_stale": true otherwise."""
+    import json
+
+    from savit_amd import fingerprint as fpr
+
+    fp = fpr.library_fingerprint(fpr.default_library())
+    dom = "gemm_wgrad_group_kernel<256,256,2,4,3,32>"
+    assert dom in fp["kernels"] and "gemm_tn_pp320_kernel<1>" in fp["kernels"] and "attn_bwd_pers_kernel<7>" in fp["kernels"]
+    assert len(fp["kernels"]) > 150 and len(fp["symbols_hash"]) == 64 and not fp["build_id"].startswith("sha256:"), "link with --build-id"
+    assert fpr.short_name("_ZN12_GLOBAL__N_123gemm_wgrad_group_kernelILi256ELi256ELi2ELi4ELi3ELi32EEEvNS_16WgradGroupParamsE") == dom
+    assert fpr.short_name("_ZN12_GLOBAL__N_112adamw_kernelILb1EEEvPf") == "adamw_kernel<true>"
+    pj = {"kernels": {dom: {"traffic_bytes": 2169000000}}, "library": {"build_id": fp["build_id"], "symbols_hash": fp["symbols_hash"],
+                                                                        "kernels": {dom: fp["kernels"][dom]}}}
+    (tmp_path / "r05_pmc_traffic.json").write_text(json.dumps(pj))
+    (tmp_path / "r04_pmc_traffic.json").write_text(json.dumps({"kernels": {dom: {"traffic_bytes": 1}}}))  # older round: must not be picked
+    r = bench.traffic_lookup(dom, True, str(tmp_path), fp)
+    assert r["traffic"] == 2169000000 and r["traffic_stale"] is False and "r05_pmc_traffic.json" in r["traffic_source"]
+    # the kernel was edited since the counters were collected
+    changed = dict(fp, kernels=dict(fp["kernels"], **{dom: "0" * 64}))
+    r = bench.traffic_lookup(dom, True, str(tmp_path), changed)
+    assert r["traffic"] is None and r["traffic_stale"] is True and "rebuilt" in r["traffic_check"]
+    # renamed / removed kernel, and a PMC file from before the fingerprints existed
+    r = bench.traffic_lookup("gemm_wgrad_group_kernel<256,256,2,4,3,64>", True, str(tmp_path), fp)
+    assert r["traffic"] is None and r["traffic_stale"] is True
+    (tmp_path / "r05_pmc_traffic.json").write_text(json.dumps({"kernels": pj["kernels"]}))
+    r = bench.traffic_lookup(dom, True, str(tmp_path), fp)
+    assert r["traffic"] is None and r["traffic_stale"] is True and "no library fingerprint" in r["traffic_check"]
+    # not the headline workload: no figure, no claim
+    assert bench.traffic_lookup(dom, False, str(tmp_path), fp) == {"traffic": None}
+
+
+def test_every_symbol_bench_can_name_exists_in_the_library():
+    """bench.tn_symbol / WG_GROUP_TILES / kernel_symbol spell kernel symbols by hand; each must be a kernel of the built library (so
+    that `roofline.kernel` always matches a row of the rocprofv3 CSV), for every TN shape the engines launch."""
+    import json
+    import os
+
+    from savit_amd import fingerprint as fpr
+
+    have = set(fpr.library_fingerprint(fpr.default_library())["kernels"])
+    L = _lib.load()
+    shapes = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gemm_shapes.json")))
+    seen = set()
+    for v in shapes.values():
+        for M, N, K, epi, alias in v["shapes"]:
+            for cus in (0, 240):
+                seen.add(bench.tn_symbol(L, M, N, K, epi, 0, cus))
+    assert len(seen) >= 8
+    for sname in seen | set(bench.WG_GROUP_TILES.values()) | set(bench.WG_VARIANTS.values()):
+        assert sname.replace(", ", ",") in have, sname

@@ -112,15 +112,25 @@ def test_two_rank_step_matches_single_engine(tmp_path, cfg_name, side_streams, m
     assert (dp["params"] - ref).abs().max().item() < 2.5e-3  # <= 2*lr + rounding over two steps
 
 
+RCCL_TEST_CHANNELS = 12  # (not RCCL's default for any topology, so seeing it in the log shows the variable took effect)
+
+
 def _rccl_rank_main(rank, port, out_path):
     """One rank on RCCL (backend 'nccl'): the exchange itself is the identity, what runs is RCCL's initialisation on this device,
     the broadcast, the async all-reduce of every bucket from the backward hooks on RCCL's stream, and the stream hand-offs of wait()."""
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from savit_amd import ddp
+
+    # the channel bounds of a data-parallel rank (ddp.rccl_channel_env), exported before the first communicator exists; RCCL's own
+    # log (NCCL_DEBUG=INFO, to a file) must then report no more channels than that
+    for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS"):
+        os.environ.pop(k, None)
+    in_effect = ddp.apply_rccl_channel_env(RCCL_TEST_CHANNELS)
+    os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_FILE=out_path + ".nccl.%p.log")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    from savit_amd import ddp
 
     cfg, eng = _make("vit_ti_patch16", 8)
     img, lab = _data(cfg, 8)
@@ -134,7 +144,8 @@ def _rccl_rank_main(rank, port, out_path):
     g = eng.grads.cpu()
     eng.optimizer_step(lr=1e-3, weight_decay=1e-4, max_norm=1.0, grad_scale=sync.grad_scale)
     torch.cuda.synchronize()
-    torch.save({"grads": g, "params": eng.params.cpu(), "nbuckets": len(sync.buckets), "backend": dist.get_backend()}, out_path)
+    torch.save({"grads": g, "params": eng.params.cpu(), "nbuckets": len(sync.buckets), "backend": dist.get_backend(),
+                "rccl_env": in_effect, "rccl_channels": ddp.rccl_channels_in_effect()}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -149,6 +160,19 @@ def test_rccl_backend_single_rank(tmp_path):
     mp.spawn(_rccl_rank_main, args=(29711, out), nprocs=1, join=True)
     got = torch.load(out)
     assert got["backend"] == "nccl" and got["nbuckets"] > 2
+    # RCCL ran under the channel bounds that keep it inside the CUs backward is planned to leave
+    assert got["rccl_env"] == {"NCCL_MAX_NCHANNELS": str(RCCL_TEST_CHANNELS), "NCCL_MIN_NCHANNELS": str(RCCL_TEST_CHANNELS)}
+    assert got["rccl_channels"] == RCCL_TEST_CHANNELS
+    import glob
+
+    from savit_amd import ddp
+
+    logs = "".join(open(f, errors="replace").read() for f in glob.glob(out + ".nccl.*.log"))
+    assert "NCCL_MAX_NCHANNELS" in logs, "RCCL's log does not mention the variable it was given: " + logs[-600:]
+    n = ddp.parse_rccl_channels(logs)
+    print(f"[rccl world 1] channels reported by RCCL: {n} (bound {RCCL_TEST_CHANNELS})")
+    if n is not None:  # (a 1-rank communicator may build no rings at all; when it reports channels they must respect the bound)
+        assert n <= RCCL_TEST_CHANNELS, n
     cfg, eng = _make("vit_ti_patch16", 8)
     img, lab = _data(cfg, 8)
     eng.forward(img)

@@ -141,22 +141,27 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise SystemExit("train.py needs an MI355X: there is no CPU execution path")
     torch.cuda.set_device(local)
+    import savit_amd  # noqa: F401
+    from savit_amd import ddp
+
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a data-parallel rank plans its backward launches for the CUs the resident all-reduce leaves (engine reserved_cus, ddp.py) -
+        # and, before the first communicator exists, bounds RCCL's channels (one channel = one resident workgroup = one CU) to that
+        # reserve, so that the plan holds (jax.lax.pmean, /root/reference/train.py:96, has no counterpart: XLA schedules its own collectives)
+        os.environ.setdefault("SAVIT_RESERVED_CUS", str(ddp.default_reserved_cus(world)))
+        rccl_env = ddp.apply_rccl_channel_env(int(os.environ["SAVIT_RESERVED_CUS"]))
+        if rank == 0 and rccl_env:
+            print("[train] RCCL channel bounds:", rccl_env, flush=True)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     bs, ragged = divmod(args.batch_size, world)
     if ragged:
         raise ValueError(f"Batch size {args.batch_size} must be divisible by num devices {world}")  # train.py:43-47
 
-    import savit_amd  # noqa: F401
-    from savit_amd import ddp
     from savit_amd.model import create_model
-
-    # a data-parallel rank plans its backward launches for the CUs the resident all-reduce leaves (engine reserved_cus, ddp.py)
-    os.environ.setdefault("SAVIT_RESERVED_CUS", str(ddp.default_reserved_cus(world)))
 
     fp32 = args.dtype == "float32"
     model = create_model(args.model_name, num_classes=1000, dtype=torch.float32 if fp32 else torch.bfloat16, img_size=args.img_size)  # train.py:222-224
