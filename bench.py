@@ -48,7 +48,7 @@ MFMA_BF16_PEAK_TFLOPS = 2516.6  # 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (MI3
 TN_TILES = {6: "gemm_tn_ring_kernel<128,128,2,2,4,%d,false>",
             12: "gemm_tn_pair_kernel<128,128,2,2,2,%d>", 13: "gemm_tn_pair_kernel<256,256,2,4,2,%d>",
             17: "gemm_tn_pair_kernel<192,128,2,2,2,%d>", 18: "gemm_tn_pair_tail_kernel<192,128,128,2,2,2,%d>",
-            20: "gemm_tn_pp_kernel<%d,0>", 21: "gemm_tn_pp320_kernel<%d>"}
+            20: "gemm_tn_pp_kernel<%d,0>", 21: "gemm_tn_pp320_kernel<%d>", 22: "gemm_tn_pp320p_kernel<%d>"}
 WG_VARIANTS = {1: "gemm_wgrad_ring_kernel<128,128,2,2,4,false>", 3: "gemm_wgrad_ring_kernel<256,256,2,4,4,false>"}
 EPI_OF = {"qkv": 0, "proj": 2, "fc1": 1, "fc2": 2, "fc2.dgrad": 3, "fc1.dgrad": 0, "proj.dgrad": 0, "qkv.dgrad": 0}
 

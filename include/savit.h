@@ -53,6 +53,25 @@ int savit_layernorm_bwd_ex(const void* dy_bf16, const float* x, const float* gam
 /* Scratch the call above needs (per-block partial column sums; 16-B aligned, contents undefined afterwards). */
 long savit_layernorm_bwd_workspace_bytes(int rows, int d);
 
+/* Deferred column sums (round 5).  Nothing inside a backward pass reads dgamma / dbeta / the bias gradients (they are the optimizer's
+ * inputs: /root/reference/train.py:94-100), so a caller may pass NULL for EVERY output pointer of savit_layernorm_bwd,
+ * savit_layernorm_bwd_mapped (wide rows, d > 64), savit_layerscale_bwd or savit_layernorm_bwd_ls: the call then only leaves its partial
+ * slab [nblk = savit_layernorm_bwd_grid(rows)][nf][d] in `workspace` (one workspace per deferred call), and ONE
+ * savit_layernorm_bwd_finalize_jobs launch reduces the slabs of many calls where the gradients must be final (a data-parallel bucket
+ * trigger, the end of backward).  Same arithmetic as the per-call finalize: out[k][c] += sum over blocks of partial[.][k][c].
+ *   nf = 3: out = {dgamma, dbeta, dcolsum} (savit_layernorm_bwd*), {d_layerscale, dbias, NULL} (savit_layerscale_bwd);
+ *   nf = 4: out = {dgamma, dbeta, d_layerscale, dbias} (savit_layernorm_bwd_ls).  extra_*: as in savit_layernorm_bwd_ex. */
+typedef struct savit_colsum_job {
+  const float* partial;
+  int nblk, d, nf;
+  float* out[4]; /* each nullable */
+  const float* extra_slab;
+  int extra_rows, extra_n;
+  float* extra_out;
+} savit_colsum_job;
+int savit_layernorm_bwd_grid(int rows);
+int savit_layernorm_bwd_finalize_jobs(const savit_colsum_job* jobs, int count, void* stream);
+
 /* Row-mapped variants for the LayerNorm over concat([cls, x]) of CaiT's token-only layers (cait.py:98-99): logical row r of x is
  * written to (read from, for dy) row (r / grp) * grp_stride + grp_off + r % grp of the bf16 matrix, so the cls rows and the patch rows
  * are normalised by two calls into ONE [B*(N+1), d] operand without materialising the fp32 concatenation. */
@@ -188,8 +207,16 @@ typedef struct savit_wgrad_problem {
   int M, Kin, Nout, ldx, lddy, lddw;
   int tile_begin, tile_count; /* a range of the weight's output tiles (row-major over tile x tile blocks of dW); 0, 0 = all of them.
                                  Lets a caller cut launches at exact multiples of the CU count: a weight may span two launches. */
+  int overwrite;              /* 0: dW += X^T dY (the contract of every weight-gradient entry point).  1: dW = X^T dY - each output tile is
+                                 written by exactly one workgroup, so when this is the only contribution of the step (no gradient
+                                 accumulation) the caller need not zero dW beforehand and the kernel does not read it (round 5: removes
+                                 the 346 MB memset of DeiT-B's gradient buffer and 4 B per element of the read-modify-write). */
 } savit_wgrad_problem;
 int savit_gemm_bf16_wgrad_grouped(const savit_wgrad_problem* problems, int count, int tile, void* stream);
+/* The same; sumsq32 (nullable): 32 fp32 accumulators (caller zeroes) that receive the sum of squares of every element the launch stored,
+ * spread over the 32 by workgroup - the weight gradients' share of optax.clip_by_global_norm's norm (train.py:25) without a pass over
+ * them; savit_sumsq_ranges adds the accumulators to the rest.  Only meaningful when what is stored is final (overwrite entries). */
+int savit_gemm_bf16_wgrad_grouped_ex(const savit_wgrad_problem* problems, int count, int tile, float* sumsq32, void* stream);
 int savit_gemm_wgrad_group_tiles(int Kin, int Nout, int tile);
 
 
@@ -297,6 +324,12 @@ int savit_softmax_xent(const float* logits, int ld_logits, const int* labels, co
  * clip = 1 if ||g*grad_scale|| < max_norm else max_norm/||.|| (optax.clip_by_global_norm), read from grad_sumsq ON DEVICE
  * (nullable / max_norm <= 0: no clipping).  step is 1-based.  n % 4 == 0. */
 int savit_sumsq(const float* g, long n, float* out, void* stream);
+/* The same over `count` ranges of one buffer, ranges = (offset, length) pairs in floats (both multiples of 4, base 16-byte aligned);
+ * slots (nullable): `nslots` <= 256 further partial sums added in (the accumulators of savit_gemm_bf16_wgrad_grouped_ex).  And the
+ * matching clear of ranges.  With the grouped weight gradients storing by first touch, these two replace the memset of the whole
+ * gradient buffer and the sum of squares over it by passes over the ranges NOTHING overwrites (biases, LayerNorm parameters, embeddings). */
+int savit_sumsq_ranges(const float* base, const long* ranges, int count, const float* slots, int nslots, float* out, void* stream);
+int savit_zero_ranges(float* base, const long* ranges, int count, void* stream);
 int savit_adamw_step(float* params, const float* grads, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                      float weight_decay, int step, const float* grad_sumsq, float max_norm, float grad_scale, void* stream);
 /* The same update; params_bf16 (nullable) additionally receives the updated parameters rounded to bf16 in the same flat layout: the

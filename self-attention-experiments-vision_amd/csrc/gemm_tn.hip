@@ -1618,7 +1618,240 @@ __global__ __launch_bounds__(512) void gemm_tn_pp320_kernel(const GemmParams p) 
   }
 }
 
-int launch_pp320(const GemmParams& p0, hipStream_t s) {
+// ------------------------------------------------------------------------------------------------------------
+// PERSISTENT form of the 320 x 256 ping-pong tile (tile 22, round 5) for launches of more than one round of tiles: one workgroup per
+// CU walks tiles b, b + G, b + 2 G ... and the K-tile stream does not stop at a tile boundary - the next tile's K-tile 0 is requested
+// by the LAST K-tile's load segments (the same (kt + 1) / (kt + 2) requests the steady state issues, with the next tile's buffer
+// descriptors), so it lands under the last MFMA phases and the epilogue's stores.  In-kernel stamps of the one-tile kernel
+// (profiles/r04_tile_stamps.log) put a tile's prologue at 2.5 us - all nine units of K-tile 0 requested at once by a CU that has
+// nothing else to do - next to 1.8 us per K-tile: on DeiT-B's three-to-four-round launches (qkv 711 tiles, fc1 / GELU' 948) that is
+// 5-7 us per launch, on ViT-L's 7..29-round launches 2-7 % of every product.
+//   LDS: buffer 0 at [0, 72 KB), 16 KB spare, buffer 1 at [88 KB, 160 KB): the whole CU.  K-tile number v of the workgroup's stream
+//   (v counts across tiles) lives in buffer v & 1, so an odd K-tile count per tile alternates by itself.
+//   Boundary: the last K-tile of a tile (buffer L) issues in p0 / p1 the units A1..A4 of the NEXT tile's K-tile 0 (buffer O = 1 - L:
+//   the same WAR argument as inside a tile: O's previous contents were last read one K-tile earlier), its p2 / p3 requests (A0 and B of
+//   K-tile 1, which would go to L) are DEFERRED behind the epilogue, because the epilogue parks the accumulators in L: 80 KB = buffer L
+//   and the 8 KB of spare next to it.  Nothing that is in flight during the epilogue targets that region (K-tile 0 of the next tile
+//   is complete in O or landing there).  Behind the epilogue: barrier (every wave is done with the park), the five deferred requests,
+//   vmcnt(5) (everything older - all of K-tile 0 - has landed), barrier, and the half-barrier stagger of the two M-halves as at a
+//   kernel start.  Same K order per accumulator, same epilogue code: results are bitwise those of tile 21.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_tn_pp320p_kernel(const GemmParams p) {
+  constexpr int BM = 320, BN = 256, RB = 128;
+  constexpr int UNIT = 64 * RB, NUA = 5, BUF = 9 * UNIT, BUF1 = BUF + 16 * 1024;  // offset of buffer 1
+  constexpr int WTM = 160, WTN = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const savit_gemm_args& a = p.a;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int G = gridDim.x;
+
+  const uint32_t a_unit = 64u * (uint32_t)(a.lda * 2), b_unit = 64u * (uint32_t)(a.ldb * 2);
+  const int KT = a.K / 64;
+
+  // tile number `it` of this workgroup -> (row tile, column tile): within a round of G tiles each XCD (blocks b, b + 8, ...) takes a
+  // contiguous run of the row-grouped tile order, as the one-tile kernel's grid does
+  auto tile_of = [&](int it, int& tm, int& tn) -> bool {
+    const int first = it * G;
+    if (first + (int)blockIdx.x >= nwg) return false;
+    const int in_round = (nwg - first) < G ? (nwg - first) : G;
+    const int tid = first + xcd_remap(blockIdx.x, in_round);
+    const int Gr = p.row_group, per = Gr * p.tiles_n;
+    const int g = tid / per, rem = tid - g * per;
+    const int rows_g = (p.tiles_m - g * Gr) < Gr ? (p.tiles_m - g * Gr) : Gr;
+    tn = rem / rows_g;
+    tm = g * Gr + (rem - tn * rows_g);
+    return true;
+  };
+#define PP5_MAKE_SRD(TM, TN, SA, SB)                                                                                              \
+  do {                                                                                                                            \
+    const int row0_ = (TM) * BM, col0_ = (TN) * BN;                                                                               \
+    const bf16_t* Ab_ = reinterpret_cast<const bf16_t*>(a.A) + (size_t)row0_ * a.lda;                                            \
+    const bf16_t* Bb_ = reinterpret_cast<const bf16_t*>(a.Bt) + (size_t)col0_ * a.ldb;                                           \
+    const size_t ta_ = (size_t)(a.M - row0_) * a.lda * 2, tb_ = (size_t)(a.N - col0_) * a.ldb * 2;                               \
+    SA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ab_), 0, (uint32_t)(ta_ > 0xfffffff0ull ? 0xfffffff0ull : ta_), 0x00020000); \
+    SB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bb_), 0, (uint32_t)(tb_ > 0xfffffff0ull ? 0xfffffff0ull : tb_), 0x00020000); \
+  } while (0)
+
+  int tm, tn;
+  if (!tile_of(0, tm, tn)) return;
+  auto srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(a.A)), 0, 0, 0x00020000);
+  auto srdB = srdA, nsrdA = srdA, nsrdB = srdA;
+  PP5_MAKE_SRD(tm, tn, srdA, srdB);
+
+  f32x4 acc[10][4];
+  bf16x8 af[5][2], bf[4][2];
+  int v = 0;  // K-tiles this workgroup has consumed: K-tile kt of the current tile sits in buffer (v + kt) & 1
+
+#define PP5_READ_A(QM)                                                                                         \
+  _Pragma("unroll") for (int i = 0; i < 5; ++i) {                                                              \
+    af[i][0] = *reinterpret_cast<const bf16x8*>(cur + a_base + (80 * (QM) + 16 * i) * RB + foff0);             \
+    af[i][1] = *reinterpret_cast<const bf16x8*>(cur + a_base + (80 * (QM) + 16 * i) * RB + foff1);             \
+  }
+#define PP5_READ_B(QN)                                                                                         \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
+    bf[2 * (QN) + j][0] = *reinterpret_cast<const bf16x8*>(cur + b_base + (2 * (QN) + j) * 16 * RB + foff0);  \
+    bf[2 * (QN) + j][1] = *reinterpret_cast<const bf16x8*>(cur + b_base + (2 * (QN) + j) * 16 * RB + foff1);  \
+  }
+#define PP5_COMPUTE(QM, QN)                                                                                    \
+  __builtin_amdgcn_s_barrier();                                                                                \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                                                           \
+  __builtin_amdgcn_s_setprio(1);                                                                               \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+        acc[5 * (QM) + i][2 * (QN) + j] =                                                                      \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[2 * (QN) + j][ks], af[i][ks], acc[5 * (QM) + i][2 * (QN) + j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                               \
+  __builtin_amdgcn_sched_barrier(0);                                                                           \
+  __builtin_amdgcn_s_barrier();
+  // One K-tile (four phases).  MODE 0: inside the tile (requests for K-tiles kt + 1 and kt + 2 of this tile).  MODE 1: the second to
+  // last K-tile (kt + 2 is the NEXT tile's K-tile 0).  MODE 2: the last K-tile (kt + 1 is the next tile's K-tile 0; the kt + 2 requests
+  // are deferred behind the epilogue; no wait: the next K-tile is waited for there).  The boundary K-tiles are branch-free: a
+  // workgroup's LAST tile "prefetches" its own K-tile 0 again (valid addresses, a free buffer, 72 KB nobody reads) - with a uniform
+  // branch around the requests hipcc renamed accumulators across the merge and spilled one, and the reload of a spill waits for
+  // every LDS-DMA issued before it (vmcnt counts in order): the prefetch would land before it could overlap anything.
+#define PP5_KTILE(MODE)                                                                                        \
+  {                                                                                                            \
+    const char* cur = smem + (((v + kt) & 1) ? BUF1 : 0);                                                      \
+    const int pn = (v + kt + 1) & 1;                                                                           \
+    PP5_READ_B(0)                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    PP5_READ_A(0)                                                                                              \
+    if (MODE < 2) { dma_to(false, pn, kt + 1, 1); dma_to(false, pn, kt + 1, 2); }                              \
+    else { dma_to(true, pn, 0, 1); dma_to(true, pn, 0, 2); }                                     \
+    PP5_COMPUTE(0, 0)                                                                                          \
+    PP5_READ_B(1)                                                                                              \
+    if (MODE < 2) { dma_to(false, pn, kt + 1, 3); dma_to(false, pn, kt + 1, 4); }                              \
+    else { dma_to(true, pn, 0, 3); dma_to(true, pn, 0, 4); }                                     \
+    PP5_COMPUTE(0, 1)                                                                                          \
+    PP5_READ_A(1)                                                                                              \
+    if (MODE == 0) dma_to(false, pn ^ 1, kt + 2, 0);                                                           \
+    else if (MODE == 1) dma_to(true, pn ^ 1, 0, 0);                                                \
+    PP5_COMPUTE(1, 1)                                                                                          \
+    if (MODE == 0) {                                                                                           \
+      dma_to(false, pn ^ 1, kt + 2, 5); dma_to(false, pn ^ 1, kt + 2, 6); dma_to(false, pn ^ 1, kt + 2, 7);    \
+      dma_to(false, pn ^ 1, kt + 2, 8);                                                                        \
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                                                         \
+    } else if (MODE == 1) {                                                                                    \
+      dma_to(true, pn ^ 1, 0, 5); dma_to(true, pn ^ 1, 0, 6); dma_to(true, pn ^ 1, 0, 7); dma_to(true, pn ^ 1, 0, 8); \
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                                                         \
+    }                                                                                                          \
+    PP5_COMPUTE(1, 0)                                                                                          \
+  }
+
+  for (int it = 0;; ++it) {
+    int ntm = 0, ntn = 0;
+    const bool has_next = tile_of(it + 1, ntm, ntn);
+    if (!has_next) { ntm = tm; ntn = tn; }
+    PP5_MAKE_SRD(ntm, ntn, nsrdA, nsrdB);
+    // Everything derived from the lane id is recomputed per tile behind an opaque copy: hoisted out of this loop it would stay live
+    // across the epilogue, whose fused-operand loads (80 registers of fp32 residual rows) already fill the register file - the
+    // one-tile kernel gets those registers back for free because its loop state is dead by then (first build: 73 spilled VGPRs).
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    // LDS-DMA geometry: one wave-instruction = 8 rows x 128 B; this wave owns rows wave*8 .. +7 of every unit
+    const int lrow = ln >> 3, pch = ln & 7;
+    const int ur = wave * 8 + lrow;
+    const int uc = (pch ^ ((ur >> 1) & 7)) * 16;
+    const uint32_t a_voff = (uint32_t)ur * (uint32_t)(a.lda * 2) + (uint32_t)uc;
+    const uint32_t b_voff = (uint32_t)ur * (uint32_t)(a.ldb * 2) + (uint32_t)uc;
+    auto dma_to = [&](bool next, int par, int kt, int u) {  // unit u (0-4 = A0..A4, 5-8 = B0..B3) of K-tile kt into buffer `par`; next: the NEXT tile's descriptors
+      char* dst = smem + (par ? BUF1 : 0) + u * UNIT + wave * 1024;
+      if (u < NUA) {
+        if (next)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(nsrdA, (__attribute__((address_space(3))) void*)dst, 16, a_voff + (uint32_t)u * a_unit, kt * RB, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (__attribute__((address_space(3))) void*)dst, 16, a_voff + (uint32_t)u * a_unit, kt * RB, 0, 0);
+      } else {
+        if (next)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(nsrdB, (__attribute__((address_space(3))) void*)dst, 16, b_voff + (uint32_t)(u - NUA) * b_unit, kt * RB, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (__attribute__((address_space(3))) void*)dst, 16, b_voff + (uint32_t)(u - NUA) * b_unit, kt * RB, 0, 0);
+      }
+    };
+    const int fr = ln & 15, fq = ln >> 4;
+    const int sw = (fr >> 1) & 7;
+    const int foff0 = fr * RB + ((fq ^ sw) << 4);
+    const int foff1 = fr * RB + (((fq + 4) ^ sw) << 4);
+    const int a_base = (WTM * wr) * RB, b_base = NUA * UNIT + (WTN * wc) * RB;
+    if (it == 0) {
+      // prologue of the FIRST tile: all of its K-tile 0 and the five units of K-tile 1 that (-1, p2), (-1, p3) would have issued
+#pragma unroll
+      for (int u = 0; u < 9; ++u) dma_to(false, 0, 0, u);
+      dma_to(false, 1, 1, 0);
+      dma_to(false, 1, 1, 5); dma_to(false, 1, 1, 6); dma_to(false, 1, 1, 7); dma_to(false, 1, 1, 8);
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (wr == 1) __builtin_amdgcn_s_barrier();  // M-half 1 runs one barrier behind M-half 0
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    {
+      int kt = 0;
+      for (; kt < KT - 2; ++kt) PP5_KTILE(0)
+      PP5_KTILE(1)
+      ++kt;
+      PP5_KTILE(2)
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count: every wave is past its last LDS read of this tile
+
+    // the accumulators are parked in the buffer that held the last K-tile (+ 8 KB of the spare next to it): 80 KB
+    const int last = (v + KT - 1) & 1;
+    char* park = smem + (last ? (BUF1 - 8 * 1024) : 0) + wave * (80 * WTN * 2);
+    const int row0 = tm * BM, col0 = tn * BN;
+    int le = lane;  // (opaque again: the epilogue's per-lane address arithmetic must not be hoisted out of the tile loop either)
+    asm volatile("" : "+v"(le));
+    if constexpr (epi_uses_lds<EPI>()) {
+      epilogue_lds<EPI, 80, WTN, 5, 4>(p, reinterpret_cast<f32x4(&)[5][4]>(acc[0]), park, row0 + wr * WTM, col0 + wc * WTN, le, (tm * 2 + wr) * 2);
+      epilogue_lds<EPI, 80, WTN, 5, 4>(p, reinterpret_cast<f32x4(&)[5][4]>(acc[5]), park, row0 + wr * WTM + 80, col0 + wc * WTN, le,
+                                       (tm * 2 + wr) * 2 + 1);
+    } else {
+      const int mrow = row0 + wr * WTM + (le & 15);
+      const int ncol = col0 + wc * WTN + (le >> 4) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 10; ++i) epilogue_store<EPI>(p, mrow + i * 16, ncol + j * 16, acc[i][j], csum);
+      }
+    }
+    if (!has_next) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the dummy prefetch of the last tile)
+      break;
+    }
+    // ---- next tile: its K-tile 0 is in (or on its way to) the other buffer; the deferred requests of K-tile 1 go where the park was
+    v += KT;
+    tm = ntm; tn = ntn;
+    srdA = nsrdA; srdB = nsrdB;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave has read its park back
+    if (KT > 1) {
+      dma_to(false, (v + 1) & 1, 1, 0);
+      dma_to(false, (v + 1) & 1, 1, 5); dma_to(false, (v + 1) & 1, 1, 6); dma_to(false, (v + 1) & 1, 1, 7);
+      dma_to(false, (v + 1) & 1, 1, 8);
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+  }
+#undef PP5_READ_A
+#undef PP5_READ_B
+#undef PP5_COMPUTE
+#undef PP5_KTILE
+#undef PP5_MAKE_SRD
+}
+
+int launch_pp320(const GemmParams& p0, hipStream_t s, bool pers) {
   GemmParams p = p0;
   p.tiles_m = (p.a.M + 319) / 320;
   p.tiles_n = (p.a.N + 255) / 256;
@@ -1629,13 +1862,23 @@ int launch_pp320(const GemmParams& p0, hipStream_t s) {
   if (p.a.epilogue == SAVIT_EPI_DGELU && g > 4) g = 4;
   if (g > p.tiles_m) g = p.tiles_m;
   p.row_group = g;
-  const dim3 grid(p.tiles_m * p.tiles_n);
-  const size_t lds = 2 * 9 * 64 * 128;
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int cus = (p.a.cu_budget > 0 && p.a.cu_budget < device_cus()) ? p.a.cu_budget : device_cus();
+  // more than one round of tiles: the persistent form (tile 22), one workgroup per CU; a single round: one tile per workgroup (tile 21)
+  const bool persistent = pers && tiles > cus && p.a.K >= 128;  // (the kernel peels the last two K-tiles of a tile)
+  const dim3 grid(persistent ? cus : tiles);
+  const size_t lds = persistent ? 160 * 1024 : 2 * 9 * 64 * 128;
 #define SAVIT_LAUNCH_EPI(E)                                                                            \
   case E: {                                                                                            \
-    auto kfn = gemm_tn_pp320_kernel<E>;                                                                \
-    SAVIT_LDS_ONCE(kfn);                                                                               \
-    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, p);                                               \
+    if (persistent) {                                                                                  \
+      auto kfn = gemm_tn_pp320p_kernel<E>;                                                             \
+      SAVIT_LDS_ONCE(kfn);                                                                             \
+      hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, p);                                             \
+    } else {                                                                                           \
+      auto kfn = gemm_tn_pp320_kernel<E>;                                                              \
+      SAVIT_LDS_ONCE(kfn);                                                                             \
+      hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, p);                                             \
+    }                                                                                                  \
   } break;
   switch (p.a.epilogue) {
     SAVIT_LAUNCH_EPI(SAVIT_EPI_BF16)
@@ -1891,7 +2134,9 @@ extern "C" int savit_gemm_tn_auto_tile_cus(int M, int N, int K, int epilogue, in
     const long t192 = (long)((M + 191) / 192) * (N / 128);
     const long c192 = ((t192 * 3 + 2L * cus - 1) / (2L * cus)) * 64 * 135 / 100;
     const long best = r320 <= r256 ? r320 : r256;
-    if (best <= c192 || (big && N >= 1024)) return r320 <= r256 ? 21 : 20;
+    //  * tile 22 = the 320 x 256 tile as a PERSISTENT grid (one workgroup per CU walking its tiles, the next tile's first K-tile
+    //    requested under the current tile's last phases and epilogue): launches of more than one round of tiles (round 5).
+    if (best <= c192 || (big && N >= 1024)) return r320 <= r256 ? ((long)(M + 319) / 320 * tn > cus ? 22 : 21) : 20;
   }
   if (big && N >= 1024 && K >= 768 && epilogue != SAVIT_EPI_PATCH) return 20;
   if (big && (epilogue == SAVIT_EPI_BIAS_GELU || K >= 1024)) return 13;
@@ -1962,7 +2207,7 @@ inline bool tile_geometry(int tile, int* bm, int* wgm) {
     case 3: *bm = 256; *wgm = 4; return true;
     case 17: case 18: *bm = 192; *wgm = 2; return true;
     case 20: *bm = 256; *wgm = 2; return true;
-    case 21: *bm = 320; *wgm = 4; return true;
+    case 21: case 22: *bm = 320; *wgm = 4; return true;
     case 30: *bm = 256; *wgm = 4; return true;
     default: return false;
   }
@@ -2013,7 +2258,7 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
   int tile = a.tile;
   if (tile == 0) {
     tile = savit_gemm_tn_auto_tile_cus(a.M, a.N, a.K, a.epilogue, a.cu_budget);
-    if ((tile == 20 || tile == 21) && a.lda < a.K) tile = 13;  // the ping-pong kernels do not take the aliased-row operand form
+    if ((tile == 20 || tile == 21 || tile == 22) && a.lda < a.K) tile = 13;  // the ping-pong kernels do not take the aliased-row operand form
   }
   if (a.colsum != nullptr && a.colsum_rows != 0) {
     int bm_ = 0, wgm_ = 0;
@@ -2029,7 +2274,8 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
     case 17: return a.K % 64 ? SAVIT_EINVAL : launch_pair<192, 128, 2, 2, 2>(p, s);
     case 18: return a.K % 64 ? SAVIT_EINVAL : launch_pair_tail<192, 128, 128, 2, 2, 2>(p, s);  // 17 with 128-row tiles for the last partial round
     case 20: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp(p, s);
-    case 21: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp320(p, s);
+    case 21: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp320(p, s, false);
+    case 22: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp320(p, s, true);  // persistent over >1 round
 #ifdef SAVIT_EXPERIMENTS
     case 7: return launch_ring<256, 256, 2, 4, 4>(p, s);
     case 1: return launch_tile<128, 128, 2, 2>(p, s);

@@ -34,7 +34,48 @@ struct WgradParams {
   long slab_stride;  // stores and wgrad_reduce_kernel sums the splits into dW: no atomics, bitwise reproducible
   int no_reduce;     // slab form only: leave the ordered sum to a later savit_gemm_wgrad_reduce call
   int rmw;           // grouped launches (one workgroup per output tile, no split): dW += tile with plain loads / stores
+  int overwrite;     // rmw form: dW = tile (the FIRST and only touch of these elements this step: no read, and no memset of dW before it)
+  float* sumsq;      // rmw form, nullable: 32 accumulators; this workgroup adds the sum of squares of what it stored to sumsq[block & 31]
+                     // (the global gradient norm of optax.clip_by_global_norm, train.py:25, without a pass over the weight gradients)
 };
+
+// Epilogue of the one-workgroup-per-tile forms: dW (+)= acc for one 32 x 32 accumulator; returns the sum of squares of what was stored.
+__device__ __forceinline__ float wgrad_store_tile(const WgradParams& p, const f32x16& acc, int ibase, int j, int hi5) {
+  float ss = 0.f;
+  if (p.overwrite) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = ibase + (r & 3) + 8 * (r >> 2) + 4 * hi5;
+      if (i < p.Kin && j < p.Nout) {
+        p.dW[(size_t)i * p.lddw + j] = acc[r];
+        ss += acc[r] * acc[r];
+      }
+    }
+    return ss;
+  }
+  float old[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = ibase + (r & 3) + 8 * (r >> 2) + 4 * hi5;
+    old[r] = (i < p.Kin && j < p.Nout) ? p.dW[(size_t)i * p.lddw + j] : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = ibase + (r & 3) + 8 * (r >> 2) + 4 * hi5;
+    if (i < p.Kin && j < p.Nout) {
+      const float v = old[r] + acc[r];
+      p.dW[(size_t)i * p.lddw + j] = v;
+      ss += v * v;
+    }
+  }
+  return ss;
+}
+// one atomic per WAVE into one of 32 accumulators (a single address would serialise 2 048 adds per launch at the memory side)
+__device__ __forceinline__ void wgrad_publish_sumsq(const WgradParams& p, float ss) {
+  if (p.sumsq == nullptr) return;
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) atomicAdd(p.sumsq + ((blockIdx.x * 8 + (threadIdx.x >> 6)) & 31), ss);
+}
 
 __device__ __forceinline__ bf16x4 ds_read_tr16_b64(const char* p) {
   // hardware transpose read; the builtin lets hipcc count the read in lgkmcnt and fold constant offsets
@@ -401,25 +442,14 @@ __device__ __forceinline__ void wgrad_ring_tile(const WgradParams& p, const int 
 
   const int jl = lane & 31, hi5 = lane >> 5;
   if (p.rmw) {
-    // the tile IS the whole sum over the tokens (no split): dW += tile, read-modify-write with plain accesses (one accumulator
-    // register = 2 rows x 128 B: whole lines per wave-instruction); no other workgroup touches these elements
+    // the tile IS the whole sum over the tokens (no split): dW (+)= tile with plain accesses (one accumulator register = 2 rows x 128 B:
+    // whole lines per wave-instruction); no other workgroup touches these elements
+    float ss = 0.f;
 #pragma unroll
     for (int a = 0; a < II; ++a)
 #pragma unroll
-      for (int b = 0; b < JJ; ++b) {
-        const int j = j0 + wj * WTJ + 32 * b + jl;
-        float old[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = i0 + wi * WTI + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi5;
-          old[r] = (i < p.Kin && j < p.Nout) ? p.dW[(size_t)i * p.lddw + j] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = i0 + wi * WTI + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi5;
-          if (i < p.Kin && j < p.Nout) p.dW[(size_t)i * p.lddw + j] = old[r] + acc[a][b][r];
-        }
-      }
+      for (int b = 0; b < JJ; ++b) ss += wgrad_store_tile(p, acc[a][b], i0 + wi * WTI + 32 * a, j0 + wj * WTJ + 32 * b + jl, hi5);
+    wgrad_publish_sumsq(p, ss);
     return;
   }
   if (p.slab != nullptr) {
@@ -632,25 +662,14 @@ __device__ __forceinline__ void wgrad_pp_tile(const WgradParams& p, const int ti
 #undef SAVIT_PP_REQUEST
 #undef SAVIT_TR_READ
 
-  // dW += tile (the tile IS the whole sum over the tokens): plain read-modify-write, whole 128-B row segments per instruction
+  // dW (+)= tile (the tile IS the whole sum over the tokens): plain accesses, whole 128-B row segments per instruction
   const int jl = lane & 31, hi5 = lane >> 5;
+  float ss = 0.f;
 #pragma unroll
   for (int a = 0; a < II; ++a)
 #pragma unroll
-    for (int b = 0; b < JJ; ++b) {
-      const int j = j0 + wj * WTJ + 32 * b + jl;
-      float old[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = i0 + wi * WTI + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi5;
-        old[r] = (i < p.Kin && j < p.Nout) ? p.dW[(size_t)i * p.lddw + j] : 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = i0 + wi * WTI + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi5;
-        if (i < p.Kin && j < p.Nout) p.dW[(size_t)i * p.lddw + j] = old[r] + acc[a][b][r];
-      }
-    }
+    for (int b = 0; b < JJ; ++b) ss += wgrad_store_tile(p, acc[a][b], i0 + wi * WTI + 32 * a, j0 + wj * WTJ + 32 * b + jl, hi5);
+  wgrad_publish_sumsq(p, ss);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -826,6 +845,7 @@ __device__ __forceinline__ void wgrad_pp16_tile(const WgradParams& p, const int 
   // dW += tile (the tile IS the whole sum over the tokens).  Accumulator (a, b): lane = (column j = lane & 15, rows 4 (lane >> 4) ..
   // + 3): one register = 16 lanes x 4 B = a 64-B row segment; once per tile over hundreds of stages
   const int jl = lane & 15, i4 = 4 * (lane >> 4);
+  float ss16 = 0.f;
 #pragma unroll
   for (int a = 0; a < II; ++a) {
     float old[JJ][4];
@@ -835,7 +855,7 @@ __device__ __forceinline__ void wgrad_pp16_tile(const WgradParams& p, const int 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + wi * WTI + 16 * a + i4 + r;
-        old[b][r] = (i < p.Kin && j < p.Nout) ? p.dW[(size_t)i * p.lddw + j] : 0.f;
+        old[b][r] = (!p.overwrite && i < p.Kin && j < p.Nout) ? p.dW[(size_t)i * p.lddw + j] : 0.f;
       }
     }
 #pragma unroll
@@ -844,10 +864,15 @@ __device__ __forceinline__ void wgrad_pp16_tile(const WgradParams& p, const int 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + wi * WTI + 16 * a + i4 + r;
-        if (i < p.Kin && j < p.Nout) p.dW[(size_t)i * p.lddw + j] = old[b][r] + acc[a][b][r];
+        if (i < p.Kin && j < p.Nout) {
+          const float v = old[b][r] + acc[a][b][r];
+          p.dW[(size_t)i * p.lddw + j] = v;
+          ss16 += v * v;
+        }
       }
     }
   }
+  wgrad_publish_sumsq(p, ss16);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -869,8 +894,11 @@ struct WgradGroupParams {
     float* dW;
     int M, Kin, Nout, ldx, lddy, lddw;
     int tile_begin;  // first output tile of this entry (an entry may cover a RANGE of a weight's tiles: the rest runs in another launch)
+    int overwrite;   // dW = tile instead of dW += tile (savit_wgrad_problem.overwrite)
   } pr[WGRAD_GROUP_MAX];
+  float* sumsq;      // nullable: 32 accumulators for the sum of squares of the stored gradients (savit_gemm_bf16_wgrad_grouped_ex)
 };
+static_assert(sizeof(WgradGroupParams) <= 4096, "kernel-argument block");
 
 // Tile 640: 256 x 384 or 384 x 256, whichever covers the weight with fewer tiles (d = 384 models: Wqkv 384 x 1152 and W1 384 x 1536 take
 // 384 x 256 - 5 and 6 tiles -, Wo 384 x 384 and W2 1536 x 384 take 256 x 384 - 2 and 6: 19 tiles per layer, 95 % of a launch inside a
@@ -894,6 +922,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad_group_mixed_kernel(const Wg
   p.splits = 1;
   p.tiles_per_split = (p.M + 31) / 32;
   p.rmw = 1;
+  p.overwrite = g.pr[pi].overwrite;
+  p.sumsq = g.sumsq;
   if (wgrad_mixed_tall(p.Kin, p.Nout)) {
     p.tiles_i = (p.Kin + 383) / 384;
     p.tiles_j = (p.Nout + 255) / 256;
@@ -925,6 +955,8 @@ __global__ __launch_bounds__(64 * WGI * WGJ, 2) void gemm_wgrad_group_kernel(con
   p.splits = 1;
   p.tiles_per_split = (p.M + 31) / 32;
   p.rmw = 1;
+  p.overwrite = g.pr[pi].overwrite;
+  p.sumsq = g.sumsq;
   const int ti = t / p.tiles_j;
   if constexpr (MF == 16)
     wgrad_pp16_tile<BI, BJ, WGI, WGJ, S>(p, ti, t - ti * p.tiles_j, smem);
@@ -1183,6 +1215,10 @@ extern "C" int savit_gemm_wgrad_group_tiles(int Kin, int Nout, int tile) {
 }
 
 extern "C" int savit_gemm_bf16_wgrad_grouped(const savit_wgrad_problem* problems, int count, int tile, void* stream) {
+  return savit_gemm_bf16_wgrad_grouped_ex(problems, count, tile, nullptr, stream);
+}
+
+extern "C" int savit_gemm_bf16_wgrad_grouped_ex(const savit_wgrad_problem* problems, int count, int tile, float* sumsq32, void* stream) {
   int tile_bi, tile_bj;
   SAVIT_CHECK_ARG(problems != nullptr && count >= 1 && count <= WGRAD_GROUP_MAX && group_tile_shape(tile, &tile_bi, &tile_bj));
   WgradGroupParams g{};
@@ -1193,7 +1229,8 @@ extern "C" int savit_gemm_bf16_wgrad_grouped(const savit_wgrad_problem* problems
     SAVIT_CHECK_ARG(q.Kin % 8 == 0 && q.Nout % 8 == 0 && q.ldx % 8 == 0 && q.ldx >= q.Kin && q.lddy % 8 == 0 && q.lddy >= q.Nout);
     SAVIT_CHECK_ARG(((uintptr_t)q.X % 16) == 0 && ((uintptr_t)q.dY % 16) == 0 && ((uintptr_t)q.dW % 4) == 0);
     SAVIT_CHECK_ARG((size_t)q.M * q.ldx * 2 <= 0xffffffe0ull && (size_t)q.M * q.lddy * 2 <= 0xffffffe0ull);  // 32-bit buffer offsets
-    if (q.M == 0) continue;  // nothing to add
+    SAVIT_CHECK_ARG(q.overwrite == 0 || q.overwrite == 1);
+    if (q.M == 0 && !q.overwrite) continue;  // nothing to add (an overwriting entry still stores its zeros)
     const int all = savit_gemm_wgrad_group_tiles(q.Kin, q.Nout, tile);
     const int cnt = q.tile_count > 0 ? q.tile_count : all - q.tile_begin;
     SAVIT_CHECK_ARG(q.tile_begin >= 0 && cnt >= 1 && q.tile_begin + cnt <= all);
@@ -1202,10 +1239,12 @@ extern "C" int savit_gemm_bf16_wgrad_grouped(const savit_wgrad_problem* problems
     g.pr[n].tile_begin = q.tile_begin;
     g.pr[n].X = (const bf16_t*)q.X; g.pr[n].dY = (const bf16_t*)q.dY; g.pr[n].dW = q.dW;
     g.pr[n].M = q.M; g.pr[n].Kin = q.Kin; g.pr[n].Nout = q.Nout; g.pr[n].ldx = q.ldx; g.pr[n].lddy = q.lddy; g.pr[n].lddw = q.lddw;
+    g.pr[n].overwrite = q.overwrite;
     ++n;
   }
   if (n == 0) return SAVIT_OK;
   g.n = n;
+  g.sumsq = sumsq32;
   for (int i = n; i < WGRAD_GROUP_MAX; ++i) g.tile_end[i] = tiles;
   if (tile == 256) {
 #ifndef WGRAD_GROUP_S

@@ -209,18 +209,17 @@ constexpr int FIN_SPLIT = 8;
 // Blocks behind the first ceil(3d/64) columns of the grid (y = 0 only) reduce an EXTRA slab [xrows][xn] into xout += column sums, in a
 // fixed order (one adder per column): the bias-gradient partials of the GELU' GEMM ride along with a LayerNorm finalize of the same
 // layer instead of paying for a launch of their own (12 per DeiT-B step).
-__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int d,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               float* __restrict__ dcolsum, const float* __restrict__ xslab = nullptr,
-                                                               int xrows = 0, int xn = 0, float* __restrict__ xout = nullptr, int nf = 3,
-                                                               float* __restrict__ out3 = nullptr) {
+__device__ __forceinline__ void ln_finalize_body(const int bx, const int by, const float* __restrict__ partial, int nblk, int d,
+                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dcolsum,
+                                                 const float* __restrict__ xslab, int xrows, int xn, float* __restrict__ xout, int nf,
+                                                 float* __restrict__ out3) {
   const int nb0 = (nf * d + 63) / 64;  // nf families of column sums in a slab row (3; 4 from ln_bwd_ls_kernel)
-  if ((int)blockIdx.x >= nb0) {
-    if (blockIdx.y != 0) return;
+  if (bx >= nb0) {
+    if (by != 0) return;
     // 64 columns = 16 lanes x float4, the rows over 16 groups (independent loads, ~rows/16 deep), then an LDS tree: fixed order
     __shared__ float4 xpart[16][16];
     const int cx = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int c = ((int)blockIdx.x - nb0) * 64 + cx * 4;
+    const int c = (bx - nb0) * 64 + cx * 4;
     float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < xn) {  // xn % 4 == 0
       for (int r = grp; r < xrows; r += 16) {
@@ -243,10 +242,10 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __res
     }
     return;
   }
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);  // in [0, nf * d)
+  const int col = bx * 64 + (threadIdx.x & 63);  // in [0, nf * d)
   const int rl = threadIdx.x >> 6;                        // row lane 0..3
   const int per = (nblk + FIN_SPLIT - 1) / FIN_SPLIT;
-  const int r0 = blockIdx.y * per;
+  const int r0 = by * per;
   const int r1 = min(nblk, r0 + per);
   float s = 0.f;
   if (col < nf * d) {
@@ -261,6 +260,36 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __res
     float* out = which == 0 ? dgamma : (which == 1 ? dbeta : (which == 2 ? dcolsum : out3));
     if (out != nullptr) atomicAdd(out + c, s);
   }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int d,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ dcolsum, const float* __restrict__ xslab = nullptr,
+                                                               int xrows = 0, int xn = 0, float* __restrict__ xout = nullptr, int nf = 3,
+                                                               float* __restrict__ out3 = nullptr) {
+  ln_finalize_body((int)blockIdx.x, (int)blockIdx.y, partial, nblk, d, dgamma, dbeta, dcolsum, xslab, xrows, xn, xout, nf, out3);
+}
+
+// Several finalizes in ONE launch (blockIdx.z = job): a backward pass issues one LayerNorm backward per sub-block and nothing inside
+// backward reads the column sums they leave (dgamma, dbeta, bias gradients: the optimizer's inputs), so the slabs of many launches -
+// each in a workspace of its own - are reduced together at the points where the gradients must be final (a data-parallel bucket
+// trigger, the end of backward): 25 launches of 7.5 us + a kernel boundary each become one or a few (round 5).
+constexpr int LN_FIN_JOBS = 28;
+struct LnFinJobs {
+  struct {
+    const float* partial;
+    float* out[4];
+    const float* xslab;
+    float* xout;
+    int nblk, d, nf, xrows, xn;
+  } j[LN_FIN_JOBS];
+};
+__global__ __launch_bounds__(256) void ln_bwd_finalize_jobs_kernel(const LnFinJobs jobs) {
+  const auto& q = jobs.j[blockIdx.z];
+  const int need = (q.nf * q.d + 63) / 64 + (q.xn + 63) / 64;
+  if ((int)blockIdx.x >= need) return;
+  ln_finalize_body((int)blockIdx.x, (int)blockIdx.y, q.partial, q.nblk, q.d, q.out[0], q.out[1], q.out[2], q.xslab, q.xrows, q.xn, q.xout, q.nf,
+                   q.out[3]);
 }
 
 
@@ -491,6 +520,33 @@ extern "C" int savit_layernorm_bwd_mapped(const void* dy, const float* x, const 
                                           int d, long x_stride, long out_stride, int round_params_bf16, int dy_grp, int dy_grp_stride,
                                           int dy_grp_off, void* workspace, long workspace_bytes, void* stream);
 
+extern "C" int savit_layernorm_bwd_grid(int rows) { return rows > 0 ? ln_bwd_grid(rows) : 0; }
+
+extern "C" int savit_layernorm_bwd_finalize_jobs(const savit_colsum_job* jobs, int count, void* stream) {
+  SAVIT_CHECK_ARG(jobs != nullptr && count >= 0);
+  for (int base = 0; base < count; base += LN_FIN_JOBS) {
+    LnFinJobs J{};
+    const int n = count - base < LN_FIN_JOBS ? count - base : LN_FIN_JOBS;
+    int gx = 1;
+    for (int i = 0; i < n; ++i) {
+      const savit_colsum_job& q = jobs[base + i];
+      SAVIT_CHECK_ARG(q.partial && q.nblk > 0 && q.d > 0 && (q.nf == 3 || q.nf == 4) && ((uintptr_t)q.partial % 16) == 0);
+      SAVIT_CHECK_ARG(q.extra_slab == nullptr || (q.extra_out && q.extra_rows >= 0 && q.extra_n > 0 && q.extra_n % 4 == 0 &&
+                                                  ((uintptr_t)q.extra_slab % 16) == 0 && ((uintptr_t)q.extra_out % 16) == 0));
+      auto& o = J.j[i];
+      o.partial = q.partial; o.nblk = q.nblk; o.d = q.d; o.nf = q.nf;
+      for (int k = 0; k < 4; ++k) o.out[k] = q.out[k];
+      o.xslab = q.extra_slab; o.xout = q.extra_out; o.xrows = q.extra_rows; o.xn = q.extra_slab ? q.extra_n : 0;
+      const int need = (q.nf * q.d + 63) / 64 + (o.xn + 63) / 64;
+      if (need > gx) gx = need;
+    }
+    hipLaunchKernelGGL(ln_bwd_finalize_jobs_kernel, dim3(gx, FIN_SPLIT, n), dim3(256), 0, (hipStream_t)stream, J);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return SAVIT_OK;
+}
+
 extern "C" long savit_layernorm_bwd_workspace_bytes(int rows, int d) {
   if (rows <= 0 || d <= 0) return 0;
   return (long)ln_bwd_grid(rows) * 4 * d * (long)sizeof(float);  // 4 families of partial column sums (savit_layernorm_bwd_ls; 3 otherwise)
@@ -561,7 +617,7 @@ extern "C" int savit_layernorm_bwd_mapped(const void* dy, const float* x, const 
 extern "C" int savit_layerscale_bwd(const float* dres, const void* branch_bf16, const float* layerscale, const float* rowscale,
                                     int rows_per_sample, void* dbranch_bf16, float* d_layerscale, float* dbias, int rows, int d,
                                     long dres_stride, void* workspace, long workspace_bytes, void* stream) {
-  SAVIT_CHECK_ARG(dres && branch_bf16 && layerscale && dbranch_bf16 && d_layerscale && rows >= 0 && d > 0 && (d % 4) == 0 &&
+  SAVIT_CHECK_ARG(dres && branch_bf16 && layerscale && dbranch_bf16 && (d_layerscale || !dbias) && rows >= 0 && d > 0 && (d % 4) == 0 &&
                   d <= 64 * 4 * LN_MAX_CHUNKS && dres_stride >= d && (dres_stride % 4) == 0 && (rowscale == nullptr || rows_per_sample >= 1));
   if (rows == 0) return SAVIT_OK;
   SAVIT_CHECK_ARG(workspace != nullptr && ((uintptr_t)workspace % 16) == 0 && workspace_bytes >= savit_layernorm_bwd_workspace_bytes(rows, d));
@@ -571,6 +627,7 @@ extern "C" int savit_layerscale_bwd(const float* dres, const void* branch_bf16, 
   float* partial = (float*)workspace;
   LN_DISPATCH(ch, layerscale_bwd_kernel, grid, dres, (const bf16_t*)branch_bf16, layerscale, rowscale, rows_per_sample, (bf16_t*)dbranch_bf16,
               partial, rows, d, dres_stride);
+  if (d_layerscale == nullptr) SAVIT_LAUNCH_RET();  // deferred: savit_layernorm_bwd_finalize_jobs reduces the slab (out[0] = d_layerscale, out[1] = dbias)
   hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * d + 63) / 64, FIN_SPLIT), dim3(256), 0, s, partial, grid, d, d_layerscale, dbias,
                      (float*)nullptr);
   SAVIT_LAUNCH_RET();
@@ -584,8 +641,9 @@ extern "C" int savit_layernorm_bwd_ls(const void* dy, const float* x, const floa
                                       float* extra_out, void* stream) {
   SAVIT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && x_stride >= d && out_stride >= d && (x_stride % 4) == 0 &&
                   (out_stride % 4) == 0 && rows >= 0 && d > 64 && (d % 4) == 0 && d <= 64 * 4 * LN_MAX_CHUNKS);
-  SAVIT_CHECK_ARG(branch_bf16 && layerscale && dbranch_bf16 && d_layerscale && (rowscale == nullptr || rows_per_sample >= 1));
-  SAVIT_CHECK_ARG(extra_slab == nullptr || (extra_out && extra_rows >= 0 && extra_n > 0 && extra_n % 4 == 0 && ((uintptr_t)extra_slab % 16) == 0 &&
+  const bool deferred = !dgamma && !dbeta && !d_layerscale && !dbias;  // the caller reduces the slab later (savit_layernorm_bwd_finalize_jobs)
+  SAVIT_CHECK_ARG(branch_bf16 && layerscale && dbranch_bf16 && (d_layerscale || deferred) && (rowscale == nullptr || rows_per_sample >= 1));
+  SAVIT_CHECK_ARG(extra_slab == nullptr || (!deferred && extra_out && extra_rows >= 0 && extra_n > 0 && extra_n % 4 == 0 && ((uintptr_t)extra_slab % 16) == 0 &&
                                             ((uintptr_t)extra_out % 16) == 0));
   if (rows == 0) return SAVIT_OK;
   SAVIT_CHECK_ARG(workspace != nullptr && ((uintptr_t)workspace % 16) == 0 && workspace_bytes >= savit_layernorm_bwd_workspace_bytes(rows, d));
@@ -595,6 +653,7 @@ extern "C" int savit_layernorm_bwd_ls(const void* dy, const float* x, const floa
   float* partial = (float*)workspace;
   LN_DISPATCH(ch, ln_bwd_ls_kernel, grid, (const bf16_t*)dy, x, gamma, mean, rstd, dres_in, dx, partial, rows, d, x_stride, out_stride,
               round_params_bf16, (const bf16_t*)branch_bf16, layerscale, rowscale, rows_per_sample, (bf16_t*)dbranch_bf16);
+  if (deferred) SAVIT_LAUNCH_RET();
   const int xn = extra_slab ? extra_n : 0;  // the extra slab's column sums ride along as in savit_layernorm_bwd_ex
   hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((4 * d + 63) / 64 + (xn + 63) / 64, FIN_SPLIT), dim3(256), 0, s, partial, grid, d, dgamma, dbeta,
                      d_layerscale, extra_slab, extra_rows, xn, extra_out, 4, dbias);

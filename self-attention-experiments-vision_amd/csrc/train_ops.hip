@@ -121,6 +121,51 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// ---- the same over a LIST of ranges of one buffer, and the matching clear (round 5).  The grouped weight-gradient launches store every
+// element of the matrices they cover (first touch: savit_wgrad_problem.overwrite) and add the sum of squares of what they stored to 32
+// accumulators (savit_gemm_bf16_wgrad_grouped_ex), so what is left of "zero the gradient buffer" / "sum of squares of the gradient
+// buffer" are the few ranges nothing overwrites: LayerNorm scales / biases, Dense biases, embeddings, head (6 MB of DeiT-B's 346 MB).
+// A block takes one 2 048-float chunk of one range; ranges are 16-byte aligned and multiples of 4 floats.
+constexpr int RANGE_MAX = 120, RANGE_CHUNK = 2048;
+struct RangeList {
+  int n;
+  int chunk_end[RANGE_MAX];  // prefix sums of the chunks per range
+  long off[RANGE_MAX], len[RANGE_MAX];
+};
+__device__ __forceinline__ bool range_chunk(const RangeList& r, long& begin, long& end) {
+  int i = 0;
+  const int b = blockIdx.x;
+  while (i < r.n && b >= r.chunk_end[i]) ++i;  // uniform scalar scan
+  if (i >= r.n) return false;
+  const long c = b - (i ? r.chunk_end[i - 1] : 0);
+  begin = r.off[i] + c * RANGE_CHUNK;
+  end = r.off[i] + r.len[i];
+  if (end > begin + RANGE_CHUNK) end = begin + RANGE_CHUNK;
+  return true;
+}
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* __restrict__ base, const RangeList r) {
+  long b0, b1;
+  if (!range_chunk(r, b0, b1)) return;
+  for (long i = b0 + 4 * threadIdx.x; i < b1; i += 4 * 256) *reinterpret_cast<float4*>(base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// out[0] += sum over the ranges of g^2; block 0 also adds the `nslots` accumulators of the grouped weight-gradient launches
+__global__ __launch_bounds__(256) void sumsq_ranges_kernel(const float* __restrict__ base, const RangeList r, const float* __restrict__ slots,
+                                                            int nslots, float* __restrict__ out) {
+  __shared__ float red[4];
+  long b0, b1;
+  float s = 0.f;
+  if (range_chunk(r, b0, b1))
+    for (long i = b0 + 4 * threadIdx.x; i < b1; i += 4 * 256) {
+      const float4 v = *reinterpret_cast<const float4*>(base + i);
+      s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  if (blockIdx.x == 0 && slots != nullptr && (int)threadIdx.x < nslots) s += slots[threadIdx.x];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
 // ---- fused AdamW over the flat parameter buffer  (optax.chain(clip_by_global_norm, scale_by_adam,
 // additive_weight_decay, scale(-lr)) + apply_updates: train.py:25-27,100 with the descent sign of
 // simple_train.py:27).  28 B/param of HBM traffic, one launch for the whole model.
@@ -282,6 +327,57 @@ extern "C" int savit_sumsq(const float* g, long n, float* out, void* stream) {
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
   SAVIT_LAUNCH_RET();
+}
+
+static int fill_ranges(RangeList& r, const long* ranges, int first, int count) {  // -> chunks; ranges = (offset, length) pairs in floats
+  r.n = count;
+  int chunks = 0;
+  for (int i = 0; i < count; ++i) {
+    r.off[i] = ranges[2 * (first + i)];
+    r.len[i] = ranges[2 * (first + i) + 1];
+    chunks += (int)((r.len[i] + RANGE_CHUNK - 1) / RANGE_CHUNK);
+    r.chunk_end[i] = chunks;
+  }
+  for (int i = count; i < RANGE_MAX; ++i) r.chunk_end[i] = chunks;
+  return chunks;
+}
+static bool ranges_ok(const void* base, const long* ranges, int count) {
+  if (!base || ((uintptr_t)base % 16) != 0 || (count > 0 && !ranges) || count < 0) return false;
+  for (int i = 0; i < count; ++i)
+    if (ranges[2 * i] < 0 || ranges[2 * i + 1] < 0 || (ranges[2 * i] % 4) != 0 || (ranges[2 * i + 1] % 4) != 0 ||
+        ranges[2 * i + 1] > (long)RANGE_CHUNK * 0x3fffff) return false;
+  return true;
+}
+
+extern "C" int savit_zero_ranges(float* base, const long* ranges, int count, void* stream) {
+  SAVIT_CHECK_ARG(ranges_ok(base, ranges, count));
+  for (int first = 0; first < count; first += RANGE_MAX) {
+    RangeList r{};
+    const int chunks = fill_ranges(r, ranges, first, count - first < RANGE_MAX ? count - first : RANGE_MAX);
+    if (chunks == 0) continue;
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, base, r);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return SAVIT_OK;
+}
+
+extern "C" int savit_sumsq_ranges(const float* base, const long* ranges, int count, const float* slots, int nslots, float* out, void* stream) {
+  SAVIT_CHECK_ARG(ranges_ok(base, ranges, count) && out && nslots >= 0 && nslots <= 256 && (nslots == 0 || slots));
+  bool slots_done = (nslots == 0);
+  for (int first = 0; first < count || !slots_done; first += RANGE_MAX) {
+    RangeList r{};
+    const int n = count - first < RANGE_MAX ? (count - first > 0 ? count - first : 0) : RANGE_MAX;
+    int chunks = fill_ranges(r, ranges, first, n);
+    if (chunks == 0 && slots_done) continue;
+    if (chunks == 0) chunks = 1;  // block 0 still adds the accumulators
+    hipLaunchKernelGGL(sumsq_ranges_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, base, r, slots_done ? nullptr : slots,
+                       slots_done ? 0 : nslots, out);
+    slots_done = true;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return SAVIT_OK;
 }
 
 extern "C" int savit_adamw_step(float* params, const float* grads, float* m, float* v, long n, float lr, float b1, float b2,

@@ -159,6 +159,14 @@ class _Plan:
         self._readers: Dict[int, List[int]] = {}  # buffer address -> side calls reading it (build-time bookkeeping)
         self._ev_ready: Dict[int, "torch.cuda.Event"] = {}
         self._ev_done: Dict[int, "torch.cuda.Event"] = {}
+        # first-touch weight gradients (round 5): element ranges of the gradient buffer that the plan's grouped launches store completely
+        # (savit_wgrad_problem.overwrite), the problem arrays holding those flags, what is left to zero / to sum squares over, and whether
+        # the launches also accumulate the sum of squares of what they store (engine.gnorm[1:33])
+        self.covered: Dict[int, int] = {}
+        self.wgrad_arrays: List[object] = []
+        self.rest_ranges = None   # ctypes c_long array of (offset, length) pairs, or None: the whole buffer
+        self.n_rest = 0
+        self.fold_sumsq = False
 
     def add(self, fn, args: tuple, label: str, side: bool = False, reads: tuple = (), writes: tuple = (), same_side_stream: bool = False):
         i = len(self.calls)
@@ -291,11 +299,21 @@ def add_wgrad_group(eng, plan: _Plan, label: str, entries: list, tile: int, defe
     behind this launch."""
     arr = (_lib.WgradProblem * len(entries))()
     flops = 0.0
+    g0, g1 = eng.grads.data_ptr(), eng.grads.data_ptr() + eng.grads.numel() * 4
+    first_touch = bool(getattr(eng, "first_touch", False))
     for q, ((X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw), t0, tc) in zip(arr, entries):
         q.X, q.dY, q.dW, q.M, q.Kin, q.Nout, q.ldx, q.lddy, q.lddw, q.tile_begin, q.tile_count = X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, t0, tc
         flops += 2.0 * Mr * Kin * Nout * tc / int(eng.L.savit_gemm_wgrad_group_tiles(Kin, Nout, tile))  # the weight's flops, by its share of tiles in this launch
+        # every tile of a queued weight goes out in SOME grouped launch of this plan, each written by exactly one workgroup: a dense
+        # matrix inside the gradient buffer is therefore stored, not accumulated, and needs no memset (first touch)
+        if first_touch and lddw == Nout and g0 <= dW and dW + Kin * Nout * 4 <= g1 and (dW - g0) % 16 == 0 and (Kin * Nout) % 4 == 0:
+            q.overwrite = 1
+            plan.covered[(dW - g0) // 4] = Kin * Nout
     plan.keep.append(arr)
-    plan.add(eng.L.savit_gemm_bf16_wgrad_grouped, (arr, len(entries), tile), label, side=side,
+    plan.wgrad_arrays.append(arr)
+    slots = eng.gnorm.data_ptr() + 4 if (first_touch and getattr(eng, "_fold_sumsq_ok", False)) else None
+    plan.fold_sumsq = slots is not None
+    plan.add(eng.L.savit_gemm_bf16_wgrad_grouped_ex, (arr, len(entries), tile, slots), label, side=side,
              reads=tuple(sorted({e[0][1] for e in entries})) if side else ())
     if deferred_hooks:
         plan.hook_alias[label] = list(deferred_hooks)
@@ -359,6 +377,27 @@ class WgradQueue:
                 if not any(o[1] == it[1] for o in self.items):
                     done.append(it[1])
         return entries, done, oldest
+
+
+def finalize_first_touch(eng, plan: _Plan):
+    """After a backward plan is recorded: the ranges of the gradient buffer its grouped launches do NOT store (everything else must be
+    zeroed before backward and summed for the gradient norm after it).  Without covered ranges the plan keeps the whole-buffer forms."""
+    total = eng.grads.numel()
+    if not plan.covered:
+        plan.rest_ranges, plan.n_rest, plan.fold_sumsq = None, 0, False
+        return
+    rest, cur = [], 0
+    for off in sorted(plan.covered):
+        if off > cur:
+            rest.append((cur, off - cur))
+        cur = max(cur, off + plan.covered[off])
+    if cur < total:
+        rest.append((cur, total - cur))
+    assert all(o % 4 == 0 and n % 4 == 0 for o, n in rest), "gradient ranges are 16-byte aligned (ParamLayout aligns every tensor)"
+    arr = (ctypes.c_long * (2 * len(rest)))(*[v for r in rest for v in r])
+    plan.keep.append(arr)
+    plan.rest_ranges, plan.n_rest = arr, len(rest)
+    plan.rest_elems = sum(n for _, n in rest)
 
 
 def finalize_wgrad_ws(eng, plan: _Plan):
@@ -495,7 +534,10 @@ class ViTEngine:
         self.adam_m = None
         self.adam_v = None
         self.step_count = 0
-        self.gnorm_sq = torch.zeros(1, dtype=f32, device=self.dev)
+        # gnorm[0]: the squared global gradient norm the fused AdamW reads; gnorm[1:33]: the accumulators the grouped weight-gradient
+        # launches add the squares of what they store to (savit_gemm_bf16_wgrad_grouped_ex)
+        self.gnorm = torch.zeros(36, dtype=f32, device=self.dev)
+        self.gnorm_sq = self.gnorm[0:1]
 
     def _init_step_state(self):
         """Loss I/O, the bf16 NHWC input buffer, launch plans, DDP hooks and the side-stream settings."""
@@ -513,7 +555,16 @@ class ViTEngine:
         self._fwd_plan: Optional[_Plan] = None
         self._bwd_plan: Optional[_Plan] = None
         self._cast_plan: Optional[_Plan] = None
-        self.bwd_hooks: Dict[str, Callable[[], None]] = {}  # label -> callback run right after that launch (DDP buckets)
+        self._bwd_hooks: Dict[str, Callable[[], None]] = {}  # label -> callback run right after that launch (DDP buckets): `bwd_hooks`
+        self._data_parallel = False  # sticky: set once hooks are attached (the plans of a data-parallel rank differ, see bwd_hooks)
+        # Round 5: grouped weight gradients store by first touch (no 346 MB memset, no read-modify-write); alone on
+        # the GPU they also carry the gradient norm's sum of squares, and the LayerNorm backward launches leave their column-sum slabs
+        # to ONE finalize launch at the end of backward.  A data-parallel rank keeps the per-launch finalizes and the separate norm
+        # pass: its bucket triggers need final bias / LayerNorm gradients layer by layer, and its norm is that of the REDUCED gradient.
+        self.first_touch = os.environ.get("SAVIT_WGRAD_FIRST_TOUCH", "1") != "0"
+        self.defer_ln_finalize = os.environ.get("SAVIT_DEFER_LN_FINALIZE", "1") != "0"
+        self._gnorm_folded = False   # True between a backward whose launches accumulated gnorm[1:33] and the optimizer step that uses them
+        self._accumulate_run = False
         self.launch_timer = None  # timing.LaunchTimer: brackets the launches it tracks (bench.py, profile_step)
         self.weights_stale = True
         # weight-gradient GEMMs on a second stream (SAVIT_OVERLAP_WGRAD=1 / 0 overrides the engine's default).  Round 2: with the
@@ -526,6 +577,24 @@ class ViTEngine:
         self._side_streams: List[torch.cuda.Stream] = []
         self._building_serial = False
         self._bwd_plan_serial: Optional[_Plan] = None  # every launch sized for the whole chip: profile_step / one-stream runs
+
+    @property
+    def bwd_hooks(self) -> Dict[str, Callable[[], None]]:
+        return self._bwd_hooks
+
+    @bwd_hooks.setter
+    def bwd_hooks(self, hooks):
+        """Attaching hooks (ddp.GradSync.hooks()) puts the engine in data-parallel planning mode for good: backward plans recorded
+        before are dropped (they may defer column sums past a bucket trigger and fold the norm of an un-reduced gradient)."""
+        self._bwd_hooks = hooks or {}
+        if hooks and not self._data_parallel:
+            self._data_parallel = True
+            self._bwd_plan = None
+            self._bwd_plan_serial = None
+
+    @property
+    def _fold_sumsq_ok(self) -> bool:
+        return self.first_touch and not self._data_parallel
 
     # ------------------------------------------------------------------------------------ parameters
     def param_tree(self) -> dict:
@@ -666,14 +735,47 @@ class ViTEngine:
                                 [f"l{j}.ln1.bwd" for j in done if j != layer])
                 n_launch[0] += 1
 
+        # LayerNorm backward launches.  Alone on the GPU (no data-parallel bucket trigger needs the bias / LayerNorm gradients layer by
+        # layer) every launch leaves its column-sum slab in a workspace of its own and ONE savit_layernorm_bwd_finalize_jobs launch at
+        # the end of backward reduces them all (25 finalize launches of 7.5 us + a kernel boundary each -> 1); otherwise each call
+        # finalizes itself as before.
+        defer = self.defer_ln_finalize and not self._data_parallel and d > 64
+        jobs: List[tuple] = []
+
+        def ln_bwd(label, head8, outs3, tail5, extra=None, writes=()):
+            rows = tail5[0]
+            if defer:
+                k = len(jobs)
+                wbuf = self._ln_ws_slot(k, rows, d)
+                P.add(L.savit_layernorm_bwd, head8 + (None, None, None) + tail5 + (wbuf.data_ptr(), wbuf.numel()), label, writes=writes)
+                jobs.append((wbuf.data_ptr(), int(L.savit_layernorm_bwd_grid(rows)), d, 3, outs3 + (None,), extra))
+            elif extra is not None:
+                P.add(L.savit_layernorm_bwd_ex, head8 + outs3 + tail5 + (ws, wsb) + extra, label, writes=writes)
+            else:
+                P.add(L.savit_layernorm_bwd, head8 + outs3 + tail5 + (ws, wsb), label, writes=writes)
+
+        def flush_ln_jobs(label):
+            if not jobs:
+                return
+            arr = (_lib.ColsumJob * len(jobs))()
+            for q, (partial, nblk, dd, nf, outs, extra) in zip(arr, jobs):
+                q.partial, q.nblk, q.d, q.nf = partial, nblk, dd, nf
+                for i, o in enumerate(outs):
+                    q.out[i] = o
+                if extra is not None:
+                    q.extra_slab, q.extra_rows, q.extra_n, q.extra_out = extra
+            P.keep.append(arr)
+            P.add(L.savit_layernorm_bwd_finalize_jobs, (arr, len(jobs)), label)
+            del jobs[:]
+
         ring, ri = [t.data_ptr() for t in self.dres_b_ring], 0
         # ---- head: dWh, d z_cls, final LayerNorm backward into the (zeroed) residual gradient
         wgrad("head.wgrad", self.zcls.data_ptr(), self.dlogits.data_ptr(), gp("Wh"), B, d, C, d, self.Cp, C)
         self._gemm(P, "head.dgrad", A=self.dlogits.data_ptr(), Bt=self.w["Wh_n"].data_ptr(), C=self.d_z.data_ptr(), M=B, N=d, K=self.Cp,
                    lda=self.Cp, ldb=self.Cp, ldc=d, epilogue=_lib.EPI_BF16)
-        P.add(L.savit_layernorm_bwd, (self.d_z.data_ptr(), self.x[NL].data_ptr(), pp("lnf_g"), self.fstats[0].data_ptr(),
-                                      self.fstats[1].data_ptr(), None, self.dres.data_ptr(), ring[0], gp("lnf_g"),
-                                      gp("lnf_b"), gp(f"l{NL - 1}.b2"), B, d, N * d, N * d, self.rp, ws, wsb), "lnf.bwd", writes=(ring[0],))
+        ln_bwd("lnf.bwd", (self.d_z.data_ptr(), self.x[NL].data_ptr(), pp("lnf_g"), self.fstats[0].data_ptr(), self.fstats[1].data_ptr(), None,
+                           self.dres.data_ptr(), ring[0]), (gp("lnf_g"), gp("lnf_b"), gp(f"l{NL - 1}.b2")), (B, d, N * d, N * d, self.rp),
+               writes=(ring[0],))
         for l in range(NL - 1, -1, -1):
             st = self.stats[l]
             w = lambda n, l=l: self.w[n][l].data_ptr()  # noqa: E731
@@ -682,8 +784,9 @@ class ViTEngine:
             wgrad(f"l{l}.W2.wgrad", self.a[l].data_ptr(), ring[ri], gp(f"l{l}.W2"), M, F, d, F, d, d, layer=l)
             # db1 = column sums of d_u: per-row-tile partials (plain stores) + a finalize launch; ~200 row tiles adding into the
             # same F addresses with atomics serialise at the memory side (16 us of this 180 us launch), and this is reproducible
+            cslab = self._colsum_slab_for(l) if defer else self.colsum_slab  # (deferred: the slab lives until the end of backward)
             self._gemm(P, f"l{l}.fc2.dgrad", writes=(d_u,), A=ring[ri], Bt=w("W2_n"), C=d_u, aux=self.u[l].data_ptr(),
-                       colsum=self.colsum_slab.data_ptr(), colsum_rows=self.colsum_slab.shape[0], M=M, N=F, K=d, lda=d, ldb=d, ldc=F,
+                       colsum=cslab.data_ptr(), colsum_rows=cslab.shape[0], M=M, N=F, K=d, lda=d, ldb=d, ldc=F,
                        ldaux=F, epilogue=_lib.EPI_DGELU)
             # the slab is reduced into db1 by the finalize launch of this layer's ln2.bwd below (savit_layernorm_bwd_ex: wide rows only)
             if d <= 64:
@@ -692,13 +795,9 @@ class ViTEngine:
             self._gemm(P, f"l{l}.fc1.dgrad", A=d_u, Bt=w("W1_n"), C=self.d_h.data_ptr(), M=M, N=d, K=F, lda=F, ldb=F,
                        ldc=d, epilogue=_lib.EPI_BF16)
             ri = (ri + 1) % len(ring)
-            ln2_args = (self.d_h.data_ptr(), self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(),
-                        self.dres.data_ptr(), self.dres.data_ptr(), ring[ri], gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b"), None, M, d, d, d, self.rp, ws, wsb)
-            if d > 64:
-                P.add(L.savit_layernorm_bwd_ex, ln2_args + (self.colsum_slab.data_ptr(), self.colsum_slab.shape[0], F, gp(f"l{l}.b1")),
-                      f"l{l}.ln2.bwd", writes=(ring[ri],))
-            else:
-                P.add(L.savit_layernorm_bwd, ln2_args, f"l{l}.ln2.bwd", writes=(ring[ri],))
+            ln_bwd(f"l{l}.ln2.bwd", (self.d_h.data_ptr(), self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(),
+                                     self.dres.data_ptr(), self.dres.data_ptr(), ring[ri]), (gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b"), None),
+                   (M, d, d, d, self.rp), extra=(cslab.data_ptr(), cslab.shape[0], F, gp(f"l{l}.b1")) if d > 64 else None, writes=(ring[ri],))
             # attention branch: x_mid = x_l + attn(LN1(x_l)) Wo     (attention.py:21-67, vit.py:19-24)
             wgrad(f"l{l}.Wo.wgrad", self.o[l].data_ptr(), ring[ri], gp(f"l{l}.Wo"), M, d, d, d, d, d, layer=l)
             self._gemm(P, f"l{l}.proj.dgrad", A=ring[ri], Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=M, N=d, K=d, lda=d, ldb=d,
@@ -711,16 +810,36 @@ class ViTEngine:
                        ldb=3 * d, ldc=d, epilogue=_lib.EPI_BF16)
             flush_group(l, last=(l == 0))
             ri = (ri + 1) % len(ring)
-            P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
-                                          self.dres.data_ptr(), self.dres.data_ptr(), ring[ri], gp(f"l{l}.ln1_g"),
-                                          gp(f"l{l}.ln1_b"), gp(f"l{l - 1}.b2") if l > 0 else None, M, d, d, d, self.rp, ws, wsb),
-                  f"l{l}.ln1.bwd", writes=(ring[ri],))
+            ln_bwd(f"l{l}.ln1.bwd", (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
+                                     self.dres.data_ptr(), self.dres.data_ptr(), ring[ri]),
+                   (gp(f"l{l}.ln1_g"), gp(f"l{l}.ln1_b"), gp(f"l{l - 1}.b2") if l > 0 else None), (M, d, d, d, self.rp), writes=(ring[ri],))
         # ---- embeddings: dpos, dcls, dWpe   (vit.py:77-85, position_embed.py:56, patch_embed.py:23-25)
         P.add(L.savit_pos_cls_grad, (self.dres.data_ptr(), gp("pos"), gp("cls"), B, N, d, 1), "pos_cls.grad")
         wgrad("Wpe.wgrad", self._img_buf.data_ptr(), ring[ri], gp("Wpe"), B * cfg.n_patches, cfg.patch_dim, d, 0, d, d,
               patch=(cfg.patch, cfg.img_size, N, 1))
+        flush_ln_jobs("ln.bwd.finalize")
         finalize_wgrad_ws(self, P)
+        finalize_first_touch(self, P)
         return P
+
+    def _ln_ws_slot(self, k: int, rows: int, d: int) -> torch.Tensor:
+        """Workspace number k of the deferred LayerNorm-backward column sums (one per launch of a backward pass; shared by the plans)."""
+        if not hasattr(self, "_ln_ws_slots"):
+            self._ln_ws_slots = []
+        need = max(16, int(self.L.savit_layernorm_bwd_workspace_bytes(rows, d)))
+        while len(self._ln_ws_slots) <= k:
+            self._ln_ws_slots.append(None)
+        buf = self._ln_ws_slots[k]
+        if buf is None or buf.numel() < need:
+            buf = self._ln_ws_slots[k] = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        return buf
+
+    def _colsum_slab_for(self, l: int) -> torch.Tensor:
+        if not hasattr(self, "_colsum_slabs"):
+            self._colsum_slabs = {}
+        if l not in self._colsum_slabs:
+            self._colsum_slabs[l] = torch.empty_like(self.colsum_slab)
+        return self._colsum_slabs[l]
 
     def _add_wgrad(self, plan: "_Plan", label: str, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, splits: int, patch=(0, 0, 0, 0),
                    side: bool = True):
@@ -836,8 +955,7 @@ class ViTEngine:
         """Loss (train.py:83-90) + full backward into self.grads.  Returns the device scalar loss."""
         s = self._stream()
         self.labels.copy_(labels.to(torch.int32))
-        if zero_grads:
-            self._zero("zero.grads", self.grads)
+        self._zero_grads_for_backward(zero_grads)
         self._zero("zero.loss", self.loss)
         ml = mr = None
         if mix_labels is not None:
@@ -850,6 +968,28 @@ class ViTEngine:
                    self.top5.data_ptr(), self.B, self.cfg.num_classes, s)
         self.backward_from_dlogits()
         return self.loss
+
+    def _current_bwd_plan(self) -> _Plan:
+        if self.overlap_wgrad:
+            if self._bwd_plan is None:
+                self._bwd_plan = self._build_bwd_plan()
+            return self._bwd_plan
+        return self._serial_bwd_plan()
+
+    def _zero_grads_for_backward(self, zero_grads: bool):
+        """Clear what backward ACCUMULATES into.  The matrices the grouped weight-gradient launches store by first touch are not
+        cleared (savit_zero_ranges over the rest: biases, LayerNorm parameters, embeddings, head - 6 of DeiT-B's 346 MB); zero_grads =
+        False (gradient accumulation over several backward passes) turns first touch off for this pass."""
+        plan = self._current_bwd_plan()
+        self._accumulate_run = not zero_grads
+        if plan.fold_sumsq:
+            self._zero("zero.gnorm", self.gnorm)
+        if not zero_grads:
+            return
+        if plan.rest_ranges is not None:
+            timed_call(self.launch_timer, "zero.grads", self.L.savit_zero_ranges, self.grads.data_ptr(), plan.rest_ranges, plan.n_rest, self._stream())
+        else:
+            self._zero("zero.grads", self.grads)
 
     def _zero(self, label: str, t: torch.Tensor):
         """hipMemsetAsync of an accumulator on the launch stream, as a labelled (timeable) launch."""
@@ -866,17 +1006,29 @@ class ViTEngine:
         engine's for the length of the issue and back to "every CU" afterwards."""
         if self.reserved_cus:
             _lib.check(self.L.savit_set_cu_budget(self.cu_budget), "savit_set_cu_budget")
+        plan = ViTEngine._current_bwd_plan(self)  # (CaiTEngine borrows this method without deriving from ViTEngine)
+        accumulate = getattr(self, "_accumulate_run", False)
+        if accumulate:  # gradient accumulation: the grouped launches must add, and what they store is not the final gradient
+            for arr in plan.wgrad_arrays:
+                for q in arr:
+                    q.overwrite = 0
         try:
             if self.overlap_wgrad:
-                if self._bwd_plan is None:
-                    self._bwd_plan = self._build_bwd_plan()
                 n = max(1, self.n_side_streams)
                 while len(self._side_streams) < n:
                     self._side_streams.append(torch.cuda.Stream(device=self.dev))
-                self._bwd_plan.run_overlapped(torch.cuda.current_stream(), self._side_streams[:n], self.bwd_hooks, self.launch_timer)
+                plan.run_overlapped(torch.cuda.current_stream(), self._side_streams[:n], self.bwd_hooks, self.launch_timer)
             else:
-                self._serial_bwd_plan().run(self._stream(), self.launch_timer, self.bwd_hooks)
+                plan.run(self._stream(), self.launch_timer, self.bwd_hooks)
+            self._gnorm_folded = plan.fold_sumsq and not accumulate
+            self._folded_plan = plan
         finally:
+            if accumulate:
+                g0 = self.grads.data_ptr()
+                for arr in plan.wgrad_arrays:
+                    for q in arr:
+                        q.overwrite = 1 if (q.dW - g0) // 4 in plan.covered else 0
+                self._accumulate_run = False
             if self.reserved_cus:
                 _lib.check(self.L.savit_set_cu_budget(0), "savit_set_cu_budget")
 
@@ -891,15 +1043,28 @@ class ViTEngine:
         ss = None
         tm = self.launch_timer
         if max_norm and max_norm > 0:
-            self._zero("zero.gnorm", self.gnorm_sq)
-            timed_call(tm, "sumsq", self.L.savit_sumsq, self.grads.data_ptr(), self.grads.numel(), self.gnorm_sq.data_ptr(), s)
-            ss = self.gnorm_sq.data_ptr()
+            ss = self._grad_sumsq(tm, s)
+        self._gnorm_folded = False
         mirror = getattr(self, "params_bf16", None)
         timed_call(tm, "adamw", self.L.savit_adamw_step_mirror, self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
                    self.adam_v.data_ptr(), self.params.numel(), float(lr), float(b1), float(b2), float(eps), float(weight_decay),
                    self.step_count, ss, float(max_norm or 0.0), float(grad_scale), mirror.data_ptr() if mirror is not None else None, s)
         self._mirror_fresh = mirror is not None
         self.refresh_weights()
+
+    def _grad_sumsq(self, tm, s) -> int:
+        """Squared global gradient norm into gnorm[0] (optax.clip_by_global_norm, train.py:25) -> its device address.  After a backward
+        whose grouped launches accumulated the squares of the weight gradients they stored (gnorm[1:33]), only the ranges nothing
+        overwrites are read (savit_sumsq_ranges); otherwise - data-parallel rank (the norm is the REDUCED gradient's), gradient
+        accumulation, gradients written from outside - the whole buffer."""
+        plan = getattr(self, "_folded_plan", None)
+        if self._gnorm_folded and plan is not None and plan.rest_ranges is not None:
+            timed_call(tm, "sumsq", self.L.savit_sumsq_ranges, self.grads.data_ptr(), plan.rest_ranges, plan.n_rest, self.gnorm.data_ptr() + 4, 32,
+                       self.gnorm.data_ptr(), s)
+        else:
+            self._zero("zero.gnorm", self.gnorm_sq)
+            timed_call(tm, "sumsq", self.L.savit_sumsq, self.grads.data_ptr(), self.grads.numel(), self.gnorm_sq.data_ptr(), s)
+        return self.gnorm.data_ptr()
 
     def profile_step(self, labels: torch.Tensor, label_smoothing: float = 0.1, reps: int = 3) -> Dict[str, float]:
         """Forward + loss + backward with EVERY launch bracketed by timing events on the launch stream, each repetition enqueued

@@ -33,7 +33,13 @@ class GemmArgs(Structure):
 class WgradProblem(Structure):
     """Mirror of `savit_wgrad_problem` (include/savit.h)."""
     _fields_ = [("X", c_void_p), ("dY", c_void_p), ("dW", c_void_p), ("M", c_int), ("Kin", c_int), ("Nout", c_int), ("ldx", c_int),
-                ("lddy", c_int), ("lddw", c_int), ("tile_begin", c_int), ("tile_count", c_int)]
+                ("lddy", c_int), ("lddw", c_int), ("tile_begin", c_int), ("tile_count", c_int), ("overwrite", c_int)]
+
+
+class ColsumJob(Structure):
+    """Mirror of `savit_colsum_job` (include/savit.h)."""
+    _fields_ = [("partial", c_void_p), ("nblk", c_int), ("d", c_int), ("nf", c_int), ("out", c_void_p * 4), ("extra_slab", c_void_p),
+                ("extra_rows", c_int), ("extra_n", c_int), ("extra_out", c_void_p)]
 
 
 class GemmF32Args(Structure):
@@ -56,6 +62,8 @@ _SIGNATURES = {
     "savit_layernorm_bwd_ex": (c_int, [c_void_p] * 11 + [c_int, c_int, c_long, c_long, c_int, c_void_p, c_long, c_void_p, c_int, c_int, c_void_p,
                                        c_void_p]),
     "savit_layernorm_bwd_workspace_bytes": (c_long, [c_int, c_int]),
+    "savit_layernorm_bwd_grid": (c_int, [c_int]),
+    "savit_layernorm_bwd_finalize_jobs": (c_int, [POINTER(ColsumJob), c_int, c_void_p]),
     "savit_layernorm_fwd_mapped": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_float, c_int, c_int, c_int, c_int, c_void_p]),
     "savit_layernorm_bwd_mapped": (c_int, [c_void_p] * 11 + [c_int, c_int, c_long, c_long, c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p]),
     "savit_layerscale_bwd": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_long, c_void_p]),
@@ -82,6 +90,7 @@ _SIGNATURES = {
     "savit_gemm_wgrad_reduce": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "savit_gemm_wgrad_split_count": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "savit_gemm_bf16_wgrad_grouped": (c_int, [POINTER(WgradProblem), c_int, c_int, c_void_p]),
+    "savit_gemm_bf16_wgrad_grouped_ex": (c_int, [POINTER(WgradProblem), c_int, c_int, c_void_p, c_void_p]),
     "savit_gemm_wgrad_group_tiles": (c_int, [c_int, c_int, c_int]),
     "savit_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "savit_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
@@ -115,6 +124,8 @@ _SIGNATURES = {
     "savit_softmax_xent": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                    c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "savit_sumsq": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
+    "savit_sumsq_ranges": (c_int, [c_void_p, POINTER(c_long), c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "savit_zero_ranges": (c_int, [c_void_p, POINTER(c_long), c_int, c_void_p]),
     "savit_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float, c_int,
                                  c_void_p, c_float, c_float, c_void_p]),
     "savit_adamw_step_mirror": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float, c_int,

@@ -122,7 +122,7 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
 def gemm_tn(A: torch.Tensor, Bt: torch.Tensor, C: torch.Tensor, epilogue: int, *, C2=None, bias=None, aux=None, colscale=None,
             rowscale=None, colsum=None, alpha: float = 1.0, alpha_cols: int = 0, rows_per_sample: int = 1,
             round_out_bf16: bool = False, round_bias_bf16: bool = True, tile: int = 0, M: Optional[int] = None,
-            patch_geom: Optional[Tuple[int, int, int, int]] = None):
+            patch_geom: Optional[Tuple[int, int, int, int]] = None, cu_budget: int = 0):
     """C = epilogue(A @ Bt^T).  A bf16 [M,K], Bt bf16 [N,K] (K contiguous).  See include/savit.h for the
     epilogues.  patch_geom = (img_size, patch, tokens, token_offset) with A = NHWC bf16 images."""
     _chk(Bt, bf16, "Bt", 2)
@@ -195,6 +195,7 @@ def gemm_tn(A: torch.Tensor, Bt: torch.Tensor, C: torch.Tensor, epilogue: int, *
     a.alpha, a.alpha_cols, a.rows_per_sample = float(alpha), int(alpha_cols), int(rows_per_sample)
     a.round_out_bf16, a.round_bias_bf16, a.tile = int(round_out_bf16), int(round_bias_bf16), int(tile)
     a.colsum_rows = colsum_rows
+    a.cu_budget = int(cu_budget)  # CUs the launch may count on (0 = all): tile choice, and the grid of the persistent 320 x 256 kernel
     L = _lib.load()
     _lib.check(L.savit_gemm_bf16_tn(ctypes.byref(a), _stream()), "savit_gemm_bf16_tn")
     return C
@@ -263,11 +264,18 @@ def gemm_wgrad(X: torch.Tensor, dY: torch.Tensor, dW: torch.Tensor, splits: int 
     return dW
 
 
-def gemm_wgrad_grouped(problems, tile: int = 256):
+def gemm_wgrad_grouped(problems, tile: int = 256, overwrite: bool = False, sumsq32: Optional[torch.Tensor] = None):
     """dW_i += X_i^T @ dY_i for every (X_i, dY_i, dW_i) of `problems` in ONE launch, one workgroup per tile x tile output tile, each
-    reducing over all rows (no split, no slabs; savit_gemm_bf16_wgrad_grouped).  At most 64 problems."""
+    reducing over all rows (no split, no slabs; savit_gemm_bf16_wgrad_grouped).  At most 64 problems.
+    overwrite: dW_i = X_i^T @ dY_i instead (first touch: dW is not read).  sumsq32: fp32 [32] accumulators that receive the sum of
+    squares of everything the launch stored (savit_gemm_bf16_wgrad_grouped_ex)."""
     arr = (_lib.WgradProblem * len(problems))()
+    if sumsq32 is not None:
+        _chk(sumsq32, f32, "sumsq32", 1)
+        if sumsq32.numel() < 32:
+            raise ValueError("sumsq32 needs 32 accumulators")
     for q, pr in zip(arr, problems):
+        q.overwrite = int(bool(overwrite))
         X, dY, dW = pr[:3]
         if len(pr) == 5:  # (X, dY, dW, tile_begin, tile_count): a range of the weight's output tiles
             q.tile_begin, q.tile_count = int(pr[3]), int(pr[4])
@@ -280,7 +288,7 @@ def gemm_wgrad_grouped(problems, tile: int = 256):
         if kx < Kin or cy < Nout or ry < Mv:
             raise ValueError("operand shapes do not match dW")
         q.X, q.dY, q.dW, q.M, q.Kin, q.Nout, q.ldx, q.lddy, q.lddw = _p(X), _p(dY), _p(dW), Mv, Kin, Nout, ldx, lddy, lddw
-    _lib.check(_lib.load().savit_gemm_bf16_wgrad_grouped(arr, len(problems), int(tile), _stream()), "savit_gemm_bf16_wgrad_grouped")
+    _lib.check(_lib.load().savit_gemm_bf16_wgrad_grouped_ex(arr, len(problems), int(tile), _p(sumsq32), _stream()), "savit_gemm_bf16_wgrad_grouped")
 
 
 def wgrad_workspace(M: int, Kin: int, Nout: int, splits: int = 0, patch: int = 0, device="cuda") -> torch.Tensor:
@@ -401,6 +409,53 @@ def sumsq(g: torch.Tensor, out: torch.Tensor):
     _chk(out, f32, "out")
     L = _lib.load()
     _lib.check(L.savit_sumsq(_p(g), g.numel(), _p(out), _stream()), "savit_sumsq")
+
+
+def _range_array(g: torch.Tensor, ranges):
+    import ctypes
+
+    flat = []
+    for off, n in ranges:
+        if off < 0 or n < 0 or off % 4 or n % 4 or off + n > g.numel():
+            raise ValueError("ranges must be multiples of 4 floats inside the buffer")
+        flat += [int(off), int(n)]
+    return (ctypes.c_long * len(flat))(*flat)
+
+
+def zero_ranges(g: torch.Tensor, ranges):
+    """g[off : off + n] = 0 for every (off, n) of `ranges` in one launch (savit_zero_ranges)."""
+    _chk(g, f32, "g", 1)
+    _lib.check(_lib.load().savit_zero_ranges(_p(g), _range_array(g, ranges), len(ranges), _stream()), "savit_zero_ranges")
+
+
+def sumsq_ranges(g: torch.Tensor, ranges, out: torch.Tensor, slots: Optional[torch.Tensor] = None):
+    """out[0] += sum of g^2 over the ranges (+ the partial sums in `slots`) (savit_sumsq_ranges)."""
+    _chk(g, f32, "g", 1)
+    _chk(out, f32, "out")
+    if slots is not None:
+        _chk(slots, f32, "slots", 1)
+    _lib.check(_lib.load().savit_sumsq_ranges(_p(g), _range_array(g, ranges), len(ranges), _p(slots), slots.numel() if slots is not None else 0,
+                                              _p(out), _stream()), "savit_sumsq_ranges")
+
+
+def layernorm_bwd_finalize_jobs(jobs):
+    """jobs = [(workspace, rows, d, nf, (out0, out1, out2, out3), (extra_slab, extra_out) or None)]: reduce the column-sum slabs that
+    deferred layernorm_bwd / layerscale_bwd calls (every output pointer None) left in their workspaces - one launch
+    (savit_layernorm_bwd_finalize_jobs)."""
+    L = _lib.load()
+    arr = (_lib.ColsumJob * len(jobs))()
+    for q, (ws, rows, d, nf, outs, extra) in zip(arr, jobs):
+        q.partial, q.nblk, q.d, q.nf = _p(ws), int(L.savit_layernorm_bwd_grid(int(rows))), int(d), int(nf)
+        for i, o in enumerate(outs):
+            if o is not None:
+                _chk(o, f32, "out", 1)
+                q.out[i] = _p(o)
+        if extra is not None:
+            slab, xout = extra
+            _chk(slab, f32, "extra_slab", 2)
+            _chk(xout, f32, "extra_out", 1)
+            q.extra_slab, q.extra_rows, q.extra_n, q.extra_out = _p(slab), slab.shape[0], slab.shape[1], _p(xout)
+    _lib.check(L.savit_layernorm_bwd_finalize_jobs(arr, len(jobs), _stream()), "savit_layernorm_bwd_finalize_jobs")
 
 
 def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float, b1: float = 0.9,

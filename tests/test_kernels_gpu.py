@@ -111,7 +111,7 @@ def _mk(rng, M, K, scale=1.0):
 
 # every tile the product library holds (= every tile the auto heuristic can pick: tests/test_abi.py); the earlier rounds' other forms
 # exist in SAVIT_EXPERIMENTS builds only
-PRODUCT_TILES = [6, 12, 13, 17, 18, 20, 21]
+PRODUCT_TILES = [6, 12, 13, 17, 18, 20, 21, 22]  # (22 on these small shapes = 21: the persistent grid needs more tiles than CUs - see test_gemm_persistent_320 below)
 
 
 @pytest.mark.parametrize("tile", PRODUCT_TILES)
@@ -1095,3 +1095,156 @@ def test_attention_cu_budget_changes_the_grid_not_the_result(ops):
     assert L.savit_set_cu_budget(-1) != 0
     for o, lse, dq in outs[1:]:
         assert torch.equal(o, outs[0][0]) and torch.equal(lse, outs[0][1]) and torch.equal(dq, outs[0][2])
+
+
+# ------------------------------------------------------------------------------------------ round 5: first touch, ranges, deferred column sums
+@pytest.mark.parametrize("tile", [256, 640, 128])
+def test_wgrad_grouped_first_touch_and_sumsq(ops, tile):
+    """savit_wgrad_problem.overwrite: dW = X^T dY whatever dW held (NaNs here: a first-touch launch must not read it), bitwise the
+    accumulate form on a zeroed dW; a weight cut over two launches; and the 32 accumulators of savit_gemm_bf16_wgrad_grouped_ex hold
+    the sum of squares of everything stored (the weight gradients' share of the global norm, train.py:25)."""
+    rng = np.random.default_rng(50 + tile)
+    shapes = [(1999, 768, 1024), (1999, 256, 256), (3001, 384, 1152), (517, 384, 1000), (64, 128, 128)]
+    probs = []
+    for M, Kin, Nout in shapes:
+        probs.append((dev(_mk(rng, M, Kin), bf16), dev(_mk(rng, M, Nout), bf16)))
+    acc = [(X, dY, torch.zeros((X.shape[1], dY.shape[1]), dtype=torch.float32, device="cuda")) for X, dY in probs]
+    ops.gemm_wgrad_grouped(acc, tile=tile)
+    slots = torch.zeros(32, dtype=torch.float32, device="cuda")
+    ft = [(X, dY, torch.full((X.shape[1], dY.shape[1]), float("nan"), dtype=torch.float32, device="cuda")) for X, dY in probs]
+    ops.gemm_wgrad_grouped(ft, tile=tile, overwrite=True, sumsq32=slots)
+    want = 0.0
+    for (_, _, a), (_, _, b) in zip(acc, ft):
+        assert torch.equal(a, b)
+        want += float((a.double() ** 2).sum())
+    assert abs(float(slots.double().sum()) - want) < 2e-6 * want
+    assert int((slots != 0).sum()) >= 8  # spread over the accumulators, not one address
+    # a weight cut over two launches, both first touch
+    X, dY = probs[0]
+    nt = ops._lib.load().savit_gemm_wgrad_group_tiles(768, 1024, tile)
+    halves = torch.full((768, 1024), float("nan"), dtype=torch.float32, device="cuda")
+    ops.gemm_wgrad_grouped([(X, dY, halves, 0, 5)], tile=tile, overwrite=True)
+    ops.gemm_wgrad_grouped([(X, dY, halves, 5, nt - 5)], tile=tile, overwrite=True)
+    assert torch.equal(halves, acc[0][2])
+    # accumulate mode with the accumulators: what is stored (old + tile) is what is squared
+    slots.zero_()
+    ops.gemm_wgrad_grouped(acc, tile=tile, sumsq32=slots)
+    want2 = sum(float((a.double() ** 2).sum()) for _, _, a in acc)
+    assert abs(float(slots.double().sum()) - want2) < 2e-6 * want2 and abs(want2 - 4 * want) < 1e-5 * want2
+
+
+def test_zero_and_sumsq_ranges(ops):
+    """savit_zero_ranges / savit_sumsq_ranges: the passes over what the first-touch weight gradients leave (biases, LayerNorm
+    parameters, embeddings): exactly the listed ranges are cleared / summed, nothing else is touched; more ranges than one launch takes."""
+    n = 3_000_000
+    g = torch.randn(n, device="cuda")
+    keep = g.clone()
+    ranges = [(0, 4), (1024, 768), (5000, 2048), (7048, 4096 + 4), (100_000, 590_000), (2_999_996, 4)] + [(1_000_000 + 64 * i, 32) for i in range(200)]
+    mask = torch.zeros(n, dtype=torch.bool, device="cuda")
+    for o, c in ranges:
+        mask[o:o + c] = True
+    out = torch.zeros(1, device="cuda")
+    slots = torch.arange(32, device="cuda", dtype=torch.float32)
+    ops.sumsq_ranges(g, ranges, out, slots)
+    want = float((g[mask].double() ** 2).sum()) + float(slots.sum())
+    assert abs(float(out) - want) < 1e-5 * want
+    ops.zero_ranges(g, ranges)
+    assert bool((g[mask] == 0).all()) and torch.equal(g[~mask], keep[~mask])
+    with pytest.raises(ValueError):
+        ops.zero_ranges(g, [(2, 4)])
+    out.zero_()
+    ops.sumsq_ranges(g, [], out, slots)  # no ranges: the accumulators alone
+    assert abs(float(out) - float(slots.sum())) < 1e-3
+
+
+@pytest.mark.parametrize("rows,d", [(197 * 8, 768), (577 * 3, 1024), (394, 384)])
+def test_layernorm_bwd_deferred_finalize_jobs(ops, rows, d):
+    """Deferred column sums: three layernorm_bwd calls with every output pointer None leave their slabs in workspaces of their own;
+    ONE savit_layernorm_bwd_finalize_jobs launch then yields dgamma / dbeta / dcolsum / the extra slab's column sums of all three -
+    the same values as the self-finalizing calls (same per-block partials; the order of the 8 atomic adds per column is the only
+    freedom), and the same dx bit for bit."""
+    rng = np.random.default_rng(rows + d)
+    L = ops._lib.load()
+    calls, jobs = [], []
+    for k in range(3):
+        x = dev((rng.standard_normal((rows, d)) * 1.5).astype(np.float32))
+        dy = dev(_mk(rng, rows, d), bf16)
+        gamma = dev((1 + 0.1 * rng.standard_normal(d)).astype(np.float32))
+        _, mean, rstd = ops.layernorm_fwd(x, gamma, torch.zeros_like(gamma))
+        dres = dev(_mk(rng, rows, d))
+        slab = dev(_mk(rng, 37 + k, 4 * d)) if k != 1 else None
+        calls.append((dy, x, gamma, mean, rstd, dres, slab))
+    ref = []
+    for dy, x, gamma, mean, rstd, dres, slab in calls:
+        dg, db, dc = (torch.zeros(d, device="cuda") for _ in range(3))
+        xo = torch.zeros(4 * d, device="cuda")
+        dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db, dres_in=dres, dcolsum=dc, **({"extra_slab": slab, "extra_out": xo} if slab is not None else {}))
+        ref.append((dx, dg, db, dc, xo))
+    outs = []
+    for dy, x, gamma, mean, rstd, dres, slab in calls:
+        ws = torch.empty(int(L.savit_layernorm_bwd_workspace_bytes(rows, d)), dtype=torch.uint8, device="cuda")
+        dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, None, None, dres_in=dres, workspace=ws)
+        dg, db, dc = (torch.zeros(d, device="cuda") for _ in range(3))
+        xo = torch.zeros(4 * d, device="cuda")
+        jobs.append((ws, rows, d, 3, (dg, db, dc, None), (slab, xo) if slab is not None else None))
+        outs.append((dx, dg, db, dc, xo))
+    ops.layernorm_bwd_finalize_jobs(jobs)
+    for (dx0, dg0, db0, dc0, xo0), (dx1, dg1, db1, dc1, xo1) in zip(ref, outs):
+        assert torch.equal(dx0, dx1)
+        for a, b in ((dg0, dg1), (db0, db1), (dc0, dc1)):
+            assert rel(host(b), host(a)) < 1e-6
+        assert torch.equal(xo0, xo1)  # one adder per column, fixed order
+
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K,cus", [(320 * 7 + 33, 512, 768, 5), (1999, 768, 128, 3), (25216 // 4, 1024, 192, 16), (3300, 256, 1024, 2),
+                                       (320 * 40, 2048, 256, 0)])
+def test_gemm_persistent_320(ops, epi, M, N, K, cus):
+    """Tile 22 = the 320 x 256 ping-pong tile as a persistent grid (gemm_tn_pp320p_kernel): one workgroup per CU walks several tiles and
+    the next tile's first K-tile lands under the current tile's last phases and epilogue.  With cu_budget = 2..16 a handful of
+    workgroups take 3-20 tiles each (odd and even K-tile counts per tile: the two LDS buffers swap roles from tile to tile; a ragged
+    last row tile; the dummy prefetch behind a workgroup's last tile); the last case is a real grid of 256 workgroups.  Same K order and
+    epilogue code as tile 21: every output must be BITWISE that of the one-tile kernel, for every epilogue."""
+    rng = np.random.default_rng(M + N + K + epi)
+    A, Bt = dev(_mk(rng, M, K), bf16), dev(_mk(rng, N, K, 1 / np.sqrt(K)), bf16)
+    bias = dev((0.1 * rng.standard_normal(N)).astype(np.float32))
+    L = ops._lib.load()
+
+    def run(tile, budget):
+        kw = {}
+        if epi in (0, 1, 3):
+            C = torch.full((M, N), float("nan"), dtype=bf16, device="cuda")
+        else:
+            C = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        outs = [C]
+        if epi == 0:
+            kw = dict(alpha=0.125, alpha_cols=N // 2)
+        elif epi == 1:
+            C2 = torch.full((M, N), float("nan"), dtype=bf16, device="cuda")
+            kw = dict(C2=C2, bias=bias)
+            outs.append(C2)
+        elif epi == 2:
+            torch.manual_seed(1)
+            kw = dict(bias=bias, aux=torch.randn(M, N, device="cuda"), colscale=bias.abs() + 0.5)
+        elif epi == 3:
+            torch.manual_seed(2)
+            rows = int(L.savit_gemm_colsum_rows(M, N, K, tile))
+            slab = torch.full((rows, N), float("nan"), dtype=torch.float32, device="cuda")
+            kw = dict(aux=torch.randn(M, N, device="cuda").to(bf16), colsum=slab)
+            outs.append(slab)
+        else:
+            kw = dict(bias=bias, round_out_bf16=True)
+        ops.gemm_tn(A, Bt, C, epi, tile=tile, cu_budget=budget, **kw)
+        torch.cuda.synchronize()
+        return outs
+
+    ref = run(21, 0)
+    got = run(22, cus)
+    for a, b in zip(ref, got):
+        assert torch.isfinite(a.float()).all()
+        assert torch.equal(a, b)
+    if epi == 0:  # and the one-tile kernel against fp64 on this shape
+        want = host(A).astype(np.float64) @ host(Bt).astype(np.float64).T
+        want[:, :N // 2] *= 0.125
+        assert rel(host(ref[0]), rb(want)) < 1e-3

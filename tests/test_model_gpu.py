@@ -370,3 +370,91 @@ def test_grouped_and_per_weight_weight_gradients_agree(name, B, monkeypatch):
         for w in ("Wqkv", "Wo", "W1", "W2"):
             if not (w == "Wo" and l in e1.wgrad_divert):
                 assert torch.equal(e0.layout.view(g1, f"l{l}.{w}"), e0.layout.view(g1b, f"l{l}.{w}")), (l, w)
+
+
+@pytest.mark.parametrize("name,B", [("vit_b_patch16", 4), ("vit_s_patch16", 6)])
+def test_first_touch_gradients_and_folded_norm(name, B, monkeypatch):
+    """Round 5: grouped weight gradients stored by first touch (no memset of the gradient buffer), the LayerNorm
+    column sums reduced by one launch at the end of backward, the gradient norm's sum of squares carried by the weight-gradient
+    launches.  Against the same engine with all three turned off: identical weight gradients bit for bit (same kernels, same order),
+    the column sums within fp32 atomic order, the same clipped update; gradient accumulation (zero_grads=False) still accumulates; an
+    engine with DDP hooks attached keeps the per-launch forms."""
+    from savit_amd.config import get_config
+    from savit_amd.engine import ViTEngine
+
+    cfg = get_config(name)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    img = torch.randn(B, 224, 224, 3, device="cuda", generator=g).to(torch.bfloat16)
+    lab = torch.randint(0, 1000, (B,), device="cuda", generator=g, dtype=torch.int32)
+
+    def make():
+        eng = ViTEngine(cfg, B)
+        eng.init_params(5)
+        eng.layout.view(eng.params, "Wh").copy_(torch.randn(cfg.embed_dim, cfg.num_classes, generator=torch.Generator().manual_seed(1)) * 0.03)
+        return eng
+
+    def run(eng, poison=True):
+        if poison:
+            eng.grads.fill_(float("nan"))  # whatever the buffer held before must not matter
+        eng.forward(img)
+        eng.loss_backward(lab)
+        torch.cuda.synchronize()
+        return eng.grads.clone()
+
+    monkeypatch.setenv("SAVIT_WGRAD_FIRST_TOUCH", "0")
+    monkeypatch.setenv("SAVIT_DEFER_LN_FINALIZE", "0")
+    e0 = make()
+    g0 = run(e0)
+    labels0 = [c[2] for c in e0._serial_bwd_plan().calls]
+    monkeypatch.delenv("SAVIT_WGRAD_FIRST_TOUCH")
+    monkeypatch.delenv("SAVIT_DEFER_LN_FINALIZE")
+    e1 = make()
+    g1 = run(e1)
+    plan = e1._serial_bwd_plan()
+    assert plan.rest_ranges is not None and plan.fold_sumsq and 0 < plan.rest_elems < 0.05 * e1.grads.numel()
+    assert sum(1 for c in plan.calls if c[2] == "ln.bwd.finalize") == 1 and len(plan.calls) < len(labels0) + 2
+    assert torch.isfinite(g1).all()
+    lay = e1.layout
+    for l in range(cfg.num_layers):
+        for w in ("Wqkv", "Wo", "W1", "W2"):
+            assert torch.equal(lay.view(g0, f"l{l}.{w}"), lay.view(g1, f"l{l}.{w}")), (l, w)
+        for v in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "b1", "b2"):
+            a, b = lay.view(g0, f"l{l}.{v}"), lay.view(g1, f"l{l}.{v}")
+            assert float((a - b).norm() / a.norm().clamp_min(1e-20)) < 2e-6, (l, v)
+    for nm in ("Wpe", "pos", "cls", "Wh", "bh", "lnf_g"):
+        a, b = lay.view(g0, nm), lay.view(g1, nm)
+        assert float((a - b).norm() / a.norm().clamp_min(1e-20)) < 2e-6, nm
+    # the folded norm is the norm: same clipped AdamW update as the engine that sums squares over the whole buffer
+    ss_full = float((g1.double() ** 2).sum())
+    for e in (e0, e1):
+        e.optimizer_step(lr=1e-3, weight_decay=1e-4, max_norm=0.5)
+    torch.cuda.synchronize()
+    assert abs(float(e1.gnorm[0]) - ss_full) < 1e-5 * ss_full and abs(float(e0.gnorm[0]) - ss_full) < 1e-5 * ss_full
+    assert float((e0.params - e1.params).abs().max()) < 2e-6
+    # second step from the updated parameters: nothing stale is left in the accumulators
+    g1b = run(e1, poison=False)
+    ss2 = float((g1b.double() ** 2).sum())
+    e1.optimizer_step(lr=1e-3, weight_decay=1e-4, max_norm=0.5)
+    torch.cuda.synchronize()
+    assert abs(float(e1.gnorm[0]) - ss2) < 1e-5 * ss2
+    # gradient accumulation: two backward passes without clearing add up (first touch is off for the second)
+    e2 = make()
+    ga = run(e2)
+    e2.forward(img)
+    e2.loss_backward(lab, zero_grads=False)
+    torch.cuda.synchronize()
+    assert float((e2.grads - 2 * ga).norm() / (2 * ga).norm()) < 2e-6
+    e2.optimizer_step(lr=1e-3, max_norm=0.5)  # the accumulators are not the norm of an accumulated gradient: whole-buffer pass
+    torch.cuda.synchronize()
+    ss3 = float((e2.grads.double() ** 2).sum())
+    assert abs(float(e2.gnorm[0]) - ss3) < 1e-5 * ss3
+    gc = run(e2, poison=False)  # and the next ordinary pass stores by first touch again
+    assert float((gc - run(make())).norm()) >= 0.0 and torch.isfinite(gc).all()
+    # a data-parallel rank (hooks attached): per-launch finalizes, whole-buffer norm, first touch kept
+    e3 = make()
+    fired = []
+    e3.bwd_hooks = {f"l{cfg.num_layers // 2}.ln1.bwd": lambda: fired.append(1), "Wpe.wgrad": lambda: fired.append(2)}
+    g3 = run(e3)
+    p3 = e3._serial_bwd_plan()
+    assert fired == [1, 2] and not p3.fold_sumsq and not any(c[2] == "ln.bwd.finalize" for c in p3.calls) and p3.rest_ranges is not None
+    assert float((g3 - g1).norm() / g1.norm()) < 2e-6
