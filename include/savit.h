@@ -221,7 +221,8 @@ int savit_gemm_wgrad_group_tiles(int Kin, int Nout, int tile);
 
 
 /* ---- Fused multi-head self-attention (attention.py:39-58): per (batch, head)
- *   S = (q/sqrt(hd)) k^T ; P = softmax_k(S) ; O = P v.      head_dim 16, 32, 48 or 64; N <= 608.
+ *   S = (q/sqrt(hd)) k^T ; P = softmax_k(S) ; O = P v.      head_dim 16, 32, 48 or 64; any N <= 65 536
+ *   (N <= 608: one head's K / V images resident in LDS; longer: K / V - in backward also Q / dO - stream through LDS in 256-row segments).
  * qkv bf16 [B*N, ld_qkv]: columns [0,d) = queries ALREADY scaled by 1/sqrt(hd) (SAVIT_EPI_BF16 alpha), [d,2d) keys,
  * [2d,3d) values, head-major (h*64+e) inside each (the DenseGeneral (H,hd) feature order, attention.py:29-33).
  * o bf16 [B*N, d]; lse fp32 [B,H,N] = log-sum-exp of each score row (saved for backward; nullable). */

@@ -1216,6 +1216,477 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const AttnParams2 pp) {
 
 
 // ------------------------------------------------------------------------------------------------------------
+// Streaming kernels: ANY sequence length (round 5; attention.py:41-58 and position_embed.py:52-57 take any image size: ViT-B/16 at
+// 512^2 is N = 1 025).  The kernels above keep one head's K / V (or Q / dO) resident in LDS, which stops at 608 tokens.  Here a
+// workgroup owns 8 row blocks of 32 (one per wave) of ONE side and the other side streams through LDS in segments of SEG_T = 8 tiles
+// (256 rows: two 32 KB images), double-buffered: the LDS-DMA of segment s + 1 is issued right behind the barrier that publishes
+// segment s and lands under its arithmetic (one barrier per segment).  Same per-tile arithmetic, rounding points and fragment code as
+// the resident general kernels (attn_fwd2 / attn_bwd2): lean per-score math, transposed fragments by inline asm.
+//   forward    : wave = 32 queries (Q fragments, running max / sum, O accumulators in registers); K, V stream; online softmax.
+//   backward dQ : wave = 32 queries (Q, dO fragments, delta = rowsum(dO * O) in registers); K, V stream.
+//   backward dKV: wave = 32 keys (K, V fragments in registers); Q, dO stream together with -LSE log2 e and delta of the segment's 256
+//                 queries - delta is recomputed per segment from O and dO rows (L2-resident) by all 512 threads, so the two backward
+//                 kernels share nothing and need no workspace (the C entry point has none).
+// Every wave takes part in staging and barriers even when its own row block lies beyond N (the last round of a sequence).
+constexpr int SEG_T = 8;
+constexpr int SEG_ROWS = SEG_T * 32;
+constexpr int SEG_IMG = SEG_ROWS * ROWB;  // 32 KB
+
+// rows row0 .. row0 + 255 of one operand into a segment image (rows >= N and chunks >= hd / 8 zero-filled); 4 LDS-DMA per wave at 8 waves
+__device__ __forceinline__ void stage_segment(char* img, __amdgpu_buffer_rsrc_t srd, long row_base, int row0, int N, int ld, int col0, int wave,
+                                              int nwv, int lane, int hd) {
+  const int lrow = lane >> 3, pc = lane & 7;
+  for (int inst = wave; inst < SEG_T * 4; inst += nwv) {
+    const int tl = inst * 8 + lrow;  // row inside the segment image
+    const int t = row0 + tl;
+    const int c = pc ^ rot3(tl);
+    uint32_t voff = 0xfffffff0u;
+    if (t < N && c * 8 < hd) voff = (uint32_t)(((size_t)(row_base + t) * ld + col0 + c * 8) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(img + inst * 1024), 16, voff, 0, 0, 0);
+  }
+}
+
+template <int KS>
+__global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const AttnParams2 pp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K image | V image]
+  const AttnParams& p = pp.a;
+  const int NT = pp.nt;
+  constexpr int hd = 16 * KS;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwv = blockDim.x >> 6;
+  const int rounds = (NT + nwv - 1) / nwv;
+  const int item = blockIdx.x / rounds, round = blockIdx.x - item * rounds;
+  const int b = item / p.H, hh = item - b * p.H;
+  const long row_base = (long)b * p.N;
+  size_t bytes = (size_t)p.B * p.N * p.ld * 2;
+  if (bytes > 0xffffffe0ull) bytes = 0xffffffe0ull;
+  const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.qkv), 0, (uint32_t)bytes, 0x00020000);
+  const int nseg = (NT + SEG_T - 1) / SEG_T;
+  auto stage = [&](int sg) {
+    char* buf = smem + (sg & 1) * 2 * SEG_IMG;
+    stage_segment(buf, srd, row_base, sg * SEG_ROWS, p.N, p.ld, p.d + hh * hd, wave, nwv, lane, hd);
+    stage_segment(buf + SEG_IMG, srd, row_base, sg * SEG_ROWS, p.N, p.ld, 2 * p.d + hh * hd, wave, nwv, lane, hd);
+  };
+  stage(0);
+
+  const int ql = lane & 31, half = lane >> 5;
+  const int g = lane >> 4, t = lane & 15;
+  const int trow = 4 * (g >> 1) + (t >> 2);
+  const int tcol = 16 * (g & 1) + 4 * (t & 3);
+  constexpr int KC = 4;
+  uint32_t trv[2][2];  // transposed-fragment addresses of tile 0 of buffer 0's V image
+#pragma unroll
+  for (int eb = 0; eb < 2; ++eb) {
+    trv[eb][0] = lds_addr32(smem + SEG_IMG) + tr_lane_off(trow, 32 * eb + tcol, false);
+    trv[eb][1] = lds_addr32(smem + SEG_IMG) + tr_lane_off(trow, 32 * eb + tcol, true);
+  }
+  const f32x16 zero16f = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int qb = round * nwv + wave;
+  const bool active = qb < NT;
+  const int q = qb * 32 + ql;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = load_row_frag_global(p.qkv, (size_t)(row_base + q), p.ld, hh * hd + 16 * ks + 8 * half, active && q < p.N);
+  float m = -INFINITY, l = 0.f;
+  f32x16 oacc[2];
+#pragma unroll
+  for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[eb][r] = 0.f;
+
+  for (int sg = 0; sg < nseg; ++sg) {
+    // segment sg (requested one segment of arithmetic ago) has landed for this wave; behind the barrier for everybody, and everybody
+    // is done reading the other buffer
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (sg + 1 < nseg) stage(sg + 1);
+    if (!active) continue;
+    const uint32_t boff = (uint32_t)((sg & 1) * 2 * SEG_IMG);
+    const char* imgK = smem + boff;
+    const int t0 = sg * SEG_T;                                   // first key tile of the segment
+    const int ntl = (NT - t0) < SEG_T ? (NT - t0) : SEG_T;       // its tiles
+    auto chunk = [&](int c0, auto kc) {  // as in attn_fwd2_kernel; c0 = tile inside the segment
+      constexpr int K = decltype(kc)::value;
+      f32x16 sc[K];
+      float cmax = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        sc[j] = zero16f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 kf = lds_row_frag(imgK, (c0 + j) * 32 + ql, 2 * ks + half);
+          sc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[j], 0, 0, 0);
+        }
+      }
+      if (t0 + c0 + K == NT) {  // only the sequence's last key tile can hold keys >= N
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = (NT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (key >= p.N) sc[K - 1][r] = -INFINITY;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cmax = fmaxf(cmax, sc[j][r]);
+      cmax = half_max(cmax);
+      const float m_new = fmaxf(m, cmax);  // finite: every chunk holds at least one valid key
+      const float alpha = __builtin_amdgcn_exp2f((m - m_new) * LOG2E);
+      const float mb = m_new * LOG2E;
+      l *= alpha;
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[eb][r] *= alpha;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        TrFrag vf[2][2];
+        const uint32_t tb = boff + (uint32_t)((c0 + j) * 32 * ROWB);
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) {
+          if (32 * eb >= hd) continue;
+          lds_tr_issue<0>(vf[0][eb], trv[eb][0] + tb, trv[eb][1] + tb);
+          lds_tr_issue<16 * ROWB>(vf[1][eb], trv[eb][0] + tb, trv[eb][1] + tb);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(sc[j][r] * LOG2E - mb);
+          sc[j][r] = e;
+          l += e;
+        }
+        if constexpr (hd > 32) lds_tr_wait(vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0].lo), "+v"(vf[0][0].hi), "+v"(vf[1][0].lo), "+v"(vf[1][0].hi));
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = acc_to_frag(sc[j], s2);
+#pragma unroll
+          for (int eb = 0; eb < 2; ++eb) {
+            if (32 * eb >= hd) continue;
+            oacc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vf[s2][eb]), pf, oacc[eb], 0, 0, 0);
+          }
+        }
+      }
+      m = m_new;
+    };
+    int c0 = 0;
+#pragma unroll 1
+    for (; c0 + KC <= ntl; c0 += KC) chunk(c0, std::integral_constant<int, KC>{});
+    switch (ntl - c0) {
+      case 1: chunk(c0, std::integral_constant<int, 1>{}); break;
+      case 2: chunk(c0, std::integral_constant<int, 2>{}); break;
+      case 3: chunk(c0, std::integral_constant<int, 3>{}); break;
+      default: break;
+    }
+  }
+  if (!active) return;
+  l = half_sum(l);
+  if (q < p.N) {
+    const float inv = 1.0f / l;
+    bf16_t* orow = p.o + (size_t)(row_base + q) * p.d + hh * hd;
+    store_row_tile(orow, oacc, half, hd, inv);
+    if (half == 0 && p.lse != nullptr) p.lse[((size_t)b * p.H + hh) * p.N + q] = m + __logf(l);
+  }
+}
+
+template <int KS>
+__global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const AttnParams2 pp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K image | V image]
+  const AttnParams& p = pp.a;
+  const int NT = pp.nt;
+  constexpr int hd = 16 * KS;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwv = blockDim.x >> 6;
+  const int rounds = (NT + nwv - 1) / nwv;
+  const int item = blockIdx.x / rounds, round = blockIdx.x - item * rounds;
+  const int b = item / p.H, hh = item - b * p.H;
+  const long row_base = (long)b * p.N;
+  size_t bytes = (size_t)p.B * p.N * p.ld * 2;
+  if (bytes > 0xffffffe0ull) bytes = 0xffffffe0ull;
+  const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.qkv), 0, (uint32_t)bytes, 0x00020000);
+  const int nseg = (NT + SEG_T - 1) / SEG_T;
+  auto stage = [&](int sg) {
+    char* buf = smem + (sg & 1) * 2 * SEG_IMG;
+    stage_segment(buf, srd, row_base, sg * SEG_ROWS, p.N, p.ld, p.d + hh * hd, wave, nwv, lane, hd);
+    stage_segment(buf + SEG_IMG, srd, row_base, sg * SEG_ROWS, p.N, p.ld, 2 * p.d + hh * hd, wave, nwv, lane, hd);
+  };
+  stage(0);
+
+  const int ql = lane & 31, half = lane >> 5;
+  const int g = lane >> 4, t = lane & 15;
+  const int trow = 4 * (g >> 1) + (t >> 2);
+  const int tcol = 16 * (g & 1) + 4 * (t & 3);
+  const f32x16 zero16f = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  uint32_t trc[2][2];  // transposed-fragment addresses of tile 0 of buffer 0's K image
+#pragma unroll
+  for (int eb = 0; eb < 2; ++eb) {
+    trc[eb][0] = lds_addr32(smem) + tr_lane_off(trow, 32 * eb + tcol, false);
+    trc[eb][1] = lds_addr32(smem) + tr_lane_off(trow, 32 * eb + tcol, true);
+  }
+  const int qb = round * nwv + wave;
+  const bool active = qb < NT;
+  const int q = qb * 32 + ql;
+  const bool ok = active && q < p.N;
+  bf16x8 qf[4], df[4];
+  float delta = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    qf[ks] = load_row_frag_global(p.qkv, (size_t)(row_base + q), p.ld, hh * hd + 16 * ks + 8 * half, ok);
+    df[ks] = load_row_frag_global(p.d_o, (size_t)(row_base + q), p.d, hh * hd + 16 * ks + 8 * half, ok);
+    const bf16x8 ov = load_row_frag_global(p.o, (size_t)(row_base + q), p.d, hh * hd + 16 * ks + 8 * half, ok);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) delta += bf16_to_f32((bf16_t)ov[j]) * bf16_to_f32((bf16_t)df[ks][j]);
+  }
+  delta = half_sum(delta);
+  const float nlse2 = ok ? -LOG2E * p.lse[((size_t)b * p.H + hh) * p.N + q] : -INFINITY;  // rows q >= N: P = 0
+  f32x16 dq[2];
+#pragma unroll
+  for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[eb][r] = 0.f;
+
+  for (int sg = 0; sg < nseg; ++sg) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (sg + 1 < nseg) stage(sg + 1);
+    if (!active) continue;
+    const uint32_t boff = (uint32_t)((sg & 1) * 2 * SEG_IMG);
+    const char* img0 = smem + boff;
+    const char* img1 = img0 + SEG_IMG;
+    const int t0 = sg * SEG_T;
+    const int ntl = (NT - t0) < SEG_T ? (NT - t0) : SEG_T;
+#pragma unroll 1
+    for (int kt = 0; kt < ntl; ++kt) {
+      f32x16 sa = zero16f, da = zero16f;
+      ATTN_PRIO(1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = lds_row_frag(img0, kt * 32 + ql, 2 * ks + half);
+        const bf16x8 vf = lds_row_frag(img1, kt * 32 + ql, 2 * ks + half);
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sa, 0, 0, 0);
+        da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[ks], da, 0, 0, 0);
+      }
+      ATTN_PRIO(0);
+      TrFrag ktf[2][2];
+      const uint32_t tb = boff + (uint32_t)(kt * 32 * ROWB);
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) {
+        if (32 * eb >= hd) continue;
+        lds_tr_issue<0>(ktf[0][eb], trc[eb][0] + tb, trc[eb][1] + tb);
+        lds_tr_issue<16 * ROWB>(ktf[1][eb], trc[eb][0] + tb, trc[eb][1] + tb);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], LOG2E, nlse2));
+        sa[r] = pr * (da[r] - delta);  // dS^T
+      }
+      if (t0 + kt == NT - 1) {  // only the sequence's last key tile can hold keys >= N
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = (NT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (key >= p.N) sa[r] = 0.f;
+        }
+      }
+      if constexpr (hd > 32) lds_tr_wait(ktf[0][0], ktf[0][1], ktf[1][0], ktf[1][1]);
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ktf[0][0].lo), "+v"(ktf[0][0].hi), "+v"(ktf[1][0].lo), "+v"(ktf[1][0].hi));
+      ATTN_PRIO(1);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 dsf = acc_to_frag(sa, s2);
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) {
+          if (32 * eb >= hd) continue;
+          dq[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(ktf[s2][eb]), dsf, dq[eb], 0, 0, 0);
+        }
+      }
+      ATTN_PRIO(0);
+    }
+  }
+  if (ok) {
+    bf16_t* drow = p.dqkv + (size_t)(row_base + q) * p.ld + hh * hd;
+    store_row_tile(drow, dq, half, hd, p.dq_scale);
+  }
+}
+
+template <int KS>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_stream_kernel(const AttnParams2 pp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][Q image | dO image], then [2 buffers][-LSE log2 e | delta][256]
+  const AttnParams& p = pp.a;
+  const int NT = pp.nt;
+  constexpr int hd = 16 * KS;
+  float* stats = reinterpret_cast<float*>(smem + 4 * SEG_IMG);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwv = blockDim.x >> 6;
+  const int rounds = (NT + nwv - 1) / nwv;
+  const int item = blockIdx.x / rounds, round = blockIdx.x - item * rounds;
+  const int b = item / p.H, hh = item - b * p.H;
+  const long row_base = (long)b * p.N;
+  size_t bytes = (size_t)p.B * p.N * p.ld * 2;
+  if (bytes > 0xffffffe0ull) bytes = 0xffffffe0ull;
+  size_t bytes_o = (size_t)p.B * p.N * p.d * 2;
+  if (bytes_o > 0xffffffe0ull) bytes_o = 0xffffffe0ull;
+  const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.qkv), 0, (uint32_t)bytes, 0x00020000);
+  const auto srdD = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.d_o), 0, (uint32_t)bytes_o, 0x00020000);
+  const int nseg = (NT + SEG_T - 1) / SEG_T;
+  auto stage = [&](int sg) {
+    char* buf = smem + (sg & 1) * 2 * SEG_IMG;
+    stage_segment(buf, srd, row_base, sg * SEG_ROWS, p.N, p.ld, hh * hd, wave, nwv, lane, hd);
+    stage_segment(buf + SEG_IMG, srdD, row_base, sg * SEG_ROWS, p.N, p.d, hh * hd, wave, nwv, lane, hd);
+  };
+  // -LSE log2 e and delta = rowsum(dO * O) of the segment's queries: a thread takes half a row (head_dim / 2 columns) of two rows' worth
+  // of threads; rows >= N get -inf / 0 (P = 0)
+  auto fill_stats = [&](int sg) {
+    float* st = stats + (sg & 1) * 2 * SEG_ROWS;
+    for (int i = threadIdx.x; i < 2 * SEG_ROWS; i += blockDim.x) {
+      const int r = i >> 1, hf = i & 1;
+      const int qg = sg * SEG_ROWS + r;
+      float part = 0.f;
+      if (qg < p.N) {
+        const bf16_t* orow = p.o + (size_t)(row_base + qg) * p.d + hh * hd + hf * (hd / 2);
+        const bf16_t* drow = p.d_o + (size_t)(row_base + qg) * p.d + hh * hd + hf * (hd / 2);
+#pragma unroll
+        for (int c = 0; c < hd / 16; ++c) {
+          const bf16x8 ov = *reinterpret_cast<const bf16x8*>(orow + 8 * c);
+          const bf16x8 dv = *reinterpret_cast<const bf16x8*>(drow + 8 * c);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) part += bf16_to_f32((bf16_t)ov[e]) * bf16_to_f32((bf16_t)dv[e]);
+        }
+      }
+      part += __shfl_xor(part, 1, 64);
+      if (hf == 0) {
+        st[r] = (qg < p.N) ? -LOG2E * p.lse[((size_t)b * p.H + hh) * p.N + qg] : -INFINITY;
+        st[SEG_ROWS + r] = part;
+      }
+    }
+  };
+  stage(0);
+  fill_stats(0);
+
+  const int ql = lane & 31, half = lane >> 5;
+  const int g = lane >> 4, t = lane & 15;
+  const int trow = 4 * (g >> 1) + (t >> 2);
+  const int tcol = 16 * (g & 1) + 4 * (t & 3);
+  const f32x16 zero16f = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  uint32_t trc[2][2];  // transposed-fragment addresses of tile 0 of buffer 0's Q image (dO image: + SEG_IMG)
+#pragma unroll
+  for (int eb = 0; eb < 2; ++eb) {
+    trc[eb][0] = lds_addr32(smem) + tr_lane_off(trow, 32 * eb + tcol, false);
+    trc[eb][1] = lds_addr32(smem) + tr_lane_off(trow, 32 * eb + tcol, true);
+  }
+  const int kb = round * nwv + wave;
+  const bool active = kb < NT;
+  const int key = kb * 32 + ql;
+  const bool ok = active && key < p.N;
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kf[ks] = load_row_frag_global(p.qkv, (size_t)(row_base + key), p.ld, p.d + hh * hd + 16 * ks + 8 * half, ok);
+    vf[ks] = load_row_frag_global(p.qkv, (size_t)(row_base + key), p.ld, 2 * p.d + hh * hd + 16 * ks + 8 * half, ok);
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dk[eb][r] = 0.f;
+      dv[eb][r] = 0.f;
+    }
+
+  for (int sg = 0; sg < nseg; ++sg) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (sg + 1 < nseg) stage(sg + 1);
+    if (active) {
+      const uint32_t boff = (uint32_t)((sg & 1) * 2 * SEG_IMG);
+      const char* img0 = smem + boff;
+      const char* img1 = img0 + SEG_IMG;
+      const uint32_t sta0 = lds_addr32(smem) + 4 * SEG_IMG + (uint32_t)((sg & 1) * 2 * SEG_ROWS * 4);
+      const int t0 = sg * SEG_T;
+      const int ntl = (NT - t0) < SEG_T ? (NT - t0) : SEG_T;
+#pragma unroll 1
+      for (int qt = 0; qt < ntl; ++qt) {
+        f32x16 sa = zero16f, da = zero16f;
+        // register r holds query qt*32 + 8*(r>>2) + 4*half + (r&3): four 16-byte reads of each statistic (inline asm: an LDS read hipcc
+        // can attribute gets `s_waitcnt vmcnt(0)` in front while the next segment's LDS-DMA is in flight)
+        f32x4 nl4[4], dl4[4];
+        const uint32_t sta = sta0 + (uint32_t)((qt * 32 + 4 * half) * 4);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          lds_read_f4(nl4[g4], sta, 32 * g4);
+          lds_read_f4(dl4[g4], sta, SEG_ROWS * 4 + 32 * g4);
+        }
+        ATTN_PRIO(1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 qfr = lds_row_frag(img0, qt * 32 + ql, 2 * ks + half);
+          const bf16x8 dfr = lds_row_frag(img1, qt * 32 + ql, 2 * ks + half);
+          sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[ks], sa, 0, 0, 0);
+          da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr, vf[ks], da, 0, 0, 0);
+        }
+        ATTN_PRIO(0);
+        TrFrag dtf[2][2], qtf[2][2];
+        const uint32_t tb = boff + (uint32_t)(qt * 32 * ROWB), imgd = (uint32_t)SEG_IMG;
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) {
+          if (32 * eb >= hd) continue;
+          lds_tr_issue<0>(dtf[0][eb], trc[eb][0] + tb + imgd, trc[eb][1] + tb + imgd);
+          lds_tr_issue<0>(qtf[0][eb], trc[eb][0] + tb, trc[eb][1] + tb);
+        }
+        lds_f4_wait(nl4[0], dl4[0], nl4[1], dl4[1]);  // (in-order LDS: this also retires the transposed reads above - waited again below)
+        lds_f4_wait(nl4[2], dl4[2], nl4[3], dl4[3]);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * g4 + j;
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], LOG2E, nl4[g4][j]));  // rows q >= N: -inf -> 0
+            sa[r] = pr;
+            da[r] = pr * (da[r] - dl4[g4][j]);
+          }
+        }
+        if constexpr (hd > 32) lds_tr_wait(dtf[0][0], dtf[0][1], qtf[0][0], qtf[0][1]);
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dtf[0][0].lo), "+v"(dtf[0][0].hi), "+v"(qtf[0][0].lo), "+v"(qtf[0][0].hi));
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) {
+          if (32 * eb >= hd) continue;
+          lds_tr_issue<16 * ROWB>(dtf[1][eb], trc[eb][0] + tb + imgd, trc[eb][1] + tb + imgd);
+          lds_tr_issue<16 * ROWB>(qtf[1][eb], trc[eb][0] + tb, trc[eb][1] + tb);
+        }
+        ATTN_PRIO(1);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = acc_to_frag(sa, s2);
+          const bf16x8 dsf = acc_to_frag(da, s2);
+          if (s2 == 1) {
+            if constexpr (hd > 32) lds_tr_wait(dtf[1][0], dtf[1][1], qtf[1][0], qtf[1][1]);
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dtf[1][0].lo), "+v"(dtf[1][0].hi), "+v"(qtf[1][0].lo), "+v"(qtf[1][0].hi));
+          }
+#pragma unroll
+          for (int eb = 0; eb < 2; ++eb) {
+            if (32 * eb >= hd) continue;
+            dv[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(dtf[s2][eb]), pf, dv[eb], 0, 0, 0);
+            dk[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(qtf[s2][eb]), dsf, dk[eb], 0, 0, 0);
+          }
+        }
+        ATTN_PRIO(0);
+      }
+    }
+    // the statistics of the next segment, behind this segment's arithmetic (its LDS-DMA was issued a whole segment ago: the waits hipcc
+    // puts in front of these global loads and LDS stores cost nothing)
+    if (sg + 1 < nseg) fill_stats(sg + 1);
+  }
+  if (ok) {
+    bf16_t* krow = p.dqkv + (size_t)(row_base + key) * p.ld + p.d + hh * hd;
+    bf16_t* vrow = krow + p.d;
+    store_row_tile(krow, dk, half, hd, 1.0f);
+    store_row_tile(vrow, dv, half, hd, 1.0f);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
 // Talking-heads attention (CaiT SA layers): attention.py:41-58 with talking_heads=True (talking_heads.py:9-14)
 //   S_h = q_h k_h^T ; S'_i = sum_h T1[h,i] S_h ; P_i = softmax_k(S'_i) ; P'_i = sum_h T2[h,i] P_h ; O_i = P'_i v_i
 // The two H x H mixings couple every head at every (q,k), so a per-head flash kernel cannot fuse them.  Round-1
@@ -2115,6 +2586,12 @@ __global__ __launch_bounds__(256) void th_softmax_bwd_kernel(const bf16_t* __res
 }  // namespace
 
 // development switch (SAVIT_EXPERIMENTS builds only): run the general online-softmax kernels where the resident ones would be chosen
+constexpr int ATTN_RESIDENT_MAX_NT = 19;  // 608 tokens: the longest sequence whose K and V (or Q and dO) images of one head fit the LDS
+#ifdef SAVIT_EXPERIMENTS
+static const bool attn_stream_forced = SAVIT_EXP_ENV_INT("SAVIT_ATTN_STREAM", 0) != 0;  // A/B runs: the streaming kernels at every length
+#else
+constexpr bool attn_stream_forced = false;
+#endif
 static bool attn_force_general() {
   static const bool f = SAVIT_EXP_ENV_INT("SAVIT_ATTN_GENERAL", 0) != 0;
   return f;
@@ -2161,13 +2638,32 @@ static int persistent_grid(int items, size_t lds_bytes, int threads) {
 extern "C" int savit_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int head_dim, int ld_qkv,
                                    void* stream) {
   SAVIT_CHECK_ARG(qkv && o && B >= 0 && N > 0 && H > 0);
-  SAVIT_CHECK_ARG((head_dim == 64 || head_dim == 48 || head_dim == 32 || head_dim == 16) && N <= 608 && ld_qkv >= 3 * H * head_dim && ld_qkv % 8 == 0);
+  SAVIT_CHECK_ARG((head_dim == 64 || head_dim == 48 || head_dim == 32 || head_dim == 16) && N <= 65536 && ld_qkv >= 3 * H * head_dim && ld_qkv % 8 == 0);
   SAVIT_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)o % 16) == 0);
   if (B == 0) return SAVIT_OK;
   AttnParams p{};
   p.qkv = (const bf16_t*)qkv; p.o = (bf16_t*)o; p.lse = lse;
   p.B = B; p.N = N; p.H = H; p.ld = ld_qkv; p.d = H * head_dim;
   const int nt = (N + 31) / 32;
+  if (nt > ATTN_RESIDENT_MAX_NT || attn_stream_forced) {  // longer than one head's K / V images fit the LDS: the streaming kernels
+    AttnParams2 pp{p, nt, head_dim};
+    const int rounds = (nt + 7) / 8;
+    const size_t lds = (size_t)4 * SEG_IMG;
+    SAVIT_CHECK_ARG((long)B * H * rounds <= 0x7fffffffL);
+#define ATTNS_LAUNCH(KERNEL, KSV, LDS)                                                                                             \
+  {                                                                                                                                \
+    auto kfn = KERNEL<KSV>;                                                                                                        \
+    SAVIT_LDS_ONCE(kfn);                                                                                                           \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(B * H * rounds)), dim3(512), (LDS), (hipStream_t)stream, pp);                           \
+  } break;
+    switch (head_dim / 16) {
+      case 1: ATTNS_LAUNCH(attn_fwd_stream_kernel, 1, lds)
+      case 2: ATTNS_LAUNCH(attn_fwd_stream_kernel, 2, lds)
+      case 3: ATTNS_LAUNCH(attn_fwd_stream_kernel, 3, lds)
+      default: ATTNS_LAUNCH(attn_fwd_stream_kernel, 4, lds)
+    }
+    SAVIT_LAUNCH_RET();
+  }
   if (head_dim != HD || nt > 8 || attn_force_general()) {
     AttnParams2 pp{p, nt, head_dim};
     const size_t lds = (size_t)2 * nt * 32 * ROWB;
@@ -2193,7 +2689,7 @@ extern "C" int savit_attention_fwd(const void* qkv, void* o, float* lse, int B, 
 extern "C" int savit_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int N,
                                    int H, int head_dim, int ld_qkv, float dq_scale, void* stream) {
   SAVIT_CHECK_ARG(qkv && o && d_o && lse && dqkv && B >= 0 && N > 0 && H > 0);
-  SAVIT_CHECK_ARG((head_dim == 64 || head_dim == 48 || head_dim == 32 || head_dim == 16) && N <= 608 && ld_qkv >= 3 * H * head_dim && ld_qkv % 8 == 0);
+  SAVIT_CHECK_ARG((head_dim == 64 || head_dim == 48 || head_dim == 32 || head_dim == 16) && N <= 65536 && ld_qkv >= 3 * H * head_dim && ld_qkv % 8 == 0);
   SAVIT_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)o % 16) == 0 && ((uintptr_t)d_o % 16) == 0 && ((uintptr_t)dqkv % 16) == 0);
   if (B == 0) return SAVIT_OK;
   AttnParams p{};
@@ -2201,6 +2697,26 @@ extern "C" int savit_attention_bwd(const void* qkv, const void* o, const void* d
   p.d_o = (const bf16_t*)d_o; p.dqkv = (bf16_t*)dqkv;
   p.B = B; p.N = N; p.H = H; p.ld = ld_qkv; p.d = H * head_dim; p.dq_scale = dq_scale;
   const int nt = (N + 31) / 32;
+  if (nt > ATTN_RESIDENT_MAX_NT || attn_stream_forced) {  // the streaming kernels: dQ (queries own, K / V stream), then dK / dV (keys own, Q / dO stream)
+    AttnParams2 pp{p, nt, head_dim};
+    const int rounds = (nt + 7) / 8;
+    const size_t lds_q = (size_t)4 * SEG_IMG, lds_kv = lds_q + (size_t)4 * SEG_ROWS * sizeof(float);
+    SAVIT_CHECK_ARG((long)B * H * rounds <= 0x7fffffffL);
+    switch (head_dim / 16) {
+      case 1: ATTNS_LAUNCH(attn_bwd_dq_stream_kernel, 1, lds_q)
+      case 2: ATTNS_LAUNCH(attn_bwd_dq_stream_kernel, 2, lds_q)
+      case 3: ATTNS_LAUNCH(attn_bwd_dq_stream_kernel, 3, lds_q)
+      default: ATTNS_LAUNCH(attn_bwd_dq_stream_kernel, 4, lds_q)
+    }
+    if (hipGetLastError() != hipSuccess) return SAVIT_EINVAL;
+    switch (head_dim / 16) {
+      case 1: ATTNS_LAUNCH(attn_bwd_dkv_stream_kernel, 1, lds_kv)
+      case 2: ATTNS_LAUNCH(attn_bwd_dkv_stream_kernel, 2, lds_kv)
+      case 3: ATTNS_LAUNCH(attn_bwd_dkv_stream_kernel, 3, lds_kv)
+      default: ATTNS_LAUNCH(attn_bwd_dkv_stream_kernel, 4, lds_kv)
+    }
+    SAVIT_LAUNCH_RET();
+  }
   if (head_dim != HD || nt > 8 || attn_force_general()) {
     AttnParams2 pp{p, nt, head_dim};
     const size_t lds = (size_t)2 * nt * 32 * ROWB + (size_t)2 * nt * 32 * sizeof(float);

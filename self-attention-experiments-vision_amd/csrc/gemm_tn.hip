@@ -1802,6 +1802,10 @@ __global__ __launch_bounds__(512) void gemm_tn_pp320p_kernel(const GemmParams p)
       PP5_KTILE(2)
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count: every wave is past its last LDS read of this tile
+    // The next tile's K-tile 0 (requested one to two phases ago) is waited for HERE, in front of the epilogue's stores: vmcnt counts
+    // in order, so a wait placed behind the epilogue - next to the deferred requests - would also wait for every store of this tile
+    // to be acknowledged before the next tile may start (first build: each persistent launch 4-7 us SLOWER than one tile per workgroup).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // the accumulators are parked in the buffer that held the last K-tile (+ 8 KB of the spare next to it): 80 KB
     const int last = (v + KT - 1) & 1;
@@ -1832,16 +1836,12 @@ __global__ __launch_bounds__(512) void gemm_tn_pp320p_kernel(const GemmParams p)
     tm = ntm; tn = ntn;
     srdA = nsrdA; srdB = nsrdB;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // every wave has read its park back
-    if (KT > 1) {
-      dma_to(false, (v + 1) & 1, 1, 0);
-      dma_to(false, (v + 1) & 1, 1, 5); dma_to(false, (v + 1) & 1, 1, 6); dma_to(false, (v + 1) & 1, 1, 7);
-      dma_to(false, (v + 1) & 1, 1, 8);
-      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();  // every wave has read its park back; every wave's share of the next K-tile 0 had landed before its epilogue
+    dma_to(false, (v + 1) & 1, 1, 0);  // (K >= 128: there is a K-tile 1)
+    dma_to(false, (v + 1) & 1, 1, 5); dma_to(false, (v + 1) & 1, 1, 6); dma_to(false, (v + 1) & 1, 1, 7);
+    dma_to(false, (v + 1) & 1, 1, 8);
+    // no wait: K-tile 0 is complete (above), these five are what the steady state leaves in flight behind its vmcnt(5) - and the
+    // epilogue's stores drain under the next tile's first K-tile
     if (wr == 1) __builtin_amdgcn_s_barrier();
   }
 #undef PP5_READ_A

@@ -434,8 +434,7 @@ class ViTEngine:
             raise NotImplementedError("ViTEngine handles the ViT family; CaiT uses CaiTEngine")
         if cfg.head_dim not in (48, 64):
             raise NotImplementedError("attention kernels are built for head_dim 48 and 64")
-        if cfg.seq_len > 608:
-            raise NotImplementedError("attention kernels keep one head's K/V in LDS: seq_len <= 608")
+        # (any sequence length: up to 608 tokens one head's K / V stay resident in LDS, longer sequences stream them - csrc/attention.hip)
         if cfg.embed_dim % 64 != 0 or cfg.patch % 8 != 0 or cfg.num_classes % 8 != 0:
             raise ValueError("embed_dim % 64, patch % 8 and num_classes % 8 must be 0")
         if not torch.cuda.is_available():

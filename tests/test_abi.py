@@ -71,7 +71,7 @@ def test_shape_contracts_are_checked_on_the_host(built):
     assert L.savit_seq16_attention_bwd(P, P, P, 8, 16, 4, 16, 200, 1.0, None) == EINVAL
     # tiled attention: head_dim outside {16, 32, 48, 64}, too many tokens
     assert L.savit_attention_fwd(P, P, None, 2, 197, 3, 40, 3 * 3 * 40, None) == EINVAL
-    assert L.savit_attention_fwd(P, P, None, 2, 700, 3, 64, 3 * 3 * 64, None) == EINVAL
+    assert L.savit_attention_fwd(P, P, None, 2, 70000, 3, 64, 3 * 3 * 64, None) == EINVAL
     # per-image transpose: pitches must be multiples of 8 and cover the matrix; residual in/out come together
     assert L.savit_transpose_bf16(P, 196 * 128, 128, P, 128 * 190, 190, 2, 196, 128, None, None, 0, None, 0, None) == EINVAL  # ld_dst < R
     assert L.savit_transpose_bf16(P, 196 * 124, 124, P, 128 * 200, 200, 2, 196, 128, None, None, 0, None, 0, None) == EINVAL  # ld_src < Cc

@@ -554,9 +554,14 @@ def test_attention_fwd_spike(ops):
 
 @pytest.mark.parametrize("B,N,H,hd", [(2, 197, 3, 48), (1, 196, 8, 48), (1, 577, 2, 64), (1, 300, 1, 48), (2, 17, 2, 48), (1, 608, 1, 64),
                                       (392, 16, 4, 16), (5, 16, 4, 32), (2, 50, 2, 16),  # TNT's inner transformer: 16 pixel tokens, padded heads
-                                      (1, 256, 2, 48), (2, 129, 2, 48), (1, 384, 1, 64), (1, 545, 1, 32)])  # key tiles: 8 = 2 chunks, 5 = 1 + 1, 12, 18 = 4 + 2
+                                      (1, 256, 2, 48), (2, 129, 2, 48), (1, 384, 1, 64), (1, 545, 1, 32),  # key tiles: 8 = 2 chunks, 5 = 1 + 1, 12, 18 = 4 + 2
+                                      # N > 608: the streaming kernels (256-row segments, 8 row blocks per workgroup): ViT-B/16 at 512^2 =
+                                      # 1 025 tokens (33 tiles = 4 segments + 1 tile, 5 rounds of query blocks, the last with one wave active),
+                                      # 609 (just over the resident limit), 640 / 897 / 1 280 with the other head widths
+                                      (1, 1025, 2, 64), (1, 609, 1, 64), (2, 640, 3, 48), (1, 897, 1, 32), (1, 1280, 2, 16)])
 def test_attention_general_fwd_bwd(ops, B, N, H, hd):
-    """General kernels: head_dim 48 (every CaiT size) and N > 256 (ViT-L/16 at 384^2: N = 577), online softmax."""
+    """General kernels: head_dim 48 (every CaiT size) and N > 256 (ViT-L/16 at 384^2: N = 577), online softmax; N > 608: the streaming
+    kernels (same arithmetic, K / V and Q / dO through LDS in segments)."""
     rng = np.random.default_rng(B * 7 + N + hd)
     d = H * hd
     qkv = rb(rng.standard_normal((B * N, 3 * d)))

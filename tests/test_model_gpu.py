@@ -49,12 +49,14 @@ CASES = {
     "s1_p32": dict(kind="vit", num_layers=1, num_heads=6, embed_dim=384, patch=32, num_classes=1000, img_size=224),
     # ViT-L/16-at-384 geometry (N = 577 tokens: the online-softmax attention kernels) at a small width
     "n577": dict(kind="vit", num_layers=1, num_heads=2, embed_dim=128, patch=16, num_classes=16, img_size=384),
+    # ViT-B/16-at-512 geometry (N = 1 025 tokens: the STREAMING attention kernels, round 5 - the resident ones stop at 608) at a small width
+    "n1025": dict(kind="vit", num_layers=1, num_heads=2, embed_dim=128, patch=16, num_classes=16, img_size=512),
     # head_dim 48 (the CaiT head width) through the ViT engine
     "hd48": dict(kind="vit", num_layers=2, num_heads=4, embed_dim=192, patch=8, num_classes=16, img_size=32),
 }
 
 
-@pytest.mark.parametrize("case,B", [("tiny", 3), ("ti2", 4), ("s1_p32", 2), ("n577", 2), ("hd48", 3)])
+@pytest.mark.parametrize("case,B", [("tiny", 3), ("ti2", 4), ("s1_p32", 2), ("n577", 2), ("n1025", 2), ("hd48", 3)])
 def test_forward_backward_parity(pkg, case, B):
     from savit_amd.engine import ViTEngine
 
