@@ -1652,13 +1652,21 @@ __global__ __launch_bounds__(512) void gemm_tn_pp320p_kernel(const GemmParams p)
   const uint32_t a_unit = 64u * (uint32_t)(a.lda * 2), b_unit = 64u * (uint32_t)(a.ldb * 2);
   const int KT = a.K / 64;
 
-  // tile number `it` of this workgroup -> (row tile, column tile): within a round of G tiles each XCD (blocks b, b + 8, ...) takes a
-  // contiguous run of the row-grouped tile order, as the one-tile kernel's grid does
+  // tile number `it` of this workgroup -> (row tile, column tile).  As in the one-tile kernel's grid (xcd_remap) each XCD - the
+  // workgroups b, b + 8, ... - owns ONE contiguous run of the row-grouped tile order for the whole launch and its workgroups walk
+  // that run together (workgroup j of the XCD takes its tiles j, j + nx, j + 2 nx, ...), so the A row panels and the W column panels
+  // an XCD's L2 holds keep being reused from round to round.  (First build: every round re-dealt all tiles over the XCDs - each XCD
+  // jumped to another row group per round and the persistent launches ran 5-10 us SLOWER than one tile per workgroup.)
+  const int nxcd = G < 8 ? G : 8;                           // (fewer than 8 workgroups: a test grid)
+  const int xcd = blockIdx.x % nxcd, xj = blockIdx.x / nxcd;
+  const int nx = (G - xcd + nxcd - 1) / nxcd;               // workgroups of this XCD
+  const int xq = nwg / nxcd, xr = nwg % nxcd;
+  const int xbase = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+  const int xcount = xq + (xcd < xr ? 1 : 0);               // tiles of this XCD
   auto tile_of = [&](int it, int& tm, int& tn) -> bool {
-    const int first = it * G;
-    if (first + (int)blockIdx.x >= nwg) return false;
-    const int in_round = (nwg - first) < G ? (nwg - first) : G;
-    const int tid = first + xcd_remap(blockIdx.x, in_round);
+    const int k = it * nx + xj;
+    if (k >= xcount) return false;
+    const int tid = xbase + k;
     const int Gr = p.row_group, per = Gr * p.tiles_n;
     const int g = tid / per, rem = tid - g * per;
     const int rows_g = (p.tiles_m - g * Gr) < Gr ? (p.tiles_m - g * Gr) : Gr;
@@ -2135,8 +2143,17 @@ extern "C" int savit_gemm_tn_auto_tile_cus(int M, int N, int K, int epilogue, in
     const long c192 = ((t192 * 3 + 2L * cus - 1) / (2L * cus)) * 64 * 135 / 100;
     const long best = r320 <= r256 ? r320 : r256;
     //  * tile 22 = the 320 x 256 tile as a PERSISTENT grid (one workgroup per CU walking its tiles, the next tile's first K-tile
-    //    requested under the current tile's last phases and epilogue): launches of more than one round of tiles (round 5).
-    if (best <= c192 || (big && N >= 1024)) return r320 <= r256 ? ((long)(M + 319) / 320 * tn > cus ? 22 : 21) : 20;
+    //    requested under the current tile's last phases and epilogue; round 5).  Measured (tools/gemm_epi_bench.py 21 22, cold operands,
+    //    profiles/r05_gemm_persistent.log): it does NOT pay on DeiT-B's 3-4-round launches (qkv 92 -> 98 us, fc1 + GELU 146 -> 145,
+    //    GELU' 160 -> 163): vmcnt counts loads and stores in ONE in-order queue, so the first counted wait of the next tile also waits
+    //    for the previous tile's 20-40 stores per wave to be acknowledged - while every CU of the chip is draining its 160 KB tile at
+    //    the same moment - which a fresh workgroup of the one-tile grid never does.  On ViT-L's launches of 7-29 rounds with K >= 1024
+    //    (a tile's main loop is 30-120 us, the store drain a small part of it) it is neutral to 8 % faster (qkv 860 -> 813 us): taken
+    //    there only.
+    if (best <= c192 || (big && N >= 1024)) {
+      const long t320 = (long)(M + 319) / 320 * tn;
+      return r320 <= r256 ? ((K >= 1024 && t320 >= 6L * cus) ? 22 : 21) : 20;
+    }
   }
   if (big && N >= 1024 && K >= 768 && epilogue != SAVIT_EPI_PATCH) return 20;
   if (big && (epilogue == SAVIT_EPI_BIAS_GELU || K >= 1024)) return 13;
