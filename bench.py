@@ -103,7 +103,7 @@ def plan_symbols(eng) -> dict:
                 a = args[0]._obj
                 out[label] = tn_symbol(lib, a.M, a.N, a.K, a.epilogue, a.tile, a.cu_budget)
                 flops[label] = 2.0 * a.M * a.N * a.K  # algorithmic (operands padded with zeros - head, Mixer tokens - count as stored)
-            elif name == "savit_gemm_bf16_wgrad_grouped":
+            elif name in ("savit_gemm_bf16_wgrad_grouped", "savit_gemm_bf16_wgrad_grouped_ex"):
                 out[label] = WG_GROUP_TILES.get(int(args[2]), "gemm_wgrad_group tile %d" % int(args[2]))
     return out
 
@@ -667,12 +667,17 @@ def main():
         # rocprofv3 --pmc measurement of the same workload (tools/pmc_summary.py -> profiles/*_pmc_traffic.json), when it
         # covers this kernel and this is the headline workload; null otherwise.
         out["roofline"].update(traffic_lookup(dom, headline=(args.model == "vit_b_patch16" and B == 128 and args.img_size == 224)))
-        if dom.startswith("gemm_wgrad_group_kernel"):
-            # operands read once (X and dY of every weight of the group) + dW written once (fp32; round 5: the first tile of a weight
-            # stores, nothing is read back)  (every weight gradient of the model, spread over the grouped launches: each takes one tile per CU)
-            n_div = len(getattr(eng, "wgrad_divert", ()))
-            per_layer = sum(2 * M * (a + b_) + 4 * a * b_ for a, b_ in ((d, 3 * d), (d, d), (d, F), (F, d)))
-            out["roofline"]["algorithmic_bytes_per_launch"] = int((cfg.num_layers * per_layer - n_div * (4 * M * d + 4 * d * d)) / max(1e-9, out["roofline"]["launches_per_step"]))
+        if dom.startswith("gemm_wgrad_group"):
+            # operands read once (X and dY of every weight of a launch, by its share of the weight's tiles) + dW written once (fp32; round 5:
+            # first touch, nothing is read back), over the grouped launches of the backward plan
+            plan = eng._serial_bwd_plan() if not eng.overlap_wgrad else eng._current_bwd_plan()
+            tot = 0.0
+            for arr in plan.wgrad_arrays:
+                for q in arr:
+                    alltiles = int(eng.L.savit_gemm_wgrad_group_tiles(q.Kin, q.Nout, eng.wgrad_tile))
+                    cnt = q.tile_count if q.tile_count > 0 else alltiles - q.tile_begin
+                    tot += cnt / alltiles * (2.0 * q.M * (q.Kin + q.Nout) + (4.0 if q.overwrite else 8.0) * q.Kin * q.Nout)
+            out["roofline"]["algorithmic_bytes_per_launch"] = int(tot / max(1, len(plan.wgrad_arrays)))
 
     # ---- other BASELINE configs on this GPU (rank 0, N=1, headline workload only): short timings, after the headline engine is freed
     headline = args.model == "vit_b_patch16" and B == 128 and args.img_size == 224

@@ -50,6 +50,18 @@ int savit_layernorm_bwd_ex(const void* dy_bf16, const float* x, const float* gam
                            const float* dres_in, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* dcolsum,
                            int rows, int d, long x_stride, long out_stride, int round_params_bf16, void* workspace,
                            long workspace_bytes, const float* extra_slab, int extra_rows, int extra_n, float* extra_out, void* stream);
+/* The same (wide rows) for a row subset with a SPARSE residual gradient (round 5: the backward of a ViT's LAST encoder layer - only the
+ * cls rows reach the head (vit.py:57,95), so behind the final LayerNorm the residual gradient is exactly zero on every other row and
+ * the layer's MLP branch is differentiated on the B cls rows alone):
+ *   stat_stride: mean / rstd of row r are read at index r * stat_stride (the cls rows inside the per-token statistics: stride N);
+ *   res_mod = 0: dres_in as in savit_layernorm_bwd.  res_mod > 0: only rows r with r % res_mod == 0 have a residual gradient, stored
+ *   compactly at dres_in + (r / res_mod) * res_stride - the first DENSE LayerNorm backward above the cls-only part merges the compact
+ *   [B, d] residual gradient of the cls rows this way, so no [B*N, d] buffer is zero-filled to carry B rows.
+ * Every output pointer NULL: deferred column sums, as in savit_layernorm_bwd.  extra_*: as in savit_layernorm_bwd_ex (nullable). */
+int savit_layernorm_bwd_sparse(const void* dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd, int stat_stride,
+                               const float* dres_in, int res_mod, long res_stride, float* dx, void* dx_bf16, float* dgamma, float* dbeta,
+                               float* dcolsum, int rows, int d, long x_stride, long out_stride, int round_params_bf16, void* workspace,
+                               long workspace_bytes, const float* extra_slab, int extra_rows, int extra_n, float* extra_out, void* stream);
 /* Scratch the call above needs (per-block partial column sums; 16-B aligned, contents undefined afterwards). */
 long savit_layernorm_bwd_workspace_bytes(int rows, int d);
 

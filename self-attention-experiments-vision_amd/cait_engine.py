@@ -27,7 +27,8 @@ import torch
 
 from . import lib as _lib
 from .config import ModelConfig
-from .engine import ViTEngine, WgradQueue, _Plan, _align, _copy_tree, add_wgrad, add_wgrad_group, finalize_wgrad_ws, wgrad_group_tile
+from .engine import (ViTEngine, WgradQueue, _Plan, _align, _copy_tree, add_wgrad, add_wgrad_group, finalize_first_touch, finalize_wgrad_ws,
+                     wgrad_group_tile)
 from .timing import timed_call
 
 bf16 = torch.bfloat16
@@ -151,7 +152,8 @@ class CaiTEngine:
         self.params, self.grads = z(self.layout.total), z(self.layout.total)
         self.adam_m = self.adam_v = None
         self.step_count = 0
-        self.gnorm_sq = z(1)
+        self.gnorm = z(36)  # [0]: squared gradient norm; [1:33]: accumulators of the grouped weight-gradient launches (engine.py, round 5)
+        self.gnorm_sq = self.gnorm[0:1]
         self.w = {}
         for pre, n in (("", NL), ("c", NC)):
             for nm, R, Cc in (("Wqkv", d, 3 * d), ("Wo", d, d), ("W1", d, F), ("W2", F, d)):
@@ -223,7 +225,14 @@ class CaiTEngine:
         self.loss, self.loss_rows, self.top1, self.top5 = z(1), z(B), z(B), z(B)
         self._img_buf = e(B, cfg.img_size, cfg.img_size, 3, dt=bf16)
         self._fwd_plan = self._bwd_plan = self._cast_plan = None
-        self.bwd_hooks: Dict[str, object] = {}
+        self._bwd_hooks: Dict[str, object] = {}
+        self._data_parallel = False
+        # round 5, as in ViTEngine: first-touch grouped weight gradients, the gradient norm's squares carried by those launches, the
+        # LayerNorm / LayerScale column sums of the SA layers reduced by one launch at the end of backward (alone on the GPU only)
+        self.first_touch = _os.environ.get("SAVIT_WGRAD_FIRST_TOUCH", "1") != "0"
+        self.defer_ln_finalize = _os.environ.get("SAVIT_DEFER_LN_FINALIZE", "1") != "0"
+        self._gnorm_folded = False
+        self._accumulate_run = False
         self.launch_timer = None  # timing.LaunchTimer (bench.py, profile_step)
         self.weights_stale = True
         self.overlap_wgrad = _os.environ.get("SAVIT_OVERLAP_WGRAD", "1") != "0"
@@ -487,6 +496,21 @@ class CaiTEngine:
 
         ring, ri = [t.data_ptr() for t in self.dbr_ring], 0
         fuse_ls = d > 64  # savit_layernorm_bwd_ls serves wide rows (every head_dim 48 / 64 geometry)
+        # alone on the GPU the fused LayerNorm + LayerScale backward launches of the SA layers leave their column-sum slabs (four
+        # families) to ONE finalize launch at the end of backward (47 finalize launches + kernel boundaries per CaiT-S24 step)
+        defer = self.defer_ln_finalize and not self._data_parallel and fuse_ls
+        jobs: List[tuple] = []
+
+        def ln_bwd_ls(label, head7, outs2, mid, tail, outs_ls, extra, writes):
+            """savit_layernorm_bwd_ls; head7 = dy .. dx, outs2 = (dgamma, dbeta), mid = rows .. round, tail = branch .. dbranch,
+            outs_ls = (d_layerscale, dbias), extra = (slab, rows, n, out) or (None, 0, 0, None)"""
+            if defer:
+                wb = self._ln_ws_slot(len(jobs), mid[0], d)
+                P.add(L.savit_layernorm_bwd_ls, head7 + (None, None) + mid + tail + (None, None, wb.data_ptr(), wb.numel(), None, 0, 0, None), label,
+                      writes=writes)
+                jobs.append((wb.data_ptr(), int(L.savit_layernorm_bwd_grid(mid[0])), d, 4, outs2 + outs_ls, extra if extra[0] is not None else None))
+            else:
+                P.add(L.savit_layernorm_bwd_ls, head7 + outs2 + mid + tail + outs_ls + (ws, wsb) + extra, label, writes=writes)
         for l in range(NL - 1, -1, -1):
             st = self.stats[l]
             w = lambda n, l=l: self.w[n][l].data_ptr()  # noqa: E731
@@ -499,8 +523,9 @@ class CaiTEngine:
             wgrad_l(f"l{l}.W2.wgrad", l, self.a[l].data_ptr(), ring[ri], gp(f"l{l}.W2"), M, F, d, F, d, d)
             # bias gradient: per-row-tile partial sums to a slab + finalize, as in the ViT engine (atomic column sums cost this launch
             # 160 instead of 117 us at CaiT-S24: 50 k rows adding into 1536 addresses)
+            cslab = self._colsum_slab_for(l) if defer else self.colsum_slab  # (deferred: the slab lives until the end of backward)
             self._gemm(P, f"l{l}.fc2.dgrad", writes=(d_u,), A=ring[ri], Bt=w("W2_n"), C=d_u, aux=self.u[l].data_ptr(),
-                       colsum=self.colsum_slab.data_ptr(), colsum_rows=self.colsum_slab.shape[0], M=M, N=F, K=d, lda=d, ldb=d, ldc=F,
+                       colsum=cslab.data_ptr(), colsum_rows=cslab.shape[0], M=M, N=F, K=d, lda=d, ldb=d, ldc=F,
                        ldaux=F, epilogue=_lib.EPI_DGELU)
             if not fuse_ls:  # (fused: the slab's column sums ride along with this layer's ln2.bwd finalize)
                 P.add(L.savit_colsum_finalize, (self.colsum_slab.data_ptr(), self.colsum_slab.shape[0], F, gp(f"l{l}.b1"), 1), f"l{l}.b1.grad")
@@ -517,11 +542,10 @@ class CaiTEngine:
                 P.add(L.savit_layerscale_bwd, (self.dres.data_ptr(), self.br1[l].data_ptr(), pp(f"l{l}.ls1"), sd0, N, ring[ri], gp(f"l{l}.ls1"),
                                                None, M, d, d, ws, wsb), f"l{l}.ls1.bwd", writes=(ring[ri],))
             else:
-                P.add(L.savit_layernorm_bwd_ls, (self.d_h.data_ptr(), self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(),
-                                                 self.dres.data_ptr(), self.dres.data_ptr(), gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b"), M, d, d, d,
-                                                 self.rp, self.br1[l].data_ptr(), pp(f"l{l}.ls1"), sd0, N, ring[ri], gp(f"l{l}.ls1"), None, ws, wsb,
-                                                 self.colsum_slab.data_ptr(), self.colsum_slab.shape[0], F, gp(f"l{l}.b1")),
-                      f"l{l}.ln2.bwd", writes=(ring[ri],))
+                ln_bwd_ls(f"l{l}.ln2.bwd", (self.d_h.data_ptr(), self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(),
+                                            self.dres.data_ptr(), self.dres.data_ptr()), (gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b")), (M, d, d, d, self.rp),
+                          (self.br1[l].data_ptr(), pp(f"l{l}.ls1"), sd0, N, ring[ri]), (gp(f"l{l}.ls1"), None),
+                          (cslab.data_ptr(), cslab.shape[0], F, gp(f"l{l}.b1")), (ring[ri],))
             wgrad_l(f"l{l}.Wo.wgrad", l, self.o[l].data_ptr(), ring[ri], gp(f"l{l}.Wo"), M, d, d, d, d, d)
             self._gemm(P, f"l{l}.proj.dgrad", A=ring[ri], Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=M, N=d, K=d, lda=d, ldb=d, ldc=d,
                        epilogue=_lib.EPI_BF16)
@@ -539,11 +563,10 @@ class CaiTEngine:
             flush_group(l, last=(l == 0))
             if l > 0 and fuse_ls:  # ... and layer l-1's second sub-block behind this layer's first LayerNorm
                 ri = (ri + 1) % len(ring)
-                P.add(L.savit_layernorm_bwd_ls, (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
-                                                 self.dres.data_ptr(), self.dres.data_ptr(), gp(f"l{l}.ln1_g"), gp(f"l{l}.ln1_b"), M, d, d, d,
-                                                 self.rp, self.br2[l - 1].data_ptr(), pp(f"l{l - 1}.ls2"), self.sd[2 * l - 1].data_ptr(), N, ring[ri],
-                                                 gp(f"l{l - 1}.ls2"), gp(f"l{l - 1}.b2"), ws, wsb, None, 0, 0, None), f"l{l}.ln1.bwd",
-                      writes=(ring[ri],))
+                ln_bwd_ls(f"l{l}.ln1.bwd", (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
+                                            self.dres.data_ptr(), self.dres.data_ptr()), (gp(f"l{l}.ln1_g"), gp(f"l{l}.ln1_b")), (M, d, d, d, self.rp),
+                          (self.br2[l - 1].data_ptr(), pp(f"l{l - 1}.ls2"), self.sd[2 * l - 1].data_ptr(), N, ring[ri]),
+                          (gp(f"l{l - 1}.ls2"), gp(f"l{l - 1}.b2")), (None, 0, 0, None), (ring[ri],))
             else:  # the bf16 copy feeds the patch-embed weight gradient
                 P.add(L.savit_layernorm_bwd, (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
                                               self.dres.data_ptr(), self.dres.data_ptr(), self.dres_b.data_ptr(), gp(f"l{l}.ln1_g"),
@@ -551,7 +574,18 @@ class CaiTEngine:
         P.add(L.savit_pos_cls_grad, (self.dres.data_ptr(), gp("pos"), None, B, N, d, 0), "pos.grad")
         self._wgrad(P, "Wpe.wgrad", self._img_buf.data_ptr(), self.dres_b.data_ptr(), gp("Wpe"), M, cfg.patch_dim, d, 0, d, d,
                     patch=(cfg.patch, cfg.img_size, N, 0))
+        if jobs:
+            arr = (_lib.ColsumJob * len(jobs))()
+            for q, (partial, nblk, dd, nf, outs, extra) in zip(arr, jobs):
+                q.partial, q.nblk, q.d, q.nf = partial, nblk, dd, nf
+                for i, o in enumerate(outs):
+                    q.out[i] = o
+                if extra is not None:
+                    q.extra_slab, q.extra_rows, q.extra_n, q.extra_out = extra
+            P.keep.append(arr)
+            P.add(L.savit_layernorm_bwd_finalize_jobs, (arr, len(jobs)), "ln.bwd.finalize")
         finalize_wgrad_ws(self, P)
+        finalize_first_touch(self, P)
         return P
 
     # ------------------------------------------------------------------------------------ execution
@@ -608,11 +642,19 @@ class CaiTEngine:
         self._fwd_plan.run(self._stream(), self.launch_timer)
         return self.logits
 
+    # (the plan / gradient-buffer plumbing of ViTEngine, which this class does not derive from)
+    bwd_hooks = ViTEngine.bwd_hooks
+    _fold_sumsq_ok = ViTEngine._fold_sumsq_ok
+    _current_bwd_plan = ViTEngine._current_bwd_plan
+    _zero_grads_for_backward = ViTEngine._zero_grads_for_backward
+    _grad_sumsq = ViTEngine._grad_sumsq
+    _ln_ws_slot = ViTEngine._ln_ws_slot
+    _colsum_slab_for = ViTEngine._colsum_slab_for
+
     def loss_backward(self, labels, label_smoothing: float = 0.1, mix_labels=None, ratio=None, zero_grads: bool = True):
         s = self._stream()
         self.labels.copy_(labels.to(torch.int32))
-        if zero_grads:
-            self._zero("zero.grads", self.grads)
+        self._zero_grads_for_backward(zero_grads)
         self._zero("zero.loss", self.loss)
         ml = mr = None
         if mix_labels is not None:
@@ -647,9 +689,8 @@ class CaiTEngine:
         ss = None
         tm = self.launch_timer
         if max_norm and max_norm > 0:
-            self._zero("zero.gnorm", self.gnorm_sq)
-            timed_call(tm, "sumsq", self.L.savit_sumsq, self.grads.data_ptr(), self.grads.numel(), self.gnorm_sq.data_ptr(), s)
-            ss = self.gnorm_sq.data_ptr()
+            ss = self._grad_sumsq(tm, s)
+        self._gnorm_folded = False
         timed_call(tm, "adamw", self.L.savit_adamw_step, self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
                    self.params.numel(), float(lr), float(b1), float(b2), float(eps), float(weight_decay), self.step_count, ss,
                    float(max_norm or 0.0), float(grad_scale), s)

@@ -19,7 +19,11 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
                                                              const float* __restrict__ rstd_in, const float* dres_in,
                                                              float* dx_out, bf16_t* __restrict__ dx_bf16,
                                                              float* __restrict__ partial, int rows, int d, long x_stride,
-                                                             long out_stride, int round_params, int grp, int grp_stride, int grp_off) {
+                                                             long out_stride, int round_params, int grp, int grp_stride, int grp_off,
+                                                             int res_mod = 0, long res_stride = 0, int stat_stride = 1) {
+  // res_mod > 0: the residual-gradient input is SPARSE - only rows r with r % res_mod == 0 have one, stored compactly at
+  // dres_in + (r / res_mod) * res_stride (the cls rows of a ViT's last layer: engine.py, round 5); stat_stride: mean / rstd of row r
+  // sit at index r * stat_stride (the cls rows' statistics inside the per-token arrays of the forward pass).
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nchunk = d >> 2;
@@ -44,8 +48,13 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * x_stride);
     const size_t dyrow = grp > 0 ? (size_t)(row / grp) * grp_stride + grp_off + (row % grp) : (size_t)row;
     const uint2* dyr = reinterpret_cast<const uint2*>(dy + dyrow * d);
-    mean_n = mean_in[row];
-    rstd_n = rstd_in[row];
+    mean_n = mean_in[(size_t)row * stat_stride];
+    rstd_n = rstd_in[(size_t)row * stat_stride];
+    const float* rsrc = nullptr;
+    if (dres_in != nullptr) {
+      if (res_mod <= 0) rsrc = dres_in + (size_t)row * out_stride;
+      else if (row % res_mod == 0) rsrc = dres_in + (size_t)(row / res_mod) * res_stride;
+    }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int ci = lane + 64 * c;
@@ -55,7 +64,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
       if (ci < nchunk) {
         xv_n[c] = xr[ci];
         dv_n[c] = dyr[ci];
-        if (dres_in) rs_n[c] = reinterpret_cast<const float4*>(dres_in + (size_t)row * out_stride)[ci];
+        if (rsrc) rs_n[c] = reinterpret_cast<const float4*>(rsrc)[ci];
       }
     }
   };
@@ -579,6 +588,31 @@ extern "C" int savit_layernorm_bwd_ex(const void* dy, const float* x, const floa
               x_stride, out_stride, round_params_bf16, 0, 0, 0);
   hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * d + 63) / 64 + (extra_n + 63) / 64, FIN_SPLIT), dim3(256), 0, s, partial, grid, d,
                      dgamma, dbeta, dcolsum, extra_slab, extra_rows, extra_n, extra_out);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_layernorm_bwd_sparse(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                          int stat_stride, const float* dres_in, int res_mod, long res_stride, float* dx, void* dx_bf16,
+                                          float* dgamma, float* dbeta, float* dcolsum, int rows, int d, long x_stride, long out_stride,
+                                          int round_params_bf16, void* workspace, long workspace_bytes, const float* extra_slab,
+                                          int extra_rows, int extra_n, float* extra_out, void* stream) {
+  SAVIT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && x_stride >= d && out_stride >= d && (x_stride % 4) == 0 &&
+                  (out_stride % 4) == 0 && rows > 0 && d > 64 && (d % 4) == 0 && d <= 64 * 4 * LN_MAX_CHUNKS && stat_stride >= 1);
+  SAVIT_CHECK_ARG(res_mod >= 0 && (res_mod == 0 || (dres_in != nullptr && res_stride >= d && (res_stride % 4) == 0)));
+  SAVIT_CHECK_ARG(extra_slab == nullptr || (extra_out && extra_rows >= 0 && extra_n > 0 && extra_n % 4 == 0 && (dgamma || dbeta || dcolsum) &&
+                                            ((uintptr_t)extra_slab % 16) == 0 && ((uintptr_t)extra_out % 16) == 0));
+  SAVIT_CHECK_ARG(workspace != nullptr && ((uintptr_t)workspace % 16) == 0 && workspace_bytes >= savit_layernorm_bwd_workspace_bytes(rows, d));
+  hipStream_t s = (hipStream_t)stream;
+  const int ch = (d / 4 + 63) / 64;
+  float* partial = (float*)workspace;
+  const int grid = ln_bwd_grid(rows);
+  LN_DISPATCH(ch, ln_bwd_kernel, grid, (const bf16_t*)dy, x, gamma, mean, rstd, dres_in, dx, (bf16_t*)dx_bf16, partial, rows, d, x_stride,
+              out_stride, round_params_bf16, 0, 0, 0, res_mod, res_stride, stat_stride);
+  if (dgamma || dbeta || dcolsum) {
+    const int xn = extra_slab ? extra_n : 0;
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * d + 63) / 64 + (xn + 63) / 64, FIN_SPLIT), dim3(256), 0, s, partial, grid, d, dgamma,
+                       dbeta, dcolsum, extra_slab, extra_rows, xn, extra_out);
+  }
   SAVIT_LAUNCH_RET();
 }
 

@@ -522,6 +522,13 @@ class ViTEngine:
         # process-wide, so it is raised around THIS engine's backward launches only (`_run_bwd`): forward and optimizer have no
         # all-reduce beside them, and another engine in the process is not affected.
         self._building_bwd = False  # set while a backward plan is recorded: only its launches run beside the all-reduce
+        # Round 5: behind the final LayerNorm only the cls rows carry a gradient (vit.py:57,95: row 0 alone reaches the head), so the LAST
+        # encoder layer's MLP branch, its second LayerNorm and its output projection are differentiated on the B cls rows instead of the
+        # B*N token rows - every other row of those cotangents is exactly zero (ViTEngine._record_bwd_plan; wide models only)
+        cfg_ = getattr(self, "cfg", None)
+        self.cls_only_last = (os.environ.get("SAVIT_CLS_ONLY_LAST", "1") != "0" and getattr(cfg_, "kind", "") == "vit" and
+                              cfg_.embed_dim > 64 and cfg_.seq_len > 1)
+        self._needs_zero_dres = True
         if wgrad_max_lag is None and os.environ.get("SAVIT_WGRAD_MAX_LAG"):
             wgrad_max_lag = int(os.environ["SAVIT_WGRAD_MAX_LAG"])
         self.wgrad_max_lag = wgrad_max_lag
@@ -741,8 +748,21 @@ class ViTEngine:
         defer = self.defer_ln_finalize and not self._data_parallel and d > 64
         jobs: List[tuple] = []
 
-        def ln_bwd(label, head8, outs3, tail5, extra=None, writes=()):
+        def ln_bwd(label, head8, outs3, tail5, extra=None, writes=(), sparse=None):
             rows = tail5[0]
+            if sparse is not None:
+                # savit_layernorm_bwd_sparse: statistics at a row stride, residual gradient of every res_mod-th row only (compact)
+                stat_stride, res_mod, res_stride = sparse
+                wbuf, outs = (ws, wsb), outs3
+                if defer:
+                    wb = self._ln_ws_slot(len(jobs), rows, d)
+                    wbuf, outs = (wb.data_ptr(), wb.numel()), (None, None, None)
+                ex = extra if (extra is not None and not defer) else (None, 0, 0, None)
+                P.add(L.savit_layernorm_bwd_sparse, head8[:5] + (stat_stride, head8[5], res_mod, res_stride) + head8[6:8] + outs + tail5 + wbuf + ex,
+                      label, writes=writes)
+                if defer:
+                    jobs.append((wbuf[0], int(L.savit_layernorm_bwd_grid(rows)), d, 3, outs3 + (None,), extra))
+                return
             if defer:
                 k = len(jobs)
                 wbuf = self._ln_ws_slot(k, rows, d)
@@ -772,13 +792,51 @@ class ViTEngine:
         wgrad("head.wgrad", self.zcls.data_ptr(), self.dlogits.data_ptr(), gp("Wh"), B, d, C, d, self.Cp, C)
         self._gemm(P, "head.dgrad", A=self.dlogits.data_ptr(), Bt=self.w["Wh_n"].data_ptr(), C=self.d_z.data_ptr(), M=B, N=d, K=self.Cp,
                    lda=self.Cp, ldb=self.Cp, ldc=d, epilogue=_lib.EPI_BF16)
-        ln_bwd("lnf.bwd", (self.d_z.data_ptr(), self.x[NL].data_ptr(), pp("lnf_g"), self.fstats[0].data_ptr(), self.fstats[1].data_ptr(), None,
-                           self.dres.data_ptr(), ring[0]), (gp("lnf_g"), gp("lnf_b"), gp(f"l{NL - 1}.b2")), (B, d, N * d, N * d, self.rp),
-               writes=(ring[0],))
+        cls_last = bool(self.cls_only_last)
+        self._needs_zero_dres = not cls_last
+        cb = self._cls_buffers() if cls_last else None
+        if cls_last:
+            # compact [B, d] residual gradient of the cls rows (fp32) and its bf16 copy: no [B*N, d] buffer is zero-filled to carry B rows
+            ln_bwd("lnf.bwd", (self.d_z.data_ptr(), self.x[NL].data_ptr(), pp("lnf_g"), self.fstats[0].data_ptr(), self.fstats[1].data_ptr(), None,
+                               cb["dres"].data_ptr(), cb["rb0"].data_ptr()), (gp("lnf_g"), gp("lnf_b"), gp(f"l{NL - 1}.b2")), (B, d, N * d, d, self.rp))
+        else:
+            ln_bwd("lnf.bwd", (self.d_z.data_ptr(), self.x[NL].data_ptr(), pp("lnf_g"), self.fstats[0].data_ptr(), self.fstats[1].data_ptr(), None,
+                               self.dres.data_ptr(), ring[0]), (gp("lnf_g"), gp("lnf_b"), gp(f"l{NL - 1}.b2")), (B, d, N * d, N * d, self.rp),
+                   writes=(ring[0],))
         for l in range(NL - 1, -1, -1):
             st = self.stats[l]
             w = lambda n, l=l: self.w[n][l].data_ptr()  # noqa: E731
             d_u, dqkv = self.d_u_ring[l % len(self.d_u_ring)].data_ptr(), self.dqkv_ring[l % len(self.dqkv_ring)].data_ptr()
+            if cls_last and l == NL - 1:
+                # ---- the LAST layer, cls rows only (B rows at pitch N * width inside the saved activations; compact cotangents).  Same
+                # kernels, same arithmetic per row: the rows left out contribute exact zeros to every sum below.
+                Nd, NF = N * d, N * F
+                rb0, rb1, du_c, dh_c, dres_c, cs = (cb[k].data_ptr() for k in ("rb0", "rb1", "d_u", "d_h", "dres", "slab"))
+                wgrad(f"l{l}.W2.wgrad", self.a[l].data_ptr(), rb0, gp(f"l{l}.W2"), B, F, d, NF, d, d)
+                self._gemm(P, f"l{l}.fc2.dgrad", A=rb0, Bt=w("W2_n"), C=du_c, aux=self.u[l].data_ptr(), colsum=cs, colsum_rows=cb["slab"].shape[0],
+                           M=B, N=F, K=d, lda=d, ldb=d, ldc=F, ldaux=NF, epilogue=_lib.EPI_DGELU)
+                wgrad(f"l{l}.W1.wgrad", self.h2[l].data_ptr(), du_c, gp(f"l{l}.W1"), B, d, F, Nd, F, F)
+                self._gemm(P, f"l{l}.fc1.dgrad", A=du_c, Bt=w("W1_n"), C=dh_c, M=B, N=d, K=F, lda=F, ldb=F, ldc=d, epilogue=_lib.EPI_BF16)
+                ln_bwd(f"l{l}.ln2.bwd", (dh_c, self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(), dres_c, dres_c, rb1),
+                       (gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b"), None), (B, d, Nd, d, self.rp),
+                       extra=(cs, cb["slab"].shape[0], F, gp(f"l{l}.b1")), sparse=(N, 0, 0))
+                wgrad(f"l{l}.Wo.wgrad", self.o[l].data_ptr(), rb1, gp(f"l{l}.Wo"), B, d, d, Nd, d, d)
+                # attention backward reads every row of d_o: zero it, then the projection's input gradient fills the cls rows
+                P.add(L.savit_zero_bytes, (self.d_o.data_ptr(), self.d_o.numel() * 2), "zero.d_o")
+                self._gemm(P, f"l{l}.proj.dgrad", A=rb1, Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=B, N=d, K=d, lda=d, ldb=d, ldc=Nd, epilogue=_lib.EPI_BF16)
+                P.add(L.savit_attention_bwd, (self.qkv[l].data_ptr(), self.o[l].data_ptr(), self.d_o.data_ptr(), self.lse[l].data_ptr(),
+                                              dqkv, B, N, H, cfg.head_dim, 3 * d, 1.0 / math.sqrt(cfg.head_dim)), f"l{l}.attn.bwd", writes=(dqkv,))
+                wgrad(f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), dqkv, gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d, layer=l)
+                self._gemm(P, f"l{l}.qkv.dgrad", A=dqkv, Bt=w("Wqkv_n"), C=self.d_h.data_ptr(), M=M, N=d, K=3 * d, lda=3 * d, ldb=3 * d, ldc=d,
+                           epilogue=_lib.EPI_BF16)
+                flush_group(l, last=(l == 0))
+                ri = (ri + 1) % len(ring)
+                # the first dense LayerNorm backward merges the compact residual gradient of the cls rows (rows r % N == 0)
+                ln_bwd(f"l{l}.ln1.bwd", (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(), dres_c,
+                                         self.dres.data_ptr(), ring[ri]),
+                       (gp(f"l{l}.ln1_g"), gp(f"l{l}.ln1_b"), gp(f"l{l - 1}.b2") if l > 0 else None), (M, d, d, d, self.rp), writes=(ring[ri],),
+                       sparse=(1, N, d))
+                continue
             # FFN branch: x_{l+1} = x_mid + gelu(h2 W1 + b1) W2 + b2     (ff.py:26-33, vit.py:26-31)
             wgrad(f"l{l}.W2.wgrad", self.a[l].data_ptr(), ring[ri], gp(f"l{l}.W2"), M, F, d, F, d, d, layer=l)
             # db1 = column sums of d_u: per-row-tile partials (plain stores) + a finalize launch; ~200 row tiles adding into the
@@ -833,6 +891,17 @@ class ViTEngine:
             buf = self._ln_ws_slots[k] = torch.empty(need, dtype=torch.uint8, device=self.dev)
         return buf
 
+    def _cls_buffers(self) -> dict:
+        """Compact cotangents of the cls rows for the last layer's backward (cls_only_last): [B, d] / [B, F], and the bias-gradient slab
+        of its B-row GELU' GEMM."""
+        if not hasattr(self, "_cls_bufs"):
+            cfg, B = self.cfg, self.B
+            d, F = cfg.embed_dim, cfg.hidden
+            e = lambda *s_, dt=bf16: torch.empty(*s_, dtype=dt, device=self.dev)  # noqa: E731
+            rows = max(1, int(self.L.savit_gemm_colsum_rows_cus(B, F, d, 0, self.cu_budget if self.reserved_cus else 0)))
+            self._cls_bufs = {"dres": e(B, d, dt=f32), "rb0": e(B, d), "rb1": e(B, d), "d_u": e(B, F), "d_h": e(B, d), "slab": e(rows, F, dt=f32)}
+        return self._cls_bufs
+
     def _colsum_slab_for(self, l: int) -> torch.Tensor:
         if not hasattr(self, "_colsum_slabs"):
             self._colsum_slabs = {}
@@ -862,7 +931,9 @@ class ViTEngine:
         sizes = [(n, int(self.L.savit_gemm_wgrad_group_tiles(a, b, tile))) for n, a, b in (("W2", F, d), ("W1", d, F), ("Wo", d, d), ("Wqkv", d, 3 * d))]
         per_layer = sum(t for _, t in sizes)
         cap = self.cu_budget
-        total = NL * per_layer
+        cls_last = bool(getattr(self, "cls_only_last", False)) and type(self)._record_bwd_plan is ViTEngine._record_bwd_plan
+        skip_last = {"W2", "W1", "Wo"} if cls_last else set()  # (cls rows only: 128-row products, one launch per weight)
+        total = NL * per_layer - sum(t for n, t in sizes if n in skip_last)
         rounds = -(-total // cap)
         need = total - (rounds - 1) * cap  # tiles in the last, partial round
         wo = dict(sizes)["Wo"]
@@ -873,7 +944,7 @@ class ViTEngine:
         q, lag = WgradQueue(cap, self.wgrad_max_lag), 0
         for l in range(NL - 1, -1, -1):
             for n, t in sizes:
-                if not (n == "Wo" and l in divert):
+                if not (n == "Wo" and l in divert) and not (l == NL - 1 and n in skip_last):
                     q.push(None, l, t)
             while q.pending() > 0 and (q.due(l) or l == 0):
                 _, _, oldest = q.take(cap)
@@ -996,8 +1067,11 @@ class ViTEngine:
 
     def backward_from_dlogits(self):
         """Backward from self.dlogits (bf16 [B, Cp], pad columns zero) into self.grads (accumulating)."""
-        self._zero("zero.dres", self.dres)
-        self._zero("zero.dres_b", self.dres_b)  # ring slot 0: lnf.bwd fills only the cls rows
+        if getattr(self, "_needs_zero_dres", True):
+            self._current_bwd_plan()  # (recording the plan decides whether the dense residual-gradient buffers carry the cls rows)
+        if getattr(self, "_needs_zero_dres", True):
+            self._zero("zero.dres", self.dres)
+            self._zero("zero.dres_b", self.dres_b)  # ring slot 0: lnf.bwd fills only the cls rows
         self._run_bwd()
 
     def _run_bwd(self):

@@ -61,6 +61,8 @@ _SIGNATURES = {
     "savit_layernorm_bwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_long, c_long, c_int, c_void_p, c_long, c_void_p]),
     "savit_layernorm_bwd_ex": (c_int, [c_void_p] * 11 + [c_int, c_int, c_long, c_long, c_int, c_void_p, c_long, c_void_p, c_int, c_int, c_void_p,
                                        c_void_p]),
+    "savit_layernorm_bwd_sparse": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_int, c_long] + [c_void_p] * 5 + [c_int, c_int, c_long, c_long, c_int, c_void_p,
+                                           c_long, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "savit_layernorm_bwd_workspace_bytes": (c_long, [c_int, c_int]),
     "savit_layernorm_bwd_grid": (c_int, [c_int]),
     "savit_layernorm_bwd_finalize_jobs": (c_int, [POINTER(ColsumJob), c_int, c_void_p]),
