@@ -504,7 +504,7 @@ def test_last_layer_backward_on_cls_rows_only(name, B, img, monkeypatch):
     torch.cuda.synchronize()
     g0 = e0.grads.clone()
     lay, NL = e1.layout, cfg.num_layers
-    assert abs(float(e0.loss) - float(e1.loss)) == 0.0
+    assert abs(float(e0.loss) - float(e1.loss)) < 2e-6 * float(e0.loss)  # same forward; the scalar loss is an fp32 atomic sum over the rows
     for l in range(NL):
         for v in ("Wqkv", "Wo", "W1", "W2", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "b1", "b2"):
             a, b = lay.view(g0, f"l{l}.{v}"), lay.view(g1, f"l{l}.{v}")
