@@ -424,6 +424,11 @@ int savit_colsum_f32(const float* x, float* out, int M, int N, int ld, void* str
 int savit_softmax_xent_grad_f32(const float* logits, const int* labels, float label_smoothing, float grad_scale, float* dlogits, int B, int C,
                                 void* stream);
 int savit_patchify_f32(const float* images, float* patches, int B, int img_size, int patch, void* stream);
+/* The same rearrange on NHWC bf16 images (patch % 8 == 0; 16-byte accesses on both sides) into patches_bf16 [B * tokens, patch*patch*3]:
+ * patch p of image b at row b * tokens + token_offset + p - the row of its token in the [B * tokens, d] activations; the other rows (the
+ * cls slot) are not written (zero-fill once).  The dense operand of the patch-embed weight gradient when it runs as tiles of
+ * savit_gemm_bf16_wgrad_grouped: X rows and cotangent rows line up, the cls rows contribute zeros (round 5). */
+int savit_patchify_bf16(const void* images_bf16, void* patches_bf16, int B, int img_size, int patch, int tokens, int token_offset, void* stream);
 int savit_assemble_tokens_f32(const float* tok, const float* cls, const float* pos, float* x0, int B, int N, int d, void* stream);
 
 /* ---- measurement (bench.py, timing.py).  Not part of the training path: brackets for it.

@@ -2126,9 +2126,10 @@ extern "C" int savit_gemm_tn_auto_tile_cus(int M, int N, int K, int epilogue, in
   //    those shapes too (SAVIT_EPI_SHAPE=50432,384,1536 tools/gemm_epi_bench.py), inside the training step - warm operands, same box,
   //    alternating runs - DeiT-S lost 1.4 % (17.63 -> 17.38 k img/s) and CaiT-S24, TNT, Mixer did not move.
   static const int pp_min_k = SAVIT_EXP_ENV_INT("SAVIT_PP_MIN_K", 768);  // SAVIT_EXPERIMENTS builds only (A/B runs)
-  // (round 5: K >= 384 for the wide outputs too - DeiT-S / CaiT-S fc1 and fc2 input gradient, N = 1536: in the training step, same box,
-  //  alternating runs: DeiT-S 19 458 / 19 515 -> 19 686 / 19 717 img/s, CaiT-S24 6 524 -> 6 552; with cold operands fc1 + GELU 121 -> 103 us)
-  if ((K >= pp_min_k || (K >= 384 && N >= 1024 && pp_min_k == 768)) && N % 256 == 0 && M >= 4096 && epilogue != SAVIT_EPI_PATCH) {
+  // (round 5: also K = 384 with a wide output - DeiT-S / CaiT-S fc1 and fc2 input gradient, N = 1536: in the training step, same box,
+  //  alternating runs: DeiT-S 19 458 / 19 515 -> 19 686 / 19 717 img/s, CaiT-S24 6 524 -> 6 552; with cold operands fc1 + GELU 121 -> 103 us.
+  //  NOT K = 512 / 640: MLP-Mixer-S/16 (d = 512, N = 2048) lost 3.2 % with it (23 403 -> 22 657 img/s), TNT-B's outer stream 0.3 %.)
+  if ((K >= pp_min_k || (K == 384 && N >= 1024 && pp_min_k == 768)) && N % 256 == 0 && M >= 4096 && epilogue != SAVIT_EPI_PATCH) {
     //  * 320x256 ping-pong (tile 21, round 3) against 256x256 (tile 20) and 192x128 (17 / 18): what a launch costs is (rounds of
     //    workgroups over the CUs) x (rows of a tile), weighted by what the tile's operand feed costs - the L2 -> LDS path of a CU, not
     //    the matrix pipe, bounds these kernels, and a 192x128 tile moves 1.7x the bytes per flop of a 256-wide one (measured: the same

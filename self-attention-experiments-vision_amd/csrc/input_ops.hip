@@ -102,6 +102,29 @@ __global__ __launch_bounds__(256) void cutmix_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// patches[b * g * g + ph * g + pw][ (y * P + x) * 3 + c ] = images[b][ph * P + y][pw * P + x][c]   (patch_embed.py:19-22 on NHWC bf16 images):
+// the dense [B * n, P * P * 3] operand of the patch-embed WEIGHT gradient, so that it can join the tile FIFO of the grouped launches
+// (round 5; the forward product and its input-gradient-free backward keep gathering from the images).  A thread moves one 16-byte
+// chunk: a patch row is P * 3 contiguous elements in the image (P % 8 == 0: whole chunks), the patch matrix is written contiguously.
+// Patch p of image b goes to row b * tokens + token_offset + p (the token's row in the [B * tokens, d] activations, so the matrix lines up
+// row by row with a cotangent of the token stream; rows of other tokens - the cls slot - are never written: the caller zero-fills once).
+__global__ __launch_bounds__(256) void patchify_bf16_kernel(const bf16_t* __restrict__ img, bf16_t* __restrict__ out, int B, int S, int P, int tokens,
+                                                            int token_offset) {
+  const int g = S / P, cpr = P * 3 / 8;       // 16-byte chunks per patch row
+  const long chunks = (long)B * g * g * P * cpr;
+  const long cpp = (long)P * cpr;              // chunks per patch
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long)gridDim.x * 256) {
+    const int ck = (int)(i % cpr);
+    long r = i / cpr;
+    const int y = (int)(r % P);
+    r /= P;
+    const int pw = (int)(r % g), ph = (int)((r / g) % g), b = (int)(r / ((long)g * g));
+    const size_t src = (((size_t)b * S + (size_t)ph * P + y) * S + (size_t)pw * P) * 3 + (size_t)ck * 8;
+    const long orow = (long)b * tokens + token_offset + (long)ph * g + pw;
+    reinterpret_cast<uint4*>(out)[orow * cpp + (long)y * cpr + ck] = *reinterpret_cast<const uint4*>(img + src);
+  }
+}
+
 }  // namespace
 
 extern "C" int savit_normalize_to_nhwc_bf16(const void* src, int src_format, void* dst, int H, int W, int C, int N, float scale,
@@ -152,5 +175,18 @@ extern "C" int savit_batch_cutmix_bf16(const void* x, void* out, const int* box,
   long bx = ((long)H * W + 255) / 256;
   if (bx > 4096) bx = 4096;
   hipLaunchKernelGGL(cutmix_kernel, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, box, index, H, W, C);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_patchify_bf16(const void* images, void* patches, int B, int img_size, int patch, int tokens, int token_offset, void* stream) {
+  SAVIT_CHECK_ARG(images && patches && B >= 0 && patch > 0 && patch % 8 == 0 && img_size > 0 && img_size % patch == 0);
+  SAVIT_CHECK_ARG(token_offset >= 0 && tokens >= token_offset + (img_size / patch) * (img_size / patch));
+  SAVIT_CHECK_ARG(((uintptr_t)images % 16) == 0 && ((uintptr_t)patches % 16) == 0);
+  if (B == 0) return SAVIT_OK;
+  const long chunks = (long)B * img_size * img_size * 3 / 8;
+  long blocks = (chunks + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(patchify_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)images, (bf16_t*)patches, B,
+                     img_size, patch, tokens, token_offset);
   SAVIT_LAUNCH_RET();
 }

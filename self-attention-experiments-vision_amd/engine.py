@@ -529,6 +529,7 @@ class ViTEngine:
         self.cls_only_last = (os.environ.get("SAVIT_CLS_ONLY_LAST", "1") != "0" and getattr(cfg_, "kind", "") == "vit" and
                               cfg_.embed_dim > 64 and cfg_.seq_len > 1)
         self._needs_zero_dres = True
+        self._cls_per_weight = frozenset({"W2", "W1", "Wo"})  # (_wgrad_group_plan moves the ones that fit the last round into the tile FIFO)
         if wgrad_max_lag is None and os.environ.get("SAVIT_WGRAD_MAX_LAG"):
             wgrad_max_lag = int(os.environ["SAVIT_WGRAD_MAX_LAG"])
         self.wgrad_max_lag = wgrad_max_lag
@@ -730,7 +731,9 @@ class ViTEngine:
                 return
             self._add_wgrad(P, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, self._wgrad_splits(Kin, Nout, patch[0]), patch)
 
-        def flush_group(layer: int, last: bool):
+        wpe_g = bool(getattr(self, "_wpe_grouped", False)) and queue is not None and not self._data_parallel
+
+        def flush_group(layer: int, last: bool, final: bool = False):
             # called between a layer's last input-gradient GEMM and its ln1.bwd (which overwrites the oldest ring slot): every
             # cotangent of the last `wgrad_lag` + 1 layers is still intact.  A launch takes one tile per CU; the DDP trigger
             # ('l{j}.ln1.bwd') of an EARLIER layer whose last tile is in it fires behind it, the current layer's own follows naturally.
@@ -738,7 +741,7 @@ class ViTEngine:
                 entries, done, oldest = queue.take(queue.cap)
                 assert oldest - layer <= self.wgrad_lag, "weight-gradient queue reaches back further than the cotangent rings"
                 add_wgrad_group(self, P, f"wgrad.group.{n_launch[0]}.l{oldest}-l{layer}", entries, self.wgrad_tile,
-                                [f"l{j}.ln1.bwd" for j in done if j != layer])
+                                [f"l{j}.ln1.bwd" for j in done if (j != layer or final)] + (["Wpe.wgrad"] if final else []))
                 n_launch[0] += 1
 
         # LayerNorm backward launches.  Alone on the GPU (no data-parallel bucket trigger needs the bias / LayerNorm gradients layer by
@@ -812,15 +815,16 @@ class ViTEngine:
                 # kernels, same arithmetic per row: the rows left out contribute exact zeros to every sum below.
                 Nd, NF = N * d, N * F
                 rb0, rb1, du_c, dh_c, dres_c, cs = (cb[k].data_ptr() for k in ("rb0", "rb1", "d_u", "d_h", "dres", "slab"))
-                wgrad(f"l{l}.W2.wgrad", self.a[l].data_ptr(), rb0, gp(f"l{l}.W2"), B, F, d, NF, d, d)
+                cq = lambda n: (None if n in self._cls_per_weight else l)  # noqa: E731  (a tile of the grouped launches, or a launch of its own)
+                wgrad(f"l{l}.W2.wgrad", self.a[l].data_ptr(), rb0, gp(f"l{l}.W2"), B, F, d, NF, d, d, layer=cq("W2"))
                 self._gemm(P, f"l{l}.fc2.dgrad", A=rb0, Bt=w("W2_n"), C=du_c, aux=self.u[l].data_ptr(), colsum=cs, colsum_rows=cb["slab"].shape[0],
                            M=B, N=F, K=d, lda=d, ldb=d, ldc=F, ldaux=NF, epilogue=_lib.EPI_DGELU)
-                wgrad(f"l{l}.W1.wgrad", self.h2[l].data_ptr(), du_c, gp(f"l{l}.W1"), B, d, F, Nd, F, F)
+                wgrad(f"l{l}.W1.wgrad", self.h2[l].data_ptr(), du_c, gp(f"l{l}.W1"), B, d, F, Nd, F, F, layer=cq("W1"))
                 self._gemm(P, f"l{l}.fc1.dgrad", A=du_c, Bt=w("W1_n"), C=dh_c, M=B, N=d, K=F, lda=F, ldb=F, ldc=d, epilogue=_lib.EPI_BF16)
                 ln_bwd(f"l{l}.ln2.bwd", (dh_c, self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(), dres_c, dres_c, rb1),
                        (gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b"), None), (B, d, Nd, d, self.rp),
                        extra=(cs, cb["slab"].shape[0], F, gp(f"l{l}.b1")), sparse=(N, 0, 0))
-                wgrad(f"l{l}.Wo.wgrad", self.o[l].data_ptr(), rb1, gp(f"l{l}.Wo"), B, d, d, Nd, d, d)
+                wgrad(f"l{l}.Wo.wgrad", self.o[l].data_ptr(), rb1, gp(f"l{l}.Wo"), B, d, d, Nd, d, d, layer=cq("Wo"))
                 # attention backward reads every row of d_o: zero it, then the projection's input gradient fills the cls rows
                 P.add(L.savit_zero_bytes, (self.d_o.data_ptr(), self.d_o.numel() * 2), "zero.d_o")
                 self._gemm(P, f"l{l}.proj.dgrad", A=rb1, Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=B, N=d, K=d, lda=d, ldb=d, ldc=Nd, epilogue=_lib.EPI_BF16)
@@ -829,7 +833,7 @@ class ViTEngine:
                 wgrad(f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), dqkv, gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d, layer=l)
                 self._gemm(P, f"l{l}.qkv.dgrad", A=dqkv, Bt=w("Wqkv_n"), C=self.d_h.data_ptr(), M=M, N=d, K=3 * d, lda=3 * d, ldb=3 * d, ldc=d,
                            epilogue=_lib.EPI_BF16)
-                flush_group(l, last=(l == 0))
+                flush_group(l, last=(l == 0 and not wpe_g))
                 ri = (ri + 1) % len(ring)
                 # the first dense LayerNorm backward merges the compact residual gradient of the cls rows (rows r % N == 0)
                 ln_bwd(f"l{l}.ln1.bwd", (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(), dres_c,
@@ -865,15 +869,24 @@ class ViTEngine:
             wgrad(f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), dqkv, gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d, layer=l)
             self._gemm(P, f"l{l}.qkv.dgrad", A=dqkv, Bt=w("Wqkv_n"), C=self.d_h.data_ptr(), M=M, N=d, K=3 * d, lda=3 * d,
                        ldb=3 * d, ldc=d, epilogue=_lib.EPI_BF16)
-            flush_group(l, last=(l == 0))
+            flush_group(l, last=(l == 0 and not wpe_g))
             ri = (ri + 1) % len(ring)
             ln_bwd(f"l{l}.ln1.bwd", (self.d_h.data_ptr(), self.x[l].data_ptr(), pp(f"l{l}.ln1_g"), st[0].data_ptr(), st[1].data_ptr(),
                                      self.dres.data_ptr(), self.dres.data_ptr(), ring[ri]),
                    (gp(f"l{l}.ln1_g"), gp(f"l{l}.ln1_b"), gp(f"l{l - 1}.b2") if l > 0 else None), (M, d, d, d, self.rp), writes=(ring[ri],))
         # ---- embeddings: dpos, dcls, dWpe   (vit.py:77-85, position_embed.py:56, patch_embed.py:23-25)
         P.add(L.savit_pos_cls_grad, (self.dres.data_ptr(), gp("pos"), gp("cls"), B, N, d, 1), "pos_cls.grad")
-        wgrad("Wpe.wgrad", self._img_buf.data_ptr(), ring[ri], gp("Wpe"), B * cfg.n_patches, cfg.patch_dim, d, 0, d, d,
-              patch=(cfg.patch, cfg.img_size, N, 1))
+        if wpe_g:
+            # the patch-embed weight gradient as tiles of the last grouped launch: X = the dense patch matrix, one row per TOKEN (the cls
+            # rows stay zero), so that it lines up with the bf16 residual gradient row by row
+            pm = self._patch_matrix()
+            P.add(L.savit_patchify_bf16, (self._img_buf.data_ptr(), pm.data_ptr(), B, cfg.img_size, cfg.patch, N, 1), "patchify")
+            queue.push((pm.data_ptr(), ring[ri], gp("Wpe"), M, cfg.patch_dim, d, cfg.patch_dim, d, d), 0,
+                       int(L.savit_gemm_wgrad_group_tiles(cfg.patch_dim, d, self.wgrad_tile)))
+            flush_group(0, last=True, final=True)
+        else:
+            wgrad("Wpe.wgrad", self._img_buf.data_ptr(), ring[ri], gp("Wpe"), B * cfg.n_patches, cfg.patch_dim, d, 0, d, d,
+                  patch=(cfg.patch, cfg.img_size, N, 1))
         flush_ln_jobs("ln.bwd.finalize")
         finalize_wgrad_ws(self, P)
         finalize_first_touch(self, P)
@@ -901,6 +914,12 @@ class ViTEngine:
             rows = max(1, int(self.L.savit_gemm_colsum_rows_cus(B, F, d, 0, self.cu_budget if self.reserved_cus else 0)))
             self._cls_bufs = {"dres": e(B, d, dt=f32), "rb0": e(B, d), "rb1": e(B, d), "d_u": e(B, F), "d_h": e(B, d), "slab": e(rows, F, dt=f32)}
         return self._cls_bufs
+
+    def _patch_matrix(self) -> torch.Tensor:
+        """[B * N, patch_dim] bf16: the patches of the current images at their tokens' rows (savit_patchify_bf16); the cls rows stay zero."""
+        if not hasattr(self, "_patches"):
+            self._patches = torch.zeros(self.B * self.cfg.seq_len, self.cfg.patch_dim, dtype=bf16, device=self.dev)
+        return self._patches
 
     def _colsum_slab_for(self, l: int) -> torch.Tensor:
         if not hasattr(self, "_colsum_slabs"):
@@ -932,8 +951,28 @@ class ViTEngine:
         per_layer = sum(t for _, t in sizes)
         cap = self.cu_budget
         cls_last = bool(getattr(self, "cls_only_last", False)) and type(self)._record_bwd_plan is ViTEngine._record_bwd_plan
-        skip_last = {"W2", "W1", "Wo"} if cls_last else set()  # (cls rows only: 128-row products, one launch per weight)
+        # The last layer's W2 / W1 / Wo gradients are 128-row products (cls rows only).  As tiles of the grouped launches they cost
+        # nothing where the last round has free slots (their tiles end after 4 stages of tokens); the ones that do not fit keep a launch
+        # of their own.  Their cotangents live in compact buffers nothing overwrites during backward, so the reach-back does not matter.
+        skip_last = {"W2", "W1", "Wo"} if cls_last else set()
         total = NL * per_layer - sum(t for n, t in sizes if n in skip_last)
+        if cls_last:
+            free = -(-total // cap) * cap - total
+            for n in ("W2", "W1", "Wo"):
+                t = dict(sizes)[n]
+                if t <= free:
+                    skip_last.discard(n)
+                    free -= t
+                    total += t
+        self._cls_per_weight = frozenset(skip_last)
+        # the patch-embed weight gradient (patch_embed.py:23-25) as tiles of the LAST grouped launch, when that round has free slots: its X
+        # operand is then the dense patch matrix savit_patchify_bf16 writes (20 us) instead of a gather inside a launch of its own (84 + 6 us)
+        wpe_tiles = int(self.L.savit_gemm_wgrad_group_tiles(cfg.patch_dim, d, tile)) if cfg.patch % 8 == 0 and cfg.patch_dim % 8 == 0 else 0
+        free = -(-total // cap) * cap - total
+        self._wpe_grouped = bool(os.environ.get("SAVIT_WPE_GROUPED", "1") != "0" and type(self)._record_bwd_plan is ViTEngine._record_bwd_plan
+                                 and 0 < wpe_tiles <= free and total > 0)
+        if self._wpe_grouped:
+            total += wpe_tiles
         rounds = -(-total // cap)
         need = total - (rounds - 1) * cap  # tiles in the last, partial round
         wo = dict(sizes)["Wo"]
@@ -946,9 +985,13 @@ class ViTEngine:
             for n, t in sizes:
                 if not (n == "Wo" and l in divert) and not (l == NL - 1 and n in skip_last):
                     q.push(None, l, t)
+            if l == 0 and getattr(self, "_wpe_grouped", False):
+                q.push(None, 0, wpe_tiles)
             while q.pending() > 0 and (q.due(l) or l == 0):
                 _, _, oldest = q.take(cap)
                 lag = max(lag, oldest - l)
+        if getattr(self, "_wpe_grouped", False):
+            lag += 1  # the last launch goes out BEHIND layer 0's LayerNorm backward (it carries the patch-embed gradient): one more ring write
         return tile, cap, divert, lag
 
     def _wgrad_splits(self, Kin: int, Nout: int, patch: int) -> int:

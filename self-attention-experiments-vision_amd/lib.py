@@ -152,6 +152,7 @@ _SIGNATURES = {
     "savit_colsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "savit_softmax_xent_grad_f32": (c_int, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int, c_int, c_void_p]),
     "savit_patchify_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "savit_patchify_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "savit_assemble_tokens_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "savit_timer_create": (c_int, [c_int, POINTER(c_void_p)]),
     "savit_timer_record": (c_int, [c_void_p, c_int, c_void_p]),
