@@ -970,7 +970,7 @@ class ViTEngine:
         wpe_tiles = int(self.L.savit_gemm_wgrad_group_tiles(cfg.patch_dim, d, tile)) if cfg.patch % 8 == 0 and cfg.patch_dim % 8 == 0 else 0
         free = -(-total // cap) * cap - total
         self._wpe_grouped = bool(os.environ.get("SAVIT_WPE_GROUPED", "1") != "0" and type(self)._record_bwd_plan is ViTEngine._record_bwd_plan
-                                 and 0 < wpe_tiles <= free and total > 0)
+                                 and 0 < wpe_tiles <= free and total > 0 and self.wgrad_max_lag is None)  # (a bound on the reach-back wins)
         if self._wpe_grouped:
             total += wpe_tiles
         rounds = -(-total // cap)
