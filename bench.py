@@ -341,6 +341,19 @@ def traffic_lookup(kernel: str, headline: bool, profiles_dir: str = None, runnin
     return res
 
 
+def executed_flops(cfg, eng, fpi, per_gpu) -> dict:
+    """What the step really executes: `flops_per_image` is SURVEY 8d's algorithmic count of the dense step (the metric's definition and
+    the numerator of `frac`); the ViT engines run the last encoder layer on the cls rows where only those are read (exact: engine.py),
+    which is fewer flops - reported here so that `frac` is not mistaken for matrix-pipe utilisation."""
+    from savit_amd.config import cls_only_saved_flops_per_image
+
+    if not getattr(eng, "cls_only_last", False):
+        return {}
+    ex = fpi - cls_only_saved_flops_per_image(cfg, bool(getattr(eng, "cls_fwd", False)))
+    return {"executed_flops_per_image": ex, "frac_executed": round(per_gpu * ex / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "executed_note": "last encoder layer behind its qkv projection on the cls rows only (vit.py:57,95: row 0 alone reaches the head)"}
+
+
 def pick_dominant(sym):
     """The GEMM kernel symbol with the largest total time; totals within 5 % of the largest (run-to-run noise: the grouped
     weight-gradient kernel and the plain-epilogue 320x256 kernel are both ~20 % of the DeiT-B step) are broken towards the kernel with
@@ -658,7 +671,8 @@ def main():
             **({"allreduce_exposed_ms": dist_info["allreduce_exposed_ms"], "reserved_cus": dist_info["reserved_cus"],
                 "rccl_channels": dist_info["rccl_channels"]} if dist_info else {}),
             "step_roofline": {"bound": "mfma", "achieved": round(per_gpu * fpi / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(per_gpu * fpi / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "flops_per_image": fpi},
+                              "frac": round(per_gpu * fpi / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "flops_per_image": fpi,
+                              **executed_flops(cfg, eng, fpi, per_gpu)},
         }
         out.update(info)
         dom = out["roofline"]["kernel"]

@@ -116,6 +116,15 @@ int savit_class_attention_fwd(const void* q, long ldq, const void* kv, int ldkv,
                               void* stream);
 int savit_class_attention_bwd(const void* q, long ldq, const void* kv, int ldkv, const float* probs, const void* d_o, void* dq, long lddq,
                               void* dkv, int B, int Nk, int H, int head_dim, float dq_scale, void* stream);
+/* The cls query of a ViT's LAST encoder layer against all Nk <= 640 keys (round 5: only row 0 of every image reaches the head, vit.py:57,95,
+ * so of that layer's attention only the cls query's output is used and only its cotangent row is non-zero).  Same tensor conventions as
+ * savit_class_attention_fwd / _bwd, but the rounding points of savit_attention_fwd / _bwd (fp32 scores, bf16 P operand with the un-rounded row
+ * sum, LSE [B, H] saved instead of the probabilities; backward recomputes P, dS passes through bf16) - a model differentiated this way
+ * agrees with the dense attention kernels to fp32 summation order.  o, d_o: bf16 [B, d]; dq row b at dq + b * lddq; dkv rows as kv. */
+int savit_cls_query_attention_fwd(const void* q, long ldq, const void* kv, int ldkv, void* o, float* lse, int B, int Nk, int H, int head_dim,
+                                  void* stream);
+int savit_cls_query_attention_bwd(const void* q, long ldq, const void* kv, int ldkv, const void* o, const float* lse, const void* d_o, void* dq,
+                                  long lddq, void* dkv, int B, int Nk, int H, int head_dim, float dq_scale, void* stream);
 
 /* ---- Dense / DenseGeneral GEMMs with fused epilogues (bf16 MFMA, fp32 accumulate).
  * C[M,N] = epilogue( A[M,K] . Bt[N,K]^T ).  A and Bt are bf16, K contiguous ("TN"); K % 64 == 0, N % 4 == 0.

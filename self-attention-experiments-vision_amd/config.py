@@ -133,3 +133,19 @@ def train_flops_per_image(cfg: ModelConfig) -> float:
     sa = 24.0 * n * d * d + 4.0 * n * n * d + 4.0 * H * H * n * n
     ca = 20.0 * d * d + 4.0 * (n + 1) * d * d + 4.0 * (n + 1) * d
     return 3.0 * (cfg.num_layers * sa + cfg.num_layers_token_only * ca + 2.0 * d * C) + 2.0 * pe
+
+
+def cls_only_saved_flops_per_image(cfg: ModelConfig, forward_too: bool) -> float:
+    """FLOPs of `train_flops_per_image` that the ViT engines do NOT execute because only the cls row of the last encoder layer's output
+    is ever read (vit.py:57,95; engine.cls_only_last / cls_fwd, round 5): the last layer's output projection and MLP - and, with
+    forward_too, the attention of its non-cls queries - on (N - 1) of N rows; backward = 2 x forward.  Reported beside the SURVEY 8d
+    count in bench.py's step_roofline (the roofline fraction keeps the SURVEY count as its numerator: the metric's definition)."""
+    if cfg.kind != "vit":
+        return 0.0
+    d, N = cfg.embed_dim, cfg.n_patches + 1
+    rows = N - 1
+    dense = 2.0 * rows * d * d + 4.0 * rows * d * cfg.hidden  # proj + fc1 + fc2 on the rows left out
+    attn_fwd = 4.0 * rows * N * d                              # QK^T and PV of the queries left out
+    # backward: input-gradient and weight-gradient products of proj / fc1 / fc2 (2 x); the attention backward of the non-cls queries
+    # (2.5 x its forward) only when the cls-query kernels replace the dense one
+    return (dense + attn_fwd) * (1.0 if forward_too else 0.0) + 2.0 * dense + (2.5 * attn_fwd if forward_too else 0.0)

@@ -142,6 +142,123 @@ __global__ __launch_bounds__(256) void class_attn_bwd_kernel(const bf16_t* __res
   if (lane == 0) store_row_bf16<HDV>(dq + (size_t)b * lddq + h * HDV, dqa);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// The cls query of a ViT's LAST encoder layer (round 5).  Only row 0 of every image reaches the head (vit.py:57,95), so of the last
+// layer's attention only the cls query's output is ever used and only its row of the cotangent is non-zero: one query per image
+// against all N keys - the shape of the kernels above - but with the ROUNDING POINTS OF THE MFMA ATTENTION KERNELS (csrc/attention.hip),
+// so that a model differentiated this way agrees with the dense plan to fp32 summation order: fp32 scores (the query is pre-scaled),
+// P operand = bf16(exp2((s - max) log2 e)) un-normalised with the row sum taken from the un-rounded values, O = sum(P v) / l, LSE saved;
+// backward: P = exp2(s log2 e - LSE log2 e) recomputed, dV = bf16(P) dO, dP = dO . v, delta = rowsum(dO * O), dS = P (dP - delta) in
+// fp32, dK = bf16(dS) q, dQ = dq_scale * sum bf16(dS) k.  One wave per (image, head); keys strided over the lanes, KPL per lane.
+constexpr float CQ_LOG2E = 1.4426950408889634f;
+
+template <int HDV, int KPL>
+__global__ __launch_bounds__(256) void cls_query_attn_fwd_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kv, int ldkv,
+                                                                  bf16_t* __restrict__ o, float* __restrict__ lse, int B, int Nk, int H) {
+  const int lane = threadIdx.x & 63;
+  const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bh >= B * H) return;
+  const int b = bh / H, h = bh - b * H, d = H * HDV;
+  float qv[HDV];
+  load_row_f32<HDV>(q + (size_t)b * ldq + h * HDV, qv);
+  float s[KPL], m = -INFINITY;
+#pragma unroll
+  for (int kk = 0; kk < KPL; ++kk) {
+    const int key = lane + 64 * kk;
+    s[kk] = -INFINITY;
+    if (key < Nk) {
+      float kr[HDV];
+      load_row_f32<HDV>(kv + ((size_t)b * Nk + key) * ldkv + h * HDV, kr);
+      float a = 0.f;
+#pragma unroll
+      for (int e = 0; e < HDV; ++e) a += qv[e] * kr[e];
+      s[kk] = a;
+    }
+    m = fmaxf(m, s[kk]);
+  }
+  m = wave_max(m);
+  const float mb = m * CQ_LOG2E;
+  float l = 0.f;
+  float acc[HDV];
+#pragma unroll
+  for (int e = 0; e < HDV; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < KPL; ++kk) {
+    const int key = lane + 64 * kk;
+    const float pe = __builtin_amdgcn_exp2f(s[kk] * CQ_LOG2E - mb);  // keys >= Nk: exp2(-inf) = 0
+    l += pe;
+    if (key < Nk) {
+      const float pb = round_bf16(pe);
+      float vr[HDV];
+      load_row_f32<HDV>(kv + ((size_t)b * Nk + key) * ldkv + d + h * HDV, vr);
+#pragma unroll
+      for (int e = 0; e < HDV; ++e) acc[e] += pb * vr[e];
+    }
+  }
+  l = wave_sum(l);
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int e = 0; e < HDV; ++e) acc[e] = wave_sum(acc[e]) * inv;
+  if (lane == 0) {
+    store_row_bf16<HDV>(o + (size_t)b * d + h * HDV, acc);
+    lse[(size_t)b * H + h] = m + __logf(l);
+  }
+}
+
+template <int HDV, int KPL>
+__global__ __launch_bounds__(256) void cls_query_attn_bwd_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kv, int ldkv,
+                                                                  const bf16_t* __restrict__ o, const float* __restrict__ lse,
+                                                                  const bf16_t* __restrict__ d_o, bf16_t* __restrict__ dq, long lddq,
+                                                                  bf16_t* __restrict__ dkv, int B, int Nk, int H, float dq_scale) {
+  const int lane = threadIdx.x & 63;
+  const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bh >= B * H) return;
+  const int b = bh / H, h = bh - b * H, d = H * HDV;
+  float qv[HDV], dov[HDV];
+  load_row_f32<HDV>(q + (size_t)b * ldq + h * HDV, qv);
+  load_row_f32<HDV>(d_o + (size_t)b * d + h * HDV, dov);
+  float del = 0.f;
+  {
+    float ov[HDV];
+    load_row_f32<HDV>(o + (size_t)b * d + h * HDV, ov);
+#pragma unroll
+    for (int e = 0; e < HDV; ++e) del += ov[e] * dov[e];
+  }
+  const float nl2 = -CQ_LOG2E * lse[(size_t)b * H + h];
+  float dqa[HDV];
+#pragma unroll
+  for (int e = 0; e < HDV; ++e) dqa[e] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < KPL; ++kk) {
+    const int key = lane + 64 * kk;
+    if (key < Nk) {
+      float kr[HDV], vr[HDV], dkr[HDV], dvr[HDV];
+      load_row_f32<HDV>(kv + ((size_t)b * Nk + key) * ldkv + h * HDV, kr);
+      load_row_f32<HDV>(kv + ((size_t)b * Nk + key) * ldkv + d + h * HDV, vr);
+      float sc = 0.f, dp = 0.f;
+#pragma unroll
+      for (int e = 0; e < HDV; ++e) {
+        sc += qv[e] * kr[e];
+        dp += dov[e] * vr[e];
+      }
+      const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc, CQ_LOG2E, nl2));
+      const float pb = round_bf16(pr), dsb = round_bf16(pr * (dp - del));
+#pragma unroll
+      for (int e = 0; e < HDV; ++e) {
+        dqa[e] += dsb * kr[e];
+        dkr[e] = dsb * qv[e];
+        dvr[e] = pb * dov[e];
+      }
+      store_row_bf16<HDV>(dkv + ((size_t)b * Nk + key) * ldkv + h * HDV, dkr);
+      store_row_bf16<HDV>(dkv + ((size_t)b * Nk + key) * ldkv + d + h * HDV, dvr);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < HDV; ++e) dqa[e] = wave_sum(dqa[e]) * dq_scale;
+  if (lane == 0) store_row_bf16<HDV>(dq + (size_t)b * lddq + h * HDV, dqa);
+}
+
 }  // namespace
 
 extern "C" int savit_class_attention_fwd(const void* q, long ldq, const void* kv, int ldkv, void* o, float* probs, int B, int Nk, int H,
@@ -175,5 +292,40 @@ extern "C" int savit_class_attention_bwd(const void* q, long ldq, const void* kv
   else
     hipLaunchKernelGGL(class_attn_bwd_kernel<64>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)q, ldq, (const bf16_t*)kv, ldkv, probs,
                        (const bf16_t*)d_o, (bf16_t*)dq, lddq, (bf16_t*)dkv, B, Nk, H, dq_scale);
+  SAVIT_LAUNCH_RET();
+}
+
+// ---- the cls query against all keys with the MFMA kernels' rounding points (see cls_query_attn_fwd_kernel)
+#define CQ_DISPATCH(KERNEL, ...)                                                                                       \
+  do {                                                                                                                 \
+    const dim3 grid((B * H + 3) / 4), block(256);                                                                      \
+    if (head_dim == 48) {                                                                                              \
+      if (Nk <= 256) hipLaunchKernelGGL((KERNEL<48, 4>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);            \
+      else hipLaunchKernelGGL((KERNEL<48, 10>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);                     \
+    } else {                                                                                                           \
+      if (Nk <= 256) hipLaunchKernelGGL((KERNEL<64, 4>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);            \
+      else hipLaunchKernelGGL((KERNEL<64, 10>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);                     \
+    }                                                                                                                  \
+  } while (0)
+
+extern "C" int savit_cls_query_attention_fwd(const void* q, long ldq, const void* kv, int ldkv, void* o, float* lse, int B, int Nk, int H,
+                                             int head_dim, void* stream) {
+  SAVIT_CHECK_ARG(q && kv && o && lse && B >= 0 && Nk > 0 && Nk <= 640 && H > 0 && (head_dim == 48 || head_dim == 64));
+  SAVIT_CHECK_ARG(ldq >= H * head_dim && ldq % 8 == 0 && ldkv >= 2 * H * head_dim && ldkv % 8 == 0);
+  SAVIT_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)kv % 16) == 0 && ((uintptr_t)o % 16) == 0);
+  if (B == 0) return SAVIT_OK;
+  CQ_DISPATCH(cls_query_attn_fwd_kernel, (const bf16_t*)q, ldq, (const bf16_t*)kv, ldkv, (bf16_t*)o, lse, B, Nk, H);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_cls_query_attention_bwd(const void* q, long ldq, const void* kv, int ldkv, const void* o, const float* lse, const void* d_o,
+                                             void* dq, long lddq, void* dkv, int B, int Nk, int H, int head_dim, float dq_scale, void* stream) {
+  SAVIT_CHECK_ARG(q && kv && o && lse && d_o && dq && dkv && B >= 0 && Nk > 0 && Nk <= 640 && H > 0 && (head_dim == 48 || head_dim == 64));
+  SAVIT_CHECK_ARG(ldq >= H * head_dim && ldq % 8 == 0 && ldkv >= 2 * H * head_dim && ldkv % 8 == 0 && lddq >= H * head_dim && lddq % 8 == 0);
+  SAVIT_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)kv % 16) == 0 && ((uintptr_t)o % 16) == 0 && ((uintptr_t)d_o % 16) == 0 &&
+                  ((uintptr_t)dq % 16) == 0 && ((uintptr_t)dkv % 16) == 0);
+  if (B == 0) return SAVIT_OK;
+  CQ_DISPATCH(cls_query_attn_bwd_kernel, (const bf16_t*)q, ldq, (const bf16_t*)kv, ldkv, (const bf16_t*)o, lse, (const bf16_t*)d_o, (bf16_t*)dq,
+              lddq, (bf16_t*)dkv, B, Nk, H, dq_scale);
   SAVIT_LAUNCH_RET();
 }

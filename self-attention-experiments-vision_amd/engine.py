@@ -528,6 +528,10 @@ class ViTEngine:
         cfg_ = getattr(self, "cfg", None)
         self.cls_only_last = (os.environ.get("SAVIT_CLS_ONLY_LAST", "1") != "0" and getattr(cfg_, "kind", "") == "vit" and
                               cfg_.embed_dim > 64 and cfg_.seq_len > 1)
+        # ... and (cls_fwd) its FORWARD behind the qkv projection as well - the cls query's attention (savit_cls_query_attention_fwd), output
+        # projection, second LayerNorm and MLP on B rows: the other rows of the last layer's output are never read (the final LayerNorm and
+        # the head take row 0), and its backward then works on compact [B, .] activations.  Needs the cls-query kernels' geometry.
+        self.cls_fwd = bool(self.cls_only_last and os.environ.get("SAVIT_CLS_FWD", "1") != "0" and cfg_.head_dim in (48, 64) and cfg_.seq_len <= 640)
         self._needs_zero_dres = True
         self._cls_per_weight = frozenset({"W2", "W1", "Wo"})  # (_wgrad_group_plan moves the ones that fit the last round into the tile FIFO)
         if wgrad_max_lag is None and os.environ.get("SAVIT_WGRAD_MAX_LAG"):
@@ -683,6 +687,8 @@ class ViTEngine:
                    img_size=cfg.img_size, patch=cfg.patch, tokens=N, token_offset=1)
         P.add(L.savit_cls_pos_rows, (pp("cls"), pp("pos"), x[0].data_ptr(), B, N * d, d), "cls_rows")
         alpha = 1.0 / math.sqrt(cfg.head_dim)
+        cfw = bool(self.cls_fwd)
+        cb = self._cls_buffers() if cfw else None
         for l in range(NL):
             st = self.stats[l]
             w = lambda n, l=l: self.w[n][l].data_ptr()  # noqa: E731
@@ -690,6 +696,20 @@ class ViTEngine:
                                           st[1].data_ptr(), M, d, d, 1e-6, self.rp), f"l{l}.ln1")
             self._gemm(P, f"l{l}.qkv", A=self.h1[l].data_ptr(), Bt=w("Wqkv_t"), C=self.qkv[l].data_ptr(), M=M, N=3 * d, K=d, lda=d, ldb=d,
                        ldc=3 * d, epilogue=_lib.EPI_BF16, alpha=alpha, alpha_cols=d)
+            if cfw and l == NL - 1:
+                # the last layer behind its qkv projection, cls rows only (B rows; row b of the dense tensors at pitch N * width): only row 0
+                # of its output is ever read.  K and V of every token are in qkv (dense: the cls query attends to all of them).
+                P.add(L.savit_cls_query_attention_fwd, (self.qkv[l].data_ptr(), N * 3 * d, self.qkv[l].data_ptr() + d * 2, 3 * d, cb["o"].data_ptr(),
+                                                        cb["lse"].data_ptr(), B, N, H, cfg.head_dim), f"l{l}.attn")
+                self._gemm(P, f"l{l}.proj", A=cb["o"].data_ptr(), Bt=w("Wo_t"), C=cb["xmid"].data_ptr(), aux=x[l].data_ptr(), M=B, N=d, K=d,
+                           lda=d, ldb=d, ldc=d, ldaux=N * d, epilogue=_lib.EPI_RESID)
+                P.add(L.savit_layernorm_fwd, (cb["xmid"].data_ptr(), pp(f"l{l}.ln2_g"), pp(f"l{l}.ln2_b"), cb["h2"].data_ptr(),
+                                              cb["stats"][0].data_ptr(), cb["stats"][1].data_ptr(), B, d, d, 1e-6, self.rp), f"l{l}.ln2")
+                self._gemm(P, f"l{l}.fc1", A=cb["h2"].data_ptr(), Bt=w("W1_t"), C=cb["u"].data_ptr(), C2=cb["a"].data_ptr(),
+                           bias=pp(f"l{l}.b1"), M=B, N=F, K=d, lda=d, ldb=d, ldc=F, epilogue=_lib.EPI_BIAS_GELU)
+                self._gemm(P, f"l{l}.fc2", A=cb["a"].data_ptr(), Bt=w("W2_t"), C=cb["xout"].data_ptr(), bias=pp(f"l{l}.b2"),
+                           aux=cb["xmid"].data_ptr(), M=B, N=d, K=F, lda=F, ldb=F, ldc=d, ldaux=d, epilogue=_lib.EPI_RESID)
+                continue
             P.add(L.savit_attention_fwd, (self.qkv[l].data_ptr(), self.o[l].data_ptr(), self.lse[l].data_ptr(), B, N, H, cfg.head_dim, 3 * d),
                   f"l{l}.attn")
             self._gemm(P, f"l{l}.proj", A=self.o[l].data_ptr(), Bt=w("Wo_t"), C=self.xmid[l].data_ptr(), aux=x[l].data_ptr(), M=M, N=d, K=d,
@@ -701,8 +721,9 @@ class ViTEngine:
             self._gemm(P, f"l{l}.fc2", A=self.a[l].data_ptr(), Bt=w("W2_t"), C=x[l + 1].data_ptr(), bias=pp(f"l{l}.b2"),
                        aux=self.xmid[l].data_ptr(), M=M, N=d, K=F, lda=F, ldb=F, ldc=d, ldaux=d, epilogue=_lib.EPI_RESID)
         # final LayerNorm on the cls rows only (vit.py:57,95: only row 0 reaches the head), then the head Dense
-        P.add(L.savit_layernorm_fwd, (x[NL].data_ptr(), pp("lnf_g"), pp("lnf_b"), self.zcls.data_ptr(), self.fstats[0].data_ptr(),
-                                      self.fstats[1].data_ptr(), B, d, N * d, 1e-6, self.rp), "lnf")
+        xlast, xlast_stride = (cb["xout"].data_ptr(), d) if cfw else (x[NL].data_ptr(), N * d)
+        P.add(L.savit_layernorm_fwd, (xlast, pp("lnf_g"), pp("lnf_b"), self.zcls.data_ptr(), self.fstats[0].data_ptr(),
+                                      self.fstats[1].data_ptr(), B, d, xlast_stride, 1e-6, self.rp), "lnf")
         self._gemm(P, "head", A=self.zcls.data_ptr(), Bt=self.w["Wh_t"].data_ptr(), C=self.logits.data_ptr(), bias=pp("bh"), M=B, N=C, K=d,
                    lda=d, ldb=d, ldc=C, epilogue=_lib.EPI_F32, round_out_bf16=self.rp)
         return P
@@ -798,10 +819,12 @@ class ViTEngine:
         cls_last = bool(self.cls_only_last)
         self._needs_zero_dres = not cls_last
         cb = self._cls_buffers() if cls_last else None
+        cfw = cls_last and bool(self.cls_fwd)
         if cls_last:
             # compact [B, d] residual gradient of the cls rows (fp32) and its bf16 copy: no [B*N, d] buffer is zero-filled to carry B rows
-            ln_bwd("lnf.bwd", (self.d_z.data_ptr(), self.x[NL].data_ptr(), pp("lnf_g"), self.fstats[0].data_ptr(), self.fstats[1].data_ptr(), None,
-                               cb["dres"].data_ptr(), cb["rb0"].data_ptr()), (gp("lnf_g"), gp("lnf_b"), gp(f"l{NL - 1}.b2")), (B, d, N * d, d, self.rp))
+            xl, xls = (cb["xout"].data_ptr(), d) if cfw else (self.x[NL].data_ptr(), N * d)
+            ln_bwd("lnf.bwd", (self.d_z.data_ptr(), xl, pp("lnf_g"), self.fstats[0].data_ptr(), self.fstats[1].data_ptr(), None,
+                               cb["dres"].data_ptr(), cb["rb0"].data_ptr()), (gp("lnf_g"), gp("lnf_b"), gp(f"l{NL - 1}.b2")), (B, d, xls, d, self.rp))
         else:
             ln_bwd("lnf.bwd", (self.d_z.data_ptr(), self.x[NL].data_ptr(), pp("lnf_g"), self.fstats[0].data_ptr(), self.fstats[1].data_ptr(), None,
                                self.dres.data_ptr(), ring[0]), (gp("lnf_g"), gp("lnf_b"), gp(f"l{NL - 1}.b2")), (B, d, N * d, N * d, self.rp),
@@ -813,23 +836,39 @@ class ViTEngine:
             if cls_last and l == NL - 1:
                 # ---- the LAST layer, cls rows only (B rows at pitch N * width inside the saved activations; compact cotangents).  Same
                 # kernels, same arithmetic per row: the rows left out contribute exact zeros to every sum below.
-                Nd, NF = N * d, N * F
                 rb0, rb1, du_c, dh_c, dres_c, cs = (cb[k].data_ptr() for k in ("rb0", "rb1", "d_u", "d_h", "dres", "slab"))
+                if cfw:   # compact activations (the forward ran on the cls rows: _build_fwd_plan)
+                    a_p, a_ld, u_p, u_ld, h2_p, h2_ld = cb["a"].data_ptr(), F, cb["u"].data_ptr(), F, cb["h2"].data_ptr(), d
+                    xm_p, xm_ld, m2, r2, sstr, o_p, o_ld = cb["xmid"].data_ptr(), d, cb["stats"][0].data_ptr(), cb["stats"][1].data_ptr(), 1, cb["o"].data_ptr(), d
+                else:     # the cls rows of the dense activations: row b at pitch N * width
+                    a_p, a_ld, u_p, u_ld, h2_p, h2_ld = self.a[l].data_ptr(), N * F, self.u[l].data_ptr(), N * F, self.h2[l].data_ptr(), N * d
+                    xm_p, xm_ld, m2, r2, sstr, o_p, o_ld = self.xmid[l].data_ptr(), N * d, st[2].data_ptr(), st[3].data_ptr(), N, self.o[l].data_ptr(), N * d
                 cq = lambda n: (None if n in self._cls_per_weight else l)  # noqa: E731  (a tile of the grouped launches, or a launch of its own)
-                wgrad(f"l{l}.W2.wgrad", self.a[l].data_ptr(), rb0, gp(f"l{l}.W2"), B, F, d, NF, d, d, layer=cq("W2"))
-                self._gemm(P, f"l{l}.fc2.dgrad", A=rb0, Bt=w("W2_n"), C=du_c, aux=self.u[l].data_ptr(), colsum=cs, colsum_rows=cb["slab"].shape[0],
-                           M=B, N=F, K=d, lda=d, ldb=d, ldc=F, ldaux=NF, epilogue=_lib.EPI_DGELU)
-                wgrad(f"l{l}.W1.wgrad", self.h2[l].data_ptr(), du_c, gp(f"l{l}.W1"), B, d, F, Nd, F, F, layer=cq("W1"))
+                wgrad(f"l{l}.W2.wgrad", a_p, rb0, gp(f"l{l}.W2"), B, F, d, a_ld, d, d, layer=cq("W2"))
+                self._gemm(P, f"l{l}.fc2.dgrad", A=rb0, Bt=w("W2_n"), C=du_c, aux=u_p, colsum=cs, colsum_rows=cb["slab"].shape[0],
+                           M=B, N=F, K=d, lda=d, ldb=d, ldc=F, ldaux=u_ld, epilogue=_lib.EPI_DGELU)
+                wgrad(f"l{l}.W1.wgrad", h2_p, du_c, gp(f"l{l}.W1"), B, d, F, h2_ld, F, F, layer=cq("W1"))
                 self._gemm(P, f"l{l}.fc1.dgrad", A=du_c, Bt=w("W1_n"), C=dh_c, M=B, N=d, K=F, lda=F, ldb=F, ldc=d, epilogue=_lib.EPI_BF16)
-                ln_bwd(f"l{l}.ln2.bwd", (dh_c, self.xmid[l].data_ptr(), pp(f"l{l}.ln2_g"), st[2].data_ptr(), st[3].data_ptr(), dres_c, dres_c, rb1),
-                       (gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b"), None), (B, d, Nd, d, self.rp),
-                       extra=(cs, cb["slab"].shape[0], F, gp(f"l{l}.b1")), sparse=(N, 0, 0))
-                wgrad(f"l{l}.Wo.wgrad", self.o[l].data_ptr(), rb1, gp(f"l{l}.Wo"), B, d, d, Nd, d, d, layer=cq("Wo"))
-                # attention backward reads every row of d_o: zero it, then the projection's input gradient fills the cls rows
-                P.add(L.savit_zero_bytes, (self.d_o.data_ptr(), self.d_o.numel() * 2), "zero.d_o")
-                self._gemm(P, f"l{l}.proj.dgrad", A=rb1, Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=B, N=d, K=d, lda=d, ldb=d, ldc=Nd, epilogue=_lib.EPI_BF16)
-                P.add(L.savit_attention_bwd, (self.qkv[l].data_ptr(), self.o[l].data_ptr(), self.d_o.data_ptr(), self.lse[l].data_ptr(),
-                                              dqkv, B, N, H, cfg.head_dim, 3 * d, 1.0 / math.sqrt(cfg.head_dim)), f"l{l}.attn.bwd", writes=(dqkv,))
+                ln_bwd(f"l{l}.ln2.bwd", (dh_c, xm_p, pp(f"l{l}.ln2_g"), m2, r2, dres_c, dres_c, rb1),
+                       (gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b"), None), (B, d, xm_ld, d, self.rp),
+                       extra=(cs, cb["slab"].shape[0], F, gp(f"l{l}.b1")), sparse=(sstr, 0, 0))
+                wgrad(f"l{l}.Wo.wgrad", o_p, rb1, gp(f"l{l}.Wo"), B, d, d, o_ld, d, d, layer=cq("Wo"))
+                if cfw:
+                    # the cls query's attention backward: dQ at the cls rows, dK / dV of every key; the q columns of the other rows of this
+                    # layer's own cotangent buffer are zero and stay zero
+                    dqkv = cb["dqkv"].data_ptr()
+                    self._gemm(P, f"l{l}.proj.dgrad", A=rb1, Bt=w("Wo_n"), C=cb["d_o"].data_ptr(), M=B, N=d, K=d, lda=d, ldb=d, ldc=d,
+                               epilogue=_lib.EPI_BF16)
+                    P.add(L.savit_cls_query_attention_bwd, (self.qkv[l].data_ptr(), N * 3 * d, self.qkv[l].data_ptr() + d * 2, 3 * d, o_p,
+                                                            cb["lse"].data_ptr(), cb["d_o"].data_ptr(), dqkv, N * 3 * d, dqkv + d * 2, B, N, H,
+                                                            cfg.head_dim, 1.0 / math.sqrt(cfg.head_dim)), f"l{l}.attn.bwd", writes=(dqkv,))
+                else:
+                    # attention backward reads every row of d_o: zero it, then the projection's input gradient fills the cls rows
+                    P.add(L.savit_zero_bytes, (self.d_o.data_ptr(), self.d_o.numel() * 2), "zero.d_o")
+                    self._gemm(P, f"l{l}.proj.dgrad", A=rb1, Bt=w("Wo_n"), C=self.d_o.data_ptr(), M=B, N=d, K=d, lda=d, ldb=d, ldc=N * d,
+                               epilogue=_lib.EPI_BF16)
+                    P.add(L.savit_attention_bwd, (self.qkv[l].data_ptr(), self.o[l].data_ptr(), self.d_o.data_ptr(), self.lse[l].data_ptr(),
+                                                  dqkv, B, N, H, cfg.head_dim, 3 * d, 1.0 / math.sqrt(cfg.head_dim)), f"l{l}.attn.bwd", writes=(dqkv,))
                 wgrad(f"l{l}.Wqkv.wgrad", self.h1[l].data_ptr(), dqkv, gp(f"l{l}.Wqkv"), M, d, 3 * d, d, 3 * d, 3 * d, layer=l)
                 self._gemm(P, f"l{l}.qkv.dgrad", A=dqkv, Bt=w("Wqkv_n"), C=self.d_h.data_ptr(), M=M, N=d, K=3 * d, lda=3 * d, ldb=3 * d, ldc=d,
                            epilogue=_lib.EPI_BF16)
@@ -913,6 +952,12 @@ class ViTEngine:
             e = lambda *s_, dt=bf16: torch.empty(*s_, dtype=dt, device=self.dev)  # noqa: E731
             rows = max(1, int(self.L.savit_gemm_colsum_rows_cus(B, F, d, 0, self.cu_budget if self.reserved_cus else 0)))
             self._cls_bufs = {"dres": e(B, d, dt=f32), "rb0": e(B, d), "rb1": e(B, d), "d_u": e(B, F), "d_h": e(B, d), "slab": e(rows, F, dt=f32)}
+            if self.cls_fwd:  # the last layer's activations behind its qkv projection, cls rows only
+                H, M = cfg.num_heads, self.M
+                self._cls_bufs.update({"o": e(B, d), "lse": e(B, H, dt=f32), "xmid": e(B, d, dt=f32), "h2": e(B, d), "stats": e(2, B, dt=f32),
+                                       "u": e(B, F), "a": e(B, F), "xout": e(B, d, dt=f32), "d_o": e(B, d),
+                                       # q columns are written at the cls rows only and stay zero elsewhere: never shared with other layers
+                                       "dqkv": torch.zeros(M, 3 * d, dtype=bf16, device=self.dev)})
         return self._cls_bufs
 
     def _patch_matrix(self) -> torch.Tensor:

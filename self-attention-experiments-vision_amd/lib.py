@@ -72,6 +72,9 @@ _SIGNATURES = {
     "savit_layernorm_bwd_ls": (c_int, [c_void_p] * 9 + [c_int, c_int, c_long, c_long, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "savit_class_attention_fwd": (c_int, [c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "savit_cls_query_attention_fwd": (c_int, [c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "savit_cls_query_attention_bwd": (c_int, [c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int,
+                                              c_int, c_int, c_float, c_void_p]),
     "savit_class_attention_bwd": (c_int, [c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int,
                                           c_int, c_float, c_void_p]),
     "savit_gemm_bf16_tn": (c_int, [POINTER(GemmArgs), c_void_p]),

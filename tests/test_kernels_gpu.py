@@ -1079,6 +1079,50 @@ def test_class_attention_fwd_bwd(ops, B, Nk, H, hd):
         assert v_ < 1e-4, (k_, v_)  # measured <= 1.9e-5 (mostly bit-exact)
 
 
+@pytest.mark.parametrize("B,N,H,hd", [(3, 197, 12, 64), (2, 577, 4, 64), (5, 50, 6, 64), (2, 197, 8, 48), (1, 640, 2, 64), (4, 1, 3, 64)])
+def test_cls_query_attention_matches_the_dense_kernels_on_the_cls_row(ops, B, N, H, hd):
+    """savit_cls_query_attention_fwd / _bwd (round 5: the last ViT layer's attention, whose cls output alone is read) against
+    savit_attention_fwd / _bwd on the same packed qkv: output and LSE of query 0, and - with a cotangent that is zero off the cls rows -
+    dQ of row 0, dK and dV of every row.  Same rounding points, other fp32 summation order: bf16 last-bit flips only."""
+    from savit_amd import lib as _lib
+
+    L = _lib.load()
+    rng = np.random.default_rng(B * 1000 + N)
+    d = H * hd
+    qkv = rb(rng.standard_normal((B * N, 3 * d)))
+    qkv[:, :d] = rb(qkv[:, :d] / np.sqrt(hd) * 2.0)
+    qkv_d = dev(qkv, bf16)
+    o, lse = ops.attention_fwd(qkv_d, B, N, H, head_dim=hd)
+    oc = torch.empty((B, d), dtype=bf16, device="cuda")
+    lc = torch.empty((B, H), dtype=torch.float32, device="cuda")
+    s0 = torch.cuda.current_stream().cuda_stream
+    rc = L.savit_cls_query_attention_fwd(qkv_d.data_ptr(), N * 3 * d, qkv_d.data_ptr() + 2 * d, 3 * d, oc.data_ptr(), lc.data_ptr(), B, N, H, hd, s0)
+    assert rc == 0
+    o_ref = host(o).reshape(B, N, d)[:, 0]
+    assert rel(host(oc), o_ref) < 4e-3
+    assert np.abs(host(lc) - host(lse).reshape(B, H, N)[:, :, 0]).max() < 1e-5 * max(1.0, np.abs(host(lse)).max())
+    d_o = np.zeros((B, N, d), np.float32)
+    d_o[:, 0] = rb(rng.standard_normal((B, d)))
+    d_o_d = dev(d_o.reshape(B * N, d), bf16)
+    ref = host(ops.attention_bwd(qkv_d, o, d_o_d, lse, B, N, H, dq_scale=0.5, head_dim=hd)).reshape(B, N, 3 * d)
+    got = torch.full((B * N, 3 * d), 7.0, dtype=bf16, device="cuda")
+    o0, lse0, do0 = o.view(B, N * d)[:, :d].contiguous(), lse.view(B, H, N)[:, :, 0].contiguous(), d_o_d.view(B, N * d)[:, :d].contiguous()
+    rc = L.savit_cls_query_attention_bwd(qkv_d.data_ptr(), N * 3 * d, qkv_d.data_ptr() + 2 * d, 3 * d, o0.data_ptr(), lse0.data_ptr(), do0.data_ptr(),
+                                         got.data_ptr(), N * 3 * d, got.data_ptr() + 2 * d, B, N, H, hd, 0.5, s0)
+    assert rc == 0
+    g = host(got).reshape(B, N, 3 * d)
+    if N > 1:
+        assert rel(g[:, 0, :d], ref[:, 0, :d]) < 4e-3                   # dQ of the cls query
+    else:
+        assert np.abs(g[:, 0, :d]).max() < 1e-5                           # one key: P = 1 and dS = 0 up to the rounding of O
+    assert np.all(g[:, 1:, :d] == 7.0)                                    # other queries' rows are not written (the engine zero-fills once)
+    assert rel(g[:, :, d:2 * d], ref[:, :, d:2 * d]) < 4e-3 or N == 1     # dK of every key
+    assert rel(g[:, :, 2 * d:], ref[:, :, 2 * d:]) < 4e-3                 # dV of every key
+    assert N == 1 or np.abs(ref[:, 1:, :d]).max() == 0.0                            # dense: zero cotangent rows give exact-zero dQ rows
+    bad = L.savit_cls_query_attention_fwd(qkv_d.data_ptr(), N * 3 * d, qkv_d.data_ptr() + 2 * d, 3 * d, oc.data_ptr(), lc.data_ptr(), B, 641, H, hd, s0)
+    assert bad == _lib.SAVIT_EINVAL
+
+
 def test_attention_cu_budget_changes_the_grid_not_the_result(ops):
     """savit_set_cu_budget: the persistent attention kernels walk the same items with fewer workgroups - bit-identical outputs."""
     from savit_amd import lib as _lib
