@@ -488,6 +488,7 @@ def measure(eng, cfg, B, world, rank, sync, steps, warmup, dist=None, breakdown=
         kb["sum_step"] = round(total, 3)
         kb["sum_step_net_of_brackets"] = round(net, 3)
         info["bracket_overhead_us"] = round(post["pair_overhead_ms"] * 1e3, 2)
+        info["launches_per_train_step"] = int(post["launches"])  # forward + loss + backward + optimizer + operand refresh, serial plan
         info["kernel_breakdown_ms"] = kb
         info["kernel_breakdown_how"] = (f"{len(post['reps'])} instrumented steps, every launch bracketed, each step enqueued behind a "
                                         f"{post['gate_us']} us gate kernel, per-label minimum; span of one instrumented step {best_span:.3f} ms")

@@ -310,6 +310,15 @@ int savit_pos_cls_grad(const float* dx0, float* dpos, float* dcls, int B, int N,
  * savit_token_mean_fwd: z[b, :] = bf16(mean over the L tokens of h[b, :, :])  (jnp.mean(x, axis=1), :62); _bwd: dh[b, l, :] = bf16(dz[b, :] / L). */
 int savit_transpose_bf16(const void* src, long src_batch_stride, int ld_src, void* dst_bf16, long dst_batch_stride, int ld_dst, int B, int R,
                          int Cc, const float* resid, float* out_f32, int round_out_bf16, float* rowsum_slab, int rowsum_ld, void* stream);
+/* Several plain transposes (no residual, no row sums) in ONE launch - at most 8 jobs; job j = `batch` matrices bf16 [rows, cols] with the
+ * pitches and strides of savit_transpose_bf16 (round 5: the [out, in] operand refresh of a ViT after the optimizer step, five launches -> one). */
+typedef struct savit_transpose_job {
+  const void* src;
+  void* dst;
+  long src_batch_stride, dst_batch_stride;
+  int ld_src, ld_dst, batch, rows, cols;
+} savit_transpose_job;
+int savit_transpose_bf16_jobs(const savit_transpose_job* jobs, int count, void* stream);
 int savit_transpose_rowsum_rows(int B, int Cc);
 int savit_token_mean_fwd(const void* h_bf16, void* z_bf16, int B, int L, int d, void* stream);
 int savit_token_mean_bwd(const void* dz_bf16, void* dh_bf16, int B, int L, int d, void* stream);

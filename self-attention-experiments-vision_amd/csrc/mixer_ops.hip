@@ -20,13 +20,11 @@ constexpr int TPITCH = TT + 2;  // bf16 elements per LDS row: 33 dwords, so the 
 //   rowsum[b * gridDim.x + tile_c][r] = sum over the tile's 64 columns of src[b][r][c]   (if rowsum: a slab of partial sums with
 //     pitch rowsum_ld, reduced by savit_colsum_finalize; atomics on the R result addresses cost 60 us per launch at B*d/64 = 1536
 //     adds per address)
-__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, long src_bs, int ld_src, bf16_t* __restrict__ dst,
-                                                              long dst_bs, int ld_dst, int R, int Cc, const float* __restrict__ resid,
-                                                              float* __restrict__ out_f32, int round_out, float* __restrict__ rowsum,
-                                                              int rowsum_ld) {
-  __shared__ bf16_t tile[TT][TPITCH];
-  const int b = blockIdx.z;
-  const int r0 = blockIdx.y * TT, c0 = blockIdx.x * TT;
+__device__ __forceinline__ void transpose_tile(bf16_t (*tile)[TPITCH], const bf16_t* __restrict__ src, long src_bs, int ld_src,
+                                               bf16_t* __restrict__ dst, long dst_bs, int ld_dst, int R, int Cc,
+                                               const float* __restrict__ resid, float* __restrict__ out_f32, int round_out,
+                                               float* __restrict__ rowsum, int rowsum_ld, int b, int ty, int tx, int ntx) {
+  const int r0 = ty * TT, c0 = tx * TT;
   const bf16_t* s = src + (size_t)b * src_bs;
   const int t = threadIdx.x;
   // ---- load: 8 lanes x 16 B per row, 32 rows per pass
@@ -56,7 +54,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
         ps += dpp_mov<0xB1>(ps);
         ps += dpp_mov<0x4E>(ps);
         ps += dpp_mov<0x141>(ps);
-        if ((t & 7) == 0 && r < R) rowsum[((size_t)b * gridDim.x + blockIdx.x) * rowsum_ld + r] = ps;
+        if ((t & 7) == 0 && r < R) rowsum[((size_t)b * ntx + tx) * rowsum_ld + r] = ps;
       }
     }
   }
@@ -101,6 +99,41 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, long src_bs, int ld_src, bf16_t* __restrict__ dst,
+                                                              long dst_bs, int ld_dst, int R, int Cc, const float* __restrict__ resid,
+                                                              float* __restrict__ out_f32, int round_out, float* __restrict__ rowsum,
+                                                              int rowsum_ld) {
+  __shared__ bf16_t tile[TT][TPITCH];
+  transpose_tile(tile, src, src_bs, ld_src, dst, dst_bs, ld_dst, R, Cc, resid, out_f32, round_out, rowsum, rowsum_ld, blockIdx.z, blockIdx.y,
+                 blockIdx.x, gridDim.x);
+}
+
+// several transposes in ONE launch (round 5: the [out, in] operand forms of a ViT's four weight families and its patch embedding are
+// refreshed from the bf16 mirror after every optimizer step - five launches of 5-26 us each with a kernel boundary between them)
+constexpr int TJ_MAX = 8;
+struct TransposeJobs {
+  const bf16_t* src[TJ_MAX];
+  bf16_t* dst[TJ_MAX];
+  long src_bs[TJ_MAX], dst_bs[TJ_MAX];
+  int ld_src[TJ_MAX], ld_dst[TJ_MAX], R[TJ_MAX], Cc[TJ_MAX], ntx[TJ_MAX], nty[TJ_MAX];
+  unsigned first[TJ_MAX + 1];  // first workgroup of job j; first[count] = grid size
+  int count;
+};
+__global__ __launch_bounds__(256) void transpose_bf16_jobs_kernel(const TransposeJobs J) {
+  __shared__ bf16_t tile[TT][TPITCH];
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < TJ_MAX; ++k)
+    if (k < J.count && blockIdx.x >= J.first[k]) j = k;
+  unsigned w = blockIdx.x - J.first[j];
+  const int tx = (int)(w % (unsigned)J.ntx[j]);
+  w /= (unsigned)J.ntx[j];
+  const int ty = (int)(w % (unsigned)J.nty[j]);
+  const int b = (int)(w / (unsigned)J.nty[j]);
+  transpose_tile(tile, J.src[j], J.src_bs[j], J.ld_src[j], J.dst[j], J.dst_bs[j], J.ld_dst[j], J.R[j], J.Cc[j], nullptr, nullptr, 0, nullptr, 0, b,
+                 ty, tx, J.ntx[j]);
 }
 
 // z[b][c] = bf16( (1/L) sum_l h[b][l][c] ): one workgroup per (image, 128 channels); the 4 waves split the tokens
@@ -159,6 +192,35 @@ extern "C" int savit_transpose_bf16(const void* src, long src_batch_stride, int 
   SAVIT_CHECK_ARG(grid.y <= 65535);
   hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, src_batch_stride, ld_src,
                      (bf16_t*)dst_bf16, dst_batch_stride, ld_dst, R, Cc, resid, out_f32, round_out_bf16, rowsum_slab, rowsum_ld);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_transpose_bf16_jobs(const savit_transpose_job* jobs, int count, void* stream) {
+  SAVIT_CHECK_ARG(count >= 0 && count <= TJ_MAX && (jobs || count == 0));
+  if (count == 0) return SAVIT_OK;
+  TransposeJobs J;
+  unsigned long total = 0;
+  int n = 0;
+  for (int i = 0; i < count; ++i) {
+    const savit_transpose_job& q = jobs[i];
+    SAVIT_CHECK_ARG(q.src && q.dst && q.batch >= 0 && q.rows > 0 && q.cols > 0 && q.ld_src >= q.cols && q.ld_dst >= q.rows && (q.ld_src % 8) == 0 &&
+                    (q.ld_dst % 8) == 0 && (q.src_batch_stride % 8) == 0 && (q.dst_batch_stride % 8) == 0);
+    SAVIT_CHECK_ARG(((uintptr_t)q.src % 16) == 0 && ((uintptr_t)q.dst % 16) == 0);
+    if (q.batch == 0) continue;
+    J.src[n] = (const bf16_t*)q.src; J.dst[n] = (bf16_t*)q.dst;
+    J.src_bs[n] = q.src_batch_stride; J.dst_bs[n] = q.dst_batch_stride;
+    J.ld_src[n] = q.ld_src; J.ld_dst[n] = q.ld_dst; J.R[n] = q.rows; J.Cc[n] = q.cols;
+    J.ntx[n] = (q.cols + TT - 1) / TT; J.nty[n] = (q.rows + TT - 1) / TT;
+    J.first[n] = (unsigned)total;
+    total += (unsigned long)J.ntx[n] * J.nty[n] * q.batch;
+    SAVIT_CHECK_ARG(total < (1ul << 31));
+    ++n;
+  }
+  if (n == 0) return SAVIT_OK;
+  for (int k = n; k <= TJ_MAX; ++k) J.first[k] = (unsigned)total;
+  for (int k = n; k < TJ_MAX; ++k) { J.src[k] = nullptr; J.dst[k] = nullptr; J.src_bs[k] = J.dst_bs[k] = 0; J.ld_src[k] = J.ld_dst[k] = J.R[k] = J.Cc[k] = 0; J.ntx[k] = J.nty[k] = 1; }
+  J.count = n;
+  hipLaunchKernelGGL(transpose_bf16_jobs_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, J);
   SAVIT_LAUNCH_RET();
 }
 

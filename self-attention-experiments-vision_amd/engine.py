@@ -667,11 +667,16 @@ class ViTEngine:
         d, F, C, NL = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.num_layers
         ls = lay.layer_stride
         mp = lambda n: self.params_bf16.data_ptr() + lay.off[n][0] * 2  # noqa: E731
-        for name, R, Cc in (("Wqkv", d, 3 * d), ("Wo", d, d), ("W1", d, F), ("W2", F, d)):
-            P.add(L.savit_transpose_bf16, (mp(f"l0.{name}"), ls, Cc, self.w[name + "_t"].data_ptr(), R * Cc, R, NL, R, Cc, None, None, 0,
-                                           None, 0), f"cast {name}")
-        P.add(L.savit_transpose_bf16, (mp("Wpe"), 0, d, self.w["Wpe_t"].data_ptr(), 0, cfg.patch_dim, 1, cfg.patch_dim, d, None, None, 0,
-                                       None, 0), "cast Wpe")
+        # the four weight families of every layer and the patch embedding in ONE launch (round 5; five launches before)
+        jobs = (_lib.TransposeJob * 5)()
+        for q, (name, R, Cc) in zip(jobs, (("Wqkv", d, 3 * d), ("Wo", d, d), ("W1", d, F), ("W2", F, d))):
+            q.src, q.dst, q.src_batch_stride, q.dst_batch_stride = mp(f"l0.{name}"), self.w[name + "_t"].data_ptr(), ls, R * Cc
+            q.ld_src, q.ld_dst, q.batch, q.rows, q.cols = Cc, R, NL, R, Cc
+        q = jobs[4]
+        q.src, q.dst, q.src_batch_stride, q.dst_batch_stride = mp("Wpe"), self.w["Wpe_t"].data_ptr(), 0, 0
+        q.ld_src, q.ld_dst, q.batch, q.rows, q.cols = d, cfg.patch_dim, 1, cfg.patch_dim, d
+        P.keep.append(jobs)
+        P.add(L.savit_transpose_bf16_jobs, (jobs, 5), "cast weights")
         P.add(L.savit_cast_transpose_bf16, (self._off_ptr(self.params, "Wh"), 0, 1, d, C, self.w["Wh_n"].data_ptr(), 0, self.Cp,
                                             self.w["Wh_t"].data_ptr(), 0, d), "cast Wh")
         return P

@@ -42,6 +42,12 @@ class ColsumJob(Structure):
                 ("extra_rows", c_int), ("extra_n", c_int), ("extra_out", c_void_p)]
 
 
+class TransposeJob(Structure):
+    """Mirror of `savit_transpose_job` (include/savit.h)."""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("src_batch_stride", c_long), ("dst_batch_stride", c_long), ("ld_src", c_int),
+                ("ld_dst", c_int), ("batch", c_int), ("rows", c_int), ("cols", c_int)]
+
+
 class GemmF32Args(Structure):
     """Mirror of `savit_gemm_f32_args` (include/savit.h)."""
     _fields_ = [("A", c_void_p), ("W", c_void_p), ("C", c_void_p), ("bias", c_void_p), ("aux", c_void_p), ("colscale", c_void_p),
@@ -114,6 +120,7 @@ _SIGNATURES = {
     "savit_pos_cls_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "savit_transpose_bf16": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                      c_void_p, c_int, c_void_p]),
+    "savit_transpose_bf16_jobs": (c_int, [POINTER(TransposeJob), c_int, c_void_p]),
     "savit_transpose_rowsum_rows": (c_int, [c_int, c_int]),
     "savit_token_mean_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "savit_token_mean_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -317,3 +317,38 @@ def test_full_size_gradient_linearity_and_descent(mixer_b):
         eng.forward(img)
         l1 = float(eng.loss_backward(lab, label_smoothing=0.1))
     assert math.isfinite(l1) and l1 < l0 - 0.05, (l0, l1)
+
+
+def test_transpose_bf16_jobs_is_the_single_launches(pkg):
+    """savit_transpose_bf16_jobs (round 5: the ViT engines' operand refresh in one launch) = the same transposes launched one by one,
+    bit for bit: batched jobs with layer strides, a ragged one (rows, cols not multiples of 64), a job with batch 0, and the limits."""
+    import ctypes
+
+    from savit_amd import lib as _lib
+
+    L = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(3, 768, 2304, 2304 + 64, 768), (3, 768, 768, 768, 776), (2, 100, 72, 72, 104), (0, 64, 64, 64, 64), (1, 768, 384, 384, 768)]
+    jobs = (_lib.TransposeJob * len(shapes))()
+    keep, want = [], []
+    s0 = torch.cuda.current_stream().cuda_stream
+    for q, (B, R, Cc, ld_src, ld_dst) in zip(jobs, shapes):
+        nb = max(B, 1)
+        src = torch.randn(nb, R, ld_src, device="cuda", generator=g).to(torch.bfloat16)
+        dst = torch.full((nb, Cc, ld_dst), 3.0, dtype=torch.bfloat16, device="cuda")
+        ref = torch.full((nb, Cc, ld_dst), 3.0, dtype=torch.bfloat16, device="cuda")
+        if B:
+            assert L.savit_transpose_bf16(src.data_ptr(), R * ld_src, ld_src, ref.data_ptr(), Cc * ld_dst, ld_dst, B, R, Cc, None, None, 0, None, 0, s0) == 0
+            assert torch.equal(ref[:, :, :R], src[:, :, :Cc].transpose(1, 2)) and bool((ref[:, :, R:] == 3.0).all())
+        q.src, q.dst, q.src_batch_stride, q.dst_batch_stride = src.data_ptr(), dst.data_ptr(), R * ld_src, Cc * ld_dst
+        q.ld_src, q.ld_dst, q.batch, q.rows, q.cols = ld_src, ld_dst, B, R, Cc
+        keep.append((src, dst))
+        want.append(ref)
+    assert L.savit_transpose_bf16_jobs(jobs, len(shapes), s0) == 0
+    torch.cuda.synchronize()
+    for (src, dst), ref in zip(keep, want):
+        assert torch.equal(dst, ref)
+    assert L.savit_transpose_bf16_jobs(jobs, 9, s0) == _lib.SAVIT_EINVAL
+    assert L.savit_transpose_bf16_jobs(None, 0, s0) == 0
+    jobs[2].ld_dst = 96  # < rows
+    assert L.savit_transpose_bf16_jobs(jobs, len(shapes), s0) == _lib.SAVIT_EINVAL
