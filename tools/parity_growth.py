@@ -45,6 +45,7 @@ def main():
     params = vit_ref.init_params(oc, seed=5, randomize=True)
     rng = np.random.default_rng(11)
     images = vit_ref.bf16_round(rng.standard_normal((B, oc.img_size, oc.img_size, 3)).astype(np.float32))
+    os.environ["SAVIT_CLS_ONLY_LAST"] = "0"  # this tool reads the whole residual stream: the dense plan writes every row of the last layer
     eng = ViTEngine(mc, B)
     eng.load_params(params)
     logits = eng.forward(torch.as_tensor(images).cuda()).float().cpu().numpy()
