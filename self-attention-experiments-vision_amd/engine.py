@@ -750,14 +750,22 @@ class ViTEngine:
         queue = WgradQueue(self.wgrad_cap, self.wgrad_max_lag) if self.wgrad_tile else None
         n_launch = [0]
 
-        def wgrad(label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0), layer=None):
+        def wgrad(label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0), layer=None, few_rows=False):
             # no later launch consumes dW: side stream.  X is a saved activation (stable until the next forward), dY is scratch
             if queue is not None and layer is not None and not (layer in self.wgrad_divert and label.endswith(".Wo.wgrad")):
                 queue.push((X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw), layer, int(L.savit_gemm_wgrad_group_tiles(Kin, Nout, self.wgrad_tile)))
                 return
+            if few_rows and queue is not None and small_groups and Kin % 8 == 0 and Nout % 8 == 0:
+                # a B-row product (the head; a cls-only weight that found no free slot in the tile FIFO): one workgroup per output tile
+                # stores it by first touch - no K-split over 128 rows, no partial slabs, no reduce launch (round 5: 15 + 11 us -> one launch)
+                tiles = int(L.savit_gemm_wgrad_group_tiles(Kin, Nout, self.wgrad_tile))
+                if 0 < tiles <= self.wgrad_cap:
+                    add_wgrad_group(self, P, label, [((X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw), 0, tiles)], self.wgrad_tile, [])
+                    return
             self._add_wgrad(P, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, self._wgrad_splits(Kin, Nout, patch[0]), patch)
 
         wpe_g = bool(getattr(self, "_wpe_grouped", False)) and queue is not None and not self._data_parallel
+        small_groups = os.environ.get("SAVIT_WGRAD_SMALL_GROUPS", "1") != "0"
 
         def flush_group(layer: int, last: bool, final: bool = False):
             # called between a layer's last input-gradient GEMM and its ln1.bwd (which overwrites the oldest ring slot): every
@@ -818,7 +826,7 @@ class ViTEngine:
 
         ring, ri = [t.data_ptr() for t in self.dres_b_ring], 0
         # ---- head: dWh, d z_cls, final LayerNorm backward into the (zeroed) residual gradient
-        wgrad("head.wgrad", self.zcls.data_ptr(), self.dlogits.data_ptr(), gp("Wh"), B, d, C, d, self.Cp, C)
+        wgrad("head.wgrad", self.zcls.data_ptr(), self.dlogits.data_ptr(), gp("Wh"), B, d, C, d, self.Cp, C)  # (as one grouped launch: 16 us against 8 + 5 for the split pair)
         self._gemm(P, "head.dgrad", A=self.dlogits.data_ptr(), Bt=self.w["Wh_n"].data_ptr(), C=self.d_z.data_ptr(), M=B, N=d, K=self.Cp,
                    lda=self.Cp, ldb=self.Cp, ldc=d, epilogue=_lib.EPI_BF16)
         cls_last = bool(self.cls_only_last)
@@ -849,15 +857,15 @@ class ViTEngine:
                     a_p, a_ld, u_p, u_ld, h2_p, h2_ld = self.a[l].data_ptr(), N * F, self.u[l].data_ptr(), N * F, self.h2[l].data_ptr(), N * d
                     xm_p, xm_ld, m2, r2, sstr, o_p, o_ld = self.xmid[l].data_ptr(), N * d, st[2].data_ptr(), st[3].data_ptr(), N, self.o[l].data_ptr(), N * d
                 cq = lambda n: (None if n in self._cls_per_weight else l)  # noqa: E731  (a tile of the grouped launches, or a launch of its own)
-                wgrad(f"l{l}.W2.wgrad", a_p, rb0, gp(f"l{l}.W2"), B, F, d, a_ld, d, d, layer=cq("W2"))
+                wgrad(f"l{l}.W2.wgrad", a_p, rb0, gp(f"l{l}.W2"), B, F, d, a_ld, d, d, layer=cq("W2"), few_rows=True)
                 self._gemm(P, f"l{l}.fc2.dgrad", A=rb0, Bt=w("W2_n"), C=du_c, aux=u_p, colsum=cs, colsum_rows=cb["slab"].shape[0],
                            M=B, N=F, K=d, lda=d, ldb=d, ldc=F, ldaux=u_ld, epilogue=_lib.EPI_DGELU)
-                wgrad(f"l{l}.W1.wgrad", h2_p, du_c, gp(f"l{l}.W1"), B, d, F, h2_ld, F, F, layer=cq("W1"))
+                wgrad(f"l{l}.W1.wgrad", h2_p, du_c, gp(f"l{l}.W1"), B, d, F, h2_ld, F, F, layer=cq("W1"), few_rows=True)
                 self._gemm(P, f"l{l}.fc1.dgrad", A=du_c, Bt=w("W1_n"), C=dh_c, M=B, N=d, K=F, lda=F, ldb=F, ldc=d, epilogue=_lib.EPI_BF16)
                 ln_bwd(f"l{l}.ln2.bwd", (dh_c, xm_p, pp(f"l{l}.ln2_g"), m2, r2, dres_c, dres_c, rb1),
                        (gp(f"l{l}.ln2_g"), gp(f"l{l}.ln2_b"), None), (B, d, xm_ld, d, self.rp),
                        extra=(cs, cb["slab"].shape[0], F, gp(f"l{l}.b1")), sparse=(sstr, 0, 0))
-                wgrad(f"l{l}.Wo.wgrad", o_p, rb1, gp(f"l{l}.Wo"), B, d, d, o_ld, d, d, layer=cq("Wo"))
+                wgrad(f"l{l}.Wo.wgrad", o_p, rb1, gp(f"l{l}.Wo"), B, d, d, o_ld, d, d, layer=cq("Wo"), few_rows=True)
                 if cfw:
                     # the cls query's attention backward: dQ at the cls rows, dK / dV of every key; the q columns of the other rows of this
                     # layer's own cotangent buffer are zero and stay zero
