@@ -127,17 +127,26 @@ def instrumented_steps(eng, run_step: Callable[[], None], reps: int = 3, gate_us
         best: Dict[str, float] = {}
         order: List[str] = []
         rep_info = []
+        retries = 0
         for _ in range(reps):
-            timer.reset()
-            torch.cuda.synchronize()
-            _lib.check(L.savit_spin(gate_us, s), "savit_spin")
-            t0 = time.perf_counter()
-            run_step()
-            host = (time.perf_counter() - t0) * 1e3
-            torch.cuda.synchronize()
-            res = timer.results()
-            if timer.dropped:
-                raise RuntimeError("instrumented step issued more launches than its counting pass")
+            # A repetition whose host issue outlasted the gate (another tenant's burst on a shared box) is not a measurement of the
+            # GPU: it is run again behind a gate twice as long, at most three times - what is reported comes from gated repetitions only
+            # (a repetition that still misses is reported with gate_reached false, and bench.py marks the line invalid).
+            for attempt in range(4):
+                timer.reset()
+                torch.cuda.synchronize()
+                _lib.check(L.savit_spin(gate_us, s), "savit_spin")
+                t0 = time.perf_counter()
+                run_step()
+                host = (time.perf_counter() - t0) * 1e3
+                torch.cuda.synchronize()
+                res = timer.results()
+                if timer.dropped:
+                    raise RuntimeError("instrumented step issued more launches than its counting pass")
+                if host * 1e3 < gate_us or attempt == 3:
+                    break
+                retries += 1
+                gate_us = int(min(150000, 2 * gate_us))
             seen: Dict[str, int] = {}
             tot = 0.0
             for label, ms in res:
@@ -160,7 +169,7 @@ def instrumented_steps(eng, run_step: Callable[[], None], reps: int = 3, gate_us
             timer.end(k, s)
         torch.cuda.synchronize()
         empties = sorted(ms for _, ms in timer.results())
-        return {"labels": {k: best[k] for k in order}, "reps": rep_info, "gate_us": gate_us, "launches": n,
+        return {"labels": {k: best[k] for k in order}, "reps": rep_info, "gate_us": gate_us, "launches": n, "gate_retries": retries,
                 "pair_overhead_ms": empties[len(empties) // 2]}
     finally:
         eng.launch_timer, eng.overlap_wgrad = saved_timer, saved_overlap
