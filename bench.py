@@ -48,7 +48,7 @@ MFMA_BF16_PEAK_TFLOPS = 2516.6  # 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (MI3
 TN_TILES = {6: "gemm_tn_ring_kernel<128,128,2,2,4,%d,false>",
             12: "gemm_tn_pair_kernel<128,128,2,2,2,%d>", 13: "gemm_tn_pair_kernel<256,256,2,4,2,%d>",
             17: "gemm_tn_pair_kernel<192,128,2,2,2,%d>", 18: "gemm_tn_pair_tail_kernel<192,128,128,2,2,2,%d>",
-            20: "gemm_tn_pp_kernel<%d,0>", 21: "gemm_tn_pp320_kernel<%d>", 22: "gemm_tn_pp320p_kernel<%d>"}
+            20: "gemm_tn_pp_kernel<%d,0>", 21: "gemm_tn_pp320_kernel<%d>", 22: "gemm_tn_pp320p_kernel<%d>", 24: "gemm_tn_rows_kernel<%d>"}
 WG_VARIANTS = {1: "gemm_wgrad_ring_kernel<128,128,2,2,4,false>", 3: "gemm_wgrad_ring_kernel<256,256,2,4,4,false>"}
 EPI_OF = {"qkv": 0, "proj": 2, "fc1": 1, "fc2": 2, "fc2.dgrad": 3, "fc1.dgrad": 0, "proj.dgrad": 0, "qkv.dgrad": 0}
 
@@ -64,8 +64,7 @@ def kernel_symbol(label: str, lib, M: int, d: int, F: int) -> str:
               "proj.dgrad": (d, d), "qkv.dgrad": (d, 3 * d)}
     if op in shapes:
         N, K = shapes[op]
-        tile = lib.savit_gemm_tn_auto_tile_epi(M, N, K, EPI_OF[op])
-        return TN_TILES.get(tile, "gemm_tn tile %d <%%d>" % tile) % EPI_OF[op]
+        return tn_symbol(lib, M, N, K, EPI_OF[op])
     wshapes = {"Wqkv.wgrad": (d, 3 * d), "Wo.wgrad": (d, d), "W1.wgrad": (d, F), "W2.wgrad": (F, d)}
     if op in wshapes:
         return WG_VARIANTS[lib.savit_gemm_wgrad_auto_variant(wshapes[op][0], wshapes[op][1], 0)]
@@ -86,6 +85,8 @@ def tn_symbol(lib, M: int, N: int, K: int, epilogue: int, tile: int = 0, cu_budg
     """The kernel symbol savit_gemm_bf16_tn launches for this problem (tile 0 = the library's own choice for cu_budget CUs)."""
     if tile == 0:
         tile = lib.savit_gemm_tn_auto_tile_cus(M, N, K, epilogue, cu_budget)
+    if tile == 24:  # the few-rows kernel: 32 x 32 outputs per wave where that leaves waves for every CU, else 16 x 16 (launch_rows)
+        return "gemm_tn_rows_kernel<%d,%d>" % (epilogue, 2 if -(-M // 16) * -(-N // 16) >= 1536 else 1)
     return TN_TILES.get(tile, "gemm_tn tile %d <%%d>" % tile) % epilogue
 
 

@@ -77,6 +77,8 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
       const float4 c4 = *reinterpret_cast<const float4*>(a.colscale + n);
       cs[0] = c4.x; cs[1] = c4.y; cs[2] = c4.z; cs[3] = c4.w;
     }
+    if (a.C2 != nullptr)  // the bf16 branch value, needed by the LayerScale gradient (layerscale.py:23) - as epilogue_lds stores it
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.C2) + (size_t)m * a.ldc + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
     float4 o;
     o.x = r.x + rs * cs[0] * round_bf16(v[0]);
     o.y = r.y + rs * cs[1] * round_bf16(v[1]);
@@ -1859,6 +1861,111 @@ __global__ __launch_bounds__(512) void gemm_tn_pp320p_kernel(const GemmParams p)
 #undef PP5_MAKE_SRD
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Few-row products (tile 24, round 5): M of a few hundred rows at most - the B cls rows a ViT's LAST encoder layer and its head work on
+// (vit.py:57,95), CaiT's class-attention layers (cait.py:96-122) - where a 128-row LDS tile is 1-6 workgroups, each walking all of K
+// behind one barrier per K-tile (DeiT-B's fc2 on 128 rows, K = 3 072: 53 us for 0.6 GFLOP).  These products are latency problems: what
+// counts is how many loads the chip has in flight.  No LDS, no barrier: ONE WAVE = one 16 x 16 output tile over all of K, both
+// fragments straight from global memory in the MFMA operand layout (both operands are K-contiguous: a lane's 8 consecutive k are ONE
+// 16-byte buffer load; rows >= M, columns >= N and k-steps >= K / 32 come back as zeros from the range check / an out-of-range
+// offset: ragged shapes and the aliased-row operand form need no branches), 16 k-steps (32 loads) per stage, the next stage requested in
+// front of the current stage's MFMAs: 64 loads in flight per wave, 384 waves for DeiT-B's 128 x 768 products.  One accumulator per output
+// tile walks K in ascending 32-steps with the operand order of the LDS tiles: BITWISE their results (a first form - eight waves of a
+// workgroup splitting K and meeting in LDS - was as fast and gave up that invariant: the data-parallel tests compare a half batch on
+// this kernel with a whole batch on the LDS tiles).  grid = (N / 16, M / 16) ONE-WAVE workgroups: 2 x 2 waves per workgroup share rows in
+// the L1 but use 96 of the 256 CUs (fc2 26.6 us against 15.0).  Measured in the DeiT-B step, 128 rows (tools/profile_step.py with
+// SAVIT_PROFILE_LAYER=11; LDS tile 12 -> this kernel): fc2 (K = 3 072) 52.4 -> 15.3 us, fc1 input gradient 49.3 -> 15.0, proj 16.2 -> 6.8,
+// fc1 + GELU (N = 3 072: 32 x 32 per wave) 16.9 -> 10.2, proj input gradient 14.9 -> 6.7, head 16.9 -> 9.1, head input gradient 18.2 -> 7.6.
+template <int EPI, int T>  // T x T sub-tiles of 16 x 16 per wave: T = 1 where the grid would otherwise be short of waves, T = 2 for wide outputs
+__global__ __launch_bounds__(64) void gemm_tn_rows_kernel(const GemmParams p) {
+  const savit_gemm_args& a = p.a;
+  const int lane = threadIdx.x & 63;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int row0 = blockIdx.y * (16 * T), col0 = blockIdx.x * (16 * T);
+  constexpr uint32_t OOB = 0x7ffffff0u;
+  const auto srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (uint32_t)((size_t)a.M * a.lda * 2), 0x00020000);
+  const auto srdB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.Bt), 0, (uint32_t)((size_t)a.N * a.ldb * 2), 0x00020000);
+  uint32_t aoff[T], boff[T];
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    const int r = row0 + 16 * i + fr, c = col0 + 16 * i + fr;
+    aoff[i] = r < a.M ? (uint32_t)r * (uint32_t)(a.lda * 2) + (uint32_t)fq * 16u : OOB;
+    boff[i] = c < a.N ? (uint32_t)c * (uint32_t)(a.ldb * 2) + (uint32_t)fq * 16u : OOB;
+  }
+  const int steps = a.K / 32;  // K % 32 == 0
+  auto frag = [&](__amdgpu_buffer_rsrc_t srd, uint32_t off, int step) -> bf16x8 {
+    union { u32x4 u; bf16x8 v; } x;
+    x.u = __builtin_amdgcn_raw_buffer_load_b128(srd, step < steps ? off + (uint32_t)step * 64u : OOB, 0, 0);
+    return x.v;
+  };
+  f32x4 acc[T][T];
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = 0; j < T; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 16 / T;  // k-steps per stage: 32 loads
+  bf16x8 af[2][U][T], bf[2][U][T];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      af[0][u][i] = frag(srdA, aoff[i], u);
+      bf[0][u][i] = frag(srdB, boff[i], u);
+    }
+  for (int s0 = 0; s0 < steps; s0 += 2 * U) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {  // stage `half` computes, stage `half ^ 1` receives the steps behind it
+      const int base = s0 + half * U;
+      if (base >= steps) break;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+          af[half ^ 1][u][i] = frag(srdA, aoff[i], base + U + u);
+          bf[half ^ 1][u][i] = frag(srdB, boff[i], base + U + u);
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+#pragma unroll
+          for (int j = 0; j < T; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[half][u][j], af[half][u][i], acc[i][j], 0, 0, 0);
+    }
+  }
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = 0; j < T; ++j) epilogue_store<EPI>(p, row0 + 16 * i + fr, col0 + 16 * j + fq * 4, acc[i][j], csum);
+}
+
+int launch_rows(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  if ((size_t)p.a.M * p.a.lda * 2 >= 0x7ffffff0ull || (size_t)p.a.N * p.a.ldb * 2 >= 0x7ffffff0ull) return SAVIT_EINVAL;
+  // 32 x 32 per wave (half the L2 -> CU bytes per flop) where that still leaves waves for every CU; else 16 x 16
+  const long w16 = (long)((p.a.M + 15) / 16) * ((p.a.N + 15) / 16);
+  const int T = w16 >= 1536 ? 2 : 1;
+  p.tiles_m = (p.a.M + 16 * T - 1) / (16 * T);
+  p.tiles_n = (p.a.N + 16 * T - 1) / (16 * T);
+  if (p.tiles_m > 65535) return SAVIT_EINVAL;
+  const dim3 grid(p.tiles_n, p.tiles_m);
+#define SAVIT_LAUNCH_EPI(E)                                                                             \
+  case E:                                                                                               \
+    if (T == 2) hipLaunchKernelGGL((gemm_tn_rows_kernel<E, 2>), grid, dim3(64), 0, s, p);               \
+    else hipLaunchKernelGGL((gemm_tn_rows_kernel<E, 1>), grid, dim3(64), 0, s, p);                      \
+    break;
+  switch (p.a.epilogue) {
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_BF16)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_BIAS_GELU)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_RESID)
+    SAVIT_LAUNCH_EPI(SAVIT_EPI_F32)
+    default: return SAVIT_EINVAL;  // (GELU' with its column-sum slab and the patch gather stay with the LDS tiles)
+  }
+#undef SAVIT_LAUNCH_EPI
+  SAVIT_LAUNCH_RET();
+}
+
 int launch_pp320(const GemmParams& p0, hipStream_t s, bool pers) {
   GemmParams p = p0;
   p.tiles_m = (p.a.M + 319) / 320;
@@ -2117,6 +2224,11 @@ extern "C" int savit_gemm_tn_auto_tile_cus(int M, int N, int K, int epilogue, in
   if (force > 0) return force;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
   const bool big = (t256 >= 512 && N % 128 == 0);
+  //  * tile 24 (round 5): few rows - no LDS, no barriers, one wave per 32 x 32 outputs.  Measured in the DeiT-B step (128 cls rows of the last
+  //    layer; tools/profile_step.py with SAVIT_PROFILE_LAYER=11): see the table at the kernel.
+  static const int rows_max = SAVIT_EXP_ENV_INT("SAVIT_ROWS_TILE_MAX_M", 256);  // SAVIT_EXPERIMENTS builds only (A/B runs)
+  if (M <= rows_max && (epilogue == SAVIT_EPI_BF16 || epilogue == SAVIT_EPI_BIAS_GELU || epilogue == SAVIT_EPI_RESID || epilogue == SAVIT_EPI_F32))
+    return 24;
   if (K % 64 != 0) return 6;  // TNT's pixel stream (K = 32 / 96 / 160): narrow outputs, the 128x128 ring (a 256x256 ring tile existed through round 3; no shape of a supported model reached it)
   //  * 256x256 ping-pong (tile 20: the two M-halves of the 8-wave workgroup run one barrier apart, one in its MFMA segment while
   //    the other reads fragments and issues LDS-DMA): wide outputs on large grids with K >= 768 - measured against the next best
@@ -2228,6 +2340,7 @@ inline bool tile_geometry(int tile, int* bm, int* wgm) {
     case 17: case 18: *bm = 192; *wgm = 2; return true;
     case 20: *bm = 256; *wgm = 2; return true;
     case 21: case 22: *bm = 320; *wgm = 4; return true;
+    case 24: *bm = 16; *wgm = 1; return true;
     case 30: *bm = 256; *wgm = 4; return true;
     default: return false;
   }
@@ -2296,6 +2409,7 @@ extern "C" int savit_gemm_bf16_tn(const savit_gemm_args* args, void* stream) {
     case 20: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp(p, s);
     case 21: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp320(p, s, false);
     case 22: return (a.K % 64 || a.lda < a.K || a.epilogue == SAVIT_EPI_PATCH) ? SAVIT_EINVAL : launch_pp320(p, s, true);  // persistent over >1 round
+    case 24: return launch_rows(p, s);  // few rows: no LDS, fragments straight from global memory
 #ifdef SAVIT_EXPERIMENTS
     case 7: return launch_ring<256, 256, 2, 4, 4>(p, s);
     case 1: return launch_tile<128, 128, 2, 2>(p, s);

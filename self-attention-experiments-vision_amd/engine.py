@@ -659,6 +659,10 @@ class ViTEngine:
             a.rows_per_sample = 1
         a.round_bias_bf16 = self.rp
         a.cu_budget = self.cu_budget if (self.reserved_cus and self._building_bwd) else 0  # the all-reduce is resident during backward only
+        if not a.tile and a.M <= 256 and os.environ.get("SAVIT_ROWS_TILE", "1") == "0":
+            # A/B and exactness tests: few-row products on the LDS tile a many-row product of the same width takes (same K order per
+            # output element as the dense plan's launches) instead of the few-rows kernel (tile 24: K split over a workgroup's waves)
+            a.tile = int(self.L.savit_gemm_tn_auto_tile_cus(257, a.N, a.K, a.epilogue, a.cu_budget))
         plan.keep.append(a)
         plan.add(self.L.savit_gemm_bf16_tn, (ctypes.byref(a),), label, writes=writes)
 
@@ -765,7 +769,9 @@ class ViTEngine:
             self._add_wgrad(P, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, self._wgrad_splits(Kin, Nout, patch[0]), patch)
 
         wpe_g = bool(getattr(self, "_wpe_grouped", False)) and queue is not None and not self._data_parallel
-        small_groups = os.environ.get("SAVIT_WGRAD_SMALL_GROUPS", "1") != "0"
+        # (opt-in: W1 of the cls-only layer 15 + 11 us -> 14 us, but a 36-tile launch then sits among the 256-tile launches of the kernel
+        #  the bench reports - its average launch time and rocprofv3's AverageNs would mix two kinds of launches for 12 us per step)
+        small_groups = os.environ.get("SAVIT_WGRAD_SMALL_GROUPS", "0") != "0"
 
         def flush_group(layer: int, last: bool, final: bool = False):
             # called between a layer's last input-gradient GEMM and its ln1.bwd (which overwrites the oldest ring slot): every

@@ -136,7 +136,7 @@ def test_every_compiled_tn_tile_is_reachable_from_the_auto_heuristic(built):
                 reach.add(13 if (t in (20, 21, 22) and alias) else t)  # the ping-pong kernels do not take aliased rows: savit_gemm_bf16_tn falls back
     family = {"gemm_tn_ring_kernel<128, 128, 2, 2, 4,": 6, "gemm_tn_pair_kernel<128, 128, 2, 2, 2,": 12, "gemm_tn_pair_kernel<256, 256, 2, 4, 2,": 13,
               "gemm_tn_pair_kernel<192, 128, 2, 2, 2,": 17, "gemm_tn_pair_tail_kernel<192, 128, 128, 2, 2, 2,": 18, "gemm_tn_pp_kernel<": 20,
-              "gemm_tn_pp320_kernel<": 21, "gemm_tn_pp320p_kernel<": 22}
+              "gemm_tn_pp320_kernel<": 21, "gemm_tn_pp320p_kernel<": 22, "gemm_tn_rows_kernel<": 24}
     assert reach == set(family.values()), sorted(reach)
     readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"

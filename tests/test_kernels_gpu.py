@@ -111,7 +111,7 @@ def _mk(rng, M, K, scale=1.0):
 
 # every tile the product library holds (= every tile the auto heuristic can pick: tests/test_abi.py); the earlier rounds' other forms
 # exist in SAVIT_EXPERIMENTS builds only
-PRODUCT_TILES = [6, 12, 13, 17, 18, 20, 21, 22]  # (22 on these small shapes = 21: the persistent grid needs more tiles than CUs - see test_gemm_persistent_320 below)
+PRODUCT_TILES = [6, 12, 13, 17, 18, 20, 21, 22, 24]  # (24: the few-rows kernel - no LDS; any M, sized for M <= 256)  # (22 on these small shapes = 21: the persistent grid needs more tiles than CUs - see test_gemm_persistent_320 below)
 
 
 @pytest.mark.parametrize("tile", PRODUCT_TILES)
@@ -283,6 +283,31 @@ def _epi_case(ops, rng_seed, M, N, K, epi, tile, plain_bias=True):
     ops.gemm_tn(A, Bt, C, epi, tile=tile, **kw)
     outs = [C] + [kw[k] for k in ("C2", "colsum") if k in kw]
     return outs, want
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2, 4])
+@pytest.mark.parametrize("M,N,K", [(128, 768, 3072), (128, 3072, 768), (256, 384, 1536), (37, 1000, 768), (4, 768, 768), (300, 64, 96)])
+def test_gemm_few_rows_kernel_is_bitwise_the_lds_tiles(ops, epi, M, N, K):
+    """Tile 24 (round 5: one wave per 16 x 16 output tile over all of K, fragments straight from global memory - the B cls rows of a
+    ViT's last layer and head, CaiT's class-attention layers) against exact fp64 math and BITWISE against the LDS tile that served
+    those shapes before (12; K % 64 != 0: the ring, 6): same K order per output element, so a half batch on this kernel and a whole
+    batch on the LDS tiles still agree to fp32 summation order of the REDUCTIONS only (tests/test_ddp_gpu.py).  The heuristic takes it for
+    M <= 256 and every epilogue but GELU' (column-sum slab) and the patch gather."""
+    from savit_amd import lib as _lib
+
+    L = _lib.load()
+    assert L.savit_gemm_tn_auto_tile_cus(min(M, 256), N, K, epi, 0) == 24 and L.savit_gemm_tn_auto_tile_cus(257, N, K, epi, 0) != 24
+    assert L.savit_gemm_tn_auto_tile_cus(128, N, K, 3, 0) != 24
+    other = 12 if K % 64 == 0 else 6
+    got = {}
+    for tile in (24, other):
+        outs, want = _epi_case(ops, 77 * epi + K, M, N, K, epi, tile)
+        assert all(torch.isfinite(o.float()).all() for o in outs), (tile, "an output element was not written")
+        e = rel(host(outs[0]), want)
+        assert e < (2e-5 if epi == 4 else 1e-3), (tile, e)
+        got[tile] = outs
+    for x, y in zip(got[24], got[other]):
+        assert torch.equal(x, y)
 
 
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])

@@ -47,4 +47,9 @@ for k, v in acc.items():
     key = {"Wqkv": "qkv", "Wo": "proj", "W1": "fc1", "W2": "fc2"}.get(k.split(".")[0], k.split(".")[0])
     tf = f"{fl[key]/avg/1e9:7.1f} TF/s" if key in fl else ""
     print(f"{k:18s} x{len(v):4d}  avg {avg*1e3:8.1f} us  total {sum(v):7.3f} ms  {tf}")
+if os.environ.get("SAVIT_PROFILE_LAYER"):  # the launches of one layer one by one (e.g. the last layer, which runs on the cls rows)
+    pre = "l%s." % os.environ["SAVIT_PROFILE_LAYER"]
+    for k, v in res["labels"].items():
+        if k.startswith(pre):
+            print(f"  {k:24s} {v*1e3:8.1f} us")
 print("sum %.3f ms; reps:" % tot, [{k: (round(x, 3) if isinstance(x, float) else x) for k, x in r.items()} for r in res["reps"]], "gate", res["gate_us"], "us")
