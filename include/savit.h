@@ -183,7 +183,11 @@ int savit_gemm_colsum_rows_cus(int M, int N, int K, int tile, int cu_budget); /*
 int savit_colsum_finalize(const float* slab, int rows, int N, float* out, int accumulate, void* stream);
 /* Tile the auto heuristic (tile == 0) picks for a shape and epilogue.  K % 64 == 0: paired-stage kernels 17 = 192x128 (4 waves, two
  * workgroups per CU; the default), 13 = 256x256 (8 waves; GELU-forward on large grids), 12 = 128x128 (small / ragged problems);
- * otherwise 6 / 7 = 128x128 / 256x256 on the 32-deep ring.  savit_gemm_tn_auto_tile = the SAVIT_EPI_BF16 choice. */
+ * otherwise 6 = 128x128 on the 32-deep ring; 18 = 17 with the last partial round in 128-row tiles; 20 / 21 / 22 = the 256x256 / 320x256 /
+ * persistent 320x256 ping-pong kernels (wide outputs, K >= 768; round 2 / 3 / 5); 24 (round 5) = M <= 256 rows, every epilogue but GELU' and
+ * the patch gather: no LDS, one wave per 16x16 or 32x32 output tile over all of K (the cls rows of a ViT's last layer and head, CaiT's
+ * class-attention layers).  Every tile gives bit-identical results (one accumulator per output element walks K in ascending 32-steps).
+ * savit_gemm_tn_auto_tile = the SAVIT_EPI_BF16 choice. */
 int savit_gemm_tn_auto_tile(int M, int N, int K);
 int savit_gemm_tn_auto_tile_epi(int M, int N, int K, int epilogue);
 int savit_gemm_tn_auto_tile_cus(int M, int N, int K, int epilogue, int cu_budget); /* the same for cu_budget CUs (0 = all) */
