@@ -1883,14 +1883,20 @@ __global__ __launch_bounds__(64) void gemm_tn_rows_kernel(const GemmParams p) {
   const int fr = lane & 15, fq = lane >> 4;
   const int row0 = blockIdx.y * (16 * T), col0 = blockIdx.x * (16 * T);
   constexpr uint32_t OOB = 0x7ffffff0u;
-  const auto srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (uint32_t)((size_t)a.M * a.lda * 2), 0x00020000);
-  const auto srdB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.Bt), 0, (uint32_t)((size_t)a.N * a.ldb * 2), 0x00020000);
+  if (row0 >= a.M || col0 >= a.N) return;
+  // descriptors start at THIS wave's first row / column and end with the matrix (capped below 2 GB): any pitch works - the cls rows of a
+  // dense [B * N, F] activation are B rows 6-8 MB apart - and the aliased-row form (lda < K) still reads zeros behind the last row
+  const size_t ta = (size_t)(a.M - row0) * a.lda * 2, tb = (size_t)(a.N - col0) * a.ldb * 2;
+  const auto srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(a.A) + (size_t)row0 * a.lda), 0,
+                                                      (uint32_t)(ta > OOB ? OOB : ta), 0x00020000);
+  const auto srdB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(a.Bt) + (size_t)col0 * a.ldb), 0,
+                                                      (uint32_t)(tb > OOB ? OOB : tb), 0x00020000);
   uint32_t aoff[T], boff[T];
 #pragma unroll
   for (int i = 0; i < T; ++i) {
-    const int r = row0 + 16 * i + fr, c = col0 + 16 * i + fr;
-    aoff[i] = r < a.M ? (uint32_t)r * (uint32_t)(a.lda * 2) + (uint32_t)fq * 16u : OOB;
-    boff[i] = c < a.N ? (uint32_t)c * (uint32_t)(a.ldb * 2) + (uint32_t)fq * 16u : OOB;
+    const int r = 16 * i + fr;
+    aoff[i] = row0 + r < a.M ? (uint32_t)r * (uint32_t)(a.lda * 2) + (uint32_t)fq * 16u : OOB;
+    boff[i] = col0 + r < a.N ? (uint32_t)r * (uint32_t)(a.ldb * 2) + (uint32_t)fq * 16u : OOB;
   }
   const int steps = a.K / 32;  // K % 32 == 0
   auto frag = [&](__amdgpu_buffer_rsrc_t srd, uint32_t off, int step) -> bf16x8 {
@@ -1942,7 +1948,7 @@ __global__ __launch_bounds__(64) void gemm_tn_rows_kernel(const GemmParams p) {
 
 int launch_rows(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
-  if ((size_t)p.a.M * p.a.lda * 2 >= 0x7ffffff0ull || (size_t)p.a.N * p.a.ldb * 2 >= 0x7ffffff0ull) return SAVIT_EINVAL;
+  if ((size_t)31 * p.a.lda * 2 + (size_t)p.a.K * 2 >= 0x7ffffff0ull || (size_t)31 * p.a.ldb * 2 + (size_t)p.a.K * 2 >= 0x7ffffff0ull) return SAVIT_EINVAL;  // (a pitch of 34 M elements)
   // 32 x 32 per wave (half the L2 -> CU bytes per flop) where that still leaves waves for every CU; else 16 x 16
   const long w16 = (long)((p.a.M + 15) / 16) * ((p.a.N + 15) / 16);
   const int T = w16 >= 1536 ? 2 : 1;

@@ -310,6 +310,25 @@ def test_gemm_few_rows_kernel_is_bitwise_the_lds_tiles(ops, epi, M, N, K):
         assert torch.equal(x, y)
 
 
+def test_gemm_few_rows_kernel_takes_any_row_pitch(ops):
+    """The cls rows of a dense [B * N, F] activation are B rows N * F elements apart (ViT-L at 1 025 tokens, 256 images: 2.1 GB from the
+    first to the last row - more than one 32-bit buffer descriptor spans): the few-rows kernel's descriptors start at each wave's own rows."""
+    M, N, K, pitch = 40, 96, 128, 29_000_000  # 39 * 29e6 * 2 B = 2.26 GB between the first and the last row
+    big = torch.empty(M * pitch, dtype=bf16, device="cuda")
+    A = big.as_strided((M, K), (pitch, 1))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A.copy_(torch.randn(M, K, device="cuda", generator=g).to(bf16))
+    Bt = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(bf16)
+    C = torch.full((M, N), float("nan"), dtype=bf16, device="cuda")
+    ops.gemm_tn(A, Bt, C, 0, tile=24)
+    ref = (A.double() @ Bt.double().T).cpu().numpy()
+    assert torch.isfinite(C.float()).all() and rel(host(C), rb(ref)) < 1e-3
+    C0 = torch.full((M, N), float("nan"), dtype=bf16, device="cuda")
+    ops.gemm_tn(A, Bt, C0, 0)  # the auto choice for 40 rows is the same kernel
+    assert torch.equal(C, C0)
+    del big
+
+
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(19700, 768, 128), (19700, 1536, 192), (3001, 1000, 256), (25216, 2304, 64)])
 def test_gemm_large_grid_tiles_vs_oracle_and_each_other(ops, epi, M, N, K):
