@@ -460,6 +460,13 @@ def test_first_touch_gradients_and_folded_norm(name, B, monkeypatch):
     p3 = e3._serial_bwd_plan()
     assert fired == [1, 2] and not p3.fold_sumsq and not any(c[2] == "ln.bwd.finalize" for c in p3.calls) and p3.rest_ranges is not None
     assert float((g3 - g1).norm() / g1.norm()) < 2e-6
+    # opt-in: a cls-only weight that found no slot in the tile FIFO as ONE grouped launch of its own (instead of the split pair + reduce)
+    monkeypatch.setenv("SAVIT_WGRAD_SMALL_GROUPS", "1")
+    e4 = make()
+    g4 = run(e4)
+    own = [c[2] for c in e4._serial_bwd_plan().calls if c[2].endswith(".wgrad") and c[2].startswith(f"l{cfg.num_layers - 1}.")]
+    assert all((lbl + ".reduce") not in [c[2] for c in e4._serial_bwd_plan().calls] for lbl in own)
+    assert torch.isfinite(g4).all() and float((g4 - g1).norm() / g1.norm()) < 2e-6
 
 
 @pytest.mark.parametrize("name,B,img", [("vit_b_patch16", 4, 224), ("vit_s_patch16", 6, 224), ("vit_ti_patch16", 3, 224)])
