@@ -150,9 +150,50 @@ __global__ __launch_bounds__(256) void class_attn_bwd_kernel(const bf16_t* __res
 // so that a model differentiated this way agrees with the dense plan to fp32 summation order: fp32 scores (the query is pre-scaled),
 // P operand = bf16(exp2((s - max) log2 e)) un-normalised with the row sum taken from the un-rounded values, O = sum(P v) / l, LSE saved;
 // backward: P = exp2(s log2 e - LSE log2 e) recomputed, dV = bf16(P) dO, dP = dO . v, delta = rowsum(dO * O), dS = P (dP - delta) in
-// fp32, dK = bf16(dS) q, dQ = dq_scale * sum bf16(dS) k.  One wave per (image, head); keys strided over the lanes, KPL per lane.
+// fp32, dK = bf16(dS) q, dQ = dq_scale * sum bf16(dS) k.  One wave per (image, head).
 constexpr float CQ_LOG2E = 1.4426950408889634f;
 
+// Backward: lane = (key slot ks = lane / 8, 16-byte piece pc = lane % 8): one wave instruction moves 8 WHOLE key rows of 128 bytes (head
+// width 48: six of the eight pieces).  (First form: a lane per key read and wrote whole rows - 64 different cache lines per instruction,
+// eight instructions per row set, 64 wave reductions for dQ: 55 us per launch at DeiT-B's layer against an HBM floor of 28; this form: 32.)  Dot products: 8 multiply-adds per lane + a 3-step fold over the row's 8 lanes; sums over the keys: a 3-step fold over
+// the 8 key slots at the end.
+__device__ __forceinline__ void cq_unpack8(const uint4 w, float (&out)[8]) {
+  out[0] = __uint_as_float(w.x << 16); out[1] = __uint_as_float(w.x & 0xffff0000u);
+  out[2] = __uint_as_float(w.y << 16); out[3] = __uint_as_float(w.y & 0xffff0000u);
+  out[4] = __uint_as_float(w.z << 16); out[5] = __uint_as_float(w.z & 0xffff0000u);
+  out[6] = __uint_as_float(w.w << 16); out[7] = __uint_as_float(w.w & 0xffff0000u);
+}
+__device__ __forceinline__ void cq_load8(const bf16_t* p, bool ok, float (&out)[8]) {
+  uint4 w = make_uint4(0u, 0u, 0u, 0u);
+  if (ok) w = *reinterpret_cast<const uint4*>(p);
+  cq_unpack8(w, out);
+}
+__device__ __forceinline__ void cq_store8(bf16_t* p, const float (&v)[8]) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+__device__ __forceinline__ float cq_row_sum(float x) {  // over the 8 lanes of a key row
+  x += __shfl_xor(x, 1, 64);
+  x += __shfl_xor(x, 2, 64);
+  x += __shfl_xor(x, 4, 64);
+  return x;
+}
+__device__ __forceinline__ float cq_slot_sum(float x) {  // over the 8 key slots (lanes with equal pc)
+  x += __shfl_xor(x, 8, 64);
+  x += __shfl_xor(x, 16, 64);
+  x += __shfl_xor(x, 32, 64);
+  return x;
+}
+__device__ __forceinline__ float cq_dot8(const float (&a)[8], const float (&b)[8]) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += a[e] * b[e];
+  return s;
+}
+
+// Forward: a lane per key (KPL keys per lane), the whole 128-byte row per lane.  The 8-lanes-per-row form of the backward below was
+// built for the forward too and is SLOWER there (21.4-24.6 us against 20.0 per launch at DeiT-B's layer, with 4 or 8 row loads in flight
+// per lane, with and without the value rows held in registers): two dependent passes over the keys (scores -> row maximum -> P V) of
+// 25 short iterations each leave a wave waiting on its own shuffles; the row-per-lane form does 64-term dot products without any.
 template <int HDV, int KPL>
 __global__ __launch_bounds__(256) void cls_query_attn_fwd_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kv, int ldkv,
                                                                   bf16_t* __restrict__ o, float* __restrict__ lse, int B, int Nk, int H) {
@@ -206,7 +247,7 @@ __global__ __launch_bounds__(256) void cls_query_attn_fwd_kernel(const bf16_t* _
   }
 }
 
-template <int HDV, int KPL>
+template <int HDV, int NIT>
 __global__ __launch_bounds__(256) void cls_query_attn_bwd_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kv, int ldkv,
                                                                   const bf16_t* __restrict__ o, const float* __restrict__ lse,
                                                                   const bf16_t* __restrict__ d_o, bf16_t* __restrict__ dq, long lddq,
@@ -215,48 +256,55 @@ __global__ __launch_bounds__(256) void cls_query_attn_bwd_kernel(const bf16_t* _
   const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (bh >= B * H) return;
   const int b = bh / H, h = bh - b * H, d = H * HDV;
-  float qv[HDV], dov[HDV];
-  load_row_f32<HDV>(q + (size_t)b * ldq + h * HDV, qv);
-  load_row_f32<HDV>(d_o + (size_t)b * d + h * HDV, dov);
-  float del = 0.f;
+  const int ks = lane >> 3, pc = lane & 7;
+  const bool pc_ok = pc * 8 < HDV;
+  float qv[8], dov[8], del;
+  cq_load8(q + (size_t)b * ldq + h * HDV + pc * 8, pc_ok, qv);
+  cq_load8(d_o + (size_t)b * d + h * HDV + pc * 8, pc_ok, dov);
   {
-    float ov[HDV];
-    load_row_f32<HDV>(o + (size_t)b * d + h * HDV, ov);
-#pragma unroll
-    for (int e = 0; e < HDV; ++e) del += ov[e] * dov[e];
+    float ov[8];
+    cq_load8(o + (size_t)b * d + h * HDV + pc * 8, pc_ok, ov);
+    del = cq_row_sum(cq_dot8(ov, dov));
   }
   const float nl2 = -CQ_LOG2E * lse[(size_t)b * H + h];
-  float dqa[HDV];
+  const size_t row0 = (size_t)b * Nk * ldkv + h * HDV + pc * 8;
+  float dqa[8];
 #pragma unroll
-  for (int e = 0; e < HDV; ++e) dqa[e] = 0.f;
+  for (int e = 0; e < 8; ++e) dqa[e] = 0.f;
+  const int nit = (Nk + 7) / 8;
+  constexpr int G = 4;  // key iterations requested together: 8 row loads in flight per lane
+  for (int it0 = 0; it0 < nit; it0 += G) {
+    float kr[G][8], vr[G][8];
+    bool ok[G];
 #pragma unroll
-  for (int kk = 0; kk < KPL; ++kk) {
-    const int key = lane + 64 * kk;
-    if (key < Nk) {
-      float kr[HDV], vr[HDV], dkr[HDV], dvr[HDV];
-      load_row_f32<HDV>(kv + ((size_t)b * Nk + key) * ldkv + h * HDV, kr);
-      load_row_f32<HDV>(kv + ((size_t)b * Nk + key) * ldkv + d + h * HDV, vr);
-      float sc = 0.f, dp = 0.f;
+    for (int g = 0; g < G; ++g) {
+      const int key = (it0 + g) * 8 + ks;
+      ok[g] = pc_ok && key < Nk;
+      cq_load8(kv + row0 + (size_t)key * ldkv, ok[g], kr[g]);
+      cq_load8(kv + row0 + (size_t)key * ldkv + d, ok[g], vr[g]);
+    }
 #pragma unroll
-      for (int e = 0; e < HDV; ++e) {
-        sc += qv[e] * kr[e];
-        dp += dov[e] * vr[e];
-      }
+    for (int g = 0; g < G; ++g) {
+      const int key = (it0 + g) * 8 + ks;
+      const float sc = cq_row_sum(cq_dot8(qv, kr[g])), dp = cq_row_sum(cq_dot8(dov, vr[g]));
       const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc, CQ_LOG2E, nl2));
       const float pb = round_bf16(pr), dsb = round_bf16(pr * (dp - del));
+      float dkr[8], dvr[8];
 #pragma unroll
-      for (int e = 0; e < HDV; ++e) {
-        dqa[e] += dsb * kr[e];
+      for (int e = 0; e < 8; ++e) {
+        dqa[e] += ok[g] ? dsb * kr[g][e] : 0.f;
         dkr[e] = dsb * qv[e];
         dvr[e] = pb * dov[e];
       }
-      store_row_bf16<HDV>(dkv + ((size_t)b * Nk + key) * ldkv + h * HDV, dkr);
-      store_row_bf16<HDV>(dkv + ((size_t)b * Nk + key) * ldkv + d + h * HDV, dvr);
+      if (ok[g]) {
+        cq_store8(dkv + row0 + (size_t)key * ldkv, dkr);
+        cq_store8(dkv + row0 + (size_t)key * ldkv + d, dvr);
+      }
     }
   }
 #pragma unroll
-  for (int e = 0; e < HDV; ++e) dqa[e] = wave_sum(dqa[e]) * dq_scale;
-  if (lane == 0) store_row_bf16<HDV>(dq + (size_t)b * lddq + h * HDV, dqa);
+  for (int e = 0; e < 8; ++e) dqa[e] = cq_slot_sum(dqa[e]) * dq_scale;
+  if (ks == 0 && pc_ok) cq_store8(dq + (size_t)b * lddq + h * HDV + pc * 8, dqa);
 }
 
 }  // namespace
@@ -296,15 +344,15 @@ extern "C" int savit_class_attention_bwd(const void* q, long ldq, const void* kv
 }
 
 // ---- the cls query against all keys with the MFMA kernels' rounding points (see cls_query_attn_fwd_kernel)
-#define CQ_DISPATCH(KERNEL, ...)                                                                                       \
+#define CQ_DISPATCH(KERNEL, SMALL, LARGE, ...)                                                                         \
   do {                                                                                                                 \
     const dim3 grid((B * H + 3) / 4), block(256);                                                                      \
     if (head_dim == 48) {                                                                                              \
-      if (Nk <= 256) hipLaunchKernelGGL((KERNEL<48, 4>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);            \
-      else hipLaunchKernelGGL((KERNEL<48, 10>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);                     \
+      if (Nk <= 256) hipLaunchKernelGGL((KERNEL<48, SMALL>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);         \
+      else hipLaunchKernelGGL((KERNEL<48, LARGE>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);                  \
     } else {                                                                                                           \
-      if (Nk <= 256) hipLaunchKernelGGL((KERNEL<64, 4>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);            \
-      else hipLaunchKernelGGL((KERNEL<64, 10>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);                     \
+      if (Nk <= 256) hipLaunchKernelGGL((KERNEL<64, SMALL>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);         \
+      else hipLaunchKernelGGL((KERNEL<64, LARGE>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);                  \
     }                                                                                                                  \
   } while (0)
 
@@ -314,7 +362,7 @@ extern "C" int savit_cls_query_attention_fwd(const void* q, long ldq, const void
   SAVIT_CHECK_ARG(ldq >= H * head_dim && ldq % 8 == 0 && ldkv >= 2 * H * head_dim && ldkv % 8 == 0);
   SAVIT_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)kv % 16) == 0 && ((uintptr_t)o % 16) == 0);
   if (B == 0) return SAVIT_OK;
-  CQ_DISPATCH(cls_query_attn_fwd_kernel, (const bf16_t*)q, ldq, (const bf16_t*)kv, ldkv, (bf16_t*)o, lse, B, Nk, H);
+  CQ_DISPATCH(cls_query_attn_fwd_kernel, 4, 10, (const bf16_t*)q, ldq, (const bf16_t*)kv, ldkv, (bf16_t*)o, lse, B, Nk, H);
   SAVIT_LAUNCH_RET();
 }
 
@@ -325,7 +373,7 @@ extern "C" int savit_cls_query_attention_bwd(const void* q, long ldq, const void
   SAVIT_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)kv % 16) == 0 && ((uintptr_t)o % 16) == 0 && ((uintptr_t)d_o % 16) == 0 &&
                   ((uintptr_t)dq % 16) == 0 && ((uintptr_t)dkv % 16) == 0);
   if (B == 0) return SAVIT_OK;
-  CQ_DISPATCH(cls_query_attn_bwd_kernel, (const bf16_t*)q, ldq, (const bf16_t*)kv, ldkv, (const bf16_t*)o, lse, (const bf16_t*)d_o, (bf16_t*)dq,
+  CQ_DISPATCH(cls_query_attn_bwd_kernel, 32, 80, (const bf16_t*)q, ldq, (const bf16_t*)kv, ldkv, (const bf16_t*)o, lse, (const bf16_t*)d_o, (bf16_t*)dq,
               lddq, (bf16_t*)dkv, B, Nk, H, dq_scale);
   SAVIT_LAUNCH_RET();
 }
