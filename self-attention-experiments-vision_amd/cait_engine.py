@@ -29,6 +29,7 @@ from . import lib as _lib
 from .config import ModelConfig
 from .engine import (ViTEngine, WgradQueue, _Plan, _align, _copy_tree, add_wgrad, add_wgrad_group, finalize_first_touch, finalize_wgrad_ws,
                      wgrad_group_tile)
+from .options import EngineOptions
 from .timing import timed_call
 
 bf16 = torch.bfloat16
@@ -129,7 +130,8 @@ def stochastic_depth_seed(seed: int, rank: int, step: int) -> int:
 
 class CaiTEngine:
     def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True,
-                 th_fused: "bool | None" = None, reserved_cus=None, wgrad_max_lag=None):
+                 th_fused: "bool | None" = None, reserved_cus=None, wgrad_max_lag=None, options=None, **opts):
+        self.opt = EngineOptions.resolve(options, th_fused=th_fused, reserved_cus=reserved_cus, wgrad_max_lag=wgrad_max_lag, **opts)
         if cfg.kind != "cait":
             raise ValueError("CaiTEngine needs a CaiT config")
         if cfg.head_dim not in (48, 64) or cfg.num_heads not in (2, 4, 6, 8, 16):
@@ -170,9 +172,9 @@ class CaiTEngine:
         # talking-heads attention: the materialising kernels (S and P' [B,H,N,Np] saved per layer for backward), or with
         # th_fused=True (or SAVIT_TH_FUSED=1, read HERE - the library reads no environment) the fused ones (S / P' in LDS, nothing kept
         # per layer; slower on MI355X: see csrc/th_fused.hip).  Default: what the library prefers for this geometry.
+        th_fused = self.opt.th_fused
         if th_fused is None:
-            env = _os.environ.get("SAVIT_TH_FUSED")
-            th_fused = (env != "0") if env is not None else bool(self.L.savit_th_fused_preferred(N, H, cfg.head_dim))
+            th_fused = bool(self.L.savit_th_fused_preferred(N, H, cfg.head_dim))
         self.th_fused = bool(th_fused) and bool(self.L.savit_th_fused_supported(N, H, cfg.head_dim))
         if self.th_fused:
             self.sbuf, self.pbuf = [], []
@@ -203,7 +205,7 @@ class CaiTEngine:
         self.d_h, self.d_o = e(M, d, dt=bf16), e(M, d, dt=bf16)
         # The SA layers' weight gradients wait in a FIFO of 256 x 256 output tiles and leave in grouped launches of one tile per CU
         # (engine.WgradQueue; a launch reaches back `wgrad_lag` layers), so the cotangents they read rotate through rings that deep.
-        ViTEngine._init_cu_budget(self, reserved_cus, wgrad_max_lag)  # n_cus, reserved_cus, cu_budget, wgrad_max_lag
+        ViTEngine._init_cu_budget(self)  # n_cus, reserved_cus, cu_budget, wgrad_max_lag
         self.wgrad_tile, self.wgrad_lag = self._wgrad_group_plan()
         depth = max(2, self.wgrad_lag + 1)
         self.dbr_ring = [e(M, d, dt=bf16) for _ in range(2 * depth)]
@@ -229,15 +231,15 @@ class CaiTEngine:
         self._data_parallel = False
         # round 5, as in ViTEngine: first-touch grouped weight gradients, the gradient norm's squares carried by those launches, the
         # LayerNorm / LayerScale column sums of the SA layers reduced by one launch at the end of backward (alone on the GPU only)
-        self.first_touch = _os.environ.get("SAVIT_WGRAD_FIRST_TOUCH", "1") != "0"
-        self.defer_ln_finalize = _os.environ.get("SAVIT_DEFER_LN_FINALIZE", "1") != "0"
+        self.first_touch = self.opt.first_touch
+        self.defer_ln_finalize = self.opt.defer_ln_finalize
         self._gnorm_folded = False
         self._accumulate_run = False
         self.launch_timer = None  # timing.LaunchTimer (bench.py, profile_step)
         self.weights_stale = True
-        self.overlap_wgrad = _os.environ.get("SAVIT_OVERLAP_WGRAD", "1") != "0"
-        self.n_side_streams = int(_os.environ.get("SAVIT_SIDE_STREAMS", "1"))
-        self.wgrad_cu_share = float(_os.environ.get("SAVIT_WGRAD_CU_SHARE", "0.56"))
+        self.overlap_wgrad = True if self.opt.overlap_wgrad is None else bool(self.opt.overlap_wgrad)
+        self.n_side_streams = int(self.opt.side_streams)
+        self.wgrad_cu_share = float(self.opt.wgrad_cu_share)
         self._side_streams = []
         self._building_serial = False
         self._bwd_plan_serial = None
@@ -308,9 +310,9 @@ class CaiTEngine:
     def _wgrad_group_plan(self):
         """(tile, layers a launch reaches back) of the SA layers' grouped weight gradients (engine.ViTEngine._wgrad_group_plan has the
         reasoning; CaiT-S24: 38 tiles per layer, a launch of 256 every ~7 layers); tile 0 (SAVIT_WGRAD_GROUP=0) = one launch per weight."""
-        if _os.environ.get("SAVIT_WGRAD_GROUP", "auto") == "0":
+        if not self.opt.wgrad_group:
             return 0, 0
-        tile = wgrad_group_tile(self.cfg.embed_dim, self.cfg.hidden)
+        tile = wgrad_group_tile(self.cfg.embed_dim, self.cfg.hidden, self.opt.wgrad_tile)
         sizes = self._layer_wgrad_tiles(tile)
         q, lag = WgradQueue(self.cu_budget, self.wgrad_max_lag), 0
         for l in range(self.cfg.num_layers - 1, -1, -1):

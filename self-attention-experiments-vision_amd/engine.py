@@ -29,6 +29,7 @@ import torch
 
 from . import lib as _lib
 from .config import ModelConfig
+from .options import EngineOptions
 from .timing import timed_call
 
 bf16 = torch.bfloat16
@@ -273,7 +274,7 @@ def add_wgrad(eng, plan: _Plan, label: str, X, dY, dW, Mr, Kin, Nout, ldx, lddy,
     whole plan is known: launches that can run at the same time must not share one, so side launches use the workspace of THEIR
     side stream (ordinal % number of side streams, the stream run_overlapped will pick) and main-chain launches a separate one."""
     need = int(eng.L.savit_gemm_wgrad_workspace_bytes(Mr, Kin, Nout, splits, patch[0]))
-    if os.environ.get("SAVIT_WGRAD_ATOMICS", "0") == "1":
+    if eng.opt.wgrad_atomics:
         need = 0
     on_side = side and eng.overlap_wgrad and not eng._building_serial
     key = ((max(plan.side.values()) + 1 if plan.side else 0) % max(1, eng.n_side_streams)) if on_side else -1
@@ -322,12 +323,12 @@ def add_wgrad_group(eng, plan: _Plan, label: str, entries: list, tile: int, defe
     eng.group_flops[label] = flops
 
 
-def wgrad_group_tile(d: int, F: int) -> int:
+def wgrad_group_tile(d: int, F: int, override: Optional[int] = None) -> int:
     """Tile code of the grouped weight-gradient launches for a model of width d / hidden width F: 256 x 256 where the matrices are
     multiples of it (DeiT-B, ViT-L); for the d = 384 models (DeiT-S, CaiT-S) 256 x 384 or 384 x 256 per weight, whichever covers it with
     fewer tiles (95 % of a launch inside a matrix; with 256 x 256 tiles 29 % hung over the matrix edges); else 256 x 256 with edge tiles."""
-    if os.environ.get("SAVIT_WGRAD_TILE"):  # A/B runs
-        return int(os.environ["SAVIT_WGRAD_TILE"])
+    if override:  # A/B runs (EngineOptions.wgrad_tile)
+        return int(override)
     if d % 256 == 0 and F % 256 == 0:
         return 256
     if d % 384 == 0 and F % 384 == 0:
@@ -426,10 +427,13 @@ class ViTEngine:
     DEFAULT_OVERLAP = False  # weight gradients on a side stream? (see _init_step_state)
 
     def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True,
-                 reserved_cus: Optional[int] = None, wgrad_max_lag: Optional[int] = None):
+                 reserved_cus: Optional[int] = None, wgrad_max_lag: Optional[int] = None, options: Optional[EngineOptions] = None, **opts):
         """reserved_cus: CUs this rank leaves to a resident RCCL all-reduce (train.py:96) - grids are then planned for the remaining
         ones (default: SAVIT_RESERVED_CUS, else 0; ddp.default_reserved_cus(world) is what bench.py / train.py pass at world > 1).
-        wgrad_max_lag: bound, in layers, on how long a weight gradient waits for a full grouped launch (WgradQueue)."""
+        wgrad_max_lag: bound, in layers, on how long a weight gradient waits for a full grouped launch (WgradQueue).
+        options / **opts: every other plan switch (options.EngineOptions: cls_only_last, cls_fwd, rows_tile, first_touch, overlap_wgrad ...);
+        a field nobody sets takes its SAVIT_* environment variable, read here, once."""
+        self.opt = EngineOptions.resolve(options, reserved_cus=reserved_cus, wgrad_max_lag=wgrad_max_lag, **opts)
         if cfg.kind != "vit":
             raise NotImplementedError("ViTEngine handles the ViT family; CaiT uses CaiTEngine")
         if cfg.head_dim not in (48, 64):
@@ -444,7 +448,7 @@ class ViTEngine:
         self.B = int(batch)
         self.dev = torch.device(device)
         self.rp = int(round_like_reference)
-        self._init_cu_budget(reserved_cus, wgrad_max_lag)
+        self._init_cu_budget()
         self.layout = ParamLayout(cfg)
         d, F, C, N, NL = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers
         self.M = self.B * N
@@ -491,7 +495,7 @@ class ViTEngine:
         # rings that deep (also what lets side-stream weight-gradient GEMMs lag behind the main chain).
         self.wgrad_tile, self.wgrad_cap, self.wgrad_divert, self.wgrad_lag = self._wgrad_group_plan()
         self.wgrad_group = self.wgrad_lag  # (layers a launch reaches back: bench.py's label for the grouping)
-        depth = max(2, int(os.environ.get("SAVIT_RING_DEPTH", "2")), self.wgrad_lag + 1 if self.wgrad_tile else 0)
+        depth = max(2, self.opt.ring_depth, self.wgrad_lag + 1 if self.wgrad_tile else 0)
         self.dres_b_ring = [e(M, d, dt=bf16) for _ in range(2 * depth)]
         self.dres_b = self.dres_b_ring[0]
         self.d_u_ring = [e(M, F, dt=bf16) for _ in range(depth)]
@@ -507,13 +511,12 @@ class ViTEngine:
         self._init_step_state()
 
     # ---- state every engine of this package shares (the Mixer / TNT engines subclass this one and lay out their own activations)
-    def _init_cu_budget(self, reserved_cus: Optional[int], wgrad_max_lag: Optional[int]):
+    def _init_cu_budget(self):
         """CUs the launch plans may count on.  Everything that sizes a grid for "one round of workgroups" reads cu_budget: the grouped
         weight-gradient launches (WgradQueue cap), the TN GEMM tile choice (savit_gemm_args.cu_budget) and the persistent attention
         kernels' grids (savit_set_cu_budget)."""
         self.n_cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
-        if reserved_cus is None:
-            reserved_cus = int(os.environ.get("SAVIT_RESERVED_CUS", "0"))
+        reserved_cus = self.opt.reserved_cus or 0
         if not 0 <= int(reserved_cus) < self.n_cus:
             raise ValueError(f"reserved_cus must be in [0, {self.n_cus})")
         self.reserved_cus = int(reserved_cus)
@@ -526,17 +529,15 @@ class ViTEngine:
         # encoder layer's MLP branch, its second LayerNorm and its output projection are differentiated on the B cls rows instead of the
         # B*N token rows - every other row of those cotangents is exactly zero (ViTEngine._record_bwd_plan; wide models only)
         cfg_ = getattr(self, "cfg", None)
-        self.cls_only_last = (os.environ.get("SAVIT_CLS_ONLY_LAST", "1") != "0" and getattr(cfg_, "kind", "") == "vit" and
+        self.cls_only_last = (self.opt.cls_only_last and getattr(cfg_, "kind", "") == "vit" and
                               cfg_.embed_dim > 64 and cfg_.seq_len > 1)
         # ... and (cls_fwd) its FORWARD behind the qkv projection as well - the cls query's attention (savit_cls_query_attention_fwd), output
         # projection, second LayerNorm and MLP on B rows: the other rows of the last layer's output are never read (the final LayerNorm and
         # the head take row 0), and its backward then works on compact [B, .] activations.  Needs the cls-query kernels' geometry.
-        self.cls_fwd = bool(self.cls_only_last and os.environ.get("SAVIT_CLS_FWD", "1") != "0" and cfg_.head_dim in (48, 64) and cfg_.seq_len <= 640)
+        self.cls_fwd = bool(self.cls_only_last and self.opt.cls_fwd and cfg_.head_dim in (48, 64) and cfg_.seq_len <= 640)
         self._needs_zero_dres = True
         self._cls_per_weight = frozenset({"W2", "W1", "Wo"})  # (_wgrad_group_plan moves the ones that fit the last round into the tile FIFO)
-        if wgrad_max_lag is None and os.environ.get("SAVIT_WGRAD_MAX_LAG"):
-            wgrad_max_lag = int(os.environ["SAVIT_WGRAD_MAX_LAG"])
-        self.wgrad_max_lag = wgrad_max_lag
+        self.wgrad_max_lag = self.opt.wgrad_max_lag
 
     def _init_flat_buffers(self):
         """Parameters, gradients, optimizer state: flat fp32 buffers in the layout's order (Adam moments allocated on first use)."""
@@ -572,8 +573,8 @@ class ViTEngine:
         # the GPU they also carry the gradient norm's sum of squares, and the LayerNorm backward launches leave their column-sum slabs
         # to ONE finalize launch at the end of backward.  A data-parallel rank keeps the per-launch finalizes and the separate norm
         # pass: its bucket triggers need final bias / LayerNorm gradients layer by layer, and its norm is that of the REDUCED gradient.
-        self.first_touch = os.environ.get("SAVIT_WGRAD_FIRST_TOUCH", "1") != "0"
-        self.defer_ln_finalize = os.environ.get("SAVIT_DEFER_LN_FINALIZE", "1") != "0"
+        self.first_touch = self.opt.first_touch
+        self.defer_ln_finalize = self.opt.defer_ln_finalize
         self._gnorm_folded = False   # True between a backward whose launches accumulated gnorm[1:33] and the optimizer step that uses them
         self._accumulate_run = False
         self.launch_timer = None  # timing.LaunchTimer: brackets the launches it tracks (bench.py, profile_step)
@@ -582,9 +583,9 @@ class ViTEngine:
         # atomic-free weight gradients and the tail-split tiles the ViT family runs as fast or faster on ONE stream (DeiT-B 6 715 vs
         # 6 650 img/s, DeiT-S 18 050 vs 17 980, same box) - the second stream only ever filled bubbles those changes removed - while
         # the Mixer (+5 %) and TNT (+12 %) engines, with their many small launches, still gain from it (DEFAULT_OVERLAP below).
-        self.overlap_wgrad = os.environ.get("SAVIT_OVERLAP_WGRAD", "1" if self.DEFAULT_OVERLAP else "0") != "0"
-        self.n_side_streams = int(os.environ.get("SAVIT_SIDE_STREAMS", "1"))
-        self.wgrad_cu_share = float(os.environ.get("SAVIT_WGRAD_CU_SHARE", "0.56"))
+        self.overlap_wgrad = self.DEFAULT_OVERLAP if self.opt.overlap_wgrad is None else bool(self.opt.overlap_wgrad)
+        self.n_side_streams = int(self.opt.side_streams)
+        self.wgrad_cu_share = float(self.opt.wgrad_cu_share)
         self._side_streams: List[torch.cuda.Stream] = []
         self._building_serial = False
         self._bwd_plan_serial: Optional[_Plan] = None  # every launch sized for the whole chip: profile_step / one-stream runs
@@ -659,9 +660,9 @@ class ViTEngine:
             a.rows_per_sample = 1
         a.round_bias_bf16 = self.rp
         a.cu_budget = self.cu_budget if (self.reserved_cus and self._building_bwd) else 0  # the all-reduce is resident during backward only
-        if not a.tile and a.M <= 256 and os.environ.get("SAVIT_ROWS_TILE", "1") == "0":
-            # A/B and exactness tests: few-row products on the LDS tile a many-row product of the same width takes (same K order per
-            # output element as the dense plan's launches) instead of the few-rows kernel (tile 24: K split over a workgroup's waves)
+        if not a.tile and a.M <= 256 and not self.opt.rows_tile:
+            # A/B runs (EngineOptions.rows_tile=False): few-row products on the LDS tile a many-row product of the same width takes instead
+            # of the few-rows kernel (tile 24).  Both walk K in the same order per output element: bit-identical results, other launch shape
             a.tile = int(self.L.savit_gemm_tn_auto_tile_cus(257, a.N, a.K, a.epilogue, a.cu_budget))
         plan.keep.append(a)
         plan.add(self.L.savit_gemm_bf16_tn, (ctypes.byref(a),), label, writes=writes)
@@ -771,7 +772,7 @@ class ViTEngine:
         wpe_g = bool(getattr(self, "_wpe_grouped", False)) and queue is not None and not self._data_parallel
         # (opt-in: W1 of the cls-only layer 15 + 11 us -> 14 us, but a 36-tile launch then sits among the 256-tile launches of the kernel
         #  the bench reports - its average launch time and rocprofv3's AverageNs would mix two kinds of launches for 12 us per step)
-        small_groups = os.environ.get("SAVIT_WGRAD_SMALL_GROUPS", "0") != "0"
+        small_groups = self.opt.wgrad_small_groups
 
         def flush_group(layer: int, last: bool, final: bool = False):
             # called between a layer's last input-gradient GEMM and its ln1.bwd (which overwrites the oldest ring slot): every
@@ -1007,10 +1008,9 @@ class ViTEngine:
         254); ViT-L: 24 x 192 = 18 x 256 exactly.  SAVIT_WGRAD_GROUP=0 turns the grouping off."""
         cfg = self.cfg
         d, F, NL = cfg.embed_dim, cfg.hidden, cfg.num_layers
-        env = os.environ.get("SAVIT_WGRAD_GROUP", "auto")
-        if env == "0" or d % 8 or F % 8:
+        if not self.opt.wgrad_group or d % 8 or F % 8:
             return 0, 0, frozenset(), 0
-        tile = wgrad_group_tile(d, F)
+        tile = wgrad_group_tile(d, F, self.opt.wgrad_tile)
         sizes = [(n, int(self.L.savit_gemm_wgrad_group_tiles(a, b, tile))) for n, a, b in (("W2", F, d), ("W1", d, F), ("Wo", d, d), ("Wqkv", d, 3 * d))]
         per_layer = sum(t for _, t in sizes)
         cap = self.cu_budget
@@ -1033,7 +1033,7 @@ class ViTEngine:
         # operand is then the dense patch matrix savit_patchify_bf16 writes (20 us) instead of a gather inside a launch of its own (84 + 6 us)
         wpe_tiles = int(self.L.savit_gemm_wgrad_group_tiles(cfg.patch_dim, d, tile)) if cfg.patch % 8 == 0 and cfg.patch_dim % 8 == 0 else 0
         free = -(-total // cap) * cap - total
-        self._wpe_grouped = bool(os.environ.get("SAVIT_WPE_GROUPED", "1") != "0" and type(self)._record_bwd_plan is ViTEngine._record_bwd_plan
+        self._wpe_grouped = bool(self.opt.wpe_grouped and type(self)._record_bwd_plan is ViTEngine._record_bwd_plan
                                  and 0 < wpe_tiles <= free and total > 0 and self.wgrad_max_lag is None)  # (a bound on the reach-back wins)
         if self._wpe_grouped:
             total += wpe_tiles

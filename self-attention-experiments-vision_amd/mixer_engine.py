@@ -25,6 +25,7 @@ import torch
 from . import lib as _lib
 from .config import ModelConfig
 from .engine import ViTEngine, _Plan, _align, _copy_tree, bf16, f32, finalize_wgrad_ws  # noqa: F401
+from .options import EngineOptions
 
 
 class MixerLayout:
@@ -114,7 +115,8 @@ class MixerEngine(ViTEngine):
     DEFAULT_OVERLAP = True  # many small launches: the side stream still pays (engine.ViTEngine._init_step_state)
 
     def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True,
-                 reserved_cus=None, wgrad_max_lag=None):
+                 reserved_cus=None, wgrad_max_lag=None, options=None, **opts):
+        self.opt = EngineOptions.resolve(options, reserved_cus=reserved_cus, wgrad_max_lag=wgrad_max_lag, **opts)
         if cfg.kind != "mixer":
             raise NotImplementedError("MixerEngine handles the MLP-Mixer family")
         if cfg.embed_dim % 64 != 0 or cfg.patch % 8 != 0 or cfg.num_classes % 8 != 0:
@@ -126,7 +128,7 @@ class MixerEngine(ViTEngine):
         self.B = int(batch)
         self.dev = torch.device(device)
         self.rp = int(round_like_reference)
-        self._init_cu_budget(reserved_cus, wgrad_max_lag)
+        self._init_cu_budget()
         self.layout = MixerLayout(cfg)
         d, F, C, n, NL = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.n_patches, cfg.num_layers
         Lp, Fp = self.layout.Lp, self.layout.Fp
@@ -161,7 +163,7 @@ class MixerEngine(ViTEngine):
         self.fstats = e(2, M)
         # ---- backward scratch (rotated where a side-stream weight-gradient GEMM reads it, as in the ViT engine)
         self.dres = e(M, d)
-        depth = max(2, int(os.environ.get("SAVIT_RING_DEPTH", "2")))
+        depth = max(2, self.opt.ring_depth)
         self.dres_b_ring = [e(M, d, dt=bf16) for _ in range(2 * depth)]
         self.dres_b = self.dres_b_ring[0]
         self.d_u_ring = [e(M, F, dt=bf16) for _ in range(depth)]

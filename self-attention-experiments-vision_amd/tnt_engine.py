@@ -25,6 +25,7 @@ import torch
 from . import lib as _lib
 from .config import ModelConfig
 from .engine import ViTEngine, _Plan, _align, _copy_tree, bf16, f32, finalize_wgrad_ws  # noqa: F401
+from .options import EngineOptions
 
 HDP = 16  # padded inner head width
 
@@ -139,7 +140,8 @@ class TNTEngine(ViTEngine):
     DEFAULT_OVERLAP = True  # many small launches: the side stream still pays (engine.ViTEngine._init_step_state)
 
     def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda", round_like_reference: bool = True,
-                 reserved_cus=None, wgrad_max_lag=None):
+                 reserved_cus=None, wgrad_max_lag=None, options=None, **opts):
+        self.opt = EngineOptions.resolve(options, reserved_cus=reserved_cus, wgrad_max_lag=wgrad_max_lag, **opts)
         if cfg.kind != "tnt":
             raise NotImplementedError("TNTEngine handles the TNT family")
         if cfg.head_dim != 64 or cfg.embed_dim % 64 or cfg.num_classes % 8 or cfg.patch % 8:
@@ -154,12 +156,12 @@ class TNTEngine(ViTEngine):
         self.B = int(batch)
         self.dev = torch.device(device)
         self.rp = int(round_like_reference)
-        self._init_cu_budget(reserved_cus, wgrad_max_lag)
+        self._init_cu_budget()
         self.layout = lay = TNTLayout(cfg)
         do, Fo, C, N, NL, n, npx = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers, cfg.n_patches, cfg.n_pixels
         Fi, dap = lay.Fi, lay.dap
         # 16 pixel tokens x 4 heads = one 64-lane wave per sequence; other geometries go through the tiled attention kernels
-        self.seq16 = cfg.n_pixels == 16 and Hi == 4 and os.environ.get("SAVIT_TNT_SEQ16", "1") != "0"
+        self.seq16 = cfg.n_pixels == 16 and Hi == 4 and self.opt.tnt_seq16
         self.Kpi = Kpi = _align(di, 32)            # GEMM K for operands of width di
         self.Kpx = Kpx = _align(lay.pix_in, 64)    # pixel-embedding operand pitch
         self.M = Mo = self.B * N                   # patch-stream rows (name shared with the ViT engine)
@@ -212,7 +214,7 @@ class TNTEngine(ViTEngine):
         self.yb = e(Ms, do, dt=bf16)                                    # Inner2Outer projection (scratch)
         self.zcls = e(self.B, do, dt=bf16)
         # ---- backward scratch
-        depth = max(2, int(os.environ.get("SAVIT_RING_DEPTH", "2")))
+        depth = max(2, self.opt.ring_depth)
         self.dres = e(Mo, do)                                           # patch-stream cotangent
         self.dres_b_ring = [e(Mo, do, dt=bf16) for _ in range(2 * depth)]
         self.dres_b = self.dres_b_ring[0]
@@ -381,7 +383,7 @@ class TNTEngine(ViTEngine):
 
         # The pixel-stream weight gradients reduce B*n*16 rows into one or two 128x128 output tiles: the library's default of 24
         # K-splits leaves them at 166 us each (4 per layer: the longest item of the step); SAVIT_TNT_INNER_SPLITS sizes them.
-        inner_splits = int(os.environ.get("SAVIT_TNT_INNER_SPLITS", "160"))
+        inner_splits = int(self.opt.tnt_inner_splits)
 
         def wgrad(label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw, patch=(0, 0, 0, 0)):
             sp = self._wgrad_splits(Kin, Nout, patch[0])

