@@ -19,7 +19,11 @@ whole-job images/s.  Rank 0 prints ONE JSON line.  Extra objects on that line:
                 that the accounting adds up: launches x avg of the dominant kernel <= ms_per_step, sum of all launches <= 1.05 x
                 ms_per_step (net of what an empty bracket costs, measured), live and instrumented averages of the dominant kernel within 10 %.  A failed check sets
                 "roofline_valid": false and dumps the per-label table to stderr.
-  step_roofline whole-step figure of SURVEY.md 8d: images/s/GPU x 105.152 GFLOP per image / peak.
+  step_roofline whole-step MFMA utilisation: images/s/GPU x the flops the step EXECUTES (98.55 GFLOP per image on DeiT-B: the last
+                encoder layer runs on the cls rows) / peak = `frac`; SURVEY.md 8d's dense count (105.152 GFLOP) gives `frac_counted`.
+  hbm_kernels   the memory-bound kernels of the step (LayerNorm forward / backward, AdamW, attention forward / backward): algorithmic
+                bytes per launch, mean launch time from the instrumented steps, achieved TB/s and the fraction of the 6.3 TB/s this
+                chip sustains (north_star: "achieved HBM GB/s on the memory-bound softmax / LayerNorm").
   cpu_baseline  the CPU restatement (oracle/torch_ref.py, JAX absent: SURVEY 8c) of BASELINE config 1 (ViT-Ti/16, batch 8,
                 fp32: forward+loss+backward = `value`, forward+loss alone = `forward_loss_value`) on this host's cores, bounded
                 sample, rank 0 at N=1 only; `headline_model_value` is the same restatement of the headline model.
@@ -151,21 +155,22 @@ def launch_ranks(n: int) -> int:
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"  # dmabuf IPC between the ranks' RCCL peers (the only mode this host driver supports)
     env.setdefault("OMP_NUM_THREADS", "4")   # torch.distributed.run would set 1; the CPU side of a rank only drives launches
-    env.update(rccl_env_for(n, env))         # RCCL's channels (= resident CUs) bounded by the CUs backward is planned to leave it
+    env.update(rccl_env_for(n, env))         # (opt-in, SAVIT_PIN_RCCL_CHANNELS=1) RCCL's channels bounded by the CUs backward leaves it
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
 
 
 def rccl_env_for(world: int, env) -> dict:
-    """NCCL_MAX/MIN_NCHANNELS for the rank processes of a `world`-rank job (ddp.rccl_channel_env; restated here without importing
-    torch: the launcher parent must stay GPU-free).  tests/test_ddp_cpu.py checks both against each other."""
-    if world <= 1:
+    """NCCL_MAX/MIN_NCHANNELS for the rank processes of a `world`-rank job - only with SAVIT_PIN_RCCL_CHANNELS=1 (ddp.rccl_channel_env:
+    opt-in, unverified on more than one GPU; restated here without importing torch: the launcher parent must stay GPU-free).
+    tests/test_ddp_cpu.py checks both against each other."""
+    if world <= 1 or env.get("SAVIT_PIN_RCCL_CHANNELS", "0") != "1":
         return {}
     if env.get("SAVIT_RESERVED_CUS"):
         reserved = int(env["SAVIT_RESERVED_CUS"])
     elif env.get("NCCL_MAX_NCHANNELS"):
-        reserved = int(env["NCCL_MAX_NCHANNELS"])
+        reserved = max(0, min(int(env["NCCL_MAX_NCHANNELS"]), 255))
     else:
         reserved = 16
     if reserved <= 0:
@@ -195,22 +200,79 @@ def rank_probe():
     dist.destroy_process_group()
 
 
-def build_engine(cfg, B, reserved_cus=None):
+def build_engine(cfg, B, reserved_cus=None, **opts):
+    """opts: options.EngineOptions fields (wgrad_max_lag, overlap_wgrad, cls_only_last, ...); None = the environment's / the default."""
     from savit_amd.engine import ViTEngine
 
     if cfg.kind == "cait":
         from savit_amd.cait_engine import CaiTEngine
 
-        return CaiTEngine(cfg, B, reserved_cus=reserved_cus)
+        return CaiTEngine(cfg, B, reserved_cus=reserved_cus, **opts)
     if cfg.kind == "mixer":
         from savit_amd.mixer_engine import MixerEngine
 
-        return MixerEngine(cfg, B, reserved_cus=reserved_cus)
+        return MixerEngine(cfg, B, reserved_cus=reserved_cus, **opts)
     if cfg.kind == "tnt":
         from savit_amd.tnt_engine import TNTEngine
 
-        return TNTEngine(cfg, B, reserved_cus=reserved_cus)
-    return ViTEngine(cfg, B, reserved_cus=reserved_cus)
+        return TNTEngine(cfg, B, reserved_cus=reserved_cus, **opts)
+    return ViTEngine(cfg, B, reserved_cus=reserved_cus, **opts)
+
+
+def engine_plan_facts(eng, bucket_mb=None) -> dict:
+    """What the launch plan of this engine was built with - printed in the JSON line (`config.engine_options`) so that a measured
+    number names the plan it ran: every EngineOptions field, plus the quantities derived from them."""
+    out = dict(eng.opt.as_dict())
+    out.update({"overlap_wgrad_in_effect": bool(getattr(eng, "overlap_wgrad", False)), "reserved_cus_in_effect": int(getattr(eng, "reserved_cus", 0)),
+                "cu_budget": int(getattr(eng, "cu_budget", 0)), "wgrad_tile": int(getattr(eng, "wgrad_tile", 0) or 0),
+                "wgrad_lag_layers": int(getattr(eng, "wgrad_lag", 0) or 0), "cls_only_last_in_effect": bool(getattr(eng, "cls_only_last", False)),
+                "cls_fwd_in_effect": bool(getattr(eng, "cls_fwd", False))})
+    if bucket_mb is not None:
+        out["bucket_mb"] = bucket_mb
+    return out
+
+
+SWEEP_RESERVED = (0, 8, 16, 32)
+
+
+def reserved_cus_sweep(cfg, B, world, rank, dist, bucket_mb, steps, warmup, opts) -> list:
+    """N > 1 only (every rank takes part): the train step timed with backward planned for 256 - r CUs, r in SWEEP_RESERVED, in ONE job -
+    same process group, same RCCL communicator, a fresh engine per point - so that the first lease of a multi-GPU node yields the
+    scaling number AND the tuning of the one planning constant nobody could measure (`reserved_cus = 16` was chosen
+    against a stand-in, profiles/r04_cu_thief.log).  -> [{reserved_cus, ms_per_step, value, allreduce_exposed_ms}] (rank 0; max over ranks)."""
+    import torch
+
+    from savit_amd import ddp
+
+    rows = []
+    for r in SWEEP_RESERVED:
+        eng = build_engine(cfg, B, reserved_cus=r, **opts)
+        init_bench_params(eng, cfg)
+        ddp.broadcast_params(eng.params)
+        sync = ddp.GradSync(eng.grads, ddp.plan_buckets_for(eng.layout, int(bucket_mb * 2 ** 20 / 4)))
+        eng.bwd_hooks = sync.hooks()
+        eng.refresh_weights()
+        step, _ = make_step(eng, cfg, B, world, rank, sync)
+        for i in range(warmup):
+            step(i)
+        del step.exposed[:]
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0, sum(a.elapsed_time(b) for a, b in step.exposed) / max(1, len(step.exposed))],
+                         device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el, ex = float(t[0].item()), float(t[1].item())
+        rows.append({"reserved_cus": r, "steps": steps, "warmup": warmup, "ms_per_step": round(el / steps * 1e3, 3),
+                     "value": round(B * world * steps / el, 1), "allreduce_exposed_ms": round(ex, 4)})
+        del step, sync, eng
+        torch.cuda.empty_cache()
+    return rows
 
 
 def make_step(eng, cfg, B, world, rank, sync):
@@ -342,17 +404,70 @@ def traffic_lookup(kernel: str, headline: bool, profiles_dir: str = None, runnin
     return res
 
 
-def executed_flops(cfg, eng, fpi, per_gpu) -> dict:
-    """What the step really executes: `flops_per_image` is SURVEY 8d's algorithmic count of the dense step (the metric's definition and
-    the numerator of `frac`); the ViT engines run the last encoder layer on the cls rows where only those are read (exact: engine.py),
-    which is fewer flops - reported here so that `frac` is not mistaken for matrix-pipe utilisation."""
-    from savit_amd.config import cls_only_saved_flops_per_image
+HBM_ACHIEVABLE_TBS = 6.3  # MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s sustained by a streaming kernel
 
-    if not getattr(eng, "cls_only_last", False):
-        return {}
-    ex = fpi - cls_only_saved_flops_per_image(cfg, bool(getattr(eng, "cls_fwd", False)))
-    return {"executed_flops_per_image": ex, "frac_executed": round(per_gpu * ex / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-            "executed_note": "last encoder layer behind its qkv projection on the cls rows only (vit.py:57,95: row 0 alone reaches the head)"}
+
+def step_roofline(cfg, per_gpu: float, cls_only_last: bool, cls_fwd: bool) -> dict:
+    """Whole-step MFMA figure.  `frac` / `achieved` use the flops the step EXECUTES (the ViT engines run the last
+    encoder layer on the cls rows where only those are read - exact, engine.py - so the dense count overstates what the matrix pipes
+    did); `frac_counted` / `achieved_counted` keep SURVEY 8d's dense count (the north-star's "% of MFMA peak" as BASELINE.md prices it:
+    40 % = 9 573 img/s on DeiT-B).  Equal for every family but ViT."""
+    from savit_amd.config import executed_flops_per_image, train_flops_per_image
+
+    fpi = train_flops_per_image(cfg)
+    ex = executed_flops_per_image(cfg, cls_only_last, cls_fwd)
+    out = {"bound": "mfma", "achieved": round(per_gpu * ex / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": round(per_gpu * ex / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "executed_flops_per_image": ex,
+           "achieved_counted": round(per_gpu * fpi / 1e12, 2), "frac_counted": round(per_gpu * fpi / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+           "flops_per_image": fpi}
+    if ex != fpi:
+        out["executed_note"] = ("last encoder layer behind its qkv projection on the cls rows only (vit.py:57,95: row 0 alone reaches the "
+                                "head); frac = executed flops, frac_counted = SURVEY 8d's dense count")
+    return out
+
+
+def hbm_kernels(labels_ms: dict, cfg, M: int, B: int, n_params: int, cls_only_last: bool, cls_fwd: bool) -> dict:
+    """The memory-bound kernels of a ViT step from the per-label times of the instrumented steps ({label: ms}): per kernel the
+    ALGORITHMIC bytes of one dense launch (what the kernel must read and write once), launches, mean time, TB/s and
+    the fraction of the sustained HBM rate.  Only launches over all M = B * N token rows count (the cls-row launches of the last layer
+    and the final LayerNorm are latency-shaped, not bandwidth-shaped)."""
+    d, N, H, NL = cfg.embed_dim, cfg.seq_len, cfg.num_heads, cfg.num_layers
+    per = {
+        "ln_fwd": (4 + 2) * M * d + 8 * M,                 # fp32 residual in, bf16 out, mean / rstd out
+        "ln_bwd": (2 + 4 + 4 + 4 + 2) * M * d + 8 * M,     # dy bf16, x fp32, residual gradient in / out fp32, bf16 copy out, statistics
+        "attn_fwd": (6 + 2) * M * d + 4 * B * H * N,       # packed q|k|v in, o out, LSE out
+        "attn_bwd": (6 + 2 + 2 + 6) * M * d + 4 * B * H * N,  # q|k|v, o, do in; dq|dk|dv out; LSE in
+        "adamw": 30 * n_params,                            # p, g, m, v in; p, m, v out (fp32) + the bf16 operand mirror
+    }
+    last = f"l{NL - 1}."
+    acc = {k: [0.0, 0] for k in per}
+    for key, ms in labels_ms.items():
+        label = key.split("#")[0]
+        op = label.split(".", 1)[1] if label.startswith("l") and "." in label and label.split(".")[0][1:].isdigit() else label
+        skip_last_fwd = cls_only_last and cls_fwd and label.startswith(last)
+        if op in ("ln1", "ln2") and not (skip_last_fwd and op == "ln2"):
+            k = "ln_fwd"
+        elif op in ("ln1.bwd", "ln2.bwd") and not (cls_only_last and label.startswith(last) and op == "ln2.bwd"):
+            k = "ln_bwd"
+        elif op == "attn" and not skip_last_fwd:
+            k = "attn_fwd"
+        elif op == "attn.bwd" and not skip_last_fwd:
+            k = "attn_bwd"
+        elif label == "adamw":
+            k = "adamw"
+        else:
+            continue
+        acc[k][0] += ms
+        acc[k][1] += 1
+    out = {}
+    for k, (ms, n) in acc.items():
+        if n == 0 or ms <= 0:
+            continue
+        avg_s = ms / n * 1e-3
+        tbs = per[k] / avg_s / 1e12
+        out[k] = {"algorithmic_bytes": int(per[k]), "launches": n, "avg_us": round(avg_s * 1e6, 1), "TB/s": round(tbs, 2),
+                  "frac_of_6.3": round(tbs / HBM_ACHIEVABLE_TBS, 3)}
+    return out
 
 
 def pick_dominant(sym, pair_overhead_ms: float = 0.0):
@@ -499,6 +614,9 @@ def measure(eng, cfg, B, world, rank, sync, steps, warmup, dist=None, breakdown=
         info["gemm_class_tflops"] = {c: round(cls1[c]["flops"] / (cls1[c]["ms"] * 1e-3) / 1e12, 2) for c in ("gemm_tn", "gemm_wgrad") if c in cls1 and cls1[c]["ms"] > 0}
         info["top_kernels_ms"] = {k: {"total_ms": round(v["ms"], 3), "launches": v["n"], "avg_us": round(v["ms"] / v["n"] * 1e3, 1)}
                                   for k, v in sorted(sym1.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+        if cfg.kind == "vit":
+            info["hbm_kernels"] = hbm_kernels(post["labels"], cfg, eng.M, B, int(eng.params.numel()), bool(getattr(eng, "cls_only_last", False)),
+                                              bool(getattr(eng, "cls_fwd", False)))
         info["_post_labels"] = post["labels"]
     info["roofline_valid"] = all(bool(v) for v in checks.values())
     info["roofline_checks"] = checks
@@ -516,18 +634,17 @@ def time_other_config(model, B, img_size, steps=10, warmup=3):
     """Short single-GPU timing of another BASELINE config (same step definition and the same per-kernel roofline as the headline)."""
     import torch
 
-    from savit_amd.config import get_config, train_flops_per_image
+    from savit_amd.config import get_config
 
     cfg = get_config(model, img_size=img_size)
     eng = build_engine(cfg, B)
     init_bench_params(eng, cfg)
     eng.refresh_weights()
     el, step, info = measure(eng, cfg, B, 1, 0, None, steps, warmup, breakdown=False)
-    ips, fpi = B * steps / el, train_flops_per_image(cfg)
+    ips = B * steps / el
     res = {"model": model, "img_size": img_size, "images_per_gpu": B, "steps": steps, "warmup": warmup, "value": round(ips, 1),
            "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 3),
-           "step_roofline": {"bound": "mfma", "achieved": round(ips * fpi / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(ips * fpi / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "flops_per_image": fpi},
+           "step_roofline": step_roofline(cfg, ips, bool(getattr(eng, "cls_only_last", False)), bool(getattr(eng, "cls_fwd", False))),
            "roofline": {k: info["roofline"][k] for k in ("kernel", "launches_per_step", "avg_launch_ms", "achieved", "frac")},
            "roofline_valid": info["roofline_valid"], "final_loss": info["final_loss"]}
     del step, eng
@@ -591,6 +708,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--bucket-mb", type=float, default=48.0)
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short timings of BASELINE configs 2, 4, 5")
+    # the data-parallel plan's knobs (options.EngineOptions; unset = SAVIT_* environment, else the defaults)
+    ap.add_argument("--reserved-cus", type=int, default=None, help="CUs backward leaves to the resident all-reduce (default: 16 at N > 1, 0 alone)")
+    ap.add_argument("--wgrad-max-lag", type=int, default=None, help="layers a weight gradient may wait for a full grouped launch")
+    ap.add_argument("--overlap-wgrad", type=int, choices=(0, 1), default=None, help="weight gradients on a side stream")
+    ap.add_argument("--no-reserved-cus-sweep", action="store_true", help="N > 1: skip the reserved_cus 0 / 8 / 16 / 32 timings behind the headline")
+    ap.add_argument("--sweep-steps", type=int, default=10)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -628,11 +751,13 @@ def main():
     if os.environ.get("SAVIT_EXP_LIB"):  # A/B runs against an experiment build of the library (tools/build_variant.sh)
         from savit_amd import lib as _l
         _l.LIB_PATH = os.path.join(os.path.dirname(_l.LIB_PATH), "exp", "libsavit_%s.so" % os.environ["SAVIT_EXP_LIB"])
-    from savit_amd.config import get_config, train_flops_per_image
+    from savit_amd.config import get_config
 
     cfg = get_config(args.model, img_size=args.img_size)
     B = args.batch
-    eng = build_engine(cfg, B, reserved_cus=ddp.default_reserved_cus(world))  # backward is planned for the CUs the all-reduce leaves
+    opts = {"wgrad_max_lag": args.wgrad_max_lag, "overlap_wgrad": None if args.overlap_wgrad is None else bool(args.overlap_wgrad)}
+    reserved = args.reserved_cus if args.reserved_cus is not None else ddp.default_reserved_cus(world)
+    eng = build_engine(cfg, B, reserved_cus=reserved, **opts)  # backward is planned for the CUs the all-reduce leaves
     init_bench_params(eng, cfg)
     sync = None
     if world > 1:
@@ -662,7 +787,6 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
-        fpi = train_flops_per_image(cfg)
         per_gpu = value / world
         out = {
             "metric": "images/sec DeiT-B/16 224^2 bf16 train step" if args.model == "vit_b_patch16" else f"images/sec {args.model} bf16 train step",
@@ -672,12 +796,11 @@ def main():
             "config": {"workload": f"{args.model} ({'DeiT-B/16' if args.model == 'vit_b_patch16' else args.model}) {S}x{S} train step: "
                                    "fwd + label-smoothed CE + bwd + grad all-reduce + AdamW",
                        "images_per_gpu": B, "global_batch": B * world, "seq_len": cfg.seq_len, "parallelism": f"dp{world}",
-                       "final_loss": round(loss, 4), **({"distributed": dist_info} if dist_info else {})},
+                       "final_loss": round(loss, 4), "engine_options": engine_plan_facts(eng, args.bucket_mb if world > 1 else None),
+                       **({"distributed": dist_info} if dist_info else {})},
             **({"allreduce_exposed_ms": dist_info["allreduce_exposed_ms"], "reserved_cus": dist_info["reserved_cus"],
                 "rccl_channels": dist_info["rccl_channels"]} if dist_info else {}),
-            "step_roofline": {"bound": "mfma", "achieved": round(per_gpu * fpi / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(per_gpu * fpi / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "flops_per_image": fpi,
-                              **executed_flops(cfg, eng, fpi, per_gpu)},
+            "step_roofline": step_roofline(cfg, per_gpu, bool(getattr(eng, "cls_only_last", False)), bool(getattr(eng, "cls_fwd", False))),
         }
         out.update(info)
         dom = out["roofline"]["kernel"]
@@ -698,8 +821,17 @@ def main():
                     tot += cnt / alltiles * (2.0 * q.M * (q.Kin + q.Nout) + (4.0 if q.overwrite else 8.0) * q.Kin * q.Nout)
             out["roofline"]["algorithmic_bytes_per_launch"] = int(tot / max(1, len(plan.wgrad_arrays)))
 
-    # ---- other BASELINE configs on this GPU (rank 0, N=1, headline workload only): short timings, after the headline engine is freed
     headline = args.model == "vit_b_patch16" and B == 128 and args.img_size == 224
+    # ---- N > 1: the same step with backward planned for 256 - {0, 8, 16, 32} CUs, behind the headline measurement (all ranks)
+    if world > 1 and not args.no_reserved_cus_sweep:
+        del step, eng, sync
+        torch.cuda.empty_cache()
+        rows = reserved_cus_sweep(cfg, B, world, rank, dist, args.bucket_mb, args.sweep_steps, 3, opts)
+        if rank == 0:
+            out["reserved_cus_sweep"] = rows
+        eng = step = None
+
+    # ---- other BASELINE configs on this GPU (rank 0, N=1, headline workload only): short timings, after the headline engine is freed
     if rank == 0 and world == 1 and headline and not args.no_other_configs:
         del step, eng
         torch.cuda.empty_cache()

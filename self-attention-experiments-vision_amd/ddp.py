@@ -16,35 +16,45 @@ import torch
 import torch.distributed as dist
 
 
-def default_reserved_cus(world: int, env=None) -> int:
+PIN_ENV = "SAVIT_PIN_RCCL_CHANNELS"
+
+
+def default_reserved_cus(world: int, env=None, n_cus: int = 256) -> int:
     """CUs a rank plans to leave to the resident RCCL all-reduce during backward (engine `reserved_cus`): 0 alone; at world > 1
-    SAVIT_RESERVED_CUS, else the channel bound the user gave RCCL (NCCL_MAX_NCHANNELS: one channel = one workgroup = one CU), else 16.
+    SAVIT_RESERVED_CUS, else the channel bound the user gave RCCL (NCCL_MAX_NCHANNELS: one channel = one workgroup = one CU; clamped to
+    n_cus - 1 so that a generous bound like 512 cannot make the engine's range check raise), else 16.
     Why plan at all (tools/cu_thief_probe.py, profiles/r04_cu_thief.log: a stand-in that holds n CUs for the length of the step,
     DeiT-B/16 at 128 images): with 16 CUs taken the step is 18 % slower when the launch plan assumes the whole chip (a grid of one tile
-    per CU runs a second, nearly empty round) and 6 % slower when it was planned for 240 CUs; with 32 taken 27 % against 17 %.  The plan
-    only holds if RCCL really stays inside the reserve: `rccl_channel_env` is the other half (round 5)."""
+    per CU runs a second, nearly empty round) and 6 % slower when it was planned for 240 CUs; with 32 taken 27 % against 17 %.
+    UNVERIFIED ON MORE THAN ONE GPU: the 16 is a planning constant measured against a stand-in, never against RCCL over xGMI (no 8-GPU
+    node was available in any round); `bench.py --gpus N` therefore also times reserved_cus 0 / 8 / 16 / 32 in the same job and prints
+    all four (`reserved_cus_sweep`)."""
     import os
 
     env = os.environ if env is None else env
     if env.get("SAVIT_RESERVED_CUS"):
         return int(env["SAVIT_RESERVED_CUS"])
     if world > 1 and env.get("NCCL_MAX_NCHANNELS"):
-        return int(env["NCCL_MAX_NCHANNELS"])  # the user bounded RCCL: plan for exactly that
+        return max(0, min(int(env["NCCL_MAX_NCHANNELS"]), n_cus - 1))  # the user bounded RCCL: plan for exactly that
     return 16 if world > 1 else 0
 
 
-def rccl_channel_env(reserved_cus: int, env=None) -> Dict[str, str]:
-    """The RCCL settings that keep its resident kernels inside `reserved_cus` CUs: an RCCL channel is one workgroup that owns a CU for
-    the length of the collective, so the bound on channels IS the bound on CUs.  NCCL_MAX_NCHANNELS = NCCL_MIN_NCHANNELS = reserved_cus
-    pins the footprint (RCCL's own choice on an 8-GPU xGMI node is 28-64 channels: 11-25 % of the chip, unplanned - profiles/r04_cu_thief.log
-    prices that at +18...27 % on the step).  Values the user already exported win (and `default_reserved_cus` then plans for THEIR bound).
-    Must be in the environment before the first RCCL communicator is created: bench.launch_ranks / train.py export it to the rank
-    processes, `apply_rccl_channel_env` sets it in a rank started by an external launcher."""
+def rccl_channel_env(reserved_cus: int, env=None, pin: Optional[bool] = None) -> Dict[str, str]:
+    """OPT-IN (SAVIT_PIN_RCCL_CHANNELS=1, or pin=True): the RCCL settings that keep its resident kernels inside `reserved_cus` CUs - an
+    RCCL channel is one workgroup that owns a CU for the length of the collective, so NCCL_MAX_NCHANNELS = NCCL_MIN_NCHANNELS =
+    reserved_cus pins the footprint to the plan.  Round 5 applied this to every multi-GPU run; no N > 1 measurement backs it (RCCL's own
+    choice on an 8-GPU xGMI node is 28-64 channels, and forcing 16 may cost all-reduce bandwidth and RAISE `allreduce_exposed_ms` - the
+    very thing the plan is meant to lower), so the default is RCCL's own choice again until one N > 1 bench compares pinned against
+    unpinned.  Values the user already exported win (and `default_reserved_cus` then plans for THEIR bound).  Must be in the
+    environment before the first RCCL communicator is created: bench.launch_ranks / train.py export it to the rank processes,
+    `apply_rccl_channel_env` sets it in a rank started by an external launcher."""
     import os
 
     env = os.environ if env is None else env
+    if pin is None:
+        pin = env.get(PIN_ENV, "0") == "1"
     out: Dict[str, str] = {}
-    if reserved_cus <= 0:
+    if not pin or reserved_cus <= 0:
         return out
     mx = env.get("NCCL_MAX_NCHANNELS") or str(int(reserved_cus))
     out["NCCL_MAX_NCHANNELS"] = mx
@@ -52,11 +62,11 @@ def rccl_channel_env(reserved_cus: int, env=None) -> Dict[str, str]:
     return out
 
 
-def apply_rccl_channel_env(reserved_cus: int) -> Dict[str, str]:
-    """Export `rccl_channel_env` into this process (call BEFORE dist.init_process_group).  -> what is now in effect."""
+def apply_rccl_channel_env(reserved_cus: int, pin: Optional[bool] = None) -> Dict[str, str]:
+    """Export `rccl_channel_env` into this process (call BEFORE dist.init_process_group).  -> what was set ({} unless pinning is on)."""
     import os
 
-    e = rccl_channel_env(reserved_cus)
+    e = rccl_channel_env(reserved_cus, pin=pin)
     os.environ.update(e)
     return e
 

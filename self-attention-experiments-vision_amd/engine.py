@@ -312,8 +312,18 @@ def add_wgrad_group(eng, plan: _Plan, label: str, entries: list, tile: int, defe
             plan.covered[(dW - g0) // 4] = Kin * Nout
     plan.keep.append(arr)
     plan.wgrad_arrays.append(arr)
-    slots = eng.gnorm.data_ptr() + 4 if (first_touch and getattr(eng, "_fold_sumsq_ok", False)) else None
-    plan.fold_sumsq = slots is not None
+    fold = first_touch and getattr(eng, "_fold_sumsq_ok", False)
+    if fold and not all(q.overwrite for q in arr):
+        # the kernel publishes the squares of EVERY problem of a launch; an entry that failed the coverage predicate is also in
+        # `rest_ranges` (finalize_first_touch) and would be counted twice in the clip norm.  No ViT / CaiT weight fails it
+        # today; a launch that ever mixes the two kinds accumulates all of its entries (they are then zeroed and summed with the rest)
+        for q in arr:
+            if q.overwrite:
+                q.overwrite = 0
+                plan.covered.pop((q.dW - g0) // 4, None)
+        fold = False
+    slots = eng.gnorm.data_ptr() + 4 if fold else None
+    plan.fold_sumsq = bool(plan.fold_sumsq or slots is not None)  # any launch publishing squares: the norm = fold slots + rest_ranges
     plan.add(eng.L.savit_gemm_bf16_wgrad_grouped_ex, (arr, len(entries), tile, slots), label, side=side,
              reads=tuple(sorted({e[0][1] for e in entries})) if side else ())
     if deferred_hooks:
@@ -1143,7 +1153,7 @@ class ViTEngine:
                    float(label_smoothing), 1.0 / self.B, self.loss_rows.data_ptr(), self.loss.data_ptr(),
                    self.dlogits.data_ptr(), self.Cp, self._off_ptr(self.grads, "bh"), self.top1.data_ptr(),
                    self.top5.data_ptr(), self.B, self.cfg.num_classes, s)
-        self.backward_from_dlogits()
+        self._backward_from_dlogits()
         return self.loss
 
     def _current_bwd_plan(self) -> _Plan:
@@ -1172,8 +1182,18 @@ class ViTEngine:
         """hipMemsetAsync of an accumulator on the launch stream, as a labelled (timeable) launch."""
         timed_call(self.launch_timer, label, self.L.savit_zero_bytes, t.data_ptr(), t.numel() * t.element_size(), self._stream())
 
-    def backward_from_dlogits(self):
-        """Backward from self.dlogits (bf16 [B, Cp], pad columns zero) into self.grads (accumulating)."""
+    def backward_from_dlogits(self, zero_grads: bool = True):
+        """Custom-loss entry point: the caller has written self.dlogits (bf16 [B, Cp], pad columns zero).  The gradient buffer is
+        prepared exactly as `loss_backward` prepares it - cleared where backward accumulates, untouched where the grouped launches store
+        by first touch, the norm's fold slots zeroed; zero_grads=False keeps the buffer and makes every launch accumulate - and then the
+        backward plan runs.  (this used to skip the preparation, so a direct caller got first-touch stores over a buffer it
+        believed was accumulated into, and never-zeroed fold slots in the next clip norm.)  The head-bias gradient is written by
+        savit_softmax_xent inside loss_backward: a custom loss adds its own column sum of dlogits into grad 'bh' after this call."""
+        self._zero_grads_for_backward(zero_grads)
+        self._backward_from_dlogits()
+
+    def _backward_from_dlogits(self):
+        """Backward from self.dlogits into self.grads; `_zero_grads_for_backward` has run (loss_backward / backward_from_dlogits)."""
         if getattr(self, "_needs_zero_dres", True):
             self._current_bwd_plan()  # (recording the plan decides whether the dense residual-gradient buffers carry the cls rows)
         if getattr(self, "_needs_zero_dres", True):

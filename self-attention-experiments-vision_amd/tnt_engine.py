@@ -481,9 +481,9 @@ class TNTEngine(ViTEngine):
         finalize_wgrad_ws(self, P)
         return P
 
-    def backward_from_dlogits(self):
+    def _backward_from_dlogits(self):
         self._zero("zero.dresi", self.dresi)  # the last layer's pixel output feeds Inner2Outer only: its cotangent starts from zero
-        super().backward_from_dlogits()
+        super()._backward_from_dlogits()
 
     def activation_bytes(self) -> int:
         tot = 0

@@ -112,3 +112,70 @@ def test_every_symbol_bench_can_name_exists_in_the_library():
     assert len(seen) >= 8
     for sname in seen | set(bench.WG_GROUP_TILES.values()) | set(bench.WG_VARIANTS.values()):
         assert sname.replace(", ", ",") in have, sname
+
+
+def test_step_roofline_leads_with_executed_flops():
+    """`frac` is matrix-pipe utilisation (executed flops), `frac_counted` keeps SURVEY 8d's dense count; they differ
+    for the ViT family only (last layer on the cls rows), by exactly what config.cls_only_saved_flops_per_image prices."""
+    from savit_amd.config import cls_only_saved_flops_per_image, executed_flops_per_image, train_flops_per_image
+
+    cfg = get_config("vit_b_patch16")
+    fpi = train_flops_per_image(cfg)
+    assert abs(fpi - 105.151758336e9) < 1 and abs(executed_flops_per_image(cfg, True, True) - 98.553212928e9) < 1
+    # backward priced at 2 x forward for every product, the attention included (ADVICE r5): forward share = 1/3 of what both save
+    d, N = 768, 197
+    dense, attn = 2.0 * 196 * d * d + 4.0 * 196 * d * 3072, 4.0 * 196 * N * d
+    assert cls_only_saved_flops_per_image(cfg, True) == 3.0 * (dense + attn) and cls_only_saved_flops_per_image(cfg, False) == 2.0 * dense
+    r = bench.step_roofline(cfg, 8000.0, True, True)
+    assert r["frac"] < r["frac_counted"] and abs(r["frac_counted"] - 8000 * fpi / 1e12 / bench.MFMA_BF16_PEAK_TFLOPS) < 1e-4
+    assert abs(r["achieved"] - 8000 * 98.553212928e9 / 1e12) < 0.01 and r["flops_per_image"] == fpi and "executed_note" in r
+    r0 = bench.step_roofline(cfg, 8000.0, False, False)
+    assert r0["frac"] == r0["frac_counted"] and "executed_note" not in r0
+    c = bench.step_roofline(get_config("cait_s_24"), 6800.0, False, False)
+    assert c["frac"] == c["frac_counted"] and abs(c["flops_per_image"] - 55.848e9) < 1e7
+
+
+def test_hbm_kernels_from_instrumented_labels():
+    """north_star's "achieved HBM GB/s on the memory-bound softmax / LayerNorm" as part of the JSON line: algorithmic bytes per dense
+    launch / mean instrumented launch time.  The cls-row launches of the last layer and the final LayerNorm are not bandwidth launches
+    and must not dilute the averages."""
+    cfg = get_config("vit_b_patch16")
+    B, M = 128, 128 * 197
+    labels = {"lnf": 0.004, "lnf.bwd": 0.004, "adamw": 0.43, "xent": 0.01}
+    for l in range(12):
+        labels.update({f"l{l}.ln1": 0.0211, f"l{l}.ln2": 0.0211 if l < 11 else 0.003, f"l{l}.ln1.bwd": 0.050,
+                       f"l{l}.ln2.bwd": 0.050 if l < 11 else 0.004, f"l{l}.attn": 0.041 if l < 11 else 0.020,
+                       f"l{l}.attn.bwd": 0.113 if l < 11 else 0.032, f"l{l}.qkv": 0.09})
+    h = bench.hbm_kernels(labels, cfg, M, B, 86_567_656, True, True)
+    assert set(h) == {"ln_fwd", "ln_bwd", "attn_fwd", "attn_bwd", "adamw"}
+    assert h["ln_fwd"]["launches"] == 23 and h["ln_bwd"]["launches"] == 23 and h["attn_fwd"]["launches"] == 11 and h["attn_bwd"]["launches"] == 11
+    assert h["ln_fwd"]["algorithmic_bytes"] == 6 * M * 768 + 8 * M and abs(h["ln_fwd"]["avg_us"] - 21.1) < 0.05
+    assert abs(h["ln_fwd"]["TB/s"] - h["ln_fwd"]["algorithmic_bytes"] / 21.1e-6 / 1e12) < 0.01
+    assert abs(h["ln_bwd"]["TB/s"] - (16 * M * 768 + 8 * M) / 50e-6 / 1e12) < 0.01 and 0.9 < h["ln_bwd"]["frac_of_6.3"] < 1.05
+    assert abs(h["attn_bwd"]["TB/s"] - (16 * M * 768 + 4 * 128 * 12 * 197) / 113e-6 / 1e12) < 0.01
+    assert h["adamw"]["algorithmic_bytes"] == 30 * 86_567_656
+    # the dense plan: the last layer's launches are bandwidth launches too
+    hd = bench.hbm_kernels(labels, cfg, M, B, 86_567_656, False, False)
+    assert hd["ln_fwd"]["launches"] == 24 and hd["attn_bwd"]["launches"] == 12
+
+
+def test_engine_options_env_and_keywords(monkeypatch):
+    """options.EngineOptions: keyword > options object > SAVIT_* environment (read at construction) > default; unknown names raise."""
+    import pytest
+    from savit_amd.options import EngineOptions
+
+    for k in [v[0] for v in EngineOptions.ENV.values()]:
+        monkeypatch.delenv(k, raising=False)
+    assert EngineOptions.resolve(None).non_default() == {}
+    monkeypatch.setenv("SAVIT_CLS_ONLY_LAST", "0")
+    monkeypatch.setenv("SAVIT_RESERVED_CUS", "24")
+    monkeypatch.setenv("SAVIT_WGRAD_GROUP", "auto")
+    monkeypatch.setenv("SAVIT_OVERLAP_WGRAD", "1")
+    o = EngineOptions.resolve(None, reserved_cus=None, wgrad_max_lag=3)
+    assert o.non_default() == {"cls_only_last": False, "reserved_cus": 24, "wgrad_max_lag": 3, "overlap_wgrad": True}
+    assert EngineOptions.resolve(None, reserved_cus=8, cls_only_last=True).non_default() == {"reserved_cus": 8, "overlap_wgrad": True}
+    base = EngineOptions(rows_tile=False)
+    assert EngineOptions.resolve(base).non_default() == {"rows_tile": False}  # an explicit object: the environment is not consulted
+    with pytest.raises(TypeError, match="unknown engine option"):
+        EngineOptions.resolve(None, clz_only_last=False)
+    assert set(EngineOptions.ENV) == set(EngineOptions().as_dict())

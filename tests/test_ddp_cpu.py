@@ -141,21 +141,26 @@ def test_bench_self_launches_its_ranks(repo_root):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    # ... and the rank processes received the RCCL channel bounds that keep the resident all-reduce inside the CUs backward is planned to
-    # leave it: one channel = one workgroup = one CU, 16 by default
-    assert d == {"launcher_probe": True, "world": 2, "rank_sum": 1.0, "ipc_mode_legacy": "0", "rccl_channels": 16,
-                 "nccl_min_nchannels": "16", "reserved_cus": 16}
-    # the user's own settings win, and the plan follows them
-    env2 = dict(env, SAVIT_RESERVED_CUS="24")
-    r = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                       env=env2, capture_output=True, text=True, timeout=300)
-    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert (d["rccl_channels"], d["nccl_min_nchannels"], d["reserved_cus"]) == (24, "24", 24)
-    env3 = dict(env, NCCL_MAX_NCHANNELS="8")
-    r = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                       env=env3, capture_output=True, text=True, timeout=300)
-    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert (d["rccl_channels"], d["nccl_min_nchannels"], d["reserved_cus"]) == (8, "8", 8)
+    # ... RCCL keeps its own channel choice by default (round 6, ADVICE r5: pinning NCCL_MAX/MIN_NCHANNELS to the reserve was never measured on
+    # more than one GPU and may cost all-reduce bandwidth); the plan still reserves 16 CUs
+    assert d == {"launcher_probe": True, "world": 2, "rank_sum": 1.0, "ipc_mode_legacy": "0", "rccl_channels": None,
+                 "nccl_min_nchannels": None, "reserved_cus": 16}
+
+    def probe(**extra):
+        rr = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                            env=dict(env, **extra), capture_output=True, text=True, timeout=300)
+        dd = json.loads([ln for ln in rr.stdout.splitlines() if ln.startswith("{")][0])
+        return dd["rccl_channels"], dd["nccl_min_nchannels"], dd["reserved_cus"]
+
+    # opt-in pin (SAVIT_PIN_RCCL_CHANNELS=1): the rank processes receive the bounds that keep the resident all-reduce inside the CUs
+    # backward is planned to leave it (one channel = one workgroup = one CU, 16 by default); the user's own settings win, the plan follows
+    assert probe(SAVIT_PIN_RCCL_CHANNELS="1") == (16, "16", 16)
+    assert probe(SAVIT_PIN_RCCL_CHANNELS="1", SAVIT_RESERVED_CUS="24") == (24, "24", 24)
+    assert probe(SAVIT_PIN_RCCL_CHANNELS="1", NCCL_MAX_NCHANNELS="8") == (8, "8", 8)
+    # unpinned, a user-bounded RCCL is still what the plan follows - clamped below the CU count (a bound of 512 must not make the engine raise)
+    assert probe(NCCL_MAX_NCHANNELS="8") == (8, None, 8)
+    assert probe(NCCL_MAX_NCHANNELS="512") == (512, None, 255)
+    assert probe(SAVIT_RESERVED_CUS="24") == (None, None, 24)
 
 
 def test_bench_rejects_mismatched_world(repo_root):
@@ -187,16 +192,20 @@ def test_rccl_channel_bounds_follow_the_reserve():
     import bench
     from savit_amd import ddp
 
-    assert ddp.rccl_channel_env(16, env={}) == {"NCCL_MAX_NCHANNELS": "16", "NCCL_MIN_NCHANNELS": "16"}
-    assert ddp.rccl_channel_env(0, env={}) == {}
-    assert ddp.rccl_channel_env(16, env={"NCCL_MAX_NCHANNELS": "8"}) == {"NCCL_MAX_NCHANNELS": "8", "NCCL_MIN_NCHANNELS": "8"}
-    assert ddp.rccl_channel_env(16, env={"NCCL_MIN_NCHANNELS": "4"}) == {"NCCL_MAX_NCHANNELS": "16", "NCCL_MIN_NCHANNELS": "4"}
+    PIN = {"SAVIT_PIN_RCCL_CHANNELS": "1"}
+    assert ddp.rccl_channel_env(16, env={}) == {} and ddp.rccl_channel_env(16, env={"NCCL_MAX_NCHANNELS": "8"}) == {}  # opt-in only
+    assert ddp.rccl_channel_env(16, env=PIN) == {"NCCL_MAX_NCHANNELS": "16", "NCCL_MIN_NCHANNELS": "16"} == ddp.rccl_channel_env(16, env={}, pin=True)
+    assert ddp.rccl_channel_env(0, env=PIN) == {}
+    assert ddp.rccl_channel_env(16, env=dict(PIN, NCCL_MAX_NCHANNELS="8")) == {"NCCL_MAX_NCHANNELS": "8", "NCCL_MIN_NCHANNELS": "8"}
+    assert ddp.rccl_channel_env(16, env=dict(PIN, NCCL_MIN_NCHANNELS="4")) == {"NCCL_MAX_NCHANNELS": "16", "NCCL_MIN_NCHANNELS": "4"}
     assert ddp.default_reserved_cus(8, env={"NCCL_MAX_NCHANNELS": "12"}) == 12  # the plan follows the user's bound
+    assert ddp.default_reserved_cus(8, env={"NCCL_MAX_NCHANNELS": "512"}) == 255 and ddp.default_reserved_cus(8, env={"NCCL_MAX_NCHANNELS": "512"}, n_cus=304) == 303
     assert ddp.default_reserved_cus(1, env={"NCCL_MAX_NCHANNELS": "12"}) == 0   # alone: nothing resident
-    for env in ({}, {"SAVIT_RESERVED_CUS": "24"}, {"NCCL_MAX_NCHANNELS": "8"}, {"SAVIT_RESERVED_CUS": "0"}, {"NCCL_MIN_NCHANNELS": "2"},
-                {"SAVIT_RESERVED_CUS": "32", "NCCL_MAX_NCHANNELS": "20"}):
-        for world in (1, 2, 8):
-            want = ddp.rccl_channel_env(ddp.default_reserved_cus(world, env=env), env=env) if world > 1 else {}
-            assert bench.rccl_env_for(world, env) == want, (env, world)
+    for env0 in ({}, {"SAVIT_RESERVED_CUS": "24"}, {"NCCL_MAX_NCHANNELS": "8"}, {"SAVIT_RESERVED_CUS": "0"}, {"NCCL_MIN_NCHANNELS": "2"},
+                 {"SAVIT_RESERVED_CUS": "32", "NCCL_MAX_NCHANNELS": "20"}, {"NCCL_MAX_NCHANNELS": "512"}):
+        for env in (env0, dict(env0, **PIN)):
+            for world in (1, 2, 8):
+                want = ddp.rccl_channel_env(ddp.default_reserved_cus(world, env=env), env=env) if world > 1 else {}
+                assert bench.rccl_env_for(world, env) == want, (env, world)
     log = "host:1:1 [0] NCCL INFO Channel 00/16 : 0\nhost:1:1 [0] NCCL INFO 16 coll channels, 0 collnet channels, 0 nvls channels, 16 p2p channels"
     assert ddp.parse_rccl_channels(log) == 16 and ddp.parse_rccl_channels("nothing here") is None

@@ -127,7 +127,7 @@ def _rccl_rank_main(rank, port, out_path):
     # log (NCCL_DEBUG=INFO, to a file) must then report no more channels than that
     for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS"):
         os.environ.pop(k, None)
-    in_effect = ddp.apply_rccl_channel_env(RCCL_TEST_CHANNELS)
+    in_effect = ddp.apply_rccl_channel_env(RCCL_TEST_CHANNELS, pin=True)  # (the opt-in pin: SAVIT_PIN_RCCL_CHANNELS=1)
     os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_FILE=out_path + ".nccl.%p.log")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))

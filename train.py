@@ -150,8 +150,8 @@ def main(argv=None):
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # a data-parallel rank plans its backward launches for the CUs the resident all-reduce leaves (engine reserved_cus, ddp.py) -
-        # and, before the first communicator exists, bounds RCCL's channels (one channel = one resident workgroup = one CU) to that
-        # reserve, so that the plan holds (jax.lax.pmean, /root/reference/train.py:96, has no counterpart: XLA schedules its own collectives)
+        # and, with SAVIT_PIN_RCCL_CHANNELS=1 (opt-in: unverified on > 1 GPU), bounds RCCL's channels (one channel = one resident
+        # workgroup = one CU) to that reserve before the first communicator exists (jax.lax.pmean, /root/reference/train.py:96, has no counterpart: XLA schedules its own collectives)
         os.environ.setdefault("SAVIT_RESERVED_CUS", str(ddp.default_reserved_cus(world)))
         rccl_env = ddp.apply_rccl_channel_env(int(os.environ["SAVIT_RESERVED_CUS"]))
         if rank == 0 and rccl_env:
