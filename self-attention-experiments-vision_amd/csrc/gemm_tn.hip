@@ -35,6 +35,7 @@ struct GemmParams {
   int desync_sleep;     // ... each delayed by (group index) x this many s_sleep(127) units (0 = all start together)
   int row_group;        // ping-pong kernel: tiles are visited in groups of this many row panels, column by column inside a group
   int big_tiles, small_tiles, big_rows;  // tail-split pair kernel: tile counts of the two heights, rows covered by the tall tiles
+  int pf_start, pf_policy;  // 320 x 256 kernel, RESID / DGELU: first K-tile of the fused operand's cache prefetch (< 0: off), its cache policy bits
 };
 
 template <int EPI>
@@ -1536,6 +1537,47 @@ __global__ __launch_bounds__(512) void gemm_tn_pp320_kernel(const GemmParams p) 
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 af[5][2], bf[4][2];
 
+  // ---- cache prefetch of the epilogue's fused operand (round 6).  The saved pre-activation tile of the GELU' epilogue (DGELU: 160 KB
+  // per workgroup, written a whole forward + half a backward ago: an HBM read) is requested by the epilogue while every CU of a round
+  // sits in its epilogue too - and HBM idles under the main loops (operands come out of L2 / the Infinity Cache).  Ten of the K-tiles
+  // therefore carry ONE extra request per wave: a 4-byte LDS-DMA per lane into a 256-byte scratch slot nobody reads, lane l touching
+  // cache line l of 16 lines of this wave's own epilogue footprint, so that the lines are in L2 / the Infinity Cache when the epilogue
+  // asks for them.  The request is the YOUNGEST one in front of a K-tile's counted wait (vmcnt(6) instead of (5)): it is waited for one
+  // K-tile later.  No arithmetic changes: results are bitwise the same.  Measured in the DeiT-B step, same box, A / B / A / B
+  // (profiles/r06_aux_prefetch_ab.log): GELU' 156.3 / 157.0 -> 151.8 / 151.7 us.  The same for the fp32 residual tile of the RESID
+  // epilogue (320 KB per workgroup, two lines per row) was built and is SLOWER (proj + residual 51.0 -> 52.5 us, fc2 + residual 108.5 ->
+  // 110.5; with the non-temporal policy 54.9 / 114.0): that epilogue already moves its 154 MB at the HBM rate, and 10 MB of prefetched
+  // lines per XCD push operand panels out of the 4 MB L2.  It stays in the code behind the launcher's switch (experiment builds).
+  [[maybe_unused]] uint32_t pf_voff = 0x7ffffff0u, pf_step = 0;
+  [[maybe_unused]] auto srdP = srdA;
+  constexpr bool PF = (EPI == SAVIT_EPI_RESID || EPI == SAVIT_EPI_DGELU);
+  constexpr int PF_N = 10;  // requests per wave: 160 rows = 10 x 16
+  if constexpr (PF) {
+    const int esz = (EPI == SAVIT_EPI_RESID) ? 4 : 2;
+    const int prow = row0 + wr * WTM, pcol = col0 + wc * WTN;
+    const char* pb = reinterpret_cast<const char*>(a.aux) + ((size_t)prow * a.ldaux + pcol) * esz;
+    const long rows_left = (long)a.M - prow;
+    const size_t tb = rows_left > 0 ? (size_t)rows_left * a.ldaux * esz : 0;
+    srdP = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pb), 0, (uint32_t)(tb > 0xfffffff0ull ? 0xfffffff0ull : tb), 0x00020000);
+    if (EPI == SAVIT_EPI_RESID) {  // 64 fp32 columns = two 128-byte lines per row: lane -> (row lane >> 1 of 16, line lane & 1), lanes 0-31
+      if (lane < 32 && pcol < a.N) pf_voff = (uint32_t)(lane >> 1) * (uint32_t)(a.ldaux * 4) + (uint32_t)(lane & 1) * 128u;
+    } else {                       // 64 bf16 columns = one line per row: lane -> row lane of 16, lanes 0-15
+      if (lane < 16 && pcol < a.N) pf_voff = (uint32_t)lane * (uint32_t)(a.ldaux * 2);
+    }
+    pf_step = 16u * (uint32_t)(a.ldaux * esz);
+  }
+  auto prefetch = [&](int kt) {
+    if constexpr (PF) {
+      const int j = kt - p.pf_start;
+      const uint32_t off = (p.pf_start >= 0 && j >= 0 && j < PF_N) ? pf_voff + (uint32_t)j * pf_step : 0x7ffffff0u;
+      char* dst = smem + 2 * BUF + wave * 256;
+      if (p.pf_policy == 2)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdP, (__attribute__((address_space(3))) void*)dst, 4, off, 0, 0, 2);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdP, (__attribute__((address_space(3))) void*)dst, 4, off, 0, 0, 0);
+    }
+  };
+
   // prologue: all of K-tile 0 and the five units of K-tile 1 that L(-1,p2), L(-1,p3) would have issued
 #pragma unroll
   for (int u = 0; u < 9; ++u) dma(0, u);
@@ -1590,10 +1632,19 @@ __global__ __launch_bounds__(512) void gemm_tn_pp320_kernel(const GemmParams p) 
     PP5_COMPUTE(1, 1)
     // ---- phase 3: quadrant (1,0); K-tile kt+1 must be complete behind this phase's first barrier
     dma(kt + 2, 5); dma(kt + 2, 6); dma(kt + 2, 7); dma(kt + 2, 8);
+    prefetch(kt);
     if (kt + 2 < KT) {
-      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      if constexpr (PF) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      }
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (PF) {  // (kt + 2 >= KT: the five dma() above were no-ops; only the prefetch request may stay in flight)
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     PP5_COMPUTE(1, 0)
   }
@@ -1988,7 +2039,17 @@ int launch_pp320(const GemmParams& p0, hipStream_t s, bool pers) {
   // more than one round of tiles: the persistent form (tile 22), one workgroup per CU; a single round: one tile per workgroup (tile 21)
   const bool persistent = pers && tiles > cus && p.a.K >= 128;  // (the kernel peels the last two K-tiles of a tile)
   const dim3 grid(persistent ? cus : tiles);
-  const size_t lds = persistent ? 160 * 1024 : 2 * 9 * 64 * 128;
+  const bool pf_epi = p.a.epilogue == SAVIT_EPI_RESID || p.a.epilogue == SAVIT_EPI_DGELU;
+  const size_t lds = persistent ? 160 * 1024 : 2 * 9 * 64 * 128 + (pf_epi ? 8 * 256 : 0);
+  {
+    // fused-operand cache prefetch (one-tile kernel): ten K-tiles ending two K-tiles before the last; off for short products
+    static const int pf_mode = SAVIT_EXP_ENV_INT("SAVIT_PP_PREFETCH", 1), pf_lead = SAVIT_EXP_ENV_INT("SAVIT_PP_PREFETCH_LEAD", 2),
+                     pf_pol = SAVIT_EXP_ENV_INT("SAVIT_PP_PREFETCH_POLICY", 0);
+    const int KT = p.a.K / 64;
+    const bool pf_on = pf_mode == 2 ? pf_epi : (pf_mode == 1 && p.a.epilogue == SAVIT_EPI_DGELU);  // (2: the RESID epilogue too - measured slower)
+    p.pf_start = (pf_on && p.a.aux != nullptr && KT >= 6) ? (KT - 10 - pf_lead > 0 ? KT - 10 - pf_lead : 0) : -1;
+    p.pf_policy = pf_pol;
+  }
 #define SAVIT_LAUNCH_EPI(E)                                                                            \
   case E: {                                                                                            \
     if (persistent) {                                                                                  \
