@@ -425,7 +425,10 @@ int savit_attention_fwd_f32(const float* qkv, float* o, int B, int N, int H, int
  * savit_head_mix_f32: TalkingHeadsBlock (talking_heads.py:13) y[b,i,e] = sum_h T[h,i] x[b,h,e], e over the N x N score positions.
  * savit_layernorm_bwd_f32: VJP of nn.LayerNorm(dtype=float32); dx (+ add, the residual cotangent), dgamma / dbeta accumulated.
  * savit_colsum_f32: out[n] += sum_m x[m,n] (Dense bias gradients).  savit_softmax_xent_grad_f32: d(mean label-smoothed CE)/dlogits
- *   in fp32 (train.py:83-90), scaled by grad_scale (1 / batch). */
+ *   in fp32 (train.py:83-90), scaled by grad_scale (1 / batch).
+ * savit_layerscale_bwd_f32 (round 6): VJP of LayerScaleBlock x StochasticDepthBlock as cait.py:36-52 composes them in fp32
+ *   (layerscale.py:18-23, stochastic_depth.py:16-27): dbranch[m,n] = dres[m,n] * ls[n] * rs[m / rows_per_sample],
+ *   dls[n] += sum_m dres[m,n] * rs * branch[m,n] (rowscale nullable = 1; fp32 atomics on dls, one per column and 32-row block). */
 typedef struct savit_gemm_f32_args {
   const float* A; const float* W; float* C; const float* bias; const float* aux; const float* colscale; const float* rowscale;
   float* C2; const float* U;
@@ -443,6 +446,8 @@ int savit_head_mix_f32(const float* T, const float* x, float* y, int B, int H, l
 int savit_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* add, float* dx, float* dgamma, float* dbeta, int rows,
                             int d, long x_stride, long dy_stride, float eps, void* stream);
 int savit_colsum_f32(const float* x, float* out, int M, int N, int ld, void* stream);
+int savit_layerscale_bwd_f32(const float* dres, const float* branch, const float* ls, const float* rowscale, int rows_per_sample, float* dbranch,
+                             float* dls, int M, int d, void* stream);
 int savit_softmax_xent_grad_f32(const float* logits, const int* labels, float label_smoothing, float grad_scale, float* dlogits, int B, int C,
                                 void* stream);
 int savit_patchify_f32(const float* images, float* patches, int B, int img_size, int patch, void* stream);

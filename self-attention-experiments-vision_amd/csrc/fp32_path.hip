@@ -441,6 +441,28 @@ __global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict
   }
 }
 
+// LayerScale x stochastic-depth VJP in fp32 (layerscale.py:18-23, stochastic_depth.py:16-27 as cait.py:36-52 composes them: the residual
+// stream received ls[n] * rs[m / rows_per_sample] * branch[m, n]).  Given the residual cotangent dres:
+//   dbranch[m, n] = dres[m, n] * ls[n] * rs ;  dls[n] += sum_m dres[m, n] * rs * branch[m, n]
+// A block takes LSB_ROWS rows, a thread the columns t, t + 256, ... (coalesced rows), one atomic per column and block.
+constexpr int LSB_ROWS = 32;
+__global__ __launch_bounds__(256) void layerscale_bwd_f32_kernel(const float* __restrict__ dres, const float* __restrict__ branch,
+                                                                  const float* __restrict__ ls, const float* __restrict__ rowscale, int rows_per_sample,
+                                                                  float* __restrict__ dbranch, float* __restrict__ dls, int M, int d) {
+  const int m0 = blockIdx.x * LSB_ROWS, m1 = min(M, m0 + LSB_ROWS);
+  for (int c = threadIdx.x; c < d; c += 256) {
+    const float l = ls[c];
+    float s = 0.f;
+    for (int m = m0; m < m1; ++m) {
+      const float rs = rowscale ? rowscale[m / rows_per_sample] : 1.0f;
+      const float g = dres[(size_t)m * d + c] * rs;
+      dbranch[(size_t)m * d + c] = g * l;
+      s = fmaf(g, branch[(size_t)m * d + c], s);
+    }
+    atomicAdd(dls + c, s);
+  }
+}
+
 // out[n] += sum_m x[m, n] (bias gradients); out[i] = a[i] + b[i]; dlogits of train.py:83-90 in fp32
 __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N, int ld) {
   const int n = blockIdx.x * 256 + threadIdx.x;
@@ -583,6 +605,15 @@ extern "C" int savit_layernorm_bwd_f32(const float* dy, const float* x, const fl
     hipLaunchKernelGGL(ln_bwd_f32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, gamma, add, dx, dgamma, dbeta, rows, d, x_stride, dy_stride, eps);
   else
     hipLaunchKernelGGL(ln_bwd_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, gamma, add, dx, dgamma, dbeta, rows, d, x_stride, dy_stride, eps);
+  SAVIT_LAUNCH_RET();
+}
+
+extern "C" int savit_layerscale_bwd_f32(const float* dres, const float* branch, const float* ls, const float* rowscale, int rows_per_sample,
+                                       float* dbranch, float* dls, int M, int d, void* stream) {
+  SAVIT_CHECK_ARG(dres && branch && ls && dbranch && dls && dbranch != dres && M >= 0 && d > 0 && (rowscale == nullptr || rows_per_sample >= 1));
+  if (M == 0) return SAVIT_OK;
+  hipLaunchKernelGGL(layerscale_bwd_f32_kernel, dim3((M + LSB_ROWS - 1) / LSB_ROWS), dim3(256), 0, (hipStream_t)stream, dres, branch, ls, rowscale,
+                     rows_per_sample > 0 ? rows_per_sample : 1, dbranch, dls, M, d);
   SAVIT_LAUNCH_RET();
 }
 

@@ -8,7 +8,8 @@ without it.  With dtype=float32 every Dense, LayerNorm, softmax and GELU compute
 Engines here run that graph on the GPU with the fp32 kernels of csrc/fp32_path.hip (exact fp32-input MFMA products on the fp32
 master weights in place - no bf16 anywhere; scores materialised per (image, head), so any sequence length):
   ViTEngineF32   forward, loss, BACKWARD (every parameter gradient) and the AdamW step - a config-1 train step in fp32;
-  CaiTEngineF32  forward (+ loss): talking-heads attention, LayerScale, stochastic depth (explicit keep masks), class attention.
+  CaiTEngineF32  forward, loss, BACKWARD and the AdamW step (round 6): talking-heads attention, LayerScale, stochastic depth
+                 (explicit keep masks), class attention - the train step of a `cait_*` model in the arithmetic the reference uses;
 They share the parameter layouts (ParamLayout / CaiTLayout: flat fp32 buffer, Flax-shaped views) with the bf16 training engines, so
 a tree moves between the two unchanged.  These paths are written for exactness and generality (the fp32 MFMA runs at 1/16 of the
 bf16 rate); throughput work lives in the bf16 engines."""
@@ -91,6 +92,35 @@ class _F32Base:
         """S[b, h] = Q[b, h] K[b, h]^T (attention.py:41) for every (image, head): [B * H, Nq, Nk]."""
         self._gemm(P, label, q_ptr, k_ptr, S.data_ptr(), Nq, Nk, hd, ldq, ldk, Nk, transW=1, batch=self.B * H, inner=H,
                    sA=(q_img_stride, hd), sW=(k_img_stride, hd), sC=(H * Nq * Nk, Nq * Nk))
+
+    def optimizer_step(self, lr: float, weight_decay: float = 0.0, max_norm: float = 0.0, b1: float = 0.9, b2: float = 0.999,
+                       eps: float = 1e-8, grad_scale: float = 1.0):
+        """optax chain of simple_train.py:25-27 / train.py:25-27 (clip, Adam, weight decay, -lr) on the fp32 parameters."""
+        if self.grads is None:
+            raise RuntimeError("optimizer_step before any loss_backward")
+        if self.adam_m is None:
+            self.adam_m, self.adam_v = torch.zeros_like(self.params), torch.zeros_like(self.params)
+        s = torch.cuda.current_stream().cuda_stream
+        self.step_count += 1
+        ss = None
+        if max_norm and max_norm > 0:
+            self.gnorm_sq.zero_()
+            _lib.check(self.L.savit_sumsq(self.grads.data_ptr(), self.grads.numel(), self.gnorm_sq.data_ptr(), s), "savit_sumsq")
+            ss = self.gnorm_sq.data_ptr()
+        _lib.check(self.L.savit_adamw_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
+                                           self.params.numel(), float(lr), float(b1), float(b2), float(eps), float(weight_decay),
+                                           self.step_count, ss, float(max_norm or 0.0), float(grad_scale), s), "savit_adamw_step")
+
+    def refresh_weights(self):  # the fp32 products read the master weights in place
+        self.weights_stale = False
+
+    def _wgrad(self, P: _Plan, label, X, dY, dW, Mr, Kin, Nout, ldx, lddy, lddw=None, **kw):
+        """dW[Kin, Nout] += X[Mr, Kin]^T dY[Mr, Nout] (the weight-gradient form of a Dense: X read transposed in place)."""
+        self._gemm(P, label, X, dY, dW, Kin, Nout, Mr, ldx, lddy, Nout if lddw is None else lddw, transA=1, accumulate=1, **kw)
+
+    def _dgrad(self, P: _Plan, label, dY, W, dX, Mr, Kin, Nout, lddy, ldw, ldx, **kw):
+        """dX[Mr, Kin] = dY[Mr, Nout] W[Kin, Nout]^T (the input-gradient form: the Flax [in, out] kernel read transposed in place)."""
+        self._gemm(P, label, dY, W, dX, Mr, Kin, Nout, lddy, ldw, ldx, transW=1, **kw)
 
     def loss_fn(self, labels: torch.Tensor, label_smoothing: float = 0.1) -> torch.Tensor:
         """train.py:83-90 on the fp32 logits (one-hot, label smoothing, softmax cross-entropy, mean); also fills top1 / top5."""
@@ -255,28 +285,15 @@ class ViTEngineF32(_F32Base):
         self._bwd.run(s)
         return self.loss
 
-    def optimizer_step(self, lr: float, weight_decay: float = 0.0, max_norm: float = 0.0, b1: float = 0.9, b2: float = 0.999,
-                       eps: float = 1e-8, grad_scale: float = 1.0):
-        """optax chain of simple_train.py:25-27 / train.py:25-27 (clip, Adam, weight decay, -lr) on the fp32 parameters."""
-        if self.adam_m is None:
-            self.adam_m, self.adam_v = torch.zeros_like(self.params), torch.zeros_like(self.params)
-        s = torch.cuda.current_stream().cuda_stream
-        self.step_count += 1
-        ss = None
-        if max_norm and max_norm > 0:
-            self.gnorm_sq.zero_()
-            _lib.check(self.L.savit_sumsq(self.grads.data_ptr(), self.grads.numel(), self.gnorm_sq.data_ptr(), s), "savit_sumsq")
-            ss = self.gnorm_sq.data_ptr()
-        _lib.check(self.L.savit_adamw_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
-                                           self.params.numel(), float(lr), float(b1), float(b2), float(eps), float(weight_decay),
-                                           self.step_count, ss, float(max_norm or 0.0), float(grad_scale), s), "savit_adamw_step")
-
-    def refresh_weights(self):  # the fp32 products read the master weights in place
-        self.weights_stale = False
-
-
 class CaiTEngineF32(_F32Base):
-    """cait.py:140-183 in fp32 - the arithmetic the reference ALWAYS uses for CaiT (its create_model branch ignores dtype)."""
+    """cait.py:140-183 in fp32 - the arithmetic the reference ALWAYS uses for CaiT (its create_model branch ignores dtype):
+    forward, loss, and (round 6) the BACKWARD of all of it plus the AdamW step, i.e. the train step `train.py:77-100` would run on a
+    `cait_*` model.  Forward-only use keeps one set of activation buffers; the first `loss_backward` switches the engine to saving
+    every layer's activations (S and P per (image, head) included: the reference's XLA graph saves them too) and re-runs the forward
+    once."""
+
+    SA_SAVED = ("x", "h1", "qkv", "S", "P", "o", "br1", "xmid", "h2", "u", "a", "br2")
+    CA_SAVED = ("clsin", "xc", "hc", "qc", "kvc", "pc", "oc", "cbr1", "clsmid", "hq", "uc", "ac", "cbr2")
 
     def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda"):
         if cfg.kind != "cait":
@@ -304,69 +321,229 @@ class CaiTEngineF32(_F32Base):
         self.zcls = e(B, d)
         self.keep: Optional[torch.Tensor] = None  # [(L + Lc), 2, B] keep masks / keep_prob of a training-mode forward, or None
         self.gen = torch.Generator(device=self.dev)
-        self._plans: Dict[bool, _Plan] = {}
+        self._plans: Dict[tuple, _Plan] = {}
+        self.save_activations = False   # set by the first loss_backward: forward then writes per-layer buffers (self.sv)
+        self.sv: Optional[Dict[str, List[torch.Tensor]]] = None
+        self._saved_training: Optional[bool] = None  # mode of the forward whose activations self.sv holds
+        self._bwd_plans: Dict[bool, _Plan] = {}
 
     def init_params(self, seed: int = 0):
         from .cait_engine import CaiTEngine
 
         CaiTEngine.init_params(self, seed)
 
-    def _build(self, training: bool) -> _Plan:
+    # ---- per-layer activation buffers of a train step
+    def _alloc_saved(self):
+        cfg, B, e = self.cfg, self.B, self.e
+        d, F, N, NL, NC, H = cfg.embed_dim, cfg.hidden, cfg.n_patches, cfg.num_layers, cfg.num_layers_token_only, cfg.num_heads
+        M, Mc, Nk = self.M, self.Mc, N + 1
+        shp = {"x": (M, d), "h1": (M, d), "qkv": (M, 3 * d), "S": (B * H, N, N), "P": (B * H, N, N), "o": (M, d), "br1": (M, d), "xmid": (M, d),
+               "h2": (M, d), "u": (M, F), "a": (M, F), "br2": (M, d)}
+        cshp = {"clsin": (B, d), "xc": (Mc, d), "hc": (Mc, d), "qc": (B, d), "kvc": (Mc, 2 * d), "pc": (B * H, 1, Nk), "oc": (B, d), "cbr1": (B, d),
+                "clsmid": (B, d), "hq": (B, d), "uc": (B, F), "ac": (B, F), "cbr2": (B, d)}
+        self.sv = {k: [e(*v) for _ in range(NL)] for k, v in shp.items()}
+        self.sv.update({k: [e(*v) for _ in range(NC)] for k, v in cshp.items()})
+        self.sv["xsa"] = [e(M, d)]  # the SA stage's output (frozen through the class-attention stage, cait.py:157-173)
+        # backward scratch
+        self.bw = {"dres": e(M, d), "d_br": e(M, d), "d_a": e(M, F), "d_h": e(M, d), "d_o": e(M, d), "dqkv": e(M, 3 * d), "sA": e(B * H, N, N),
+                   "sB": e(B * H, N, N), "dT": e(B, H, H), "Tt": e(NL, 2, H, H), "dcls": e(B, d), "d_cbr": e(B, d), "d_ac": e(B, F), "d_hq": e(B, d),
+                   "d_oc": e(B, d), "dpc": e(B * H, 1, Nk), "dqc": e(B, d), "dkvc": e(Mc, 2 * d), "d_hc": e(Mc, d), "dxc": e(Mc, d), "d_z": e(B, d)}
+
+    def _build(self, training: bool, save: bool = False) -> _Plan:
         P, L, cfg = _Plan(), self.L, self.cfg
         d, F, C, N, NL, NC, H, B, M, Mc, hd = (cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.n_patches, cfg.num_layers, cfg.num_layers_token_only,
                                               cfg.num_heads, self.B, self.M, self.Mc, cfg.head_dim)
         pp = self._off
-        x, xm, h, qkv, o, a, s, s2 = (t.data_ptr() for t in (self.x, self.xmid, self.h, self.qkv, self.o, self.a, self.s, self.s2))
         sd = training and cfg.stoch_depth_rate > 0
+        sv = self.sv if save else None
+        ptr = lambda t: t.data_ptr()  # noqa: E731
 
         def rs(block, which):  # stochastic depth as the per-image row scale of the residual epilogue (stochastic_depth.py:16-27)
             return dict(rowscale=self.keep[block, which].data_ptr()) if sd else {}
 
+        x0 = ptr(sv["x"][0]) if save else ptr(self.x)
         P.add(L.savit_patchify_f32, (self.images.data_ptr(), self.patches.data_ptr(), B, cfg.img_size, cfg.patch), "patchify")
-        self._gemm(P, "patch_embed", self.patches.data_ptr(), pp("Wpe"), x, M, d, cfg.patch_dim, cfg.patch_dim, d, d, aux=pp("pos"), ldaux=d,
+        self._gemm(P, "patch_embed", self.patches.data_ptr(), pp("Wpe"), x0, M, d, cfg.patch_dim, cfg.patch_dim, d, d, aux=pp("pos"), ldaux=d,
                    aux_row_mod=N)  # + pos_embed, shared by the images (cait.py:143-145, position_embed.py:56)
+        x = x0
         for l in range(NL):
-            P.add(L.savit_layernorm_fwd_f32, (x, pp(f"l{l}.ln1_g"), pp(f"l{l}.ln1_b"), h, M, d, d, d, 1e-6), f"l{l}.ln1")
-            self._gemm(P, f"l{l}.qkv", h, pp(f"l{l}.Wqkv"), qkv, M, 3 * d, d, d, 3 * d, 3 * d, alpha=1.0 / math.sqrt(hd), alpha_cols=d)
-            self._scores(P, f"l{l}.scores", qkv, qkv + 4 * d, self.s, N, N, H, hd, 3 * d, 3 * d, N * 3 * d, N * 3 * d)
-            P.add(L.savit_head_mix_f32, (pp(f"l{l}.T1"), s, s2, B, H, N * N), f"l{l}.th1")          # attention.py:44-46
-            P.add(L.savit_softmax_rows_f32, (s2, s2, B * H * N, N, N), f"l{l}.softmax")               # :48
-            P.add(L.savit_head_mix_f32, (pp(f"l{l}.T2"), s2, s, B, H, N * N), f"l{l}.th2")          # :50-52
-            self._gemm(P, f"l{l}.pv", s, qkv + 8 * d, o, N, hd, N, N, 3 * d, d, batch=B * H, inner=H, sA=(H * N * N, N * N), sW=(N * 3 * d, hd),
+            if save:
+                h1, qkv, S, Pm, o, xm, h2, a = (ptr(sv[k][l]) for k in ("h1", "qkv", "S", "P", "o", "xmid", "h2", "a"))
+                s2, xn = ptr(self.s2), (ptr(sv["x"][l + 1]) if l + 1 < NL else ptr(sv["xsa"][0]))
+                extra1, extra_u, extra2 = dict(C2=ptr(sv["br1"][l])), dict(C2=ptr(sv["u"][l])), dict(C2=ptr(sv["br2"][l]))
+            else:
+                h1 = h2 = ptr(self.h)
+                qkv, S, Pm, o, xm, a, s2, xn = ptr(self.qkv), ptr(self.s), ptr(self.s2), ptr(self.o), ptr(self.xmid), ptr(self.a), ptr(self.s), x
+                extra1 = extra_u = extra2 = {}
+            P.add(L.savit_layernorm_fwd_f32, (x, pp(f"l{l}.ln1_g"), pp(f"l{l}.ln1_b"), h1, M, d, d, d, 1e-6), f"l{l}.ln1")
+            self._gemm(P, f"l{l}.qkv", h1, pp(f"l{l}.Wqkv"), qkv, M, 3 * d, d, d, 3 * d, 3 * d, alpha=1.0 / math.sqrt(hd), alpha_cols=d)
+            self._gemm(P, f"l{l}.scores", qkv, qkv + 4 * d, S, N, N, hd, 3 * d, 3 * d, N, transW=1, batch=B * H, inner=H, sA=(N * 3 * d, hd),
+                       sW=(N * 3 * d, hd), sC=(H * N * N, N * N))                                    # attention.py:41
+            P.add(L.savit_head_mix_f32, (pp(f"l{l}.T1"), S, Pm, B, H, N * N), f"l{l}.th1")          # attention.py:44-46  (S' into the P buffer)
+            P.add(L.savit_softmax_rows_f32, (Pm, Pm, B * H * N, N, N), f"l{l}.softmax")               # :48  (in place: P)
+            P.add(L.savit_head_mix_f32, (pp(f"l{l}.T2"), Pm, s2, B, H, N * N), f"l{l}.th2")         # :50-52  (P')
+            self._gemm(P, f"l{l}.pv", s2, qkv + 8 * d, o, N, hd, N, N, 3 * d, d, batch=B * H, inner=H, sA=(H * N * N, N * N), sW=(N * 3 * d, hd),
                        sC=(N * d, hd))
-            self._gemm(P, f"l{l}.proj", o, pp(f"l{l}.Wo"), xm, M, d, d, d, d, d, aux=x, ldaux=d, colscale=pp(f"l{l}.ls1"), rows_per_sample=N, **rs(l, 0))
-            P.add(L.savit_layernorm_fwd_f32, (xm, pp(f"l{l}.ln2_g"), pp(f"l{l}.ln2_b"), h, M, d, d, d, 1e-6), f"l{l}.ln2")
-            self._gemm(P, f"l{l}.fc1", h, pp(f"l{l}.W1"), a, M, F, d, d, F, F, bias=pp(f"l{l}.b1"), act=1)
-            self._gemm(P, f"l{l}.fc2", a, pp(f"l{l}.W2"), x, M, d, F, F, d, d, bias=pp(f"l{l}.b2"), aux=xm, ldaux=d, colscale=pp(f"l{l}.ls2"),
-                       rows_per_sample=N, **rs(l, 1))
+            self._gemm(P, f"l{l}.proj", o, pp(f"l{l}.Wo"), xm, M, d, d, d, d, d, aux=x, ldaux=d, colscale=pp(f"l{l}.ls1"), rows_per_sample=N, **rs(l, 0),
+                       **extra1)
+            P.add(L.savit_layernorm_fwd_f32, (xm, pp(f"l{l}.ln2_g"), pp(f"l{l}.ln2_b"), h2, M, d, d, d, 1e-6), f"l{l}.ln2")
+            self._gemm(P, f"l{l}.fc1", h2, pp(f"l{l}.W1"), a, M, F, d, d, F, F, bias=pp(f"l{l}.b1"), act=1, **extra_u)
+            self._gemm(P, f"l{l}.fc2", a, pp(f"l{l}.W2"), xn, M, d, F, F, d, d, bias=pp(f"l{l}.b2"), aux=xm, ldaux=d, colscale=pp(f"l{l}.ls2"),
+                       rows_per_sample=N, **rs(l, 1), **extra2)
+            x = xn
+        self._x_final = x  # (device address of the SA stage's output: _concat_rows reads the tensor below)
+        self._x_final_t = (sv["xsa"][0] if NL > 0 else sv["x"][0]) if save else self.x
         # class-attention stage (cait.py:157-173): cls starts as the parameter; x is frozen
-        xc, hc, cls, clsm, hq = (t.data_ptr() for t in (self.xc, self.hc, self.cls, self.clsmid, self.hq))
-        qc, kvc, oc, ac, sc, pc = (t.data_ptr() for t in (self.qc, self.kvc, self.oc, self.ac, self.sc, self.pc))
         Nk = N + 1
         for c in range(NC):
-            P.add(_concat_rows, (self, ), f"c{c}.concat")  # xc = [cls ; x] (cait.py:98): device-side row copies
+            if save:
+                xc, hc, qc, kvc, pc, oc, clsm, hq, ac = (ptr(sv[k][c]) for k in ("xc", "hc", "qc", "kvc", "pc", "oc", "clsmid", "hq", "ac"))
+                cls_in = ptr(sv["clsin"][c])
+                cls_out = ptr(sv["clsin"][c + 1]) if c + 1 < NC else ptr(self.cls)
+                extra1, extra_u, extra2 = dict(C2=ptr(sv["cbr1"][c])), dict(C2=ptr(sv["uc"][c])), dict(C2=ptr(sv["cbr2"][c]))
+            else:
+                xc, hc, qc, kvc, pc, oc, clsm, hq, ac = (ptr(t) for t in (self.xc, self.hc, self.qc, self.kvc, self.pc, self.oc, self.clsmid, self.hq, self.ac))
+                cls_in = cls_out = ptr(self.cls)
+                extra1 = extra_u = extra2 = {}
+            sc = ptr(self.sc)
+            P.add(_concat_rows, (self, c, save), f"c{c}.concat")  # xc = [cls ; x] (cait.py:98): device-side row copies
             P.add(L.savit_layernorm_fwd_f32, (xc, pp(f"c{c}.ln1_g"), pp(f"c{c}.ln1_b"), hc, Mc, d, d, d, 1e-6), f"c{c}.ln1")
             # q from row 0 only (cait.py:13-15), k and v from all N + 1 rows
             self._gemm(P, f"c{c}.q", hc, pp(f"c{c}.Wqkv"), qc, B, d, d, Nk * d, 3 * d, d, alpha=1.0 / math.sqrt(hd), alpha_cols=d)
             self._gemm(P, f"c{c}.kv", hc, pp(f"c{c}.Wqkv") + 4 * d, kvc, Mc, 2 * d, d, d, 3 * d, 2 * d)
-            self._scores(P, f"c{c}.scores", qc, kvc, self.sc, 1, Nk, H, hd, d, 2 * d, d, Nk * 2 * d)
+            self._gemm(P, f"c{c}.scores", qc, kvc, sc, 1, Nk, hd, d, 2 * d, Nk, transW=1, batch=B * H, inner=H, sA=(d, hd), sW=(Nk * 2 * d, hd),
+                       sC=(H * Nk, Nk))
             P.add(L.savit_softmax_rows_f32, (sc, pc, B * H, Nk, Nk), f"c{c}.softmax")
             self._gemm(P, f"c{c}.pv", pc, kvc + 4 * d, oc, 1, hd, Nk, Nk, 2 * d, d, batch=B * H, inner=H, sA=(H * Nk, Nk), sW=(Nk * 2 * d, hd), sC=(d, hd))
-            self._gemm(P, f"c{c}.proj", oc, pp(f"c{c}.Wo"), clsm, B, d, d, d, d, d, aux=cls, ldaux=d, colscale=pp(f"c{c}.ls1"), rows_per_sample=1,
-                       **rs(NL + c, 0))
+            self._gemm(P, f"c{c}.proj", oc, pp(f"c{c}.Wo"), clsm, B, d, d, d, d, d, aux=cls_in, ldaux=d, colscale=pp(f"c{c}.ls1"), rows_per_sample=1,
+                       **rs(NL + c, 0), **extra1)
             P.add(L.savit_layernorm_fwd_f32, (clsm, pp(f"c{c}.ln2_g"), pp(f"c{c}.ln2_b"), hq, B, d, d, d, 1e-6), f"c{c}.ln2")
-            self._gemm(P, f"c{c}.fc1", hq, pp(f"c{c}.W1"), ac, B, F, d, d, F, F, bias=pp(f"c{c}.b1"), act=1)
-            self._gemm(P, f"c{c}.fc2", ac, pp(f"c{c}.W2"), cls, B, d, F, F, d, d, bias=pp(f"c{c}.b2"), aux=clsm, ldaux=d, colscale=pp(f"c{c}.ls2"),
-                       rows_per_sample=1, **rs(NL + c, 1))
+            self._gemm(P, f"c{c}.fc1", hq, pp(f"c{c}.W1"), ac, B, F, d, d, F, F, bias=pp(f"c{c}.b1"), act=1, **extra_u)
+            self._gemm(P, f"c{c}.fc2", ac, pp(f"c{c}.W2"), cls_out, B, d, F, F, d, d, bias=pp(f"c{c}.b2"), aux=clsm, ldaux=d, colscale=pp(f"c{c}.ls2"),
+                       rows_per_sample=1, **rs(NL + c, 1), **extra2)
         # final LayerNorm over [cls ; x], of which only row 0 reaches the head (cait.py:175-182)
-        P.add(L.savit_layernorm_fwd_f32, (cls, pp("lnf_g"), pp("lnf_b"), self.zcls.data_ptr(), B, d, d, d, 1e-6), "lnf")
+        P.add(L.savit_layernorm_fwd_f32, (ptr(self.cls), pp("lnf_g"), pp("lnf_b"), self.zcls.data_ptr(), B, d, d, d, 1e-6), "lnf")
         self._gemm(P, "head", self.zcls.data_ptr(), pp("Wh"), self.logits.data_ptr(), B, C, d, d, C, C, bias=pp("bh"))
+        return P
+
+    def _build_bwd(self, training: bool) -> _Plan:
+        """Reverse-mode gradient of `_build(training, save=True)` (jax.value_and_grad of train.py:94-95 on a CaiT): the class-attention
+        stage, the talking-heads SA stage, the embeddings.  Every product is the transposed form of its forward GEMM; the talking-heads
+        mixes transpose their H x H matrices; LayerScale x stochastic depth through savit_layerscale_bwd_f32."""
+        P, L, cfg, sv, bw = _Plan(), self.L, self.cfg, self.sv, self.bw
+        d, F, C, N, NL, NC, H, B, M, Mc, hd = (cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.n_patches, cfg.num_layers, cfg.num_layers_token_only,
+                                              cfg.num_heads, self.B, self.M, self.Mc, cfg.head_dim)
+        pp = self._off
+        gp = lambda n: self._off(n, self.grads)  # noqa: E731
+        ptr = lambda t: t.data_ptr()  # noqa: E731
+        sd = training and cfg.stoch_depth_rate > 0
+        rsp = lambda block, which: (self.keep[block, which].data_ptr() if sd else None)  # noqa: E731
+        alpha = 1.0 / math.sqrt(hd)
+        Nk, E = N + 1, N * N
+        dres, d_br, d_a, d_h, d_o, dqkv, sA, sB, dT = (ptr(bw[k]) for k in ("dres", "d_br", "d_a", "d_h", "d_o", "dqkv", "sA", "sB", "dT"))
+        dcls, d_cbr, d_ac, d_hq, d_oc, dpc, dqc, dkvc, d_hc, dxc, d_z = (ptr(bw[k]) for k in ("dcls", "d_cbr", "d_ac", "d_hq", "d_oc", "dpc", "dqc", "dkvc",
+                                                                                            "d_hc", "dxc", "d_z"))
+        dl = self.dlogits.data_ptr()
+        ln_bwd, colsum = L.savit_layernorm_bwd_f32, L.savit_colsum_f32
+
+        def ls_bwd(label, dres_p, branch, ls_name, rs_ptr, rps, out, rows):
+            P.add(L.savit_layerscale_bwd_f32, (dres_p, branch, pp(ls_name), rs_ptr, rps, out, gp(ls_name), rows, d), label)
+
+        # ---- head (cait.py:178-182) and the final LayerNorm, whose row 0 alone is read (cait.py:175-178)
+        self._wgrad(P, "head.wgrad", self.zcls.data_ptr(), dl, gp("Wh"), B, d, C, d, C)
+        P.add(colsum, (dl, gp("bh"), B, C, C), "head.bgrad")
+        self._dgrad(P, "head.dgrad", dl, pp("Wh"), d_z, B, d, C, C, C, d)
+        P.add(ln_bwd, (d_z, ptr(self.cls), pp("lnf_g"), None, dcls, gp("lnf_g"), gp("lnf_b"), B, d, d, d, 1e-6), "lnf.bwd")
+        # ---- class-attention stage, last layer first (cait.py:96-122).  dxc accumulates d / d[cls ; x] over the layers: x is the same
+        # tensor for all of them; the cls row is handed to and from the compact cls cotangent by strided device copies.
+        P.add(L.savit_zero_bytes, (dxc, Mc * d * 4), "zero.dxc")
+        for c in range(NC - 1, -1, -1):
+            p = f"c{c}."
+            xc, hc, qc, kvc, pc, oc, cbr1, clsm, hq, uc, ac, cbr2 = (ptr(sv[k][c]) for k in ("xc", "hc", "qc", "kvc", "pc", "oc", "cbr1", "clsmid", "hq", "uc",
+                                                                                             "ac", "cbr2"))
+            # cls_{c+1} = clsmid + ls2 rs2 (gelu(hq W1 + b1) W2 + b2)
+            ls_bwd(p + "ls2.bwd", dcls, cbr2, p + "ls2", rsp(NL + c, 1), 1, d_cbr, B)
+            self._wgrad(P, p + "W2.wgrad", ac, d_cbr, gp(p + "W2"), B, F, d, F, d)
+            P.add(colsum, (d_cbr, gp(p + "b2"), B, d, d), p + "b2.grad")
+            self._dgrad(P, p + "fc2.dgrad", d_cbr, pp(p + "W2"), d_ac, B, F, d, d, d, F, act=2, U=uc)
+            self._wgrad(P, p + "W1.wgrad", hq, d_ac, gp(p + "W1"), B, d, F, d, F)
+            P.add(colsum, (d_ac, gp(p + "b1"), B, F, F), p + "b1.grad")
+            self._dgrad(P, p + "fc1.dgrad", d_ac, pp(p + "W1"), d_hq, B, d, F, F, F, d)
+            P.add(ln_bwd, (d_hq, clsm, pp(p + "ln2_g"), dcls, dcls, gp(p + "ln2_g"), gp(p + "ln2_b"), B, d, d, d, 1e-6), p + "ln2.bwd")
+            # clsmid = cls_c + ls1 rs1 (class-attention(LN1([cls_c ; x])) Wo)
+            ls_bwd(p + "ls1.bwd", dcls, cbr1, p + "ls1", rsp(NL + c, 0), 1, d_cbr, B)
+            self._wgrad(P, p + "Wo.wgrad", oc, d_cbr, gp(p + "Wo"), B, d, d, d, d)
+            self._dgrad(P, p + "proj.dgrad", d_cbr, pp(p + "Wo"), d_oc, B, d, d, d, d, d)
+            bh = dict(batch=B * H, inner=H)
+            # per (image, head): dp = do V^T ; dV = p^T do ; ds = p (dp - sum dp p) ; dq = ds K / sqrt(hd) ; dK = ds^T q
+            self._gemm(P, p + "dP", d_oc, kvc + 4 * d, dpc, 1, Nk, hd, d, 2 * d, Nk, transW=1, sA=(d, hd), sW=(Nk * 2 * d, hd), sC=(H * Nk, Nk), **bh)
+            self._gemm(P, p + "dV", pc, d_oc, dkvc + 4 * d, Nk, hd, 1, Nk, d, 2 * d, transA=1, sA=(H * Nk, Nk), sW=(d, hd), sC=(Nk * 2 * d, hd), **bh)
+            P.add(L.savit_softmax_rows_bwd_f32, (pc, dpc, dpc, B * H, Nk, Nk), p + "softmax.bwd")
+            self._gemm(P, p + "dQ", dpc, kvc, dqc, 1, hd, Nk, Nk, 2 * d, d, sA=(H * Nk, Nk), sW=(Nk * 2 * d, hd), sC=(d, hd), alpha=alpha, alpha_cols=hd, **bh)
+            self._gemm(P, p + "dK", dpc, qc, dkvc, Nk, hd, 1, Nk, d, 2 * d, transA=1, sA=(H * Nk, Nk), sW=(d, hd), sC=(Nk * 2 * d, hd), **bh)
+            # q from row 0 of every image (pitch Nk * d), k | v from all rows: one fused Wqkv [d, 3 d]
+            self._wgrad(P, p + "Wq.wgrad", hc, dqc, gp(p + "Wqkv"), B, d, d, Nk * d, d, 3 * d)
+            self._wgrad(P, p + "Wkv.wgrad", hc, dkvc, gp(p + "Wqkv") + 4 * d, Mc, d, 2 * d, d, 2 * d, 3 * d)
+            self._dgrad(P, p + "kv.dgrad", dkvc, pp(p + "Wqkv") + 4 * d, d_hc, Mc, d, 2 * d, 2 * d, 3 * d, d)
+            self._dgrad(P, p + "q.dgrad", dqc, pp(p + "Wqkv"), d_hc, B, d, d, d, 3 * d, Nk * d, accumulate=1)
+            # d[cls_c ; x] += LN1 VJP; the cls row also carries the residual path: put the compact cotangent in before, take the sum out after
+            P.add(_cls_rows_copy, (self, "dcls", "dxc", True), p + "dcls.in")
+            P.add(ln_bwd, (d_hc, xc, pp(p + "ln1_g"), dxc, dxc, gp(p + "ln1_g"), gp(p + "ln1_b"), Mc, d, d, d, 1e-6), p + "ln1.bwd")
+            P.add(_cls_rows_copy, (self, "dcls", "dxc", False), p + "dcls.out")  # (the next layer's dcls.in overwrites row 0 again)
+        P.add(colsum, (dcls, gp("cls"), B, d, d), "cls.grad")   # the cls parameter is broadcast over the images (cait.py:157-160)
+        P.add(_patch_rows_copy, (self,), "dx.gather")            # dres = d / dx of the SA stage's output: rows 1.. of dxc
+        # ---- SA stage, last layer first (cait.py:28-60)
+        for l in range(NL - 1, -1, -1):
+            p = f"l{l}."
+            x, h1, qkv, S, Pm, o, br1, xm, h2, u, a, br2 = (ptr(sv[k][l]) for k in self.SA_SAVED)
+            T1t, T2t = ptr(bw["Tt"][l, 0]), ptr(bw["Tt"][l, 1])
+            # x_{l+1} = xmid + ls2 rs2 (gelu(h2 W1 + b1) W2 + b2)
+            ls_bwd(p + "ls2.bwd", dres, br2, p + "ls2", rsp(l, 1), N, d_br, M)
+            self._wgrad(P, p + "W2.wgrad", a, d_br, gp(p + "W2"), M, F, d, F, d)
+            P.add(colsum, (d_br, gp(p + "b2"), M, d, d), p + "b2.grad")
+            self._dgrad(P, p + "fc2.dgrad", d_br, pp(p + "W2"), d_a, M, F, d, d, d, F, act=2, U=u)
+            self._wgrad(P, p + "W1.wgrad", h2, d_a, gp(p + "W1"), M, d, F, d, F)
+            P.add(colsum, (d_a, gp(p + "b1"), M, F, F), p + "b1.grad")
+            self._dgrad(P, p + "fc1.dgrad", d_a, pp(p + "W1"), d_h, M, d, F, F, F, d)
+            P.add(ln_bwd, (d_h, xm, pp(p + "ln2_g"), dres, dres, gp(p + "ln2_g"), gp(p + "ln2_b"), M, d, d, d, 1e-6), p + "ln2.bwd")
+            # xmid = x_l + ls1 rs1 (talking-heads attention(LN1(x_l)) Wo)
+            ls_bwd(p + "ls1.bwd", dres, br1, p + "ls1", rsp(l, 0), N, d_br, M)
+            self._wgrad(P, p + "Wo.wgrad", o, d_br, gp(p + "Wo"), M, d, d, d, d)
+            self._dgrad(P, p + "proj.dgrad", d_br, pp(p + "Wo"), d_o, M, d, d, d, d, d)
+            bh = dict(batch=B * H, inner=H)
+            sAE = (H * E, E)
+            # O = P' V: dP' = dO V^T ; dV = P'^T dO with P' = mix(T2, P) recomputed (attention.py:50-57)
+            self._gemm(P, p + "dPp", d_o, qkv + 8 * d, sA, N, N, hd, d, 3 * d, N, transW=1, sA=(N * d, hd), sW=(N * 3 * d, hd), sC=sAE, **bh)
+            P.add(L.savit_head_mix_f32, (pp(p + "T2"), Pm, sB, B, H, E), p + "th2.re")
+            self._gemm(P, p + "dV", sB, d_o, dqkv + 8 * d, N, hd, N, N, d, 3 * d, transA=1, sA=sAE, sW=(N * d, hd), sC=(N * 3 * d, hd), **bh)
+            # P'_i = sum_h T2[h, i] P_h (talking_heads.py:13): dT2[h, i] = sum_(b, q, k) P_h dP'_i ; dP_h = sum_i T2[h, i] dP'_i
+            self._gemm(P, p + "dT2.part", Pm, sA, dT, H, H, E, E, E, H, transW=1, batch=B, sA=(H * E, 0), sW=(H * E, 0), sC=(H * H, 0))
+            P.add(colsum, (dT, gp(p + "T2"), B, H * H, H * H), p + "dT2")
+            P.add(L.savit_head_mix_f32, (T2t, sA, sB, B, H, E), p + "th2.bwd")
+            P.add(L.savit_softmax_rows_bwd_f32, (Pm, sB, sB, B * H * N, N, N), p + "softmax.bwd")   # dS' (attention.py:48)
+            # S'_i = sum_h T1[h, i] S_h: dT1[h, i] = sum S_h dS'_i ; dS_h = sum_i T1[h, i] dS'_i
+            self._gemm(P, p + "dT1.part", S, sB, dT, H, H, E, E, E, H, transW=1, batch=B, sA=(H * E, 0), sW=(H * E, 0), sC=(H * H, 0))
+            P.add(colsum, (dT, gp(p + "T1"), B, H * H, H * H), p + "dT1")
+            P.add(L.savit_head_mix_f32, (T1t, sB, sA, B, H, E), p + "th1.bwd")                      # dS
+            # S = (q / sqrt(hd)) k^T (attention.py:39-41; q is stored scaled): dQ = dS K / sqrt(hd) ; dK = dS^T q
+            self._gemm(P, p + "dQ", sA, qkv + 4 * d, dqkv, N, hd, N, N, 3 * d, 3 * d, sA=sAE, sW=(N * 3 * d, hd), sC=(N * 3 * d, hd), alpha=alpha,
+                       alpha_cols=hd, **bh)
+            self._gemm(P, p + "dK", sA, qkv, dqkv + 4 * d, N, hd, N, N, 3 * d, 3 * d, transA=1, sA=sAE, sW=(N * 3 * d, hd), sC=(N * 3 * d, hd), **bh)
+            self._wgrad(P, p + "Wqkv.wgrad", h1, dqkv, gp(p + "Wqkv"), M, d, 3 * d, d, 3 * d)
+            self._dgrad(P, p + "qkv.dgrad", dqkv, pp(p + "Wqkv"), d_h, M, d, 3 * d, 3 * d, 3 * d, d)
+            P.add(ln_bwd, (d_h, x, pp(p + "ln1_g"), dres, dres, gp(p + "ln1_g"), gp(p + "ln1_b"), M, d, d, d, 1e-6), p + "ln1.bwd")
+        # ---- embeddings: x0 = patches Wpe + pos (cait.py:143-145): dpos = sum over the images, dWpe = patches^T dx0
+        P.add(colsum, (dres, gp("pos"), B, N * d, N * d), "pos.grad")
+        self._wgrad(P, "Wpe.wgrad", self.patches.data_ptr(), dres, gp("Wpe"), M, cfg.patch_dim, d, cfg.patch_dim, d)
         return P
 
     def set_images(self, images: torch.Tensor):
         S = self.cfg.img_size
+        if images.is_cuda and tuple(images.shape) == (S, S, 3, self.B):  # the loader's [H, W, C, N] (train.py:80): a permuted device copy
+            self.images.copy_(images.permute(3, 0, 1, 2).to(f32))
+            return
         if not images.is_cuda or tuple(images.shape) != (self.B, S, S, 3):
-            raise ValueError(f"images must be a GPU tensor [B={self.B},{S},{S},3] (NHWC)")
+            raise ValueError(f"images must be a GPU tensor [B={self.B},{S},{S},3] (NHWC) or [{S},{S},3,B={self.B}]")
         self.images.copy_(images.to(f32))
 
     def forward(self, images: Optional[torch.Tensor] = None, is_training: bool = False, keep_masks: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -383,20 +560,51 @@ class CaiTEngineF32(_F32Base):
             if self.keep is None:
                 self.keep = torch.empty(nb, 2, self.B, dtype=f32, device=self.dev)
             self.keep.copy_(keep_masks.to(device=self.dev, dtype=f32) / keep)
-        if training not in self._plans:
-            if training and self.keep is None:
-                raise RuntimeError("keep masks missing")
-            self._plans[training] = self._build(training)
-        # the cls stream starts from the parameter (cait.py:157-160)
-        self.cls.copy_(self.layout.view(self.params, "cls").view(1, -1).expand(self.B, -1))
-        self._plans[training].run(torch.cuda.current_stream().cuda_stream)
+        self._run_forward(training)
         return self.logits
 
-    def loss_backward(self, *a, **k):
-        raise NotImplementedError("CaiT fp32 arithmetic covers forward + loss; CaiT training runs on the bf16 MFMA engine "
-                                  "(create_model(..., dtype=torch.bfloat16))")
+    def _run_forward(self, training: bool):
+        save = bool(self.save_activations)
+        if save and self.sv is None:
+            self._alloc_saved()
+        key = (training, save)
+        if key not in self._plans:
+            if training and self.keep is None:
+                raise RuntimeError("keep masks missing")
+            self._plans[key] = self._build(training, save)
+        # the cls stream starts from the parameter (cait.py:157-160)
+        first = self.sv["clsin"][0] if (save and self.cfg.num_layers_token_only > 0) else self.cls
+        first.copy_(self.layout.view(self.params, "cls").view(1, -1).expand(self.B, -1))
+        self._plans[key].run(torch.cuda.current_stream().cuda_stream)
+        self._saved_training = training if save else None
+        self._last_training = training
 
-    optimizer_step = backward_from_dlogits = loss_backward
+    def loss_backward(self, labels: torch.Tensor, label_smoothing: float = 0.1, zero_grads: bool = True) -> torch.Tensor:
+        """Loss (train.py:83-90) + the full backward pass of the LAST forward (same images, same stochastic-depth masks) into
+        self.grads (fp32).  The first call switches the engine to saving activations and re-runs that forward once."""
+        if self.cfg.num_layers_token_only < 1:
+            raise NotImplementedError("CaiT fp32 backward expects at least one class-attention layer (every create_model name has two)")
+        if self.grads is None:
+            self.grads = torch.zeros_like(self.params)
+        elif zero_grads:
+            self.grads.zero_()
+        training = bool(getattr(self, "_last_training", False))
+        if self._saved_training is None or self._saved_training != training:
+            self.save_activations = True
+            self._run_forward(training)  # (the images and the keep masks of the last forward are still in place)
+        s = torch.cuda.current_stream().cuda_stream
+        self.loss_fn(labels, label_smoothing)
+        _lib.check(self.L.savit_softmax_xent_grad_f32(self.logits.data_ptr(), self.labels.data_ptr(), float(label_smoothing), 1.0 / self.B,
+                                                      self.dlogits.data_ptr(), self.B, self.cfg.num_classes, s), "savit_softmax_xent_grad_f32")
+        # the transposed talking-heads matrices the two mix VJPs read (strided device copies: memory plumbing, no arithmetic)
+        lay = self.layout
+        for l in range(self.cfg.num_layers):
+            self.bw["Tt"][l, 0].copy_(lay.view(self.params, f"l{l}.T1").t())
+            self.bw["Tt"][l, 1].copy_(lay.view(self.params, f"l{l}.T2").t())
+        if training not in self._bwd_plans:
+            self._bwd_plans[training] = self._build_bwd(training)
+        self._bwd_plans[training].run(s)
+        return self.loss
 
 
 class _ForwardOnlyF32(_F32Base):
@@ -557,12 +765,30 @@ class TNTEngineF32(_ForwardOnlyF32):
         return P
 
 
-def _concat_rows(eng: "CaiTEngineF32", stream: int) -> int:
+def _concat_rows(eng: "CaiTEngineF32", c: int, save: bool, stream: int) -> int:
     """xc = concat([cls, x], axis=1) (cait.py:98): two strided device copies on the current stream (memory plumbing, no arithmetic)."""
     B, N, d = eng.B, eng.cfg.n_patches, eng.cfg.embed_dim
-    xc = eng.xc.view(B, N + 1, d)
-    xc[:, 0].copy_(eng.cls)
-    xc[:, 1:].copy_(eng.x.view(B, N, d))
+    xc = (eng.sv["xc"][c] if save else eng.xc).view(B, N + 1, d)
+    xc[:, 0].copy_(eng.sv["clsin"][c] if save else eng.cls)
+    xc[:, 1:].copy_(eng._x_final_t.view(B, N, d))
+    return 0
+
+
+def _cls_rows_copy(eng: "CaiTEngineF32", compact: str, concat: str, into_concat: bool, stream: int) -> int:
+    """Row 0 of every image of a [B (N + 1), d] cotangent <-> the compact [B, d] cls cotangent (strided device copy, no arithmetic)."""
+    B, N, d = eng.B, eng.cfg.n_patches, eng.cfg.embed_dim
+    rows = eng.bw[concat].view(B, N + 1, d)[:, 0]
+    if into_concat:
+        rows.copy_(eng.bw[compact])
+    else:
+        eng.bw[compact].copy_(rows)
+    return 0
+
+
+def _patch_rows_copy(eng: "CaiTEngineF32", stream: int) -> int:
+    """dres = rows 1.. of d / d[cls ; x] (the patch rows: the cotangent of the SA stage's output), contiguous."""
+    B, N, d = eng.B, eng.cfg.n_patches, eng.cfg.embed_dim
+    eng.bw["dres"].view(B, N, d).copy_(eng.bw["dxc"].view(B, N + 1, d)[:, 1:])
     return 0
 
 

@@ -160,6 +160,7 @@ _SIGNATURES = {
     "savit_head_mix_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p]),
     "savit_layernorm_bwd_f32": (c_int, [c_void_p] * 7 + [c_int, c_int, c_long, c_long, c_float, c_void_p]),
     "savit_colsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "savit_layerscale_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "savit_softmax_xent_grad_f32": (c_int, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int, c_int, c_void_p]),
     "savit_patchify_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "savit_patchify_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

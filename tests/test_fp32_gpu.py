@@ -409,6 +409,76 @@ def test_cait_fp32_stochastic_depth_masks(L):
     assert torch.equal(a, eng.forward(torch.as_tensor(images).cuda(), is_training=True))  # the masks come from the engine's seeded generator
 
 
+def test_layerscale_bwd_f32(L):
+    """savit_layerscale_bwd_f32 (round 6): the VJP of LayerScale x stochastic depth as cait.py:36-52 composes them, against fp64."""
+    rng = np.random.default_rng(47)
+    for M, d, rps in ((197 * 3, 192, 197), (5, 64, 1), (100, 384, 0)):
+        dres, br = rng.standard_normal((M, d)).astype(np.float32), rng.standard_normal((M, d)).astype(np.float32)
+        ls = rng.standard_normal(d).astype(np.float32)
+        nb = (M + rps - 1) // rps if rps else 0
+        rs = (rng.random(nb) < 0.7).astype(np.float32) / 0.7 if rps else None
+        rows = np.repeat(rs, rps)[:M].astype(np.float64) if rps else np.ones(M)
+        dls0 = rng.standard_normal(d).astype(np.float32)
+        t = [dev(x) for x in (dres, br, ls)]
+        trs = dev(rs) if rps else None
+        out, dls = torch.empty(M, d, device="cuda"), dev(dls0)
+        rc = L.savit_layerscale_bwd_f32(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), trs.data_ptr() if rps else None, max(rps, 1), out.data_ptr(),
+                                        dls.data_ptr(), M, d, st())
+        assert rc == 0
+        g = dres.astype(np.float64) * rows[:, None]
+        assert rel(out.cpu().numpy(), g * ls[None, :]) < 1e-6
+        assert rel(dls.cpu().numpy(), dls0 + (g * br).sum(0)) < 2e-6  # accumulates into dls
+
+
+@pytest.mark.parametrize("case,B,training", [("small", 5, True), ("small", 5, False), ("cait_xxs_24", 2, False)])
+def test_cait_fp32_train_step_vs_autograd(L, case, B, training):
+    """Round 6: the fp32 TRAIN step of a CaiT - the arithmetic the reference always uses for this family
+    (cait.py:147-154 / create_model.py:115-123 drop dtype) and what train.py:77-100 would differentiate: loss, EVERY parameter gradient
+    (talking-heads matrices, LayerScale, class attention included) against fp32 autograd of the oracle, with explicit stochastic-depth
+    keep masks in training mode, and the AdamW update."""
+    from oracle import torch_ref
+    from savit_amd.config import ModelConfig, get_config
+    from savit_amd.engine_f32 import CaiTEngineF32
+
+    if case == "small":
+        kw = dict(kind="cait", img_size=32, patch=8, embed_dim=64, num_layers=3, num_layers_token_only=2, num_heads=4, expand_ratio=4, num_classes=10,
+                  stoch_depth_rate=0.3, layerscale_eps=0.1)
+        mc, oc, img = ModelConfig(**kw), vit_ref.Cfg(**kw), 32
+    else:
+        mc, oc, img = get_config(case), vit_ref.get_cfg(case), 224
+    rng = np.random.default_rng(53)
+    params = vit_ref.init_params(oc, seed=12, randomize=True)
+    images = rng.standard_normal((B, img, img, 3)).astype(np.float32)
+    labels = rng.integers(0, oc.num_classes, B)
+    masks = (rng.random((oc.num_layers + oc.num_layers_token_only, 2, B)) < 0.7).astype(np.float32) if training else None
+    eng = CaiTEngineF32(mc, B)
+    eng.load_params(params)
+    logits = eng.forward(torch.as_tensor(images).cuda(), is_training=training, keep_masks=None if masks is None else torch.as_tensor(masks)).clone()
+    loss = float(eng.loss_backward(torch.as_tensor(labels).cuda(), 0.1))
+    assert torch.equal(logits, eng.logits)  # the re-run of the forward that saves activations reproduces it bit for bit
+    loss_ref, logits_ref, g_ref = torch_ref.loss_and_grads(params, images, labels, oc, 0.1, is_training=training, keep_masks=masks)
+    assert rel(logits.cpu().numpy(), logits_ref) < 2e-5
+    assert abs(loss - loss_ref) < 1e-5 * max(1.0, abs(loss_ref))
+    got = _flat(eng.grad_tree()["params"])
+    assert set(got) == set(g_ref)
+    worst = max((rel(got[k], g_ref[k]), k) for k in got)
+    print(f"[fp32 CaiT train step {case} training={training}] loss {loss:.6f} (oracle {loss_ref:.6f}); worst gradient rel-L2 {worst[0]:.2e} ({worst[1]})")
+    assert worst[0] < 2e-5, worst
+    # a second forward + backward (now saving activations in the forward itself) reproduces the gradients
+    g1 = eng.grads.clone()
+    eng.forward(torch.as_tensor(images).cuda(), is_training=training, keep_masks=None if masks is None else torch.as_tensor(masks))
+    eng.loss_backward(torch.as_tensor(labels).cuda(), 0.1)
+    assert rel(eng.grads.cpu().numpy(), g1.cpu().numpy()) < 1e-6
+    # optax chain of train.py:25-27 (descent sign of simple_train.py:27): clip_by_global_norm(1.0), adam, add_decayed_weights(1e-4), -lr
+    p0, g = eng.params.double().clone(), eng.grads.double().clone()
+    eng.optimizer_step(lr=1e-3, weight_decay=1e-4, max_norm=1.0)
+    gn = float(g.norm())
+    g = g * min(1.0, 1.0 / gn)
+    m, v = 0.1 * g, 0.001 * g * g
+    upd = (m / 0.1) / ((v / 0.001).sqrt() + 1e-8) + 1e-4 * p0
+    assert rel(eng.params.cpu().numpy(), (p0 - 1e-3 * upd).cpu().numpy()) < 1e-6
+
+
 def _leaves(t):
     for v in t.values():
         if isinstance(v, dict):
