@@ -75,7 +75,7 @@ def kernel_symbol(label: str, lib, M: int, d: int, F: int) -> str:
     if op.endswith(".wgrad.reduce"):
         return "wgrad_reduce_kernel"
     if "attn" in op:
-        return "attn_bwd_pers_kernel" if op.endswith(".bwd") else "attn_fwd_kernel"  # the N <= 224, head_dim 64 kernels (csrc/attention.hip)
+        return "attn_bwd_persl_kernel" if op.endswith(".bwd") else "attn_fwdl_kernel"  # the N <= 224, head_dim 64 kernels with a loader wave (csrc/attention.hip, round 6)
     if op.startswith("ln"):
         return "ln_bwd_kernel(+finalize)" if op.endswith(".bwd") else "ln_fwd_kernel"
     return "other(" + op + ")"

@@ -321,6 +321,139 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_kernel(const AttnParams p) {
   }
 }
 
+// Round 6: the same kernel with a LOADER wave (NT <= 7: eight waves, two per SIMD).  The K / V images of the next item are requested
+// by one extra wave that does nothing else (56 LDS-DMA instructions per item: no registers), so the compute waves no longer queue them
+// in front of their score MFMAs - a CU takes one vector-memory instruction per ~50 cycles (see attn_bwd_persl_kernel).  One bare barrier
+// per item: the loader reaches it behind its own vmcnt(0) (this item's images landed), the compute waves behind their last read of the
+// other image pair.  Same arithmetic: bitwise the results of attn_fwd_kernel.
+template <int NT>
+__global__ __launch_bounds__(64 * (NT + 1)) void attn_fwdl_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int IMG = NT * 32 * ROWB;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nitems = p.B * p.H;
+  size_t bytes = (size_t)p.B * p.N * p.ld * 2;
+  if (bytes > 0xffffffe0ull) bytes = 0xffffffe0ull;
+  const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.qkv), 0, (uint32_t)bytes, 0x00020000);
+  const int ql = lane & 31, half = lane >> 5;
+  const int q = wave * 32 + ql;
+  const int g = lane >> 4, t = lane & 15;
+  const int trow = 4 * (g >> 1) + (t >> 2);        // + 32*kt + 16*s2
+  const int tcol = 16 * (g & 1) + 4 * (t & 3);      // + 32*eb
+
+  const bool loader = wave == NT;
+  auto stage_item = [&](int item, char* buf) {  // (loader) both images, every instruction
+    const int b = item / p.H, hh = item - b * p.H;
+    const long row_base = (long)b * p.N;
+    stage_image<1, NT>(buf, srd, row_base, p.N, p.ld, p.d + hh * HD, 0, lane);
+    stage_image<1, NT>(buf + IMG, srd, row_base, p.N, p.ld, 2 * p.d + hh * HD, 0, lane);
+  };
+  // Q fragments of this wave's 32 queries straight from HBM (B operand: lane = (q, half), 8 consecutive e)
+  bf16x8 qf[4];
+  auto load_q = [&](int item) {
+    const int b = item / p.H, hh = item - b * p.H;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (q < p.N) qf[ks] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)((long)b * p.N + q) * p.ld + hh * HD + 16 * ks + 8 * half);
+    }
+  };
+
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+  int cur = 0;
+  if (loader) {
+    stage_item(item, smem);
+#pragma unroll 1
+    for (; item < nitems; item += gridDim.x) {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // this item's images landed; the other pair is free
+      const int nxt = item + gridDim.x;
+      if (nxt < nitems) stage_item(nxt, smem + (cur ^ 1) * 2 * IMG);
+      cur ^= 1;
+    }
+    return;
+  }
+  load_q(item);
+#pragma unroll 1
+  for (; item < nitems; item += gridDim.x) {
+    // this item's images have landed (the loader waited for them) and every wave is done reading the other pair.  Bare: the wait for
+    // this wave's own Q rows is the compiler's, in front of their first use - the barrier does not wait for the previous item's stores
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int nxt = item + gridDim.x;
+    char* imgK = smem + cur * 2 * IMG;
+    char* imgV = imgK + IMG;
+    const int b = item / p.H, hh = item - b * p.H;
+    const long row_base = (long)b * p.N;
+
+    // S^T tiles: rows = keys (registers), column = query (lane)
+    f32x16 s[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = lds_row_frag(imgK, kt * 32 + ql, 2 * ks + half);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+      }
+    }
+    if (nxt < nitems) load_q(nxt);  // qf is dead: the next item's queries arrive under the softmax
+    // mask keys >= N, row max
+    // only the last key tile can hold keys >= N (NT = ceil(N / 32))
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (NT - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (key >= p.N) s[NT - 1][r] = -INFINITY;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kt][r]);
+    }
+    m = half_max(m);
+    const float mb = m * LOG2E;
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[kt][r] * LOG2E - mb);
+        s[kt][r] = e;
+        l += e;
+      }
+    }
+    l = half_sum(l);
+
+    // O^T[e][q] = sum_key V^T[e][key] P^T[key][q]
+    f32x16 oacc[2];
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[eb][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_to_frag(s[kt], s2);
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) {
+          const bf16x8 vf = lds_tr_frag(imgV, kt * 32 + 16 * s2 + trow, 32 * eb + tcol);
+          oacc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[eb], 0, 0, 0);
+        }
+      }
+    }
+    {
+      const float inv = 1.0f / l;  // rows q >= N: finite (every key of the last tile masked alike), never stored
+      store_tile_rows(smem + 4 * IMG + wave * (32 * ROWB), p.o + (size_t)(row_base + wave * 32) * p.d + hh * HD, p.d, p.N - wave * 32, oacc, ql,
+                      half, lane, inv);
+      if (q < p.N && half == 0 && p.lse != nullptr) p.lse[((size_t)b * p.H + hh) * p.N + q] = m + __logf(l);
+    }
+    cur ^= 1;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ backward
 template <int NT>
 __global__ __launch_bounds__(64 * NT) void attn_bwd_kernel(const AttnParams p) {
@@ -837,6 +970,367 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd_pers_kernel(const AttnParams
     item = nxt;
   }
 }
+
+// Round 6: the persistent backward with a LOADER wave (N <= 224; NT compute waves + 1).  Stamps of the kernel above put 4.3 + 2.2 us of
+// an item's 17.1 between and behind its passes, where all seven waves queue ~45 vector-memory instructions each and the CU takes one
+// every ~50 cycles while nothing computes.  Two thirds of them are LDS-DMA requests (the four images, the O rows), which need no
+// registers: here ONE extra wave - the second wave of the SIMD that held a single compute wave - issues every LDS-DMA of the
+// workgroup (140 per item) beside the passes, and the compute waves keep their K / V row loads, LSE loads and result stores.
+//   compute wave:  [a] pass B | own Q, dO rows -> registers | K / V rows + LSE of item i+1 requested | dK, dV stores  [b] pass A
+//                  [c] own vmcnt(0) | delta, LSE -> LDS; K, V rows -> fragments | dQ stores  [a] ...
+//   loader wave:   [a] LDS-DMA K, V(i); vmcnt(0)  [b] LDS-DMA O rows(i+1) -> every wave's transposition image, Q, dO(i+1); vmcnt(0)  [c] [a]
+// Barriers are bare (s_waitcnt lgkmcnt(0); s_barrier): no wave waits for another's stores.  WAR: the loader overwrites the K / V
+// images behind barrier a (last read: pass A, before c), the Q / dO images and the transposition images behind b (last read: pass B,
+// the own-row fragments and the dK / dV transposition, all before b); RAW: its vmcnt(0) precedes the barrier that publishes the data.
+// Same arithmetic per element as attn_bwd_pers_kernel: bitwise the same results.  Measured (profiles/r06_attn_loader_ab.log, DeiT-B's
+// layer, same box, A / B / A / B): 129-130 -> 119-120 us alone, 120 -> 109.5 us per dense launch in the step.  Tried on top and dropped:
+// the loader at raised priority (+1 us), the SIMD partners (waves 4-6) started half a tile late in both passes (+3...6 us).
+template <int NT>
+__global__ __launch_bounds__(64 * (NT + 1)) void attn_bwd_persl_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int IMG = NT * 32 * ROWB;
+  char* imgK = smem;
+  char* imgV = smem + IMG;
+  char* imgQ = smem + 2 * IMG;
+  char* imgD = smem + 3 * IMG;  // dO
+  float* lse_s = reinterpret_cast<float*>(smem + 4 * IMG);
+  float* del_s = lse_s + NT * 32;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool loader = wave == NT;  // the extra wave: issues every LDS-DMA of the workgroup (see above the kernel)
+  char* scr0 = smem + 4 * IMG + 2 * NT * 32 * (int)sizeof(float);
+  char* scr = scr0 + (loader ? 0 : wave) * (32 * ROWB);  // this wave's 4 KB transposition image
+  const int nitems = p.B * p.H;
+  size_t bytes = (size_t)p.B * p.N * p.ld * 2;
+  if (bytes > 0xffffffe0ull) bytes = 0xffffffe0ull;
+  size_t bytes_o = (size_t)p.B * p.N * p.d * 2;
+  if (bytes_o > 0xffffffe0ull) bytes_o = 0xffffffe0ull;
+  const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.qkv), 0, (uint32_t)bytes, 0x00020000);
+  const auto srdD = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.d_o), 0, (uint32_t)bytes_o, 0x00020000);
+  const int ql = lane & 31, half = lane >> 5;
+  const int g = lane >> 4, t = lane & 15;
+  const int trow = 4 * (g >> 1) + (t >> 2);
+  const int tcol = 16 * (g & 1) + 4 * (t & 3);
+  const int q = wave * 32 + ql;  // this wave's row in both passes (key in B, query in A)
+  uint32_t trc[2][2];  // [eb][lo / hi]: transposed-fragment addresses of tile 0 in the first image
+#pragma unroll
+  for (int eb = 0; eb < 2; ++eb) {
+    trc[eb][0] = lds_addr32(smem) + tr_lane_off(trow, 32 * eb + tcol, false);
+    trc[eb][1] = lds_addr32(smem) + tr_lane_off(trow, 32 * eb + tcol, true);
+  }
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // (loader) every 32-row block of an image pair: NT x 4 wave-instructions per image, straight-line
+  auto stage_kv = [&](int item) {
+    const int b = item / p.H, hh = item - b * p.H;
+#pragma unroll
+    for (int w = 0; w < NT; ++w) {
+      stage_image_u<NT, NT>(imgK, srd, (long)b * p.N, p.N, p.ld, p.d + hh * HD, w, lane);
+      stage_image_u<NT, NT>(imgV, srd, (long)b * p.N, p.N, p.ld, 2 * p.d + hh * HD, w, lane);
+    }
+  };
+  auto stage_qd = [&](int item) {
+    const int b = item / p.H, hh = item - b * p.H;
+#pragma unroll
+    for (int w = 0; w < NT; ++w) {
+      stage_image_u<NT, NT>(imgQ, srd, (long)b * p.N, p.N, p.ld, hh * HD, w, lane);
+      stage_image_u<NT, NT>(imgD, srdD, (long)b * p.N, p.N, p.d, hh * HD, w, lane);
+    }
+  };
+  // this wave's 32 rows of O (for delta = rowsum(dO * O); dO comes out of its LDS image) go by LDS-DMA into the wave's transposition
+  // image (no registers), its LSE values and its rows of K, V (B operands of pass B) into registers; all as whole 128-byte rows.
+  bf16x8 kf[4], vf[4];
+  float lse_q = 0.f;
+  const auto srdO = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.o), 0, (uint32_t)bytes_o, 0x00020000);
+  auto request_lse = [&](int item) {  // (compute wave) LSE of its 32 queries
+    const int b = item / p.H, hh = item - b * p.H;
+    lse_q = INFINITY;  // rows q >= N: -LSE * log2 e = -inf, P = 0
+    if (q < p.N) lse_q = p.lse[((size_t)b * p.H + hh) * p.N + q];
+  };
+  auto request_o = [&](int item) {    // (loader) every wave's 32 rows of O into that wave's transposition image
+    const int b = item / p.H, hh = item - b * p.H;
+    const int lrow = lane >> 3, pc = lane & 7;
+#pragma unroll
+    for (int w = 0; w < NT; ++w)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = 8 * j + lrow;
+        const int c = pc ^ rot3(t);
+        uint32_t voff = 0xfffffff0u;
+        if (w * 32 + t < p.N) voff = (uint32_t)(((size_t)((long)b * p.N + w * 32 + t) * p.d + hh * HD + c * 8) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdO, (__attribute__((address_space(3))) void*)(scr0 + w * (32 * ROWB) + j * 1024), 16, voff, 0, 0, 0);
+      }
+  };
+  auto request_rows = [&](int item, bf16x8 (&f)[4], int col0) {  // whole rows again (kf / vf hold them raw until rows_to_frags)
+    const int b = item / p.H, hh = item - b * p.H;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wave * 32 + 8 * j + (lane >> 3);
+      f[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (row < p.N) f[j] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)((long)b * p.N + row) * p.ld + col0 + hh * HD + 8 * (lane & 7));
+    }
+  };
+  auto request_kv = [&](int item) {
+    request_rows(item, kf, p.d);
+    request_rows(item, vf, 2 * p.d);
+  };
+  // raw rows -> B-operand fragments (lane = (row, half), 16-byte chunks 2 ks + half) through the transposition image
+  auto rows_to_frags = [&](bf16x8 (&f)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16x8*>(scr + img_off(8 * j + (lane >> 3), lane & 7)) = f[j];
+    uint4 v[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) lds_read_u4(v[ks], lds_addr32(scr) + (uint32_t)img_off(ql, 2 * ks + half));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f[ks] = __builtin_bit_cast(bf16x8, v[ks]);
+  };
+  // delta and -LSE * log2 e of this wave's queries, once ITS rows of the item's dO image and of O have landed (its own LDS-DMA: no
+  // barrier needed): LDS for everybody's pass B (published by barrier a), registers for this wave's pass A.
+  float delta = 0.f, nlse2 = 0.f;
+  auto finish_delta = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wave * 32 + 8 * j + (lane >> 3);
+      const bf16x8 dv = lds_row_frag(imgD, row, lane & 7);  // rows >= N are zero in both
+      const bf16x8 ov = lds_row_frag(scr, 8 * j + (lane >> 3), lane & 7);
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part += bf16_to_f32((bf16_t)ov[e]) * bf16_to_f32((bf16_t)dv[e]);
+      part += dpp_mov<0xB1>(part);   // quad_perm [1,0,3,2]
+      part += dpp_mov<0x4E>(part);   // quad_perm [2,3,0,1]
+      part += dpp_mov<0x141>(part);  // row_half_mirror: the other quad of the 8 lanes of this row
+      if ((lane & 7) == 0) del_s[row] = part;
+    }
+    nlse2 = -LOG2E * lse_q;
+    if (half == 0) lse_s[q] = nlse2;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(delta) : "v"(lds_addr32(smem) + 4 * IMG + (uint32_t)((NT * 32 + q) * 4)) : "memory");
+  };
+
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+#define ATTN_BARE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  if (loader) {
+    // ---- the loader wave: nothing but LDS-DMA requests, its own vmcnt(0) and the workgroup's barriers (p, a, then b, c, a per item)
+    stage_qd(item);
+    request_o(item);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATTN_BARE_BARRIER();  // p: Q, dO images and O rows of the first item landed
+    ATTN_BARE_BARRIER();  // a
+#pragma unroll 1
+    for (;;) {
+      const int nxt = item + gridDim.x;
+      const bool has_next = nxt < nitems;
+      stage_kv(item);  // K, V images (pass A) land under pass B
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ATTN_BARE_BARRIER();  // b: K, V landed; Q, dO images, statistics and the transposition images are free
+      if (has_next) {
+        request_o(nxt);
+        stage_qd(nxt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      ATTN_BARE_BARRIER();  // c: the next item's Q, dO images and O rows landed (under pass A)
+      ATTN_BARE_BARRIER();  // a
+      if (!has_next) break;
+      item = nxt;
+    }
+    return;
+  }
+  request_kv(item);
+  request_lse(item);
+  ATTN_BARE_BARRIER();  // p
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  finish_delta();
+  rows_to_frags(kf);
+  rows_to_frags(vf);
+  ATTN_BARE_BARRIER();  // barrier a of the first item
+#pragma unroll 1
+  for (;;) {
+    const int nxt = item + gridDim.x;
+    const bool has_next = nxt < nitems;
+    const int b = item / p.H, hh = item - b * p.H;
+    const long row_base = (long)b * p.N;
+    // ---- pass B: this wave owns keys (lane = key).  S[q][key] non-swapped: rows = queries (registers).
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) {
+      dk[eb] = zero16;
+      dv[eb] = zero16;
+    }
+#pragma unroll 1
+    for (int qt = 0; qt < NT; ++qt) {
+      f32x16 sa = zero16, da = zero16;
+      // -LSE*log2e and delta of this tile's queries: register r holds query qt*32 + 8*(r>>2) + 4*half + (r&3): four 16-byte reads
+      // each, as inline asm in two halves (any LDS load the compiler knows the address space of gets `s_waitcnt vmcnt(0)` in front
+      // while an LDS-DMA is in flight - these did, and the K, V prefetch landed before the pass went on)
+      f32x4 nl4[4], dl4[4];
+      const uint32_t sta = lds_addr32(smem) + 4 * IMG + (uint32_t)((qt * 32 + 4 * half) * 4);
+#pragma unroll
+      for (int g4 = 0; g4 < 2; ++g4) {
+        lds_read_f4(nl4[g4], sta, 32 * g4);
+        lds_read_f4(dl4[g4], sta, NT * 32 * 4 + 32 * g4);
+      }
+      ATTN_PRIO(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 qfr = lds_row_frag(imgQ, qt * 32 + ql, 2 * ks + half);
+        const bf16x8 dfr = lds_row_frag(imgD, qt * 32 + ql, 2 * ks + half);
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[ks], sa, 0, 0, 0);
+        da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr, vf[ks], da, 0, 0, 0);
+        if (ks == 1) __builtin_amdgcn_sched_barrier(0);  // the second half's fragments are requested under these MFMAs: 16 registers less
+      }
+      ATTN_PRIO(0);
+      TrFrag dtf[2][2], qtf[2][2];  // k-step 1's are requested under k-step 0's MFMAs
+      const uint32_t tb = (uint32_t)(qt * 32 * ROWB);
+#ifdef ATTN_TR_EARLY
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) {
+        lds_tr_issue<3 * IMG - 2 * IMG>(dtf[0][eb], trc[eb][0] + tb + 2 * IMG, trc[eb][1] + tb + 2 * IMG);
+        lds_tr_issue<0>(qtf[0][eb], trc[eb][0] + tb + 2 * IMG, trc[eb][1] + tb + 2 * IMG);
+      }
+#endif
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        if (g4 == 0) {
+          lds_f4_wait(nl4[0], dl4[0], nl4[1], dl4[1]);
+#pragma unroll
+          for (int h4 = 2; h4 < 4; ++h4) {  // the second half arrives under the first half's arithmetic
+            lds_read_f4(nl4[h4], sta, 32 * h4);
+            lds_read_f4(dl4[h4], sta, NT * 32 * 4 + 32 * h4);
+          }
+        }
+        if (g4 == 2) lds_f4_wait(nl4[2], dl4[2], nl4[3], dl4[3]);
+        const float nl[4] = {nl4[g4][0], nl4[g4][1], nl4[g4][2], nl4[g4][3]};
+        const float dl[4] = {dl4[g4][0], dl4[g4][1], dl4[g4][2], dl4[g4][3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g4 + j;
+          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], LOG2E, nl[j]));  // rows q >= N: -inf -> 0
+          sa[r] = pr;
+          da[r] = pr * (da[r] - dl[j]);
+        }
+      }
+#ifndef ATTN_TR_EARLY
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) {
+        lds_tr_issue<3 * IMG - 2 * IMG>(dtf[0][eb], trc[eb][0] + tb + 2 * IMG, trc[eb][1] + tb + 2 * IMG);
+        lds_tr_issue<0>(qtf[0][eb], trc[eb][0] + tb + 2 * IMG, trc[eb][1] + tb + 2 * IMG);
+      }
+#endif
+      lds_tr_wait(dtf[0][0], dtf[0][1], qtf[0][0], qtf[0][1]);
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) {
+        lds_tr_issue<IMG + 16 * ROWB>(dtf[1][eb], trc[eb][0] + tb + 2 * IMG, trc[eb][1] + tb + 2 * IMG);
+        lds_tr_issue<16 * ROWB>(qtf[1][eb], trc[eb][0] + tb + 2 * IMG, trc[eb][1] + tb + 2 * IMG);
+      }
+      ATTN_PRIO(1);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_to_frag(sa, s2);
+        const bf16x8 dsf = acc_to_frag(da, s2);
+        if (s2 == 1) lds_tr_wait(dtf[1][0], dtf[1][1], qtf[1][0], qtf[1][1]);
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) {
+          dv[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(dtf[s2][eb]), pf, dv[eb], 0, 0, 0);
+          dk[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(qtf[s2][eb]), dsf, dk[eb], 0, 0, 0);
+        }
+      }
+      ATTN_PRIO(0);
+    }
+    // this wave's Q, dO rows for pass A, before the images are released
+    bf16x8 qf[4], df[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = lds_row_frag(imgQ, q, 2 * ks + half);
+      df[ks] = lds_row_frag(imgD, q, 2 * ks + half);
+    }
+    const float delta_a = delta, nlse2_a = nlse2;
+    // dK, dV leave BEFORE barrier b (through the wave's transposition image, which the loader refills with the next item's O rows
+    // behind that barrier); the barrier is bare - it must not wait for these stores.  The K / V images are the loader's: it waits for
+    // its own vmcnt(0) in front of barrier b.
+    if (has_next) {  // kf / vf are dead behind pass B: the next item's rows are requested in front of the stores (119 -> 115 us)
+      request_kv(nxt);
+      request_lse(nxt);
+    }
+    {
+      bf16_t* ktile = p.dqkv + (size_t)(row_base + wave * 32) * p.ld + p.d + hh * HD;
+      store_tile_rows(scr, ktile, p.ld, p.N - wave * 32, dk, ql, half, lane, 1.0f);
+      store_tile_rows(scr, ktile + p.d, p.ld, p.N - wave * 32, dv, ql, half, lane, 1.0f);
+    }
+    ATTN_BARE_BARRIER();  // barrier b: K, V landed; Q, dO images and the statistics free
+    // ---- pass A: this wave owns queries (lane = query).  dQ^T[e][q] = sum_key K^T[e][key] dS^T[key][q]
+    f32x16 dq[2];
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) dq[eb] = zero16;
+#pragma unroll 1
+    for (int kt = 0; kt < NT; ++kt) {
+      // accumulators start from the MFMA's inline-constant zero C operand (no per-tile register initialisation); the LSE /
+      // delta offsets fold into the exp argument and the dS product: this loop is VALU-bound, every instruction per score counts
+      f32x16 sa = zero16, da = zero16;
+      ATTN_PRIO(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kfr = lds_row_frag(imgK, kt * 32 + ql, 2 * ks + half);
+        const bf16x8 vfr = lds_row_frag(imgV, kt * 32 + ql, 2 * ks + half);
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[ks], sa, 0, 0, 0);
+        da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, df[ks], da, 0, 0, 0);
+        if (ks == 1) __builtin_amdgcn_sched_barrier(0);
+      }
+      ATTN_PRIO(0);
+      TrFrag ktf[2][2];
+      const uint32_t tb = (uint32_t)(kt * 32 * ROWB);
+#ifdef ATTN_TR_EARLY
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) {
+        lds_tr_issue<0>(ktf[0][eb], trc[eb][0] + tb, trc[eb][1] + tb);
+        lds_tr_issue<16 * ROWB>(ktf[1][eb], trc[eb][0] + tb, trc[eb][1] + tb);
+      }
+#endif
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], LOG2E, nlse2_a));
+        sa[r] = pr * (da[r] - delta_a);  // dS^T
+      }
+      if (kt == NT - 1) {  // only the last key tile can hold keys >= N
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (key >= p.N) sa[r] = 0.f;
+        }
+      }
+#ifndef ATTN_TR_EARLY
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) {
+        lds_tr_issue<0>(ktf[0][eb], trc[eb][0] + tb, trc[eb][1] + tb);
+        lds_tr_issue<16 * ROWB>(ktf[1][eb], trc[eb][0] + tb, trc[eb][1] + tb);
+      }
+#endif
+      lds_tr_wait(ktf[0][0], ktf[0][1], ktf[1][0], ktf[1][1]);
+      ATTN_PRIO(1);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 dsf = acc_to_frag(sa, s2);
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) dq[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(ktf[s2][eb]), dsf, dq[eb], 0, 0, 0);
+      }
+      ATTN_PRIO(0);
+    }
+    ATTN_BARE_BARRIER();  // barrier c: the loader's requests for the next item (Q, dO images, O rows) have landed
+    if (has_next) {  // this wave's K, V rows and LSE values of the next item are here after ITS vmcnt(0): statistics, B operands of pass B
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      finish_delta();
+      rows_to_frags(kf);
+      rows_to_frags(vf);
+    }
+    store_tile_rows(scr, p.dqkv + (size_t)(row_base + wave * 32) * p.ld + hh * HD, p.ld, p.N - wave * 32, dq, ql, half, lane, p.dq_scale);
+    // barrier a of the next item: its Q, dO landed (every wave waited for its share above), its statistics written; K, V images
+    // free.  Bare: a __syncthreads() would wait for the dQ stores as well.
+    ATTN_BARE_BARRIER();
+    if (!has_next) break;
+    item = nxt;
+  }
+}
+#undef ATTN_BARE_BARRIER
 
 // ------------------------------------------------------------------------------------------------------------
 // General kernels: any N <= 608 (19 key tiles: ViT-L/16 at 384^2 has N = 577), head_dim 48 or 64 (48 = every CaiT size;
@@ -2682,6 +3176,26 @@ extern "C" int savit_attention_fwd(const void* qkv, void* o, float* lse, int B, 
     SAVIT_LAUNCH_RET();
   }
   // persistent workgroups: as many as fit the CUs' LDS at once (two K/V image pairs each), every one walking over items
+  static const int fwd_loader = SAVIT_EXP_ENV_INT("SAVIT_ATTN_FWD_LOADER", 1);
+  if (fwd_loader && nt <= 7) {  // round 6: + one loader wave (attn_fwdl_kernel; nine waves at nt = 8 would not fit two per SIMD)
+#define ATTN_CASE_FL(NTV)                                                                                          \
+  {                                                                                                                \
+    const size_t lds = (size_t)5 * NTV * 32 * ROWB;                                                                \
+    auto kfn = attn_fwdl_kernel<NTV>;                                                                              \
+    SAVIT_LDS_ONCE(kfn);                                                                                           \
+    hipLaunchKernelGGL(kfn, dim3(persistent_grid(B * H, lds, 64 * (NTV + 1))), dim3(64 * (NTV + 1)), lds, (hipStream_t)stream, p); \
+  } break;
+    switch (nt) {
+      case 1: ATTN_CASE_FL(1)
+      case 2: ATTN_CASE_FL(2)
+      case 3: ATTN_CASE_FL(3)
+      case 4: ATTN_CASE_FL(4)
+      case 5: ATTN_CASE_FL(5)
+      case 6: ATTN_CASE_FL(6)
+      default: ATTN_CASE_FL(7)
+    }
+    SAVIT_LAUNCH_RET();
+  }
   ATTN_DISPATCH(attn_fwd_kernel, (size_t)5 * NT * 32 * ROWB, persistent_grid(B * H, (size_t)5 * NT * 32 * ROWB, 64 * NT))
   SAVIT_LAUNCH_RET();
 }
@@ -2735,6 +3249,29 @@ extern "C" int savit_attention_bwd(const void* qkv, const void* o, const void* d
 #ifndef ATTN_BWD_ONE_ITEM
   if (nt <= 7) {  // persistent form: four images + statistics + one 4 KB transposition image per wave (N <= 224: 145 KB of LDS)
 #define ATTN_PERS_LDS ((size_t)4 * NT * 32 * ROWB + (size_t)2 * NT * 32 * sizeof(float) + (size_t)NT * 32 * ROWB)
+    // round 6: NT compute waves + one loader wave that issues every LDS-DMA of the workgroup (attn_bwd_persl_kernel); the form
+    // without it stays for experiment builds (SAVIT_ATTN_BWD_LOADER=0)
+    static const int with_loader = SAVIT_EXP_ENV_INT("SAVIT_ATTN_BWD_LOADER", 1);
+#define ATTN_CASE_L(NTV)                                                                                           \
+  {                                                                                                                \
+    constexpr int NT = NTV;                                                                                        \
+    const size_t lds = ATTN_PERS_LDS;                                                                              \
+    auto kfn = attn_bwd_persl_kernel<NTV>;                                                                         \
+    SAVIT_LDS_ONCE(kfn);                                                                                           \
+    hipLaunchKernelGGL(kfn, dim3(persistent_grid(B * H, lds, 64 * (NTV + 1))), dim3(64 * (NTV + 1)), lds, (hipStream_t)stream, p); \
+  } break;
+    if (with_loader) {
+      switch (nt) {
+        case 1: ATTN_CASE_L(1)
+        case 2: ATTN_CASE_L(2)
+        case 3: ATTN_CASE_L(3)
+        case 4: ATTN_CASE_L(4)
+        case 5: ATTN_CASE_L(5)
+        case 6: ATTN_CASE_L(6)
+        default: ATTN_CASE_L(7)
+      }
+      SAVIT_LAUNCH_RET();
+    }
     switch (nt) {
       case 1: ATTN_CASE(attn_bwd_pers_kernel, 1, ATTN_PERS_LDS, persistent_grid(B * H, lds, 64 * NT))
       case 2: ATTN_CASE(attn_bwd_pers_kernel, 2, ATTN_PERS_LDS, persistent_grid(B * H, lds, 64 * NT))

@@ -546,11 +546,15 @@ class CaiTEngineF32(_F32Base):
             raise ValueError(f"images must be a GPU tensor [B={self.B},{S},{S},3] (NHWC) or [{S},{S},3,B={self.B}]")
         self.images.copy_(images.to(f32))
 
-    def forward(self, images: Optional[torch.Tensor] = None, is_training: bool = False, keep_masks: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """keep_masks [(L + Lc), 2, B] of 0 / 1 (tests); drawn from the engine's generator in training mode when absent."""
+    def forward(self, images: Optional[torch.Tensor] = None, is_training: bool = False, keep_masks: Optional[torch.Tensor] = None,
+                sd_seed: Optional[int] = None) -> torch.Tensor:
+        """keep_masks [(L + Lc), 2, B] of 0 / 1 (tests); drawn from the engine's generator in training mode when absent (sd_seed reseeds
+        it first: cait_engine.stochastic_depth_seed, as the bf16 engine)."""
         cfg = self.cfg
         if images is not None:
             self.set_images(images)
+        if sd_seed is not None:
+            self.gen.manual_seed(int(sd_seed))
         training = bool(is_training) and cfg.stoch_depth_rate > 0
         if training:
             keep = 1.0 - cfg.stoch_depth_rate

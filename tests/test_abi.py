@@ -265,13 +265,13 @@ def test_overlapped_kernels_hold_no_scratch_and_no_builtin_waits(built, tmp_path
         scratch[name] = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
     checked = 0
     for mangled, bytes_ in scratch.items():
-        if not re.search(r"attn_bwd_pers_kernelILi[567]E|attn_fwd_kernelILi7E|attn_[fb]wd2_kernelILi4E", mangled):
+        if not re.search(r"attn_bwd_persl?_kernelILi[567]E|attn_fwdl?_kernelILi7E|attn_[fb]wd2_kernelILi4E", mangled):
             continue
         checked += 1
         assert bytes_ == 0, f"{mangled}: {bytes_} bytes of scratch"
         body = isa.split("<" + mangled + ">:")[1].split("\n\n")[0]
         assert "scratch_" not in body, mangled
-    assert checked >= 6, checked
+    assert checked >= 10, checked
     # the persistent backward for DeiT's N = 197: every full vmcnt wait sits right in front of an s_barrier (its passes have none)
     body = isa.split("<" + [m for m in scratch if "attn_bwd_pers_kernelILi7E" in m][0] + ">:")[1].split("\n\n")[0]
     lines = [ln.split("//")[0].strip() for ln in body.splitlines() if ln.strip()]
@@ -293,7 +293,7 @@ def _load_tool(name):
 
 
 INFLIGHT_KERNELS = {  # object -> kernels whose LDS reads are inline asm with a hand-placed wait
-    "attention.o": r"attn_bwd_pers_kernelILi[1-7]E|attn_[fb]wd2_kernelILi[1-4]E|attn_fwd_kernelILi[1-8]E|th_softmax_(fwd|bwd)_kernel",
+    "attention.o": r"attn_bwd_persl?_kernelILi[1-7]E|attn_[fb]wd2_kernelILi[1-4]E|attn_fwdl?_kernelILi[1-8]E|th_softmax_(fwd|bwd)_kernel",
     "gemm_wgrad.o": r"gemm_wgrad_group_kernel|gemm_wgrad_group_mixed_kernel|gemm_wgrad_ring_kernel",
     "gemm_tn.o": r"gemm_tn_pp320_kernel|gemm_tn_pp_kernel|gemm_tn_pers_kernel",
 }
@@ -321,7 +321,7 @@ def test_no_vgpr_is_touched_while_its_lds_read_is_in_flight(built, tmp_path, obj
     if obj == "gemm_wgrad.o":  # the kernels the verdict names must be among them
         assert any("gemm_wgrad_group_kernel" in k for k in kernels) and any("gemm_wgrad_group_mixed_kernel" in k for k in kernels)
     if obj == "attention.o":
-        for need in ("attn_bwd_pers_kernelILi7E", "attn_fwd2_kernelILi4E", "attn_bwd2_kernelILi4E"):
+        for need in ("attn_bwd_pers_kernelILi7E", "attn_bwd_persl_kernelILi7E", "attn_fwdl_kernelILi7E", "attn_fwd2_kernelILi4E", "attn_bwd2_kernelILi4E"):
             assert any(need in k for k in kernels), need
 
 
@@ -422,3 +422,37 @@ def test_every_entry_point_is_named_in_integration_md():
     assert len(names) > 80
     missing = [n for n in names if n not in guide]
     assert not missing, missing
+
+
+def test_loader_wave_kernels_publish_their_lds_dma_behind_a_full_vmcnt_wait(built, tmp_path):
+    """Round 6: attn_fwdl_kernel / attn_bwd_persl_kernel give every LDS-DMA of a workgroup to ONE extra wave; the other waves read the
+    images after a bare barrier.  The loader's `s_waitcnt vmcnt(0)` must therefore sit directly in front of the barriers that publish its
+    requests (source: inline asm, not something hipcc attaches to a builtin), and no other wave may issue an LDS-DMA: the only
+    `buffer_load ... lds` instructions of these kernels are the loader branch's - checked as a count against the launch geometry."""
+    isa = _device_isa("attention.o", tmp_path)
+
+    def ops_of(sym):
+        body = isa.split(sym, 1)[1].split("s_endpgm")[0]
+        ops = [ln.split("//")[0].strip() for ln in body.splitlines() if ln.strip()]
+        return [o for o in ops if re.match(r"^[sv]_|^ds_|^buffer_|^global_", o)]
+
+    def waits_before_barrier(ops):
+        n = 0
+        for i, o in enumerate(ops):
+            if o == "s_waitcnt vmcnt(0)":
+                j = i + 1
+                while j < len(ops) and ops[j].startswith("s_waitcnt"):
+                    j += 1
+                n += j < len(ops) and ops[j] == "s_barrier"
+        return n
+
+    for nt in (5, 6, 7):
+        bwd, fwd = ops_of("attn_bwd_persl_kernelILi%dE" % nt), ops_of("attn_fwdl_kernelILi%dE" % nt)
+        # backward loader: prologue (barrier p), K / V (barrier b), next item's O rows + Q / dO (barrier c); forward loader: one per item
+        assert waits_before_barrier(bwd) >= 3, (nt, waits_before_barrier(bwd))
+        assert waits_before_barrier(fwd) >= 1, nt
+        dma = lambda ops: sum(1 for o in ops if o.startswith("buffer_load_dwordx4") and " lds" in o)  # noqa: E731
+        # backward: Q, dO images + O rows in the prologue and again per item, K, V per item: (2 * 4 nt + 4 nt) * 2 + 2 * 4 nt = 32 nt
+        assert dma(bwd) == 32 * nt, (nt, dma(bwd))
+        # forward: stage_image's loop over the instructions is rolled (one LDS-DMA instruction per image and call site: 2 images x 2 sites)
+        assert 1 <= dma(fwd) <= 4 * 4 * nt, (nt, dma(fwd))
