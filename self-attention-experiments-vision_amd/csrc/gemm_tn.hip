@@ -38,6 +38,29 @@ struct GemmParams {
   int pf_start, pf_policy;  // 320 x 256 kernel, RESID / DGELU: first K-tile of the fused operand's cache prefetch (< 0: off), its cache policy bits
 };
 
+// Output stores of the coalesced epilogues.  SAVIT_EPI_SC1 (experiment builds): write-through `sc1` stores - nothing of the output stays
+// dirty in the XCD's L2, so the release at the end of the kernel has nothing to write back (the dependent-launch boundary grows with the
+// bytes a kernel leaves dirty: MI355X_MICROARCH.md, price list row 'boundary').  Measured in the DeiT-B step (profiles/r06_sc1_stores_ab.log,
+// A / B / A / B on one box): bf16 outputs 1-2 us faster per launch (proj input gradient 31.1 -> 30.0, GELU' 153 -> 151), the fp32
+// residual-stream outputs 4-6 us SLOWER (proj + residual 50 -> 56, fc2 + residual 109 -> 112.7: the next LayerNorm reads them from L2
+// otherwise), the step 16.25 -> 16.36 ms: not taken.
+__device__ __forceinline__ void epi_store_u4(void* p, uint4 v) {
+#ifdef SAVIT_EPI_SC1
+  const u32x4 t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(t) : "memory");
+#else
+  *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void epi_store_f4(void* p, float4 v) {
+#ifdef SAVIT_EPI_SC1
+  const f32x4 t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(t) : "memory");
+#else
+  *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, f32x4 acc, float (&csum)[4]) {
   const savit_gemm_args& a = p.a;
@@ -206,7 +229,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[M
       float4 o = make_float4(r.x + rs * cscale[0] * __uint_as_float(raw.x << 16), r.y + rs * cscale[1] * __uint_as_float(raw.x & 0xffff0000u),
                              r.z + rs * cscale[2] * __uint_as_float(raw.y << 16), r.w + rs * cscale[3] * __uint_as_float(raw.y & 0xffff0000u));
       if (a.round_out_bf16) o = make_float4(round_bf16(o.x), round_bf16(o.y), round_bf16(o.z), round_bf16(o.w));  // bf16 residual stream
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + nn) = o;
+      epi_store_f4(reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + nn, o);
     }
     return;
   }
@@ -229,7 +252,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[M
     if (m >= a.M || !ncol_ok) continue;
     const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
     if (EPI == SAVIT_EPI_BF16) {
-      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n) = raw;
+      epi_store_u4(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n, raw);
     } else if (EPI == SAVIT_EPI_BIAS_GELU) {
       uint32_t g[4];
 #pragma unroll
@@ -239,7 +262,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[M
       }
       // the pre-activation is only read again in backward: non-temporal, so it does not push the activation out of the cache
       nt_store_u4(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n, raw);
-      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C2) + (size_t)m * a.ldc + n) = make_uint4(g[0], g[1], g[2], g[3]);
+      epi_store_u4(reinterpret_cast<bf16_t*>(a.C2) + (size_t)m * a.ldc + n, make_uint4(g[0], g[1], g[2], g[3]));
     } else if (EPI == SAVIT_EPI_DGELU) {
       const uint4 uraw = uaux[it];
       const uint32_t uw[4] = {uraw.x, uraw.y, uraw.z, uraw.w};
@@ -252,7 +275,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmParams& p, f32x4 (&acc)[M
         cs8[2 * k] += r.x;
         cs8[2 * k + 1] += r.y;
       }
-      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n) = make_uint4(o[0], o[1], o[2], o[3]);
+      epi_store_u4(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n, make_uint4(o[0], o[1], o[2], o[3]));
     }
   }
   if (EPI == SAVIT_EPI_DGELU && a.colsum != nullptr) {
