@@ -826,9 +826,13 @@ def main():
     if world > 1 and not args.no_reserved_cus_sweep:
         del step, eng, sync
         torch.cuda.empty_cache()
-        rows = reserved_cus_sweep(cfg, B, world, rank, dist, args.bucket_mb, args.sweep_steps, 3, opts)
-        if rank == 0:
-            out["reserved_cus_sweep"] = rows
+        try:
+            rows = reserved_cus_sweep(cfg, B, world, rank, dist, args.bucket_mb, args.sweep_steps, 3, opts)
+            if rank == 0:
+                out["reserved_cus_sweep"] = rows
+        except Exception as e:  # (the headline above is already measured: a failure here - the same on every rank - must not lose the line)
+            if rank == 0:
+                out["reserved_cus_sweep_error"] = f"{type(e).__name__}: {e}"
         eng = step = None
 
     # ---- other BASELINE configs on this GPU (rank 0, N=1, headline workload only): short timings, after the headline engine is freed
