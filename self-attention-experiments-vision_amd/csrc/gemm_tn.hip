@@ -2055,6 +2055,10 @@ int launch_pp320(const GemmParams& p0, hipStream_t s, bool pers) {
   if (g < 1) g = 1;
   if (g > 8) g = 8;
   if (p.a.epilogue == SAVIT_EPI_DGELU && g > 4) g = 4;
+  {
+    static const int force_g = SAVIT_EXP_ENV_INT("SAVIT_PP320_ROW_GROUP", 0);  // experiment builds: the tile order's row-panel group
+    if (force_g > 0) g = force_g;
+  }
   if (g > p.tiles_m) g = p.tiles_m;
   p.row_group = g;
   const int tiles = p.tiles_m * p.tiles_n;

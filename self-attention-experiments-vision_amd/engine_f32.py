@@ -391,8 +391,7 @@ class CaiTEngineF32(_F32Base):
             self._gemm(P, f"l{l}.fc2", a, pp(f"l{l}.W2"), xn, M, d, F, F, d, d, bias=pp(f"l{l}.b2"), aux=xm, ldaux=d, colscale=pp(f"l{l}.ls2"),
                        rows_per_sample=N, **rs(l, 1), **extra2)
             x = xn
-        self._x_final = x  # (device address of the SA stage's output: _concat_rows reads the tensor below)
-        self._x_final_t = (sv["xsa"][0] if NL > 0 else sv["x"][0]) if save else self.x
+        x_final_t = (sv["xsa"][0] if NL > 0 else sv["x"][0]) if save else self.x  # the SA stage's output, as a tensor (row copies below)
         # class-attention stage (cait.py:157-173): cls starts as the parameter; x is frozen
         Nk = N + 1
         for c in range(NC):
@@ -406,7 +405,7 @@ class CaiTEngineF32(_F32Base):
                 cls_in = cls_out = ptr(self.cls)
                 extra1 = extra_u = extra2 = {}
             sc = ptr(self.sc)
-            P.add(_concat_rows, (self, c, save), f"c{c}.concat")  # xc = [cls ; x] (cait.py:98): device-side row copies
+            P.add(_concat_rows, (self, c, save, x_final_t), f"c{c}.concat")  # xc = [cls ; x] (cait.py:98): device-side row copies
             P.add(L.savit_layernorm_fwd_f32, (xc, pp(f"c{c}.ln1_g"), pp(f"c{c}.ln1_b"), hc, Mc, d, d, d, 1e-6), f"c{c}.ln1")
             # q from row 0 only (cait.py:13-15), k and v from all N + 1 rows
             self._gemm(P, f"c{c}.q", hc, pp(f"c{c}.Wqkv"), qc, B, d, d, Nk * d, 3 * d, d, alpha=1.0 / math.sqrt(hd), alpha_cols=d)
@@ -769,12 +768,12 @@ class TNTEngineF32(_ForwardOnlyF32):
         return P
 
 
-def _concat_rows(eng: "CaiTEngineF32", c: int, save: bool, stream: int) -> int:
+def _concat_rows(eng: "CaiTEngineF32", c: int, save: bool, x_final: torch.Tensor, stream: int) -> int:
     """xc = concat([cls, x], axis=1) (cait.py:98): two strided device copies on the current stream (memory plumbing, no arithmetic)."""
     B, N, d = eng.B, eng.cfg.n_patches, eng.cfg.embed_dim
     xc = (eng.sv["xc"][c] if save else eng.xc).view(B, N + 1, d)
     xc[:, 0].copy_(eng.sv["clsin"][c] if save else eng.cls)
-    xc[:, 1:].copy_(eng._x_final_t.view(B, N, d))
+    xc[:, 1:].copy_(x_final.view(B, N, d))
     return 0
 
 
