@@ -185,3 +185,31 @@ def test_rccl_backend_single_rank(tmp_path):
     eng.optimizer_step(lr=1e-3, weight_decay=1e-4, max_norm=1.0)
     torch.cuda.synchronize()
     assert float((eng.params.cpu() - got["params"]).abs().max()) < 2.5e-3  # <= 2 lr where a ~0 gradient flips sign
+
+
+def test_bench_two_ranks_gloo_rehearsal_with_reserved_cus_sweep():
+    """Round 6: the complete N > 1 code path of bench.py - the self-launching parent, two rank processes sharing this
+    GPU over gloo (SAVIT_DIST_BACKEND=gloo: RCCL needs a GPU per rank), hooks and bucket all-reduces, the `distributed` block of the JSON
+    line, and the reserved_cus 0 / 8 / 16 / 32 sweep that follows the headline measurement - on a small model so that it takes seconds.
+    What it cannot show is RCCL over xGMI: no multi-GPU node was available in any round."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SAVIT_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "vit_ti_patch16",
+                        "--batch", "16", "--sweep-steps", "2", "--no-cpu-baseline", "--no-other-configs"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 32 and d["value"] > 0
+    dist_info = d["config"]["distributed"]
+    assert dist_info["world_size"] == 2 and dist_info["backend"] == "gloo" and dist_info["buckets"] >= 1 and len(dist_info["ranks"]) == 2
+    assert d["reserved_cus"] == 16 and d["config"]["engine_options"]["reserved_cus_in_effect"] == 16 and d["config"]["engine_options"]["bucket_mb"] == 48.0
+    assert d["rccl_channels"] is None  # the channel pin is opt-in (SAVIT_PIN_RCCL_CHANNELS=1)
+    sweep = d["reserved_cus_sweep"]
+    assert [row["reserved_cus"] for row in sweep] == [0, 8, 16, 32]
+    assert all(row["ms_per_step"] > 0 and row["value"] > 0 and row["allreduce_exposed_ms"] >= 0 for row in sweep)
+    assert "reserved_cus_sweep_error" not in d
