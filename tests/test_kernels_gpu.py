@@ -565,7 +565,8 @@ def _attn_emul(qkv, B, N, H, hd=64, d_o=None, o_saved=None, dq_scale=1.0, chunk=
     return o, g
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (3, 196, 6), (1, 50, 12), (2, 32, 1), (1, 256, 2), (2, 17, 2), (1, 1, 1)])
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (3, 196, 6), (1, 50, 12), (2, 32, 1), (1, 256, 2), (2, 17, 2), (1, 1, 1),
+                                   (37, 197, 12), (90, 100, 3)])  # (the last two: more items than CUs - persistent workgroups with 1 and 2 items)
 def test_attention_fwd(ops, B, N, H):
     rng = np.random.default_rng(B * 100 + N)
     d = H * 64
