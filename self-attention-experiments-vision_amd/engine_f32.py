@@ -55,6 +55,15 @@ class _F32Base:
     def e(self, *shape) -> torch.Tensor:
         return torch.empty(*shape, dtype=f32, device=self.dev)
 
+    def set_images(self, images: torch.Tensor):
+        S = self.cfg.img_size
+        if images.is_cuda and tuple(images.shape) == (S, S, 3, self.B):  # the loader's [H, W, C, N] (train.py:80): a permuted device copy
+            self.images.copy_(images.permute(3, 0, 1, 2).to(f32))
+            return
+        if not images.is_cuda or tuple(images.shape) != (self.B, S, S, 3):
+            raise ValueError(f"images must be a GPU tensor [B={self.B},{S},{S},3] (NHWC) or [{S},{S},3,B={self.B}]")
+        self.images.copy_(images.to(f32))
+
     # ---- parameters (same tree as the bf16 engine)
     def param_tree(self) -> dict:
         return self.layout.flax_tree(self.params)
@@ -251,15 +260,6 @@ class ViTEngineF32(_F32Base):
         P.add(_gather_patch_rows, (self,), "dtok.gather")  # the patch rows of dx0 (token 0 of each image is cls), contiguous
         wgrad("Wpe.wgrad", self.patches.data_ptr(), self.tok.data_ptr(), gp("Wpe"), B * cfg.n_patches, cfg.patch_dim, d, cfg.patch_dim, d)
         return P
-
-    def set_images(self, images: torch.Tensor):
-        S = self.cfg.img_size
-        if images.is_cuda and tuple(images.shape) == (S, S, 3, self.B):  # the loader's [H, W, C, N] (train.py:80): a permuted device copy
-            self.images.copy_(images.permute(3, 0, 1, 2).to(f32))
-            return
-        if not images.is_cuda or tuple(images.shape) != (self.B, S, S, 3):
-            raise ValueError(f"images must be a GPU tensor [B={self.B},{S},{S},3] (NHWC) or [{S},{S},3,B={self.B}]")
-        self.images.copy_(images.to(f32))
 
     def forward(self, images: Optional[torch.Tensor] = None) -> torch.Tensor:
         if images is not None:
@@ -536,15 +536,6 @@ class CaiTEngineF32(_F32Base):
         self._wgrad(P, "Wpe.wgrad", self.patches.data_ptr(), dres, gp("Wpe"), M, cfg.patch_dim, d, cfg.patch_dim, d)
         return P
 
-    def set_images(self, images: torch.Tensor):
-        S = self.cfg.img_size
-        if images.is_cuda and tuple(images.shape) == (S, S, 3, self.B):  # the loader's [H, W, C, N] (train.py:80): a permuted device copy
-            self.images.copy_(images.permute(3, 0, 1, 2).to(f32))
-            return
-        if not images.is_cuda or tuple(images.shape) != (self.B, S, S, 3):
-            raise ValueError(f"images must be a GPU tensor [B={self.B},{S},{S},3] (NHWC) or [{S},{S},3,B={self.B}]")
-        self.images.copy_(images.to(f32))
-
     def forward(self, images: Optional[torch.Tensor] = None, is_training: bool = False, keep_masks: Optional[torch.Tensor] = None,
                 sd_seed: Optional[int] = None) -> torch.Tensor:
         """keep_masks [(L + Lc), 2, B] of 0 / 1 (tests); drawn from the engine's generator in training mode when absent (sd_seed reseeds
@@ -610,34 +601,63 @@ class CaiTEngineF32(_F32Base):
         return self.loss
 
 
-class _ForwardOnlyF32(_F32Base):
-    """Shared by the forward (+ loss) fp32 engines of the families that train on the bf16 MFMA engines."""
+class _SavedPlanF32(_F32Base):
+    """Shared by the MLP-Mixer and TNT fp32 engines.  Inference keeps one set of activation buffers (`_build(False)`); the first
+    `loss_backward` switches the engine to the plan that saves every layer's activations (`_build(True)`) and re-runs that forward
+    once (bit-identical logits: the same products in the same order, only the destinations differ)."""
 
-    def set_images(self, images: torch.Tensor):
-        S = self.cfg.img_size
-        if not images.is_cuda or tuple(images.shape) != (self.B, S, S, 3):
-            raise ValueError(f"images must be a GPU tensor [B={self.B},{S},{S},3] (NHWC)")
-        self.images.copy_(images.to(f32))
+    _plan: Optional[_Plan] = None
+    _plan_save: Optional[_Plan] = None
+    _bwd: Optional[_Plan] = None
+    save_activations = False
+    sv: Optional[Dict[str, List[torch.Tensor]]] = None
+    _saved = False
 
     def forward(self, images: Optional[torch.Tensor] = None, is_training: bool = False) -> torch.Tensor:
         if images is not None:
             self.set_images(images)
-        if self._plan is None:
-            self._plan = self._build()
-        self._plan.run(torch.cuda.current_stream().cuda_stream)
+        self._run_forward()
         return self.logits
 
-    def loss_backward(self, *a, **k):
-        raise NotImplementedError(f"{type(self).__name__}: fp32 arithmetic covers forward + loss; this family trains on the bf16 MFMA engine "
-                                  "(create_model(..., dtype=torch.bfloat16))")
+    def _run_forward(self):
+        save = bool(self.save_activations)
+        if save:
+            if self.sv is None:
+                self._alloc_saved()
+            if self._plan_save is None:
+                self._plan_save = self._build(True)
+            plan = self._plan_save
+        else:
+            if self._plan is None:
+                self._plan = self._build(False)
+            plan = self._plan
+        plan.run(torch.cuda.current_stream().cuda_stream)
+        self._saved = save
 
-    optimizer_step = backward_from_dlogits = loss_backward
+    def loss_backward(self, labels: torch.Tensor, label_smoothing: float = 0.1, zero_grads: bool = True) -> torch.Tensor:
+        """Loss (train.py:83-90) + the full backward pass of the LAST forward into self.grads (fp32)."""
+        if self.grads is None:
+            self.grads = torch.zeros_like(self.params)
+        elif zero_grads:
+            self.grads.zero_()
+        if not self._saved:
+            self.save_activations = True
+            self._run_forward()
+        s = torch.cuda.current_stream().cuda_stream
+        self.loss_fn(labels, label_smoothing)
+        _lib.check(self.L.savit_softmax_xent_grad_f32(self.logits.data_ptr(), self.labels.data_ptr(), float(label_smoothing), 1.0 / self.B,
+                                                      self.dlogits.data_ptr(), self.B, self.cfg.num_classes, s), "savit_softmax_xent_grad_f32")
+        if self._bwd is None:
+            self._bwd = self._build_bwd()
+        self._bwd.run(s)
+        return self.loss
 
 
-class MixerEngineF32(_ForwardOnlyF32):
-    """mlp_mixer.py:44-64 in fp32.  Token mixing (MixerBlock :17-24: FFBlock on the transposed activation) reads the [n, d]
-    activation of an image as its transposed operand in place and produces the second product already transposed back
-    (x[b] += tW2^T a[b]^T, the Dense bias then runs along the rows) - no transposed copy exists."""
+class MixerEngineF32(_SavedPlanF32):
+    """mlp_mixer.py:44-64 in fp32: forward, loss and (round 6) the backward + AdamW step.  Token mixing (MixerBlock :17-24: FFBlock on the
+    transposed activation) reads the [n, d] activation of an image as its transposed operand in place and produces the second product
+    already transposed back (x[b] += tW2^T a[b]^T, the Dense bias then runs along the rows) - no transposed copy exists, in either
+    direction."""
 
     def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda"):
         from .mixer_engine import MixerLayout
@@ -651,83 +671,185 @@ class MixerEngineF32(_ForwardOnlyF32):
         self.patches = e(self.M, cfg.patch_dim)
         self.x, self.h, self.a = e(self.M, d), e(self.M, d), e(self.M, F)
         self.at = e(B, d, self.layout.Fp)  # token-mixing hidden activation, [image, channel, Ft]
-        self.ones = torch.ones(n, dtype=f32, device=self.dev)
+        self.ones = torch.ones(max(n, d), dtype=f32, device=self.dev)
         self.zmean = e(B, d)
-        self._plan: Optional[_Plan] = None
 
     def init_params(self, seed: int = 0):
         from .mixer_engine import MixerEngine
 
         MixerEngine.init_params(self, seed)
 
-    def _build(self) -> _Plan:
+    def _alloc_saved(self):
+        cfg, B, e, lay = self.cfg, self.B, self.e, self.layout
+        d, F, n, NL, M = cfg.embed_dim, cfg.hidden, cfg.n_patches, cfg.num_layers, self.M
+        Lp, Fp = lay.Lp, lay.Fp
+        z = lambda *s_: torch.zeros(*s_, dtype=f32, device=self.dev)  # noqa: E731
+        self.sv = {"x": [e(M, d) for _ in range(NL + 1)], "h1": [e(M, d) for _ in range(NL)], "ut": [z(B, d, Fp) for _ in range(NL)],
+                   "at": [z(B, d, Fp) for _ in range(NL)], "xmid": [e(M, d) for _ in range(NL)], "h2": [e(M, d) for _ in range(NL)],
+                   "u": [e(M, F) for _ in range(NL)], "a": [e(M, F) for _ in range(NL)], "hf": [e(M, d)]}
+        # backward scratch; the per-image partials of the token-kernel gradients carry the parameter's padded storage shape (pads stay zero)
+        self.bw = {"dres": e(M, d), "d_a": e(M, F), "d_h": e(M, d), "d_ut": z(B, d, Fp), "d_z": e(B, d), "part1": z(B, Lp * Fp), "part2": z(B, Fp * Lp),
+                   "rows": z(n * d)}
+
+    def _build(self, save: bool = False) -> _Plan:
         P, L, cfg, lay = _Plan(), self.L, self.cfg, self.layout
         d, F, C, n, NL, B, M = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.n_patches, cfg.num_layers, self.B, self.M
         Ft, Lp, Fp = cfg.tokens_hidden, lay.Lp, lay.Fp
         pp = self._off
-        x, h, a, at = (t.data_ptr() for t in (self.x, self.h, self.a, self.at))
+        ptr = lambda t: t.data_ptr()  # noqa: E731
+        sv = self.sv if save else None
+        x = ptr(sv["x"][0]) if save else ptr(self.x)
         P.add(L.savit_patchify_f32, (self.images.data_ptr(), self.patches.data_ptr(), B, cfg.img_size, cfg.patch), "patchify")
         self._gemm(P, "patch_embed", self.patches.data_ptr(), pp("Wpe"), x, M, d, cfg.patch_dim, cfg.patch_dim, d, d, bias=pp("bpe"))
         for l in range(NL):
-            P.add(L.savit_layernorm_fwd_f32, (x, pp(f"l{l}.ln1_g"), pp(f"l{l}.ln1_b"), h, M, d, d, d, 1e-6), f"l{l}.ln1")
+            if save:
+                h1, h2, at, a, xm = (ptr(sv[k][l]) for k in ("h1", "h2", "at", "a", "xmid"))
+                xn = ptr(sv["x"][l + 1])
+                s_ut, s_u = dict(C2=ptr(sv["ut"][l])), dict(C2=ptr(sv["u"][l]))
+                r1, r2 = dict(aux=x, ldaux=d), dict(aux=xm, ldaux=d)          # x_mid = x + ..., x_next = x_mid + ... into fresh buffers
+            else:
+                h1 = h2 = ptr(self.h)
+                at, a, xm, xn = ptr(self.at), ptr(self.a), x, x
+                s_ut = s_u = {}
+                r1 = r2 = dict(accumulate=1)                                   # in place
+            P.add(L.savit_layernorm_fwd_f32, (x, pp(f"l{l}.ln1_g"), pp(f"l{l}.ln1_b"), h1, M, d, d, d, 1e-6), f"l{l}.ln1")
             # a[b] [d, Ft] = gelu(h[b]^T tW1 + tb1)
-            self._gemm(P, f"l{l}.tok.fc1", h, pp(f"l{l}.tW1"), at, d, Ft, n, d, Fp, Fp, transA=1, bias=pp(f"l{l}.tb1"), act=1, batch=B,
-                       sA=(n * d, 0), sC=(d * Fp, 0))
+            self._gemm(P, f"l{l}.tok.fc1", h1, pp(f"l{l}.tW1"), at, d, Ft, n, d, Fp, Fp, transA=1, bias=pp(f"l{l}.tb1"), act=1, batch=B,
+                       sA=(n * d, 0), sC=(d * Fp, 0), **s_ut)
             # x[b] [n, d] += tW2^T a[b]^T + tb2 along the rows
-            self._gemm(P, f"l{l}.tok.fc2", pp(f"l{l}.tW2"), at, x, n, d, Ft, Lp, Fp, d, transA=1, transW=1, rowbias=pp(f"l{l}.tb2"), accumulate=1,
-                       batch=B, sW=(d * Fp, 0), sC=(n * d, 0))
-            P.add(L.savit_layernorm_fwd_f32, (x, pp(f"l{l}.ln2_g"), pp(f"l{l}.ln2_b"), h, M, d, d, d, 1e-6), f"l{l}.ln2")
-            self._gemm(P, f"l{l}.fc1", h, pp(f"l{l}.W1"), a, M, F, d, d, F, F, bias=pp(f"l{l}.b1"), act=1)
-            self._gemm(P, f"l{l}.fc2", a, pp(f"l{l}.W2"), x, M, d, F, F, d, d, bias=pp(f"l{l}.b2"), accumulate=1)
-        P.add(L.savit_layernorm_fwd_f32, (x, pp("lnf_g"), pp("lnf_b"), h, M, d, d, d, 1e-6), "lnf")
+            self._gemm(P, f"l{l}.tok.fc2", pp(f"l{l}.tW2"), at, xm, n, d, Ft, Lp, Fp, d, transA=1, transW=1, rowbias=pp(f"l{l}.tb2"),
+                       batch=B, sW=(d * Fp, 0), sC=(n * d, 0), **r1)
+            P.add(L.savit_layernorm_fwd_f32, (xm, pp(f"l{l}.ln2_g"), pp(f"l{l}.ln2_b"), h2, M, d, d, d, 1e-6), f"l{l}.ln2")
+            self._gemm(P, f"l{l}.fc1", h2, pp(f"l{l}.W1"), a, M, F, d, d, F, F, bias=pp(f"l{l}.b1"), act=1, **s_u)
+            self._gemm(P, f"l{l}.fc2", a, pp(f"l{l}.W2"), xn, M, d, F, F, d, d, bias=pp(f"l{l}.b2"), **r2)
+            x = xn
+        hf = ptr(sv["hf"][0]) if save else ptr(self.h)
+        P.add(L.savit_layernorm_fwd_f32, (x, pp("lnf_g"), pp("lnf_b"), hf, M, d, d, d, 1e-6), "lnf")
         # mean over the tokens (mlp_mixer.py:61-62) as (1 / n) 1^T z[b]
-        self._gemm(P, "token_mean", self.ones.data_ptr(), h, self.zmean.data_ptr(), 1, d, n, n, d, d, batch=B, sW=(n * d, 0), sC=(d, 0), alpha=1.0 / n,
+        self._gemm(P, "token_mean", self.ones.data_ptr(), hf, self.zmean.data_ptr(), 1, d, n, n, d, d, batch=B, sW=(n * d, 0), sC=(d, 0), alpha=1.0 / n,
                    alpha_cols=d)
         self._gemm(P, "head", self.zmean.data_ptr(), pp("Wh"), self.logits.data_ptr(), B, C, d, d, C, C, bias=pp("bh"))
         return P
 
+    def _build_bwd(self) -> _Plan:
+        """Reverse-mode gradient of `_build(save=True)`: every product is the transposed form of its forward GEMM; the token-kernel
+        gradients, which sum over the images, go through per-image partials (padded like the parameters) and a column sum - two
+        images must not add into one output tile at the same time."""
+        P, L, cfg, lay, sv, bw = _Plan(), self.L, self.cfg, self.layout, self.sv, self.bw
+        d, F, C, n, NL, B, M = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.n_patches, cfg.num_layers, self.B, self.M
+        Ft, Lp, Fp = cfg.tokens_hidden, lay.Lp, lay.Fp
+        pp = self._off
+        gp = lambda nm: self._off(nm, self.grads)  # noqa: E731
+        ptr = lambda t: t.data_ptr()  # noqa: E731
+        dres, d_a, d_h, d_ut, d_z, part1, part2, rows = (ptr(bw[k]) for k in ("dres", "d_a", "d_h", "d_ut", "d_z", "part1", "part2", "rows"))
+        dl, ones = self.dlogits.data_ptr(), self.ones.data_ptr()
+        ln_bwd, colsum = L.savit_layernorm_bwd_f32, L.savit_colsum_f32
+        # head (mlp_mixer.py:63-64) and the token mean (:61-62): d hf[b, t, :] = d zmean[b] / n for every token
+        self._wgrad(P, "head.wgrad", self.zmean.data_ptr(), dl, gp("Wh"), B, d, C, d, C)
+        P.add(colsum, (dl, gp("bh"), B, C, C), "head.bgrad")
+        self._dgrad(P, "head.dgrad", dl, pp("Wh"), d_z, B, d, C, C, C, d)
+        self._gemm(P, "token_mean.bwd", ones, d_z, d_h, n, d, 1, 1, d, d, batch=B, sW=(d, 0), sC=(n * d, 0), alpha=1.0 / n, alpha_cols=d)
+        P.add(ln_bwd, (d_h, ptr(sv["x"][NL]), pp("lnf_g"), None, dres, gp("lnf_g"), gp("lnf_b"), M, d, d, d, 1e-6), "lnf.bwd")
+        for l in range(NL - 1, -1, -1):
+            p = f"l{l}."
+            x, h1, ut, at, xm, h2, u, a = (ptr(sv[k][l]) for k in ("x", "h1", "ut", "at", "xmid", "h2", "u", "a"))
+            # channel mixing: x_next = x_mid + gelu(h2 W1 + b1) W2 + b2   (mlp_mixer.py:26-30, ff.py:26-33)
+            self._wgrad(P, p + "W2.wgrad", a, dres, gp(p + "W2"), M, F, d, F, d)
+            P.add(colsum, (dres, gp(p + "b2"), M, d, d), p + "b2.grad")
+            self._dgrad(P, p + "fc2.dgrad", dres, pp(p + "W2"), d_a, M, F, d, d, d, F, act=2, U=u)
+            self._wgrad(P, p + "W1.wgrad", h2, d_a, gp(p + "W1"), M, d, F, d, F)
+            P.add(colsum, (d_a, gp(p + "b1"), M, F, F), p + "b1.grad")
+            self._dgrad(P, p + "fc1.dgrad", d_a, pp(p + "W1"), d_h, M, d, F, F, F, d)
+            P.add(ln_bwd, (d_h, xm, pp(p + "ln2_g"), dres, dres, gp(p + "ln2_g"), gp(p + "ln2_b"), M, d, d, d, 1e-6), p + "ln2.bwd")
+            # token mixing: x_mid[b][t, c] = x[b][t, c] + sum_f tW2[f, t] at[b][c, f] + tb2[t];  at = gelu(ut), ut[b][c, f] = sum_t h1[b][t, c] tW1[t, f] + tb1[f]
+            # d tb2[t] = sum over images and channels: first over the images (column sum of [B, n d]), then over the channels of a row
+            P.add(L.savit_zero_bytes, (rows, n * d * 4), p + "zero.rows")
+            P.add(colsum, (dres, rows, B, n * d, n * d), p + "tb2.part")
+            self._gemm(P, p + "tb2.grad", rows, ones, gp(p + "tb2"), n, 1, d, d, 1, 1, accumulate=1)
+            # d tW2[f, t] = sum_b sum_c at[b][c, f] dres[b][t, c]: per image into part2 [Fp, Lp], then summed over the images
+            self._gemm(P, p + "tW2.part", at, dres, part2, Ft, n, d, Fp, d, Lp, transA=1, transW=1, batch=B, sA=(d * Fp, 0), sW=(n * d, 0), sC=(Fp * Lp, 0))
+            P.add(colsum, (part2, gp(p + "tW2"), B, Fp * Lp, Fp * Lp), p + "tW2.grad")
+            # d ut[b][c, f] = (sum_t dres[b][t, c] tW2[f, t]) gelu'(ut)
+            self._gemm(P, p + "tok.fc2.dgrad", dres, pp(p + "tW2"), d_ut, d, Ft, n, d, Lp, Fp, transA=1, transW=1, act=2, U=ut, batch=B,
+                       sA=(n * d, 0), sC=(d * Fp, 0))
+            P.add(colsum, (d_ut, gp(p + "tb1"), B * d, Ft, Fp), p + "tb1.grad")
+            # d tW1[t, f] = sum_b sum_c h1[b][t, c] d ut[b][c, f]
+            self._gemm(P, p + "tW1.part", h1, d_ut, part1, n, Ft, d, d, Fp, Fp, batch=B, sA=(n * d, 0), sW=(d * Fp, 0), sC=(Lp * Fp, 0))
+            P.add(colsum, (part1, gp(p + "tW1"), B, Lp * Fp, Lp * Fp), p + "tW1.grad")
+            # d h1[b][t, c] = sum_f tW1[t, f] d ut[b][c, f]
+            self._gemm(P, p + "tok.fc1.dgrad", pp(p + "tW1"), d_ut, d_h, n, d, Ft, Fp, Fp, d, transW=1, batch=B, sW=(d * Fp, 0), sC=(n * d, 0))
+            P.add(ln_bwd, (d_h, x, pp(p + "ln1_g"), dres, dres, gp(p + "ln1_g"), gp(p + "ln1_b"), M, d, d, d, 1e-6), p + "ln1.bwd")
+        # patch embedding with bias (mlp_mixer.py:53-55, patch_embed.py:23-25)
+        self._wgrad(P, "Wpe.wgrad", self.patches.data_ptr(), dres, gp("Wpe"), M, cfg.patch_dim, d, cfg.patch_dim, d)
+        P.add(colsum, (dres, gp("bpe"), M, d, d), "bpe.grad")
+        return P
 
-class TNTEngineF32(_ForwardOnlyF32):
-    """tnt.py:150-193 in fp32: the pixel stream [B n npx, di] and the patch stream [B (n + 1), do] (EncoderBlock :66-93).  The inner
-    attention kernels are stored head-padded to 16 columns (tnt_engine.TNTLayout); the pad columns are zero, so the products over
-    the padded head width are exact."""
+
+class TNTEngineF32(_SavedPlanF32):
+    """tnt.py:150-193 in fp32: the pixel stream [B n npx, di] and the patch stream [B (n + 1), do] (EncoderBlock :66-93): forward, loss
+    and (round 6) the backward + AdamW step.  The inner attention kernels are stored head-padded to 16 columns
+    (tnt_engine.TNTLayout); the pad columns are zero, so the products over the padded head width are exact - and so are their
+    gradients (every cotangent that reaches a pad column is a product with a zero pad)."""
+
+    INNER = ("hi1", "qkvi", "pi", "oi", "ximid", "hi2", "ui", "ai")
+    OUTER = ("outer", "ho1", "qkvo", "po", "oo", "xmid", "ho2", "uo", "ao")
 
     def __init__(self, cfg: ModelConfig, batch: int, device: str = "cuda"):
         from .tnt_engine import HDP, TNTLayout
 
         self.layout = lay = TNTLayout(cfg)
         self._init_common(cfg, batch, device)
-        do, Fo, N, n, npx, di, Hi, Ho = cfg.embed_dim, cfg.hidden, cfg.seq_len, cfg.n_patches, cfg.n_pixels, cfg.inner_embed_dim, cfg.inner_num_heads, cfg.num_heads
+        do, n, npx = cfg.embed_dim, cfg.n_patches, cfg.n_pixels
         B = self.B
         self.HDP = HDP
-        self.Mi, self.Ms, self.Mo = B * n * npx, B * n, B * N
+        self.Mi, self.Ms, self.Mo = B * n * npx, B * n, B * cfg.seq_len
         e = self.e
         self.images = e(B, cfg.img_size, cfg.img_size, 3)
         self.pix = e(self.Mi, lay.pix_in)
         self.patches = e(self.Ms, cfg.patch_dim)
         self.tok = e(self.Ms, do)
-        self.xi, self.hi, self.qkvi, self.oi, self.ai = e(self.Mi, di), e(self.Mi, di), e(self.Mi, 3 * lay.dap), e(self.Mi, lay.dap), e(self.Mi, lay.Fi)
-        self.si = e(self.Ms * Hi, npx, npx)
-        self.xo, self.outer, self.ho, self.xmid = e(self.Mo, do), e(self.Mo, do), e(self.Mo, do), e(self.Mo, do)
-        self.qkvo, self.oo, self.ao = e(self.Mo, 3 * do), e(self.Mo, do), e(self.Mo, Fo)
-        self.so = e(B * Ho, N, N)
-        self._plan: Optional[_Plan] = None
+        self.act = self._alloc_layer()                               # one set of activations: inference
+        self.xi0, self.xo0 = e(self.Mi, cfg.inner_embed_dim), e(self.Mo, do)
+        self.si, self.so = e(self.Ms * cfg.inner_num_heads, npx, npx), e(B * cfg.num_heads, cfg.seq_len, cfg.seq_len)  # scores / dP / dS scratch
+
+    def _alloc_layer(self) -> Dict[str, torch.Tensor]:
+        cfg, lay, e, B = self.cfg, self.layout, self.e, self.B
+        do, Fo, N, npx, di, Hi, Ho = cfg.embed_dim, cfg.hidden, cfg.seq_len, cfg.n_pixels, cfg.inner_embed_dim, cfg.inner_num_heads, cfg.num_heads
+        Mi, Ms, Mo, dap, Fi = self.Mi, self.Ms, self.Mo, lay.dap, lay.Fi
+        return {"hi1": e(Mi, di), "qkvi": e(Mi, 3 * dap), "pi": e(Ms * Hi, npx, npx), "oi": e(Mi, dap), "ximid": e(Mi, di), "hi2": e(Mi, di),
+                "ui": e(Mi, Fi), "ai": e(Mi, Fi), "outer": e(Mo, do), "ho1": e(Mo, do), "qkvo": e(Mo, 3 * do), "po": e(B * Ho, N, N), "oo": e(Mo, do),
+                "xmid": e(Mo, do), "ho2": e(Mo, do), "uo": e(Mo, Fo), "ao": e(Mo, Fo)}
 
     def init_params(self, seed: int = 0):
         from .tnt_engine import TNTEngine
 
         TNTEngine.init_params(self, seed)
 
-    def _build(self) -> _Plan:
+    def _alloc_saved(self):
+        cfg, lay, e = self.cfg, self.layout, self.e
+        do, Fo, di, NL = cfg.embed_dim, cfg.hidden, cfg.inner_embed_dim, cfg.num_layers
+        Mi, Ms, Mo = self.Mi, self.Ms, self.Mo
+        layers = [self._alloc_layer() for _ in range(NL)]
+        self.sv = {k: [layers[l][k] for l in range(NL)] for k in self.INNER + self.OUTER}
+        self.sv["xi"] = [e(Mi, di) for _ in range(NL + 1)]
+        self.sv["xo"] = [e(Mo, do) for _ in range(NL + 1)]
+        self.bw = {"dxo": e(Mo, do), "d_outer": e(Mo, do), "d_ao": e(Mo, Fo), "d_ho": e(Mo, do), "d_oo": e(Mo, do), "dqkvo": e(Mo, 3 * do),
+                   "d_tok": e(Ms, do), "rows": e(cfg.seq_len * do), "dxi": e(Mi, di), "d_ai": e(Mi, lay.Fi), "d_hi": e(Mi, di), "d_oi": e(Mi, lay.dap),
+                   "dqkvi": e(Mi, 3 * lay.dap)}
+
+    def _build(self, save: bool = False) -> _Plan:
         P, L, cfg, lay = _Plan(), self.L, self.cfg, self.layout
         do, Fo, C, N, NL, n, npx = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers, cfg.n_patches, cfg.n_pixels
         di, Hi, Ho, Fi, dap, HDP, B = cfg.inner_embed_dim, cfg.inner_num_heads, cfg.num_heads, lay.Fi, lay.dap, self.HDP, self.B
         hdi, hdo = di // Hi, do // Ho
         Mi, Ms, Mo = self.Mi, self.Ms, self.Mo
         pp = self._off
-        xi, hi, qkvi, oi, ai, si = (t.data_ptr() for t in (self.xi, self.hi, self.qkvi, self.oi, self.ai, self.si))
-        xo, outer, ho, xmid, qkvo, oo, ao, so = (t.data_ptr() for t in (self.xo, self.outer, self.ho, self.xmid, self.qkvo, self.oo, self.ao, self.so))
+        ptr = lambda t: t.data_ptr()  # noqa: E731
+        si, so = ptr(self.si), ptr(self.so)
         ln = L.savit_layernorm_fwd_f32
+        xi = ptr(self.sv["xi"][0]) if save else ptr(self.xi0)
+        xo_t = self.sv["xo"][0] if save else self.xo0
+        xo = ptr(xo_t)
         # embeddings: pixel tokens (tnt.py:17-33,155-158) and patch tokens + cls + position (tnt.py:160-167)
         P.add(_gather_pixels, (self,), "pixel_gather")
         self._gemm(P, "pixel_embed", self.pix.data_ptr(), pp("Wpx"), xi, Mi, di, lay.pix_in, lay.pix_in, di, di, bias=pp("bpx"), aux=pp("ppos"), ldaux=di,
@@ -737,34 +859,126 @@ class TNTEngineF32(_ForwardOnlyF32):
         P.add(L.savit_assemble_tokens_f32, (self.tok.data_ptr(), pp("cls"), pp("pos"), xo, B, N, do), "tokens")
         for l in range(NL):
             p = f"l{l}."
+            a = {k: ptr((self.sv[k][l] if save else self.act[k])) for k in self.INNER + self.OUTER}
+            # in place without saving; into the next saved buffers with (x_mid = x + ..., x_next = x_mid + ... : the same sums)
+            xi_mid, xi_next, xo_next = (a["ximid"], ptr(self.sv["xi"][l + 1]), ptr(self.sv["xo"][l + 1])) if save else (xi, xi, xo)
+            res = (lambda src: dict(aux=src, ldaux=di)) if save else (lambda src: dict(accumulate=1))
             # inner block on the pixel stream (tnt.py:68-80): sequences of npx pixel tokens, Hi heads padded to HDP columns
-            P.add(ln, (xi, pp(p + "iln1_g"), pp(p + "iln1_b"), hi, Mi, di, di, di, 1e-6), p + "iln1")
-            self._gemm(P, p + "iqkv", hi, pp(p + "iWqkv"), qkvi, Mi, 3 * dap, di, di, 3 * dap, 3 * dap, alpha=1.0 / math.sqrt(hdi), alpha_cols=dap)
-            self._gemm(P, p + "iscores", qkvi, qkvi + 4 * dap, si, npx, npx, HDP, 3 * dap, 3 * dap, npx, transW=1, batch=Ms * Hi, inner=Hi,
+            P.add(ln, (xi, pp(p + "iln1_g"), pp(p + "iln1_b"), a["hi1"], Mi, di, di, di, 1e-6), p + "iln1")
+            self._gemm(P, p + "iqkv", a["hi1"], pp(p + "iWqkv"), a["qkvi"], Mi, 3 * dap, di, di, 3 * dap, 3 * dap, alpha=1.0 / math.sqrt(hdi), alpha_cols=dap)
+            self._gemm(P, p + "iscores", a["qkvi"], a["qkvi"] + 4 * dap, si, npx, npx, HDP, 3 * dap, 3 * dap, npx, transW=1, batch=Ms * Hi, inner=Hi,
                        sA=(npx * 3 * dap, HDP), sW=(npx * 3 * dap, HDP), sC=(Hi * npx * npx, npx * npx))
-            P.add(L.savit_softmax_rows_f32, (si, si, Ms * Hi * npx, npx, npx), p + "isoftmax")
-            self._gemm(P, p + "ipv", si, qkvi + 8 * dap, oi, npx, HDP, npx, npx, 3 * dap, dap, batch=Ms * Hi, inner=Hi, sA=(Hi * npx * npx, npx * npx),
-                       sW=(npx * 3 * dap, HDP), sC=(npx * dap, HDP))
-            self._gemm(P, p + "iproj", oi, pp(p + "iWo"), xi, Mi, di, dap, dap, di, di, accumulate=1)
-            P.add(ln, (xi, pp(p + "iln2_g"), pp(p + "iln2_b"), hi, Mi, di, di, di, 1e-6), p + "iln2")
-            self._gemm(P, p + "ifc1", hi, pp(p + "iW1"), ai, Mi, Fi, di, di, Fi, Fi, bias=pp(p + "ib1"), act=1)
-            self._gemm(P, p + "ifc2", ai, pp(p + "iW2"), xi, Mi, di, Fi, Fi, di, di, bias=pp(p + "ib2"), accumulate=1)
+            P.add(L.savit_softmax_rows_f32, (si, a["pi"], Ms * Hi * npx, npx, npx), p + "isoftmax")
+            self._gemm(P, p + "ipv", a["pi"], a["qkvi"] + 8 * dap, a["oi"], npx, HDP, npx, npx, 3 * dap, dap, batch=Ms * Hi, inner=Hi,
+                       sA=(Hi * npx * npx, npx * npx), sW=(npx * 3 * dap, HDP), sC=(npx * dap, HDP))
+            self._gemm(P, p + "iproj", a["oi"], pp(p + "iWo"), xi_mid, Mi, di, dap, dap, di, di, **res(xi))
+            P.add(ln, (xi_mid, pp(p + "iln2_g"), pp(p + "iln2_b"), a["hi2"], Mi, di, di, di, 1e-6), p + "iln2")
+            self._gemm(P, p + "ifc1", a["hi2"], pp(p + "iW1"), a["ai"], Mi, Fi, di, di, Fi, Fi, bias=pp(p + "ib1"), act=1, C2=a["ui"])
+            self._gemm(P, p + "ifc2", a["ai"], pp(p + "iW2"), xi_next, Mi, di, Fi, Fi, di, di, bias=pp(p + "ib2"), **res(xi_mid))
+            xi = xi_next
             # Inner2Outer (tnt.py:40-51,82-84): outer[b, 1 + j] = pixels[b, j].flatten() Wio + bio + patches[b, 1 + j]; outer[b, 0] = patches[b, 0]
-            P.add(_copy_cls_rows, (self,), p + "i2o.cls")
-            self._gemm(P, p + "i2o", xi, pp(p + "Wio"), outer + 4 * do, n, do, npx * di, npx * di, do, do, bias=pp(p + "bio"), aux=xo + 4 * do, ldaux=do,
+            P.add(_copy_cls_rows, (self, self.sv["outer"][l] if save else self.act["outer"], xo_t), p + "i2o.cls")
+            self._gemm(P, p + "i2o", xi, pp(p + "Wio"), a["outer"] + 4 * do, n, do, npx * di, npx * di, do, do, bias=pp(p + "bio"), aux=xo + 4 * do, ldaux=do,
                        batch=B, sA=(n * npx * di, 0), sC=(N * do, 0))
             # outer block (tnt.py:85-92): attention reads the Inner2Outer sum, its residual adds the patch stream (tnt.py:86)
-            P.add(ln, (outer, pp(p + "ln1_g"), pp(p + "ln1_b"), ho, Mo, do, do, do, 1e-6), p + "ln1")
-            self._gemm(P, p + "qkv", ho, pp(p + "Wqkv"), qkvo, Mo, 3 * do, do, do, 3 * do, 3 * do, alpha=1.0 / math.sqrt(hdo), alpha_cols=do)
-            self._scores(P, p + "scores", qkvo, qkvo + 4 * do, self.so, N, N, Ho, hdo, 3 * do, 3 * do, N * 3 * do, N * 3 * do)
-            P.add(L.savit_softmax_rows_f32, (so, so, B * Ho * N, N, N), p + "softmax")
-            self._gemm(P, p + "pv", so, qkvo + 8 * do, oo, N, hdo, N, N, 3 * do, do, batch=B * Ho, inner=Ho, sA=(Ho * N * N, N * N), sW=(N * 3 * do, hdo),
-                       sC=(N * do, hdo))
-            self._gemm(P, p + "proj", oo, pp(p + "Wo"), xmid, Mo, do, do, do, do, do, aux=xo, ldaux=do)
-            P.add(ln, (xmid, pp(p + "ln2_g"), pp(p + "ln2_b"), ho, Mo, do, do, do, 1e-6), p + "ln2")
-            self._gemm(P, p + "fc1", ho, pp(p + "W1"), ao, Mo, Fo, do, do, Fo, Fo, bias=pp(p + "b1"), act=1)
-            self._gemm(P, p + "fc2", ao, pp(p + "W2"), xo, Mo, do, Fo, Fo, do, do, bias=pp(p + "b2"), aux=xmid, ldaux=do)
+            P.add(ln, (a["outer"], pp(p + "ln1_g"), pp(p + "ln1_b"), a["ho1"], Mo, do, do, do, 1e-6), p + "ln1")
+            self._gemm(P, p + "qkv", a["ho1"], pp(p + "Wqkv"), a["qkvo"], Mo, 3 * do, do, do, 3 * do, 3 * do, alpha=1.0 / math.sqrt(hdo), alpha_cols=do)
+            self._scores(P, p + "scores", a["qkvo"], a["qkvo"] + 4 * do, self.so, N, N, Ho, hdo, 3 * do, 3 * do, N * 3 * do, N * 3 * do)
+            P.add(L.savit_softmax_rows_f32, (so, a["po"], B * Ho * N, N, N), p + "softmax")
+            self._gemm(P, p + "pv", a["po"], a["qkvo"] + 8 * do, a["oo"], N, hdo, N, N, 3 * do, do, batch=B * Ho, inner=Ho, sA=(Ho * N * N, N * N),
+                       sW=(N * 3 * do, hdo), sC=(N * do, hdo))
+            self._gemm(P, p + "proj", a["oo"], pp(p + "Wo"), a["xmid"], Mo, do, do, do, do, do, aux=xo, ldaux=do)
+            P.add(ln, (a["xmid"], pp(p + "ln2_g"), pp(p + "ln2_b"), a["ho2"], Mo, do, do, do, 1e-6), p + "ln2")
+            self._gemm(P, p + "fc1", a["ho2"], pp(p + "W1"), a["ao"], Mo, Fo, do, do, Fo, Fo, bias=pp(p + "b1"), act=1, C2=a["uo"])
+            self._gemm(P, p + "fc2", a["ao"], pp(p + "W2"), xo_next, Mo, do, Fo, Fo, do, do, bias=pp(p + "b2"), aux=a["xmid"], ldaux=do)
+            xo = xo_next
+            xo_t = self.sv["xo"][l + 1] if save else self.xo0
         self._gemm(P, "head", xo, pp("Wh"), self.logits.data_ptr(), B, C, do, N * do, C, C, bias=pp("bh"))  # cls rows, no final LayerNorm (tnt.py:188-192)
+        return P
+
+    def _attention_bwd(self, P: _Plan, label: str, qkv: int, pr: int, d_o: int, dqkv: int, s: int, seqs: int, T: int, H: int, hd: int, width: int,
+                       scale: float):
+        """dqkv of softmax(q k^T) v for `seqs` sequences of T tokens, H heads of (stored) width hd in rows of 3 * width columns (q already
+        carries 1 / sqrt(head_dim): attention.py:41-48): dP = dO V^T ; dV = P^T dO ; dS = P (dP - sum dP P) ; dQ = scale dS K ; dK = dS^T Q."""
+        bh = dict(batch=seqs * H, inner=H)
+        sS, sQ, sO = (H * T * T, T * T), (T * 3 * width, hd), (T * width, hd)
+        self._gemm(P, label + "dP", d_o, qkv + 8 * width, s, T, T, hd, width, 3 * width, T, transW=1, sA=sO, sW=sQ, sC=sS, **bh)
+        self._gemm(P, label + "dV", pr, d_o, dqkv + 8 * width, T, hd, T, T, width, 3 * width, transA=1, sA=sS, sW=sO, sC=sQ, **bh)
+        P.add(self.L.savit_softmax_rows_bwd_f32, (pr, s, s, seqs * H * T, T, T), label + "softmax.bwd")
+        self._gemm(P, label + "dQ", s, qkv + 4 * width, dqkv, T, hd, T, T, 3 * width, 3 * width, sA=sS, sW=sQ, sC=sQ, alpha=scale, alpha_cols=hd, **bh)
+        self._gemm(P, label + "dK", s, qkv, dqkv + 4 * width, T, hd, T, T, 3 * width, 3 * width, transA=1, sA=sS, sW=sQ, sC=sQ, **bh)
+
+    def _build_bwd(self) -> _Plan:
+        """Reverse-mode gradient of `_build(save=True)` (jax.value_and_grad at train.py:94-95 through tnt.py:150-193): two cotangent
+        streams - dxo for the patch stream, dxi for the pixel stream - meet in every layer's Inner2Outer."""
+        P, L, cfg, lay, sv, bw = _Plan(), self.L, self.cfg, self.layout, self.sv, self.bw
+        do, Fo, C, N, NL, n, npx = cfg.embed_dim, cfg.hidden, cfg.num_classes, cfg.seq_len, cfg.num_layers, cfg.n_patches, cfg.n_pixels
+        di, Hi, Ho, Fi, dap, HDP, B = cfg.inner_embed_dim, cfg.inner_num_heads, cfg.num_heads, lay.Fi, lay.dap, self.HDP, self.B
+        hdi, hdo = di // Hi, do // Ho
+        Mi, Ms, Mo = self.Mi, self.Ms, self.Mo
+        pp = self._off
+        gp = lambda nm: self._off(nm, self.grads)  # noqa: E731
+        ptr = lambda t: t.data_ptr()  # noqa: E731
+        dxo, d_outer, d_ao, d_ho, d_oo, dqkvo, d_tok, rows, dxi, d_ai, d_hi, d_oi, dqkvi = (ptr(bw[k]) for k in (
+            "dxo", "d_outer", "d_ao", "d_ho", "d_oo", "dqkvo", "d_tok", "rows", "dxi", "d_ai", "d_hi", "d_oi", "dqkvi"))
+        si, so, dl = ptr(self.si), ptr(self.so), self.dlogits.data_ptr()
+        ln_bwd, colsum = L.savit_layernorm_bwd_f32, L.savit_colsum_f32
+        # head on the cls rows, no final LayerNorm (tnt.py:188-192); the last layer's pixel stream has no reader but its Inner2Outer
+        self._wgrad(P, "head.wgrad", ptr(sv["xo"][NL]), dl, gp("Wh"), B, do, C, N * do, C)
+        P.add(colsum, (dl, gp("bh"), B, C, C), "head.bgrad")
+        P.add(L.savit_zero_bytes, (dxo, Mo * do * 4), "zero.dxo")
+        P.add(L.savit_zero_bytes, (dxi, Mi * di * 4), "zero.dxi")
+        self._dgrad(P, "head.dgrad", dl, pp("Wh"), dxo, B, do, C, C, C, N * do)
+        for l in range(NL - 1, -1, -1):
+            p = f"l{l}."
+            a = {k: ptr(sv[k][l]) for k in self.INNER + self.OUTER}
+            xi_in, xi_out, xo_in = ptr(sv["xi"][l]), ptr(sv["xi"][l + 1]), ptr(sv["xo"][l])
+            # outer FFBlock: xo_next = xmid + gelu(ho2 W1 + b1) W2 + b2   (tnt.py:89-92, ff.py:26-33)
+            self._wgrad(P, p + "W2.wgrad", a["ao"], dxo, gp(p + "W2"), Mo, Fo, do, Fo, do)
+            P.add(colsum, (dxo, gp(p + "b2"), Mo, do, do), p + "b2.grad")
+            self._dgrad(P, p + "fc2.dgrad", dxo, pp(p + "W2"), d_ao, Mo, Fo, do, do, do, Fo, act=2, U=a["uo"])
+            self._wgrad(P, p + "W1.wgrad", a["ho2"], d_ao, gp(p + "W1"), Mo, do, Fo, do, Fo)
+            P.add(colsum, (d_ao, gp(p + "b1"), Mo, Fo, Fo), p + "b1.grad")
+            self._dgrad(P, p + "fc1.dgrad", d_ao, pp(p + "W1"), d_ho, Mo, do, Fo, Fo, Fo, do)
+            P.add(ln_bwd, (d_ho, a["xmid"], pp(p + "ln2_g"), dxo, dxo, gp(p + "ln2_g"), gp(p + "ln2_b"), Mo, do, do, do, 1e-6), p + "ln2.bwd")
+            # outer attention: xmid = xo + attn(LN(outer)) Wo - the residual is the patch stream, the attention reads outer (tnt.py:85-88)
+            self._wgrad(P, p + "Wo.wgrad", a["oo"], dxo, gp(p + "Wo"), Mo, do, do, do, do)
+            self._dgrad(P, p + "proj.dgrad", dxo, pp(p + "Wo"), d_oo, Mo, do, do, do, do, do)
+            self._attention_bwd(P, p, a["qkvo"], a["po"], d_oo, dqkvo, so, B, N, Ho, hdo, do, 1.0 / math.sqrt(hdo))
+            self._wgrad(P, p + "Wqkv.wgrad", a["ho1"], dqkvo, gp(p + "Wqkv"), Mo, do, 3 * do, do, 3 * do)
+            self._dgrad(P, p + "qkv.dgrad", dqkvo, pp(p + "Wqkv"), d_ho, Mo, do, 3 * do, 3 * do, 3 * do, do)
+            P.add(ln_bwd, (d_ho, a["outer"], pp(p + "ln1_g"), None, d_outer, gp(p + "ln1_g"), gp(p + "ln1_b"), Mo, do, do, do, 1e-6), p + "ln1.bwd")
+            # Inner2Outer (tnt.py:40-51): outer = patches + pad(flatten(pixels) Wio + bio): every row's cotangent joins the patch stream,
+            # the patch rows' also feeds the Dense and, through it, the pixel stream
+            P.add(L.savit_add_rows_periodic, (dxo, d_outer, Mo, Mo, do), p + "i2o.dpatches")
+            P.add(_gather_patch_rows_tnt, (self, "d_outer"), p + "i2o.gather")
+            self._wgrad(P, p + "Wio.wgrad", xi_out, d_tok, gp(p + "Wio"), Ms, npx * di, do, npx * di, do)
+            P.add(colsum, (d_tok, gp(p + "bio"), Ms, do, do), p + "bio.grad")
+            self._dgrad(P, p + "i2o.dgrad", d_tok, pp(p + "Wio"), dxi, Ms, npx * di, do, do, do, npx * di, accumulate=1)
+            # inner FFBlock (tnt.py:76-80)
+            self._wgrad(P, p + "iW2.wgrad", a["ai"], dxi, gp(p + "iW2"), Mi, Fi, di, Fi, di)
+            P.add(colsum, (dxi, gp(p + "ib2"), Mi, di, di), p + "ib2.grad")
+            self._dgrad(P, p + "ifc2.dgrad", dxi, pp(p + "iW2"), d_ai, Mi, Fi, di, di, di, Fi, act=2, U=a["ui"])
+            self._wgrad(P, p + "iW1.wgrad", a["hi2"], d_ai, gp(p + "iW1"), Mi, di, Fi, di, Fi)
+            P.add(colsum, (d_ai, gp(p + "ib1"), Mi, Fi, Fi), p + "ib1.grad")
+            self._dgrad(P, p + "ifc1.dgrad", d_ai, pp(p + "iW1"), d_hi, Mi, di, Fi, Fi, Fi, di)
+            P.add(ln_bwd, (d_hi, a["ximid"], pp(p + "iln2_g"), dxi, dxi, gp(p + "iln2_g"), gp(p + "iln2_b"), Mi, di, di, di, 1e-6), p + "iln2.bwd")
+            # inner attention over the npx pixel tokens of a patch (tnt.py:68-75), heads of stored width HDP
+            self._wgrad(P, p + "iWo.wgrad", a["oi"], dxi, gp(p + "iWo"), Mi, dap, di, dap, di)
+            self._dgrad(P, p + "iproj.dgrad", dxi, pp(p + "iWo"), d_oi, Mi, dap, di, di, di, dap)
+            self._attention_bwd(P, p + "i", a["qkvi"], a["pi"], d_oi, dqkvi, si, Ms, npx, Hi, HDP, dap, 1.0 / math.sqrt(hdi))
+            self._wgrad(P, p + "iWqkv.wgrad", a["hi1"], dqkvi, gp(p + "iWqkv"), Mi, di, 3 * dap, di, 3 * dap)
+            self._dgrad(P, p + "iqkv.dgrad", dqkvi, pp(p + "iWqkv"), d_hi, Mi, di, 3 * dap, 3 * dap, 3 * dap, di)
+            P.add(ln_bwd, (d_hi, xi_in, pp(p + "iln1_g"), dxi, dxi, gp(p + "iln1_g"), gp(p + "iln1_b"), Mi, di, di, di, 1e-6), p + "iln1.bwd")
+        # patch stream: position / cls / patch embedding with bias (tnt.py:160-167)
+        P.add(L.savit_pos_cls_grad, (dxo, gp("pos"), gp("cls"), B, N, do, 1), "pos_cls.grad")
+        P.add(_gather_patch_rows_tnt, (self, "dxo"), "dtok.gather")
+        self._wgrad(P, "Wpe.wgrad", self.patches.data_ptr(), d_tok, gp("Wpe"), Ms, cfg.patch_dim, do, cfg.patch_dim, do)
+        P.add(colsum, (d_tok, gp("bpa"), Ms, do, do), "bpa.grad")
+        # pixel stream: Dense + bias + the pixel position table shared by every patch (tnt.py:155-158)
+        self._wgrad(P, "Wpx.wgrad", self.pix.data_ptr(), dxi, gp("Wpx"), Mi, lay.pix_in, di, lay.pix_in, di)
+        P.add(colsum, (dxi, gp("bpx"), Mi, di, di), "bpx.grad")
+        P.add(colsum, (dxi, gp("ppos"), Ms, npx * di, npx * di), "ppos.grad")
         return P
 
 
@@ -812,8 +1026,15 @@ def _gather_pixels(eng: "TNTEngineF32", stream: int) -> int:
     return 0
 
 
-def _copy_cls_rows(eng: "TNTEngineF32", stream: int) -> int:
-    """outer[:, 0] = patches[:, 0]: Inner2Outer pads a zero row for cls (tnt.py:48-50)."""
+def _copy_cls_rows(eng: "TNTEngineF32", outer: torch.Tensor, xo: torch.Tensor, stream: int) -> int:
+    """outer[:, 0] = patches[:, 0]: Inner2Outer pads a zero row for cls (tnt.py:48-50).  One strided device copy (memory plumbing)."""
     B, N, do = eng.B, eng.cfg.seq_len, eng.cfg.embed_dim
-    eng.outer.view(B, N, do)[:, 0].copy_(eng.xo.view(B, N, do)[:, 0])
+    outer.view(B, N, do)[:, 0].copy_(xo.view(B, N, do)[:, 0])
+    return 0
+
+
+def _gather_patch_rows_tnt(eng: "TNTEngineF32", src: str, stream: int) -> int:
+    """d_tok = cotangent[:, 1:, :] (the patch rows of every image, contiguous): one strided device copy on the current stream."""
+    B, N, do = eng.B, eng.cfg.seq_len, eng.cfg.embed_dim
+    eng.bw["d_tok"].view(B, N - 1, do).copy_(eng.bw[src].view(B, N, do)[:, 1:])
     return 0

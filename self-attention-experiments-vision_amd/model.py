@@ -14,7 +14,7 @@ Every tensor lives on the GPU; the arithmetic is the HIP engine (engine.py).  Th
 
 dtype (create_model.py:6-8: `dtype=jnp.float32` by default; train.py passes bfloat16):
   torch.bfloat16  the training path: bf16 MFMA kernels with fp32 residual stream / statistics / parameters (all four families);
-  torch.float32   the reference default: every op in fp32 (engine_f32.py, exact fp32-input MFMA) - forward and loss, ViT family.
+  torch.float32   the reference default: every op in fp32 (engine_f32.py, exact fp32-input MFMA) - forward, loss and train step, all four families.
                   Training entry points raise on it, and the other families raise at construction: they compute in bf16 only.
 """
 from __future__ import annotations
@@ -40,7 +40,7 @@ class ViT:
     def __init__(self, cfg: ModelConfig, dtype=torch.float32):
         if dtype not in (torch.bfloat16, torch.float32):
             raise NotImplementedError("dtype must be torch.bfloat16 (the MFMA training path) or torch.float32 (exact fp32 arithmetic: every "
-                                      "family's forward + loss, and the ViT train step)")
+                                      "family's forward, loss and train step)")
         assert cfg.embed_dim % cfg.num_heads == 0  # vit.py:75
         self.cfg = cfg
         self.dtype = dtype

@@ -133,7 +133,8 @@ def test_vit_tiny_fp32_forward_and_loss_vs_oracle(L):
 @pytest.mark.parametrize("name", ["mixer_s_patch32", "tnt_s_patch16"])
 def test_mixer_and_tnt_fp32_default_dtype_vs_oracle(L, name):
     """create_model(name) at the reference's default dtype for the two remaining families (models/mlp_mixer.py:44-64, models/tnt.py:150-193):
-    logits within 2e-5 of the fp32 oracle; training stays on the bf16 engines and says so."""
+    logits within 2e-5 of the fp32 oracle (their fp32 train steps: test_mixer_fp32_train_step_vs_autograd,
+    test_tnt_fp32_train_step_vs_autograd)."""
     from savit_amd.model import create_model
 
     model = create_model(name)
@@ -152,8 +153,6 @@ def test_mixer_and_tnt_fp32_default_dtype_vs_oracle(L, name):
     labels = rng.integers(0, 1000, 3)
     loss = float(model.engine(3).loss_fn(torch.as_tensor(labels).cuda(), 0.1))
     assert abs(loss - vit_ref.loss_fn(ref64, labels, 0.1)) < 2e-5 * max(1.0, abs(loss))
-    with pytest.raises(NotImplementedError, match="dtype=torch.bfloat16"):
-        model.engine(3).loss_backward(torch.as_tensor(labels).cuda())
     # the reference initialisers through the same boundary (mlp_mixer_test.py / tnt_test.py shapes)
     out, _ = create_model(name).init_with_output(0, torch.ones(2, 224, 224, 3, device="cuda"), is_training=False)
     assert tuple(out.shape) == (2, 1000) and bool(torch.isfinite(out).all())
@@ -470,6 +469,119 @@ def test_cait_fp32_train_step_vs_autograd(L, case, B, training):
     eng.loss_backward(torch.as_tensor(labels).cuda(), 0.1)
     assert rel(eng.grads.cpu().numpy(), g1.cpu().numpy()) < 1e-6
     # optax chain of train.py:25-27 (descent sign of simple_train.py:27): clip_by_global_norm(1.0), adam, add_decayed_weights(1e-4), -lr
+    p0, g = eng.params.double().clone(), eng.grads.double().clone()
+    eng.optimizer_step(lr=1e-3, weight_decay=1e-4, max_norm=1.0)
+    gn = float(g.norm())
+    g = g * min(1.0, 1.0 / gn)
+    m, v = 0.1 * g, 0.001 * g * g
+    upd = (m / 0.1) / ((v / 0.001).sqrt() + 1e-8) + 1e-4 * p0
+    assert rel(eng.params.cpu().numpy(), (p0 - 1e-3 * upd).cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("case,B", [("tiny", 5), ("p16", 3), ("mixer_s_patch32", 2)])
+def test_mixer_fp32_train_step_vs_autograd(L, case, B):
+    """The fp32 TRAIN step of an MLP-Mixer - the reference's default arithmetic for this family (mlp_mixer.py:44-64 with dtype=float32,
+    differentiated by train.py:77-100): loss and EVERY parameter gradient (token-mixing kernels and their biases included: padded
+    storage, pads stay zero) against fp32 autograd of the oracle, then the AdamW update."""
+    from oracle import torch_ref
+    from savit_amd.config import ModelConfig, get_config
+    from savit_amd.engine_f32 import MixerEngineF32
+
+    small = {"tiny": dict(kind="mixer", num_layers=2, num_heads=1, embed_dim=128, patch=8, num_classes=16, img_size=32),
+             "p16": dict(kind="mixer", num_layers=2, num_heads=1, embed_dim=128, patch=16, num_classes=104, img_size=224)}
+    if case in small:
+        mc, oc, img = ModelConfig(**small[case]), vit_ref.Cfg(**small[case]), small[case]["img_size"]
+    else:
+        mc, oc, img = get_config(case), vit_ref.get_cfg(case), 224
+    rng = np.random.default_rng(57)
+    params = vit_ref.init_params(oc, seed=13, randomize=True)
+    images = rng.standard_normal((B, img, img, 3)).astype(np.float32)
+    labels = rng.integers(0, oc.num_classes, B)
+    eng = MixerEngineF32(mc, B)
+    eng.load_params(params)
+    logits = eng.forward(torch.as_tensor(images).cuda(), is_training=True).clone()
+    loss = float(eng.loss_backward(torch.as_tensor(labels).cuda(), 0.1))
+    assert torch.equal(logits, eng.logits)  # the re-run of the forward that saves activations reproduces it bit for bit
+    loss_ref, logits_ref, g_ref = torch_ref.loss_and_grads(params, images, labels, oc, 0.1)
+    assert rel(logits.cpu().numpy(), logits_ref) < 2e-5
+    assert abs(loss - loss_ref) < 1e-5 * max(1.0, abs(loss_ref))
+    got = _flat(eng.grad_tree()["params"])
+    assert set(got) == set(g_ref)
+    # the bias of the second token-mixing Dense shifts every channel of a token alike and only LayerNorms over the channels read the
+    # stream after it: its gradient is zero up to rounding in the oracle and here - held to an absolute bar, not a relative one
+    floor = 1e-6 * max(float(np.linalg.norm(v)) for v in g_ref.values())
+    null = [k for k in got if float(np.linalg.norm(g_ref[k])) < floor]
+    assert all(k.endswith("FFBlock_0/Dense_1/bias") for k in null) and all(float(np.linalg.norm(got[k])) < floor for k in null), null
+    worst = max((rel(got[k], g_ref[k]), k) for k in got if k not in null)
+    print(f"[fp32 Mixer train step {case}] loss {loss:.6f} (oracle {loss_ref:.6f}); worst gradient rel-L2 {worst[0]:.2e} ({worst[1]})")
+    assert worst[0] < 2e-5, worst
+    # the padding of the token-mixing kernels received no gradient
+    lay = eng.layout
+    for l in range(mc.num_layers):
+        for nm, logical in ((f"l{l}.tW1", (mc.n_patches, mc.tokens_hidden)), (f"l{l}.tW2", (mc.tokens_hidden, mc.n_patches))):
+            off, shape = lay.off[nm]
+            g = eng.grads[off:off + int(np.prod(shape))].view(*shape).clone()
+            g[:logical[0], :logical[1]] = 0
+            assert float(g.abs().max()) == 0.0, nm
+    # a second forward + backward (now saving activations in the forward itself) reproduces the gradients
+    g1 = eng.grads.clone()
+    eng.forward(torch.as_tensor(images).cuda(), is_training=True)
+    eng.loss_backward(torch.as_tensor(labels).cuda(), 0.1)
+    assert rel(eng.grads.cpu().numpy(), g1.cpu().numpy()) < 1e-6
+    p0, g = eng.params.double().clone(), eng.grads.double().clone()
+    eng.optimizer_step(lr=1e-3, weight_decay=1e-4, max_norm=1.0)
+    gn = float(g.norm())
+    g = g * min(1.0, 1.0 / gn)
+    m, v = 0.1 * g, 0.001 * g * g
+    upd = (m / 0.1) / ((v / 0.001).sqrt() + 1e-8) + 1e-4 * p0
+    assert rel(eng.params.cpu().numpy(), (p0 - 1e-3 * upd).cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("case,B", [("tiny", 3), ("two_inner_heads", 2), ("tnt_s_patch16", 2)])
+def test_tnt_fp32_train_step_vs_autograd(L, case, B):
+    """The fp32 TRAIN step of a TNT (tnt.py:150-193 at create_model's default dtype, differentiated by train.py:77-100): loss and EVERY
+    parameter gradient - pixel stream, patch stream and the Inner2Outer that joins them in every layer, both position tables, the
+    head-padded inner attention kernels (their pad columns receive exactly zero) - against fp32 autograd of the oracle; AdamW."""
+    from oracle import torch_ref
+    from savit_amd.config import ModelConfig, get_config
+    from savit_amd.engine_f32 import TNTEngineF32
+
+    small = {"tiny": dict(kind="tnt", num_layers=2, num_heads=2, embed_dim=32, patch=16, num_classes=10, img_size=32, inner_num_heads=2,
+                          inner_embed_dim=8),
+             "two_inner_heads": dict(kind="tnt", num_layers=3, num_heads=4, embed_dim=64, patch=16, num_classes=24, img_size=64, inner_num_heads=2,
+                                     inner_embed_dim=24)}
+    if case in small:
+        mc, oc, img = ModelConfig(**small[case]), vit_ref.Cfg(**small[case]), small[case]["img_size"]
+    else:
+        mc, oc, img = get_config(case), vit_ref.get_cfg(case), 224
+    rng = np.random.default_rng(59)
+    params = vit_ref.init_params(oc, seed=14, randomize=True)
+    images = rng.standard_normal((B, img, img, 3)).astype(np.float32)
+    labels = rng.integers(0, oc.num_classes, B)
+    eng = TNTEngineF32(mc, B)
+    eng.load_params(params)
+    logits = eng.forward(torch.as_tensor(images).cuda(), is_training=True).clone()
+    loss = float(eng.loss_backward(torch.as_tensor(labels).cuda(), 0.1))
+    assert torch.equal(logits, eng.logits)  # the re-run of the forward that saves activations reproduces it bit for bit
+    loss_ref, logits_ref, g_ref = torch_ref.loss_and_grads(params, images, labels, oc, 0.1)
+    assert rel(logits.cpu().numpy(), logits_ref) < 2e-5
+    assert abs(loss - loss_ref) < 1e-5 * max(1.0, abs(loss_ref))
+    got = _flat(eng.grad_tree()["params"])
+    assert set(got) == set(g_ref)
+    worst = max((rel(got[k], g_ref[k]), k) for k in got)
+    print(f"[fp32 TNT train step {case}] loss {loss:.6f} (oracle {loss_ref:.6f}); worst gradient rel-L2 {worst[0]:.2e} ({worst[1]})")
+    assert worst[0] < 2e-5, worst
+    # the head padding of the inner attention kernels received no gradient: everything outside the logical corner is exactly zero
+    lay, di, Hi = eng.layout, mc.inner_embed_dim, mc.inner_num_heads
+    hdi = di // Hi
+    for l in range(mc.num_layers):
+        gq = lay.view(eng.grads, f"l{l}.iWqkv").view(di, 3, Hi, eng.HDP)[..., hdi:]
+        go = lay.view(eng.grads, f"l{l}.iWo").view(Hi, eng.HDP, di)[:, hdi:, :]
+        assert float(gq.abs().max()) == 0.0 and float(go.abs().max()) == 0.0, l
+    g1 = eng.grads.clone()
+    eng.forward(torch.as_tensor(images).cuda(), is_training=True)
+    eng.loss_backward(torch.as_tensor(labels).cuda(), 0.1)
+    assert rel(eng.grads.cpu().numpy(), g1.cpu().numpy()) < 1e-6
     p0, g = eng.params.double().clone(), eng.grads.double().clone()
     eng.optimizer_step(lr=1e-3, weight_decay=1e-4, max_norm=1.0)
     gn = float(g.norm())

@@ -153,11 +153,20 @@ def test_short_run_float32_simple_train_mode(tmp_path, capsys):
     assert all(np.isfinite(t["train/loss"]) for t in train) and any("eval/loss" in l for l in lines)
     assert os.path.exists(os.path.join(ck, "checkpoint_3"))
     assert train_cli.main(common + ["--num_epochs", "2"]) == 6  # resumes
-    # round 6: CaiT trains in fp32 too - the arithmetic the reference always uses for it (cait.py:147-154); the other families say why not
+    # round 6: CaiT trains in fp32 too - the arithmetic the reference always uses for it (cait.py:147-154); as do the MLP-Mixer and TNT; mixup says why not
     capsys.readouterr()
     assert train_cli.main(["--model_name", "cait_xxs_24", "--dtype", "float32", "--batch_size", "2", "--max_steps", "2", "--log_every", "1",
                            "--clip_grad", "1.0", "--lr", "1e-3"]) == 2
     tl = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{") and "train/loss" in l]
     assert len(tl) == 2 and abs(tl[0]["train/loss"] - 6.9078) < 1e-4 and np.isfinite(tl[1]["train/loss"])
+    assert train_cli.main(["--model_name", "mixer_s_patch32", "--dtype", "float32", "--batch_size", "2", "--max_steps", "2", "--log_every", "1",
+                           "--clip_grad", "1.0", "--lr", "1e-3"]) == 2
+    tl = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{") and "train/loss" in l]
+    assert len(tl) == 2 and 5.5 < tl[0]["train/loss"] < 8.5 and np.isfinite(tl[1]["train/loss"])
+    capsys.readouterr()
+    assert train_cli.main(["--model_name", "tnt_s_patch16", "--dtype", "float32", "--batch_size", "2", "--max_steps", "2", "--log_every", "1",
+                           "--clip_grad", "1.0", "--lr", "1e-3"]) == 2
+    tl = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{") and "train/loss" in l]
+    assert len(tl) == 2 and all(np.isfinite(t["train/loss"]) for t in tl)
     with pytest.raises(SystemExit, match="bfloat16"):
-        train_cli.main(["--model_name", "mixer_s_patch32", "--dtype", "float32", "--batch_size", "2", "--max_steps", "1"])
+        train_cli.main(["--model_name", "vit_ti_patch16", "--dtype", "float32", "--batch_size", "2", "--max_steps", "1", "--mixup_alpha", "0.8"])

@@ -132,7 +132,7 @@ def main(argv=None):
     ap.add_argument("--mix_prob", type=float, default=1.0, help="probability of applying the drawn mix augmentation to a batch")
     ap.add_argument("--dtype", default="bfloat16", choices=("bfloat16", "float32"),
                     help="bfloat16 = what train.py:222-224 passes to create_model; float32 = create_model's default, the arithmetic of "
-                         "simple_train.py:72-90 (ViT family, one GPU: the exact-fp32 engine)")
+                         "simple_train.py:72-90 (one GPU, no mixup: the exact-fp32 engines)")
     args = ap.parse_args(argv)
 
     import torch
@@ -165,9 +165,9 @@ def main(argv=None):
 
     fp32 = args.dtype == "float32"
     model = create_model(args.model_name, num_classes=1000, dtype=torch.float32 if fp32 else torch.bfloat16, img_size=args.img_size)  # train.py:222-224
-    if fp32 and (model.cfg.kind not in ("vit", "cait") or world > 1 or args.mixup_alpha > 0 or args.cutmix_alpha > 0):
-        raise SystemExit("--dtype float32 trains the ViT family (simple_train.py) and CaiT (whose reference arithmetic is always fp32: "
-                         "cait.py:147-154) on one GPU without mix augmentation; MLP-Mixer / TNT and the data-parallel / mixup paths train in bfloat16")
+    if fp32 and (world > 1 or args.mixup_alpha > 0 or args.cutmix_alpha > 0):
+        raise SystemExit("--dtype float32 (create_model's default arithmetic, simple_train.py; what the reference always computes CaiT in: "
+                         "cait.py:147-154) trains every family on one GPU without mix augmentation; the data-parallel / mixup paths train in bfloat16")
     model.init(args.seed, torch.ones(1, args.img_size, args.img_size, 3, device="cuda"), is_training=False)  # train.py:29-31
     eng = model.engine(bs)
     start = restore_checkpoint(eng, args.checkpoint_dir) if args.checkpoint_dir else 0
