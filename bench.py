@@ -275,6 +275,24 @@ def reserved_cus_sweep(cfg, B, world, rank, dist, bucket_mb, steps, warmup, opts
     return rows
 
 
+def arm_sweep_watchdog(seconds: float, out: dict, rank: int):
+    """The headline is measured before the sweep starts; a sweep that hangs (a collective one rank never enters) must not lose it.  After
+    `seconds` every rank leaves the process; rank 0 prints the line first, with the reason.  -> the timer (cancel() it when the sweep is done)."""
+    import threading
+
+    def fire():
+        if rank == 0:
+            line = dict(out, reserved_cus_sweep_error=f"watchdog: the sweep was still running after {seconds:g} s; headline printed without it")
+            sys.stdout.write(json.dumps(line) + "\n")
+            sys.stdout.flush()
+        os._exit(0)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def make_step(eng, cfg, B, world, rank, sync):
     """Engine + synthetic batches resident in HBM -> step(i): N(0,1) NHWC images cast to bf16 (train.py:81), uniform labels,
     seed 42+rank; lr*bs/512 (train.py:171,214-220), wd 1e-4 (:172-176), label smoothing 0.1, clip 1.0."""
@@ -714,6 +732,8 @@ def main():
     ap.add_argument("--overlap-wgrad", type=int, choices=(0, 1), default=None, help="weight gradients on a side stream")
     ap.add_argument("--no-reserved-cus-sweep", action="store_true", help="N > 1: skip the reserved_cus 0 / 8 / 16 / 32 timings behind the headline")
     ap.add_argument("--sweep-steps", type=int, default=10)
+    ap.add_argument("--sweep-timeout", type=float, default=240.0,
+                    help="N > 1: seconds after which a sweep that has not returned is abandoned (the headline line is printed without it)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -826,6 +846,7 @@ def main():
     if world > 1 and not args.no_reserved_cus_sweep:
         del step, eng, sync
         torch.cuda.empty_cache()
+        dog = arm_sweep_watchdog(args.sweep_timeout, out if rank == 0 else {}, rank)
         try:
             rows = reserved_cus_sweep(cfg, B, world, rank, dist, args.bucket_mb, args.sweep_steps, 3, opts)
             if rank == 0:
@@ -833,6 +854,7 @@ def main():
         except Exception as e:  # (the headline above is already measured: a failure here - the same on every rank - must not lose the line)
             if rank == 0:
                 out["reserved_cus_sweep_error"] = f"{type(e).__name__}: {e}"
+        dog.cancel()
         eng = step = None
 
     # ---- other BASELINE configs on this GPU (rank 0, N=1, headline workload only): short timings, after the headline engine is freed

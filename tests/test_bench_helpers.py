@@ -1,5 +1,7 @@
 """bench.py's accounting helpers (no GPU): launch label -> kernel class / rocprofv3 symbol / algorithmic flops, and the choice of the
 dominant kernel - the parts of the `roofline` object that are not measurements."""
+import json
+import os
 import types
 
 import bench
@@ -179,3 +181,29 @@ def test_engine_options_env_and_keywords(monkeypatch):
     with pytest.raises(TypeError, match="unknown engine option"):
         EngineOptions.resolve(None, clz_only_last=False)
     assert set(EngineOptions.ENV) == set(EngineOptions().as_dict())
+
+
+def test_sweep_watchdog_prints_the_headline_and_leaves():
+    """N > 1: a reserved_cus sweep that hangs behind the measured headline must not lose the line - after the timeout rank 0 prints it
+    (with the reason) and every rank leaves with status 0; other ranks print nothing."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "rank = int(sys.argv[1])\n"
+            "bench.arm_sweep_watchdog(0.3, {'metric': 'images_per_sec', 'value': 1.0} if rank == 0 else {}, rank)\n"
+            "time.sleep(30)\nprint('not reached')\n" % root)
+    for rank in (0, 1):
+        r = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, timeout=25)
+        assert r.returncode == 0 and "not reached" not in r.stdout
+        if rank == 0:
+            line = json.loads(r.stdout.strip().splitlines()[-1])
+            assert line["value"] == 1.0 and "watchdog" in line["reserved_cus_sweep_error"]
+        else:
+            assert r.stdout.strip() == ""
+    # a cancelled watchdog never fires
+    code2 = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+             "t = bench.arm_sweep_watchdog(0.2, {'value': 1.0}, 0); t.cancel(); time.sleep(0.6); print('done')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=25)
+    assert r.returncode == 0 and r.stdout.strip() == "done"
