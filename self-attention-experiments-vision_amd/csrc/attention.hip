@@ -2239,6 +2239,28 @@ __device__ __forceinline__ bf16x8 load_tile_T_frag(const bf16_t* rowp, bool row_
   if (row_ok && k0 + 8 < Np) r.u[1] = *reinterpret_cast<const uint2*>(rowp + k0 + 8);
   return r.v;
 }
+// The same fragment in NATURAL contraction order (round 6): element j <-> key = kt*32 + 16*s2 + 8*half + j - ONE 16-byte load per lane, so
+// a wave instruction moves 32 rows x 32 B = 1 KB instead of 512 B (a CU accepts about one vector-memory instruction per ~50 cycles
+// whatever it carries: the P' / dS reads of th_pv and of the scores backward were half-width requests).  An MFMA sums over its 16
+// contraction slots whatever keys they hold, as long as the A operand uses the same order: lds_tr_frag_nat below.
+__device__ __forceinline__ bf16x8 load_tile_T_frag16(const bf16_t* rowp, bool row_ok, int kt, int s2, int half, int Np) {
+  bf16x8 r = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  const int k0 = kt * 32 + 16 * s2 + 8 * half;  // Np % 8 == 0: the chunk is entirely inside or outside the row
+  if (row_ok && k0 < Np) r = *reinterpret_cast<const bf16x8*>(rowp + k0);
+  return r;
+}
+// transposed A fragment whose contraction slots are rows row0 .. row0 + 7 (this lane addresses row0 + (t >> 2), row0 = tile row + 8 * half)
+__device__ __forceinline__ bf16x8 lds_tr_frag_nat(const char* img, int row0, int col) {
+  const int r = row0, r4 = row0 + 4;
+  const int o0 = r * ROWB + (((col >> 3) ^ rot3(r)) << 4) + ((col & 7) << 1);
+  const int o1 = r4 * ROWB + (((col >> 3) ^ rot3(r4)) << 4) + ((col & 7) << 1);
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(img + o0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(img + o1));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+#ifndef SAVIT_TH_NAT16
+#define SAVIT_TH_NAT16 1
+#endif
 // B-operand fragment with the contraction index on the ROWS of buf (column gather): element j <-> row
 // q = qt*32 + 16*s2 + 8*(j>>2) + 4*half + (j&3), fixed column `key`
 __device__ __forceinline__ bf16x8 load_tile_col_frag(const bf16_t* base, int key, int qt, int s2, int half, int N, int Np) {
@@ -2301,6 +2323,7 @@ __global__ __launch_bounds__(512) void th_pv_kernel(const ThParams p) {
   __syncthreads();
   const int ql = lane & 31, half = lane >> 5, g = lane >> 4, t = lane & 15;
   const int trow = 4 * (g >> 1) + (t >> 2), tcol = 16 * (g & 1) + 4 * (t & 3);
+  [[maybe_unused]] const int trow_n = 8 * (g >> 1) + (t >> 2);
   const bf16_t* pb = p.pbuf + ((size_t)b * p.H + hh) * p.N * p.Np;
   for (int qb = wave; qb < NT; qb += nwv) {
     const int q = qb * 32 + ql;
@@ -2315,7 +2338,9 @@ __global__ __launch_bounds__(512) void th_pv_kernel(const ThParams p) {
 #pragma unroll
     for (int kt = 0; kt < TH_MAX_NT; ++kt)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) pf[kt][s2] = load_tile_T_frag(pb + (size_t)q * p.Np, q < p.N && kt < NT, kt, s2, half, p.Np);
+      for (int s2 = 0; s2 < 2; ++s2)
+        pf[kt][s2] = SAVIT_TH_NAT16 ? load_tile_T_frag16(pb + (size_t)q * p.Np, q < p.N && kt < NT, kt, s2, half, p.Np)
+                                    : load_tile_T_frag(pb + (size_t)q * p.Np, q < p.N && kt < NT, kt, s2, half, p.Np);
 #pragma unroll
     for (int kt = 0; kt < TH_MAX_NT; ++kt) {
       if (kt >= NT) break;
@@ -2323,7 +2348,9 @@ __global__ __launch_bounds__(512) void th_pv_kernel(const ThParams p) {
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb)
-          oacc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(smem, kt * 32 + 16 * s2 + trow, 32 * eb + tcol), pf[kt][s2], oacc[eb], 0, 0, 0);
+          oacc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SAVIT_TH_NAT16 ? lds_tr_frag_nat(smem, kt * 32 + 16 * s2 + trow_n, 32 * eb + tcol)
+                                                                            : lds_tr_frag(smem, kt * 32 + 16 * s2 + trow, 32 * eb + tcol),
+                                                             pf[kt][s2], oacc[eb], 0, 0, 0);
     }
     if (q < p.N) {
       bf16_t* orow = p.o + (size_t)(row_base + q) * p.d + hh * hd;
@@ -2353,6 +2380,7 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
   const auto srdO = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.o), 0, (uint32_t)bytes_o, 0x00020000);
   const int ql = lane & 31, half = lane >> 5, g = lane >> 4, t = lane & 15;
   const int trow = 4 * (g >> 1) + (t >> 2), tcol = 16 * (g & 1) + 4 * (t & 3);
+  [[maybe_unused]] const int trow_n = 8 * (g >> 1) + (t >> 2);
   const size_t bh = ((size_t)b * p.H + hh) * p.N * p.Np;
   // One wave owns one 32-row block in each pass (the launch uses NT waves).  Everything a pass reads from HBM into registers
   // is requested BEFORE the wait for the staged image, so a workgroup exposes the HBM latency twice (once per pass) instead of
@@ -2372,7 +2400,9 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
 #pragma unroll
     for (int kt = 0; kt < TH_MAX_NT; ++kt)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) dsf[kt][s2] = load_tile_T_frag(p.sbuf + bh + (size_t)q * p.Np, q < p.N && kt < NT, kt, s2, half, p.Np);
+      for (int s2 = 0; s2 < 2; ++s2)
+        dsf[kt][s2] = SAVIT_TH_NAT16 ? load_tile_T_frag16(p.sbuf + bh + (size_t)q * p.Np, q < p.N && kt < NT, kt, s2, half, p.Np)
+                                     : load_tile_T_frag(p.sbuf + bh + (size_t)q * p.Np, q < p.N && kt < NT, kt, s2, half, p.Np);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -2402,7 +2432,9 @@ __global__ __launch_bounds__(512) void th_bwd_kernel(const ThParams p) {
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
           for (int eb = 0; eb < 2; ++eb)
-            dq[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(smem, kt * 32 + 16 * s2 + trow, 32 * eb + tcol), dsf[kt][s2], dq[eb], 0, 0, 0);
+            dq[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SAVIT_TH_NAT16 ? lds_tr_frag_nat(smem, kt * 32 + 16 * s2 + trow_n, 32 * eb + tcol)
+                                                                            : lds_tr_frag(smem, kt * 32 + 16 * s2 + trow, 32 * eb + tcol),
+                                                             dsf[kt][s2], dq[eb], 0, 0, 0);
       }
       if (q < p.N) {
         bf16_t* drow = p.dqkv + (size_t)(row_base + q) * p.ld + hh * hd;
