@@ -2335,7 +2335,13 @@ extern "C" int savit_gemm_tn_auto_tile_cus(int M, int N, int K, int epilogue, in
   // (round 5: also K = 384 with a wide output - DeiT-S / CaiT-S fc1 and fc2 input gradient, N = 1536: in the training step, same box,
   //  alternating runs: DeiT-S 19 458 / 19 515 -> 19 686 / 19 717 img/s, CaiT-S24 6 524 -> 6 552; with cold operands fc1 + GELU 121 -> 103 us.
   //  NOT K = 512 / 640: MLP-Mixer-S/16 (d = 512, N = 2048) lost 3.2 % with it (23 403 -> 22 657 img/s), TNT-B's outer stream 0.3 %.)
-  if ((K >= pp_min_k || (K == 384 && N >= 1024 && pp_min_k == 768)) && N % 256 == 0 && M >= 4096 && epilogue != SAVIT_EPI_PATCH) {
+  // (round 6, measured and NOT taken: K = 384 with N = 1152 - the qkv projection of DeiT-S / CaiT-S / TNT-S's outer stream - on the ping-pong
+  //  tiles with the fifth column tile half empty (rows of W past N read as zeros, the stores are masked).  Cold operands: 77.6 (192 x 128)
+  //  -> 72.4 (256 x 256) / 70.2 us (320 x 256); inside the training step, same box: qkv 65.4 -> 66.7 / 69.0 us, DeiT-S 20.44-20.52 k
+  //  img/s either way, CaiT-S24 -0.3..-0.9 % (profiles/r06_ragged_n_ab.log) - warm operands again decide for the pair kernel.)
+  static const int ragged_n = SAVIT_EXP_ENV_INT("SAVIT_PP_RAGGED_N", 0);  // SAVIT_EXPERIMENTS builds only: 1 = the round model's tile, 2 = 320 x 256
+  const bool n_ok = N % 256 == 0 || (ragged_n && K == 384 && N % 256 == 128 && N >= 1024);
+  if ((K >= pp_min_k || (K == 384 && N >= 1024 && pp_min_k == 768)) && n_ok && M >= 4096 && epilogue != SAVIT_EPI_PATCH) {
     //  * 320x256 ping-pong (tile 21, round 3) against 256x256 (tile 20) and 192x128 (17 / 18): what a launch costs is (rounds of
     //    workgroups over the CUs) x (rows of a tile), weighted by what the tile's operand feed costs - the L2 -> LDS path of a CU, not
     //    the matrix pipe, bounds these kernels, and a 192x128 tile moves 1.7x the bytes per flop of a 256-wide one (measured: the same
@@ -2344,7 +2350,7 @@ extern "C" int savit_gemm_tn_auto_tile_cus(int M, int N, int K, int epilogue, in
     //    proj + residual 69 -> 58; N = 2304: 3 rounds of 320 rows against 4 of 256: qkv 108 -> 96 us; N = 3072: 4 x 320 = 5 x 256, the
     //    320-row tile moves 10 % fewer bytes: fc1 + GELU 147 -> 143, GELU' 167 -> 162 (tools/gemm_epi_bench.py, cold operands).
     const int cus = (cu_budget > 0 && cu_budget < device_cus()) ? cu_budget : device_cus();
-    const long tn = N / 256;
+    const long tn = (N + 255) / 256;
     const long r256 = (((long)(M + 255) / 256 * tn + cus - 1) / cus) * 256;
     const long r320 = (((long)(M + 319) / 320 * tn + cus - 1) / cus) * 320;
     // 192x128, two workgroups per CU, the last partial round cut into 128-row tiles: rounds in thirds of a tile time
@@ -2361,6 +2367,7 @@ extern "C" int savit_gemm_tn_auto_tile_cus(int M, int N, int K, int epilogue, in
     //    there only.
     if (best <= c192 || (big && N >= 1024)) {
       const long t320 = (long)(M + 319) / 320 * tn;
+      if (ragged_n == 2 && N % 256 != 0) return 21;
       return r320 <= r256 ? ((K >= 1024 && t320 >= 6L * cus) ? 22 : 21) : 20;
     }
   }
