@@ -834,7 +834,7 @@ class TNTEngineF32(_SavedPlanF32):
         self.sv["xi"] = [e(Mi, di) for _ in range(NL + 1)]
         self.sv["xo"] = [e(Mo, do) for _ in range(NL + 1)]
         self.bw = {"dxo": e(Mo, do), "d_outer": e(Mo, do), "d_ao": e(Mo, Fo), "d_ho": e(Mo, do), "d_oo": e(Mo, do), "dqkvo": e(Mo, 3 * do),
-                   "d_tok": e(Ms, do), "rows": e(cfg.seq_len * do), "dxi": e(Mi, di), "d_ai": e(Mi, lay.Fi), "d_hi": e(Mi, di), "d_oi": e(Mi, lay.dap),
+                   "d_tok": e(Ms, do), "dxi": e(Mi, di), "d_ai": e(Mi, lay.Fi), "d_hi": e(Mi, di), "d_oi": e(Mi, lay.dap),
                    "dqkvi": e(Mi, 3 * lay.dap)}
 
     def _build(self, save: bool = False) -> _Plan:
@@ -919,8 +919,8 @@ class TNTEngineF32(_SavedPlanF32):
         pp = self._off
         gp = lambda nm: self._off(nm, self.grads)  # noqa: E731
         ptr = lambda t: t.data_ptr()  # noqa: E731
-        dxo, d_outer, d_ao, d_ho, d_oo, dqkvo, d_tok, rows, dxi, d_ai, d_hi, d_oi, dqkvi = (ptr(bw[k]) for k in (
-            "dxo", "d_outer", "d_ao", "d_ho", "d_oo", "dqkvo", "d_tok", "rows", "dxi", "d_ai", "d_hi", "d_oi", "dqkvi"))
+        dxo, d_outer, d_ao, d_ho, d_oo, dqkvo, d_tok, dxi, d_ai, d_hi, d_oi, dqkvi = (ptr(bw[k]) for k in (
+            "dxo", "d_outer", "d_ao", "d_ho", "d_oo", "dqkvo", "d_tok", "dxi", "d_ai", "d_hi", "d_oi", "dqkvi"))
         si, so, dl = ptr(self.si), ptr(self.so), self.dlogits.data_ptr()
         ln_bwd, colsum = L.savit_layernorm_bwd_f32, L.savit_colsum_f32
         # head on the cls rows, no final LayerNorm (tnt.py:188-192); the last layer's pixel stream has no reader but its Inner2Outer
@@ -932,7 +932,7 @@ class TNTEngineF32(_SavedPlanF32):
         for l in range(NL - 1, -1, -1):
             p = f"l{l}."
             a = {k: ptr(sv[k][l]) for k in self.INNER + self.OUTER}
-            xi_in, xi_out, xo_in = ptr(sv["xi"][l]), ptr(sv["xi"][l + 1]), ptr(sv["xo"][l])
+            xi_in, xi_out = ptr(sv["xi"][l]), ptr(sv["xi"][l + 1])
             # outer FFBlock: xo_next = xmid + gelu(ho2 W1 + b1) W2 + b2   (tnt.py:89-92, ff.py:26-33)
             self._wgrad(P, p + "W2.wgrad", a["ao"], dxo, gp(p + "W2"), Mo, Fo, do, Fo, do)
             P.add(colsum, (dxo, gp(p + "b2"), Mo, do, do), p + "b2.grad")
